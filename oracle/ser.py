@@ -1,0 +1,59 @@
+"""ark-serialize ^0.4.0 ``serialize_compressed`` restated for the types that cross the
+reference's wire (mpc-net/src/ser_net.rs:24-25,111-112) and for ``Proof``.
+
+TEST INFRASTRUCTURE ONLY (see oracle/params.py).  ark-serialize is third-party
+and not vendored; format per SURVEY.md 8c: Fp -> canonical
+little-endian bytes (non-Montgomery); Vec<T> -> u64 LE length + items;
+short-Weierstrass affine -> x (Fq2: c0 || c1) with flag bits in the top bits of
+the last byte: bit 7 = y is the lexicographically larger of (y, -y), bit 6 =
+point at infinity (x = 0).
+"""
+
+
+def fp_bytes(v, nbytes):
+    return int(v).to_bytes(nbytes, "little")
+
+
+def fr_vec(vals, nbytes=32):
+    return len(vals).to_bytes(8, "little") + b"".join(fp_bytes(v, nbytes) for v in vals)
+
+
+def _fq_size(q):
+    return (q.bit_length() + 7) // 8
+
+
+def g1_compressed(p, q):
+    n = _fq_size(q)
+    if p is None:
+        b = bytearray(n)
+        b[-1] |= 1 << 6
+        return bytes(b)
+    x, y = p
+    b = bytearray(fp_bytes(x, n))
+    if y > (q - y) % q:
+        b[-1] |= 1 << 7
+    return bytes(b)
+
+
+def _fq2_gt(a, b):
+    # ark-ff QuadExtField Ord: compare c1 first, then c0
+    return (a[1], a[0]) > (b[1], b[0])
+
+
+def g2_compressed(p, q):
+    n = _fq_size(q)
+    if p is None:
+        b = bytearray(2 * n)
+        b[-1] |= 1 << 6
+        return bytes(b)
+    x, y = p
+    b = bytearray(fp_bytes(x[0], n) + fp_bytes(x[1], n))
+    neg = ((q - y[0]) % q, (q - y[1]) % q)
+    if _fq2_gt(y, neg):
+        b[-1] |= 1 << 7
+    return bytes(b)
+
+
+def proof_compressed(a, b, c, q):
+    """ark_groth16::Proof {a: G1, b: G2, c: G1} (128 B for BN254, 192 B for BLS12-381)."""
+    return g1_compressed(a, q) + g2_compressed(b, q) + g1_compressed(c, q)
