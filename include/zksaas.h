@@ -1,0 +1,126 @@
+/* zksaas.h -- C ABI of the MI355X-native zkSaaS hot path (libzksaas_hip.so).
+ *
+ * The reference (tangle-network/zk-SaaS, pure Rust) has no FFI seam; the seam is the set of generic
+ * Rust functions listed below.  Every entry point here cites the reference function it
+ * replaces, so that a thin Rust shim can forward the same arguments.
+ *
+ * Data layout at the boundary = arkworks in-memory representation:
+ *   Fr / Fq      : little-endian u64 limbs in MONTGOMERY form, fully reduced
+ *                  (4 limbs: BN254 Fr/Fq, BLS12-381 Fr, BLS12-377 Fr; 6 limbs: BLS12-381/377 Fq).
+ *   affine point : x || y (Fq2: c0 || c1), (0,0) = identity sentinel.
+ *   group value  : Jacobian X || Y || Z, Z = 0 = identity.
+ *   share vectors: what one party holds, `Vec<F>` of length m/l; all-party buffers are [n][m/l]
+ *                  (party-major, party p's vector contiguous).
+ *
+ * Pointers whose name ends in _d are DEVICE pointers (hipMalloc / torch tensors); everything else is
+ * host memory.  `stream` is a hipStream_t (NULL = default stream).  All functions return a zk_status;
+ * zk_last_error() returns the message and, for ZK_ERR_PROTOCOL, the offending party
+ * (mpc-net/src/lib.rs:19-24 MpcNetError).  Nothing here falls back to a CPU implementation.
+ */
+#ifndef ZKSAAS_H
+#define ZKSAAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+
+enum zk_curve { ZK_BN254 = 0, ZK_BLS12_381 = 1, ZK_BLS12_377 = 2 };
+enum zk_group { ZK_G1 = 1, ZK_G2 = 2 };
+/* mpc-net/src/lib.rs:19-24 */
+enum zk_status { ZK_OK = 0, ZK_ERR_GENERIC = 1, ZK_ERR_PROTOCOL = 2, ZK_ERR_NOT_CONNECTED = 3, ZK_ERR_BAD_INPUT = 4 };
+
+/* ---- context ------------------------------------------------------------------------------------
+ * PackedSharingParams::new(l) (secret-sharing/src/pss.rs:39-66): n = 4l parties, t = l, share domain
+ * H_n, secret domain g*H_{l+t}, secret2 domain g*H_{2(l+t)}.  `device` is the HIP device ordinal. */
+int zk_ctx_create(int curve, int l, int device, zk_ctx** out);
+void zk_ctx_destroy(zk_ctx* ctx);
+const char* zk_last_error(zk_ctx* ctx, int* party);
+int zk_ctx_n(const zk_ctx* ctx);        /* pp.n */
+int zk_ctx_l(const zk_ctx* ctx);        /* pp.l */
+size_t zk_fr_bytes(const zk_ctx* ctx);  /* 32 */
+size_t zk_fq_bytes(const zk_ctx* ctx);  /* 32 or 48 */
+const char* zk_version(void);
+
+/* ---- device memory helpers (so that non-torch hosts can drive the library) ---------------------- */
+int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d);
+int zk_free(zk_ctx* ctx, void* p_d);
+int zk_memcpy_h2d(zk_ctx* ctx, void* dst_d, const void* src, size_t bytes, void* stream);
+int zk_memcpy_d2h(zk_ctx* ctx, void* dst, const void* src_d, size_t bytes, void* stream);
+int zk_stream_sync(zk_ctx* ctx, void* stream);
+
+/* ---- packed secret sharing over Fr (secret-sharing/src/pss.rs) ------------------------------------
+ * `order`: 0 = chunk j packs secrets[j*l .. j*l+l-1]  (pack_vec, dist-primitives/src/utils/pack.rs:8-20)
+ *          1 = chunk j packs secrets[j], secrets[j+nchunks], ...  (stride packing, dfft/mod.rs:286-299,
+ *              groth16/src/qap.rs:103-112)
+ * Share randomness: counter-based PRNG documented in DESIGN.md (chunk j uses indices j*t..j*t+t-1 of
+ * stream `seed`).  Output shares_d is [n][nchunks]. */
+int zk_pss_pack(zk_ctx* ctx, const void* secrets_d, size_t nchunks, int order, uint64_t seed, void* shares_d,
+                void* stream);                                                   /* pss.rs:90-122 pack     */
+int zk_pss_det_pack(zk_ctx* ctx, const void* secrets_d, size_t nchunks, int order, void* shares_d,
+                    void* stream);                                               /* pss.rs:69-87 det_pack  */
+/* shares_d is [nparties][nchunks] for the listed parties (ascending ids); secrets_d gets nchunks*l values in
+ * order 0.  unpack requires all n parties (pss.rs:125-138); unpack2 falls back to lagrange_unpack when
+ * nparties < n (pss.rs:141-221 unpack2 / lagrange_unpack / unpack_missing_shares). */
+int zk_pss_unpack(zk_ctx* ctx, const void* shares_d, size_t nchunks, void* secrets_d, void* stream);
+int zk_pss_unpack2(zk_ctx* ctx, const void* shares_d, const uint32_t* parties, int nparties, size_t nchunks,
+                   void* secrets_d, void* stream);
+
+/* ---- vector helpers ------------------------------------------------------------------------------ */
+int zk_bitrev(zk_ctx* ctx, void* x_d, int log2_len, void* stream);  /* dfft/mod.rs:322-335 fft_in_place_rearrange */
+int zk_vec_add(zk_ctx* ctx, void* x_d, const void* y_d, size_t len, void* stream);              /* x += y      */
+int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, const void* c_d, size_t len,
+                   void* stream);                                   /* out = a*b - c, groth16/src/ext_wit.rs:173-177 */
+
+/* ---- d_fft / d_ifft (dist-primitives/src/dfft/mod.rs) --------------------------------------------
+ * zk_fft1: fft1_in_place (:178-208) on `batch` share vectors of length m/l each, in place; `inverse`
+ *          selects gen = group_gen_inv.  If add_d != NULL it is added element-wise afterwards (the
+ *          `share + in_mask` of :254-258 fused into the last pass).
+ * zk_fft2_king: the king closure of fft2_with_rearrange (:264-304): unpack_missing_shares per chunk ->
+ *          fft2_in_place (:210-237) -> distribute_powers(g) (:278-280) -> (bit-reverse + stride) pack.
+ *          in_d is [nparties][m/l], out_d is [n][m/l].  g (Montgomery Fr, host pointer) may be NULL for 1.
+ *          scale_size_inv != 0 additionally multiplies by 1/m (d_ifft's :159 folded in).
+ * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l] in place,
+ *          masks [n][m/l] each or NULL for FftMask::zero. */
+int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream);
+int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int nparties, int log2_m, int inverse,
+                 const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out_d,
+                 const void* out_mask_d, void* stream);
+int zk_d_fft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange,
+             int log2_m, uint64_t seed, void* stream);
+int zk_d_ifft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange,
+              int log2_m, const void* g, uint64_t seed, void* stream);
+/* FftMask::sample (:30-85): in_mask_d/out_mask_d are [n][m/l]. */
+int zk_fft_mask_sample(zk_ctx* ctx, int rearrange, const void* g, int inverse, int log2_m, uint64_t seed,
+                       void* in_mask_d, void* out_mask_d, void* stream);
+
+/* ---- deg_red / d_pp over Fr (dist-primitives/src/utils/deg_red.rs:80-126, dpp/mod.rs:15-87) ------
+ * x_d [n][len] in place; masks [n][len] or NULL. */
+int zk_deg_red(zk_ctx* ctx, void* x_d, const void* in_mask_d, const void* out_mask_d, size_t len, uint64_t seed,
+               void* stream);
+int zk_degred_mask_sample(zk_ctx* ctx, size_t len, uint64_t seed, void* in_mask_d, void* out_mask_d,
+                          void* stream);                              /* deg_red.rs:40-66 with gen = 1 */
+/* num_d, den_d [n][len]; out_d [n][len].  Returns ZK_ERR_GENERIC if a reconstructed denominator is zero
+ * (the reference panics on inverse().unwrap(), dpp/mod.rs:55). */
+int zk_d_pp(zk_ctx* ctx, const void* num_d, const void* den_d, const void* in_mask_d, const void* out_mask_d,
+            size_t len, uint64_t seed, void* out_d, void* stream);
+
+/* ---- MSM / d_msm (dist-primitives/src/dmsm/mod.rs) ---------------------------------------------------
+ * zk_msm: G::msm(bases, scalars) (:73, ark-ec VariableBaseMSM): bases affine, scalars Montgomery Fr;
+ *         out (HOST pointer) receives one Jacobian point.  `len_bases != len_scalars` -> ZK_ERR_GENERIC
+ *         carrying min(len) like arkworks' Err(usize).
+ * zk_d_msm: :59-102 for all n parties on this device: bases_d [n][len], scalars_d [n][len];
+ *         in_mask/out_mask: n Jacobian points each (host) or NULL for MsmMask::zero; out: n Jacobian points. */
+int zk_msm(zk_ctx* ctx, int group, const void* bases_d, size_t len_bases, const void* scalars_d,
+           size_t len_scalars, void* out, void* stream);
+int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, const void* in_mask,
+             const void* out_mask, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKSAAS_H */

@@ -1,0 +1,169 @@
+"""GPU parity for MSM / d_msm (dist-primitives/src/dmsm) and deg_red / d_pp, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import zksaas_amd as zk
+from zksaas_amd.api import ZK_G1, ZK_G2, msm
+from oracle import dist as od
+from oracle.curve import g1, g2, GroupOps
+from oracle.params import CURVES
+from oracle.prng import rand_fp, rand_vec
+
+from gpu_util import ctx, opp, up, up_parties, down_parties, enc_affine, dec_jacobian, enc_jacobian
+
+
+def _points(G, curve, count, seed):
+    gen = G.from_affine(G.gen)
+    return G.batch_to_affine([G.mul(gen, rand_fp(seed, i, curve.r)) for i in range(count)])
+
+
+@pytest.mark.parametrize("curve,count", [("bn254", 1), ("bn254", 7), ("bn254", 300), ("bls12_377", 65),
+                                          ("bls12_381", 40)])
+def test_msm_g1_matches_oracle(curve, count):
+    c = CURVES[curve]
+    pp = ctx(curve, 2)
+    G = g1(c)
+    pts = _points(G, c, count, 60)
+    sc = rand_vec(61, count, c.r)
+    got = msm(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts)), up(pp, sc), count)
+    assert G.eq(dec_jacobian(pp, got), G.msm(pts, sc))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_msm_g2_matches_oracle(curve):
+    c = CURVES[curve]
+    pp = ctx(curve, 2)
+    G = g2(c)
+    pts = _points(G, c, 33, 62)
+    sc = rand_vec(63, 33, c.r)
+    got = msm(pp, ZK_G2, zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts, True)), up(pp, sc), 33)
+    assert G.eq(dec_jacobian(pp, got, True), G.msm(pts, sc))
+
+
+def test_msm_edge_cases():
+    """all-ones scalars (dmsm/mod.rs:147, one bucket), zeros, r-1, identity bases, repeated and opposite points."""
+    c = CURVES["bn254"]
+    pp = ctx("bn254", 2)
+    G = g1(c)
+    pts = _points(G, c, 200, 64)
+    bases = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts))
+    for sc in ([1] * 200, [0] * 200, [c.r - 1] * 200, [1 << 253 if i % 2 else 3 for i in range(200)]):
+        got = msm(pp, ZK_G1, bases, up(pp, sc), 200)
+        assert G.eq(dec_jacobian(pp, got), G.msm(pts, sc))
+    P = pts[0]
+    negP = (P[0], (-P[1]) % c.q)
+    special = [P, P, negP, None, P, None, negP, negP]
+    sc = [5, 5, 5, 9, 1, 0, 6, 2]          # 5P + 5P - 5P + P - 6P - 2P = -2P
+    got = msm(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, special)), up(pp, sc), 8)
+    want = G.neg(G.double(G.from_affine(P)))
+    assert G.eq(dec_jacobian(pp, got), want)
+    # empty msm is the identity
+    got = msm(pp, ZK_G1, pp.alloc_fr(0), pp.alloc_fr(0), 0)
+    assert G.is_identity(dec_jacobian(pp, got))
+
+
+def test_msm_length_mismatch_is_generic_error():  # dmsm/mod.rs:73 `G::msm(..)?` -> MpcNetError::Generic
+    pp = ctx("bn254", 2)
+    with pytest.raises(zk.ZkError) as e:
+        msm(pp, ZK_G1, pp.alloc_fr(4), pp.alloc_fr(1), 2, len_scalars=1)
+    assert e.value.code == 1 and e.value.msg == "1"
+
+
+def test_msm_window_sizes(monkeypatch):
+    """Exercise several window widths, including multi-workgroup bucket reduction (c = 14 -> 8192 buckets)."""
+    c = CURVES["bn254"]
+    pp = ctx("bn254", 2)
+    G = g1(c)
+    pts = _points(G, c, 50, 65)
+    sc = rand_vec(66, 50, c.r)
+    want = G.msm(pts, sc)
+    bases = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts))
+    for cc in ("2", "5", "9", "13", "14"):
+        monkeypatch.setenv("ZK_MSM_C", cc)
+        assert G.eq(dec_jacobian(pp, msm(pp, ZK_G1, bases, up(pp, sc), 50)), want)
+
+
+@pytest.mark.parametrize("group", [ZK_G1, ZK_G2])
+@pytest.mark.parametrize("masked", [False, True])
+def test_d_msm_matches_oracle(group, masked):  # dmsm_test.rs:13-93
+    curve = "bn254"
+    c = CURVES[curve]
+    m, l = 16, 2
+    pp, o = ctx(curve, l), opp(curve, l)
+    is2 = group == ZK_G2
+    G = g2(c) if is2 else g1(c)
+    ops = GroupOps(G)
+    gen = G.from_affine(G.gen)
+    y_pub = rand_vec(70, m, c.r)
+    x_pub = [G.mul(gen, rand_fp(71, i, c.r)) for i in range(m)]
+    want = G.msm(G.batch_to_affine(x_pub), y_pub)
+    x_sh = od.transpose([o.det_pack(x_pub[j:j + l], ops) for j in range(0, m, l)])
+    y_sh = od.transpose(od.pack_vec(y_pub, o, 72))
+    bases = zk.DeviceBuffer.from_numpy(pp, np.concatenate([enc_affine(pp, G.batch_to_affine(v), is2) for v in x_sh]))
+    scal = up_parties(pp, y_sh)
+    mask = zk.MsmMask.zero()
+    omasks = [od.MsmMask.zero(G)] * pp.n
+    if masked:
+        omasks = od.MsmMask.sample(o, G, ops, 73)
+        mask = zk.MsmMask(np.stack([enc_jacobian(pp, mk.in_mask, is2) for mk in omasks]),
+                          np.stack([enc_jacobian(pp, mk.out_mask, is2) for mk in omasks]))
+    out = zk.d_msm(pp, group, bases, scal, m // l, mask)
+    got = [dec_jacobian(pp, out[i], is2) for i in range(pp.n)]
+    ref = od.d_msm([G.batch_to_affine(v) for v in x_sh], y_sh, omasks, o, G, ops)
+    assert all(G.eq(a, b) for a, b in zip(got, ref))
+    assert G.eq(o.unpack2(got, ops)[0], want)        # dmsm_test.rs:50-51
+
+
+@pytest.mark.parametrize("l", [2, 4])
+def test_deg_red_matches_oracle(l):  # deg_red.rs:142-191
+    curve = "bls12_377"
+    pp, o = ctx(curve, l), opp(curve, l)
+    nch = 21
+    secrets = rand_vec(80, nch * l, o.p)
+    shares = od.transpose(od.pack_vec(secrets, o, 81))
+    mul = [[x * x % o.p for x in v] for v in shares]
+    masks = od.DegRedMask.sample(o, 1, nch, 82)
+    want = od.deg_red(mul, masks, o, seed=83)
+    buf = up_parties(pp, mul)
+    zk.deg_red(pp, buf, zk.DegRedMask(up_parties(pp, [m.in_mask for m in masks]),
+                                      up_parties(pp, [m.out_mask for m in masks])), nch, seed=83)
+    assert down_parties(pp, buf, pp.n, nch) == want
+    assert pp.download_fr(pp.unpack(buf, nch)) == [x * x % o.p for x in secrets]
+    # device-side mask sampling equals the oracle's
+    dm = zk.DegRedMask.sample(pp, nch, 82)
+    assert down_parties(pp, dm.in_mask, pp.n, nch) == [m.in_mask for m in masks]
+    assert down_parties(pp, dm.out_mask, pp.n, nch) == [m.out_mask for m in masks]
+
+
+@pytest.mark.parametrize("m", [32, 4096 + 64])
+def test_d_pp_matches_oracle(m):  # dpp_test.rs:16-91 and a multi-block scan
+    curve, l = "bls12_377", 2
+    pp, o = ctx(curve, l), opp(curve, l)
+    m -= m % l
+    num, den = rand_vec(90, m, o.p), rand_vec(91, m, o.p)
+    ns, ds = od.transpose(od.pack_vec(num, o, 92)), od.transpose(od.pack_vec(den, o, 93))
+    masks = od.DegRedMask.sample(o, 1, m // l, 94)
+    want = od.d_pp(ns, ds, masks, o, seed=95)
+    out = zk.d_pp(pp, up_parties(pp, ns), up_parties(pp, ds),
+                  zk.DegRedMask(up_parties(pp, [k.in_mask for k in masks]), up_parties(pp, [k.out_mask for k in masks])),
+                  m // l, seed=95)
+    assert down_parties(pp, out, pp.n, m // l) == want
+    # x = 1..m with num = den reconstructs to all ones (dpp_test.rs:51,62-65)
+    x = list(range(1, m + 1))
+    xs = up_parties(pp, od.transpose(od.pack_vec(x, o, 96)))
+    out = zk.d_pp(pp, xs, xs, zk.DegRedMask.zero(), m // l, seed=97)
+    assert pp.download_fr(pp.unpack(out, m // l)) == [1] * m
+
+
+def test_d_pp_zero_denominator_is_error():  # dpp/mod.rs:55 inverse().unwrap()
+    curve, l, m = "bls12_377", 2, 8
+    pp, o = ctx(curve, l), opp(curve, l)
+    num = rand_vec(98, m, o.p)
+    den = list(num)
+    den[5] = 0
+    with pytest.raises(zk.ZkError) as e:
+        zk.d_pp(pp, up_parties(pp, od.transpose(od.pack_vec(num, o, 1))),
+                up_parties(pp, od.transpose(od.pack_vec(den, o, 2))), zk.DegRedMask.zero(), m // l)
+    assert e.value.code == 1

@@ -1,0 +1,78 @@
+"""GPU parity (through the C ABI) for the PSS layer: secret-sharing/src/pss.rs, utils/pack.rs, dfft bitrev."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.dist import pack_vec, stride_pack, transpose
+from oracle.field import bitrev_permute
+from oracle.prng import rand_vec
+
+from gpu_util import ctx, opp, up, up_parties, down_parties
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_377", "bls12_381"])
+@pytest.mark.parametrize("l", [2, 4])
+@pytest.mark.parametrize("order", [0, 1])
+def test_pack_matches_oracle_bit_for_bit(curve, l, order):
+    pp, o = ctx(curve, l), opp(curve, l)
+    nch = 37
+    secrets = rand_vec(11, nch * l, o.p)
+    got = down_parties(pp, pp.pack(up(pp, secrets), nch, seed=77, order=order), pp.n, nch)
+    want = transpose(pack_vec(secrets, o, 77) if order == 0 else stride_pack(secrets, o, 77))
+    assert got == want
+
+
+@pytest.mark.parametrize("l", [1, 2, 4, 8])
+def test_det_pack_unpack_roundtrip(l):
+    pp, o = ctx("bls12_377", l), opp("bls12_377", l)
+    nch = 19
+    secrets = rand_vec(12, nch * l, o.p)
+    sh = pp.det_pack(up(pp, secrets), nch)
+    got = down_parties(pp, sh, pp.n, nch)
+    want = transpose([o.det_pack(secrets[j * l:(j + 1) * l]) for j in range(nch)])
+    assert got == want
+    assert pp.download_fr(pp.unpack(sh, nch)) == secrets
+    assert pp.download_fr(pp.unpack2(sh, nch)) == secrets
+
+
+@pytest.mark.parametrize("l", [2, 4])
+def test_unpack2_of_products_and_dropout(l):  # pss.rs:288-310
+    pp, o = ctx("bls12_377", l), opp("bls12_377", l)
+    nch = 9
+    secrets = rand_vec(13, nch * l, o.p)
+    shares = transpose(pack_vec(secrets, o, 5))
+    mul = [[x * x % o.p for x in v] for v in shares]
+    expected = [x * x % o.p for x in secrets]
+    assert pp.download_fr(pp.unpack2(up_parties(pp, mul), nch)) == expected
+    for drop in (0, 3, pp.n - 1):
+        parties = [i for i in range(pp.n) if i != drop]
+        buf = up_parties(pp, [mul[i] for i in parties])
+        assert pp.download_fr(pp.lagrange_unpack(buf, nch, parties)) == expected
+    # `unpack` truncates to l+t coefficients (pss.rs:131-135): compare with the oracle on degree-2(l+t-1) shares
+    want = [v for j in range(nch) for v in o.unpack([mul[i][j] for i in range(pp.n)])]
+    assert pp.download_fr(pp.unpack(up_parties(pp, mul), nch)) == want
+
+
+def test_not_enough_shares_is_protocol_error():
+    import zksaas_amd as zk
+    pp = ctx("bls12_377", 2)
+    buf = pp.alloc_fr(6 * 4)
+    with pytest.raises(zk.ZkError) as e:
+        pp.lagrange_unpack(buf, 4, [0, 1, 2, 3, 4, 5])     # needs > 2(t+l-1) = 6 shares
+    assert e.value.code == 2
+
+
+def test_empty_inputs():
+    pp = ctx("bn254", 2)
+    assert pp.download_fr(pp.pack(pp.alloc_fr(0), 0, seed=1)) == []
+
+
+@pytest.mark.parametrize("logn", [0, 1, 5, 12])
+def test_bitrev(logn):
+    pp = ctx("bn254", 2)
+    x = list(range(1, (1 << logn) + 1))
+    buf = up(pp, x)
+    pp._check(pp.lib.zk_bitrev(pp.h, buf.ptr, logn, None))
+    want = list(x)
+    bitrev_permute(want)
+    assert pp.download_fr(buf) == want

@@ -1,0 +1,73 @@
+"""ctypes binding of libzksaas_hip.so (include/zksaas.h).  No CPU fallback: if the library is missing the
+import of anything that computes fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzksaas_hip.so")
+
+# every symbol include/zksaas.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "zk_version", "zk_ctx_create", "zk_ctx_destroy", "zk_last_error", "zk_ctx_n", "zk_ctx_l", "zk_fr_bytes",
+    "zk_fq_bytes", "zk_malloc", "zk_free", "zk_memcpy_h2d", "zk_memcpy_d2h", "zk_stream_sync", "zk_pss_pack",
+    "zk_pss_det_pack", "zk_pss_unpack", "zk_pss_unpack2", "zk_bitrev", "zk_vec_add", "zk_vec_mul_sub", "zk_fft1",
+    "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
+    "zk_msm", "zk_d_msm",
+]
+
+_lib = None
+
+
+class ZkError(RuntimeError):
+    """MpcNetError mirror (mpc-net/src/lib.rs:19-24): code 1 Generic, 2 Protocol, 3 NotConnected, 4 BadInput."""
+
+    def __init__(self, code, msg, party=-1):
+        super().__init__("zk status %d: %s%s" % (code, msg, (" (party %d)" % party) if party >= 0 else ""))
+        self.code, self.msg, self.party = code, msg, party
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libzksaas_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                          "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
+    lib.zk_version.restype = C.c_char_p
+    lib.zk_ctx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    lib.zk_ctx_destroy.argtypes = [vp]
+    lib.zk_ctx_destroy.restype = None
+    lib.zk_last_error.argtypes = [vp, C.POINTER(i32)]
+    lib.zk_last_error.restype = C.c_char_p
+    lib.zk_ctx_n.argtypes = [vp]
+    lib.zk_ctx_l.argtypes = [vp]
+    lib.zk_fr_bytes.argtypes = [vp]
+    lib.zk_fr_bytes.restype = sz
+    lib.zk_fq_bytes.argtypes = [vp]
+    lib.zk_fq_bytes.restype = sz
+    lib.zk_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.zk_free.argtypes = [vp, vp]
+    lib.zk_memcpy_h2d.argtypes = [vp, vp, vp, sz, vp]
+    lib.zk_memcpy_d2h.argtypes = [vp, vp, vp, sz, vp]
+    lib.zk_stream_sync.argtypes = [vp, vp]
+    lib.zk_pss_pack.argtypes = [vp, vp, sz, i32, u64, vp, vp]
+    lib.zk_pss_det_pack.argtypes = [vp, vp, sz, i32, vp, vp]
+    lib.zk_pss_unpack.argtypes = [vp, vp, sz, vp, vp]
+    lib.zk_pss_unpack2.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, sz, vp, vp]
+    lib.zk_bitrev.argtypes = [vp, vp, i32, vp]
+    lib.zk_vec_add.argtypes = [vp, vp, vp, sz, vp]
+    lib.zk_vec_mul_sub.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.zk_fft1.argtypes = [vp, vp, i32, i32, sz, vp, vp]
+    lib.zk_fft2_king.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, i32, i32, vp, i32, i32, u64, vp, vp, vp]
+    lib.zk_d_fft.argtypes = [vp, vp, vp, vp, i32, i32, u64, vp]
+    lib.zk_d_ifft.argtypes = [vp, vp, vp, vp, i32, i32, vp, u64, vp]
+    lib.zk_fft_mask_sample.argtypes = [vp, i32, vp, i32, i32, u64, vp, vp, vp]
+    lib.zk_deg_red.argtypes = [vp, vp, vp, vp, sz, u64, vp]
+    lib.zk_degred_mask_sample.argtypes = [vp, sz, u64, vp, vp, vp]
+    lib.zk_d_pp.argtypes = [vp, vp, vp, vp, vp, sz, u64, vp, vp]
+    lib.zk_msm.argtypes = [vp, i32, vp, sz, vp, sz, vp, vp]
+    lib.zk_d_msm.argtypes = [vp, i32, vp, vp, sz, vp, vp, vp, vp]
+    _lib = lib
+    return lib

@@ -1,0 +1,192 @@
+// C ABI (include/zksaas.h) -> IEngine dispatch.  No compute lives here.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/zksaas.h"
+#include "engine.hpp"
+
+struct zk_ctx {
+  zk::IEngine* eng;
+};
+
+using zk::IEngine;
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+extern "C" {
+
+const char* zk_version(void) { return "zksaas-hip 0.1 (gfx950)"; }
+
+int zk_ctx_create(int curve, int l, int device, zk_ctx** out) {
+  if (!out) return ZK_ERR_BAD_INPUT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZK_ERR_NOT_CONNECTED;   // no GPU: fail loudly
+  if (device < 0 || device >= ndev) return ZK_ERR_BAD_INPUT;
+  IEngine* e = nullptr;
+  switch (curve) {
+    case ZK_BN254: e = zk::make_engine_bn254(l, device); break;
+    case ZK_BLS12_381: e = zk::make_engine_bls381(l, device); break;
+    case ZK_BLS12_377: e = zk::make_engine_bls377(l, device); break;
+    default: return ZK_ERR_BAD_INPUT;
+  }
+  if (!e) return ZK_ERR_GENERIC;
+  zk_ctx* c = new (std::nothrow) zk_ctx{e};
+  if (!c) {
+    delete e;
+    return ZK_ERR_GENERIC;
+  }
+  *out = c;
+  return e->last.code;
+}
+
+void zk_ctx_destroy(zk_ctx* ctx) {
+  if (!ctx) return;
+  delete ctx->eng;
+  delete ctx;
+}
+
+const char* zk_last_error(zk_ctx* ctx, int* party) {
+  if (!ctx) return "null context";
+  if (party) *party = ctx->eng->last.party;
+  return ctx->eng->last.msg.c_str();
+}
+int zk_ctx_n(const zk_ctx* ctx) { return ctx ? ctx->eng->n : 0; }
+int zk_ctx_l(const zk_ctx* ctx) { return ctx ? ctx->eng->l : 0; }
+size_t zk_fr_bytes(const zk_ctx* ctx) { return ctx ? ctx->eng->fr_bytes() : 0; }
+size_t zk_fq_bytes(const zk_ctx* ctx) { return ctx ? ctx->eng->fq_bytes() : 0; }
+
+#define CTX_OR_FAIL() \
+  if (!ctx) return ZK_ERR_BAD_INPUT; \
+  IEngine* e = ctx->eng; \
+  (void)hipSetDevice(e->device)
+
+int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
+  CTX_OR_FAIL();
+  if (!out_d) return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  hipError_t h = hipMalloc(out_d, bytes ? bytes : 1);
+  return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipMalloc");
+}
+int zk_free(zk_ctx* ctx, void* p_d) {
+  CTX_OR_FAIL();
+  hipError_t h = hipFree(p_d);
+  return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipFree");
+}
+int zk_memcpy_h2d(zk_ctx* ctx, void* dst_d, const void* src, size_t bytes, void* stream) {
+  CTX_OR_FAIL();
+  hipError_t h = hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, S(stream));
+  if (h == hipSuccess) h = hipStreamSynchronize(S(stream));
+  return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipMemcpy h2d");
+}
+int zk_memcpy_d2h(zk_ctx* ctx, void* dst, const void* src_d, size_t bytes, void* stream) {
+  CTX_OR_FAIL();
+  hipError_t h = hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, S(stream));
+  if (h == hipSuccess) h = hipStreamSynchronize(S(stream));
+  return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipMemcpy d2h");
+}
+int zk_stream_sync(zk_ctx* ctx, void* stream) {
+  CTX_OR_FAIL();
+  hipError_t h = hipStreamSynchronize(S(stream));
+  return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipStreamSynchronize");
+}
+
+int zk_pss_pack(zk_ctx* ctx, const void* secrets_d, size_t nchunks, int order, uint64_t seed, void* shares_d,
+                void* stream) {
+  CTX_OR_FAIL();
+  return e->pss_pack(secrets_d, nchunks, order, seed, false, shares_d, S(stream));
+}
+int zk_pss_det_pack(zk_ctx* ctx, const void* secrets_d, size_t nchunks, int order, void* shares_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->pss_pack(secrets_d, nchunks, order, 0, true, shares_d, S(stream));
+}
+int zk_pss_unpack(zk_ctx* ctx, const void* shares_d, size_t nchunks, void* secrets_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->pss_unpack(shares_d, nullptr, e->n, nchunks, false, secrets_d, S(stream));
+}
+int zk_pss_unpack2(zk_ctx* ctx, const void* shares_d, const uint32_t* parties, int nparties, size_t nchunks,
+                   void* secrets_d, void* stream) {
+  CTX_OR_FAIL();
+  if (!parties && nparties != e->n) return e->fail(ZK_ERR_BAD_INPUT, "parties list required when some are missing");
+  return e->pss_unpack(shares_d, parties, nparties, nchunks, true, secrets_d, S(stream));
+}
+
+int zk_bitrev(zk_ctx* ctx, void* x_d, int log2_len, void* stream) {
+  CTX_OR_FAIL();
+  return e->bitrev(x_d, log2_len, S(stream));
+}
+int zk_vec_add(zk_ctx* ctx, void* x_d, const void* y_d, size_t len, void* stream) {
+  CTX_OR_FAIL();
+  return e->vec_add(x_d, y_d, len, S(stream));
+}
+int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, const void* c_d, size_t len,
+                   void* stream) {
+  CTX_OR_FAIL();
+  return e->vec_mul_sub(out_d, a_d, b_d, c_d, len, S(stream));
+}
+
+int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->fft1(shares_d, log2_m, inverse, batch, add_d, S(stream));
+}
+int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int nparties, int log2_m, int inverse,
+                 const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out_d,
+                 const void* out_mask_d, void* stream) {
+  CTX_OR_FAIL();
+  if (!parties && nparties != e->n) return e->fail(ZK_ERR_BAD_INPUT, "parties list required when some are missing");
+  return e->fft2_king(in_d, nullptr, parties, nparties, log2_m, inverse, g, scale_size_inv, rearrange, seed, out_d,
+                      out_mask_d, S(stream));
+}
+// d_fft (dfft/mod.rs:99-134): fft1 on every party's vector, then the king closure with the mask adds fused.
+int zk_d_fft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange, int log2_m,
+             uint64_t seed, void* stream) {
+  CTX_OR_FAIL();
+  int rc = e->fft1(shares_d, log2_m, 0, (size_t)e->n, nullptr, S(stream));
+  if (rc) return rc;
+  return e->fft2_king(shares_d, in_mask_d, nullptr, e->n, log2_m, 0, nullptr, 0, rearrange, seed, shares_d,
+                      out_mask_d, S(stream));
+}
+// d_ifft (dfft/mod.rs:137-175): the 1/m scaling of :159 is applied by the king together with g^i.
+int zk_d_ifft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange, int log2_m,
+              const void* g, uint64_t seed, void* stream) {
+  CTX_OR_FAIL();
+  int rc = e->fft1(shares_d, log2_m, 1, (size_t)e->n, nullptr, S(stream));
+  if (rc) return rc;
+  return e->fft2_king(shares_d, in_mask_d, nullptr, e->n, log2_m, 1, g, 1, rearrange, seed, shares_d, out_mask_d,
+                      S(stream));
+}
+int zk_fft_mask_sample(zk_ctx* ctx, int rearrange, const void* g, int inverse, int log2_m, uint64_t seed,
+                       void* in_mask_d, void* out_mask_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->fft_mask_sample(rearrange, g, inverse, log2_m, seed, in_mask_d, out_mask_d, S(stream));
+}
+
+int zk_deg_red(zk_ctx* ctx, void* x_d, const void* in_mask_d, const void* out_mask_d, size_t len, uint64_t seed,
+               void* stream) {
+  CTX_OR_FAIL();
+  return e->deg_red(x_d, in_mask_d, out_mask_d, len, seed, S(stream));
+}
+int zk_degred_mask_sample(zk_ctx* ctx, size_t len, uint64_t seed, void* in_mask_d, void* out_mask_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->degred_mask_sample(len, seed, in_mask_d, out_mask_d, S(stream));
+}
+int zk_d_pp(zk_ctx* ctx, const void* num_d, const void* den_d, const void* in_mask_d, const void* out_mask_d,
+            size_t len, uint64_t seed, void* out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->d_pp(num_d, den_d, in_mask_d, out_mask_d, len, seed, out_d, S(stream));
+}
+
+int zk_msm(zk_ctx* ctx, int group, const void* bases_d, size_t len_bases, const void* scalars_d, size_t len_scalars,
+           void* out, void* stream) {
+  CTX_OR_FAIL();
+  return e->msm(group, bases_d, len_bases, scalars_d, len_scalars, out, S(stream));
+}
+int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, const void* in_mask,
+             const void* out_mask, void* out, void* stream) {
+  CTX_OR_FAIL();
+  return e->d_msm(group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Host side of the library: context, cached tables, PSS matrices, kernel launches.
+// One Engine<Cfg> instantiation per curve (compiled in its own translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/zksaas.h"
+#include "field.hpp"
+#include "ntt.hpp"
+#include "pss.hpp"
+
+namespace zk {
+
+struct Status {
+  int code = ZK_OK;
+  int party = -1;
+  std::string msg;
+};
+
+// Abstract interface the C ABI dispatches to (one implementation per curve).
+class IEngine {
+ public:
+  virtual ~IEngine() {}
+  int l = 0, n = 0, t = 0, device = 0;
+  Status last;
+  int fail(int code, const std::string& m, int party = -1) {
+    last.code = code;
+    last.msg = m;
+    last.party = party;
+    return code;
+  }
+  int hip_fail(hipError_t e, const char* where) {
+    return fail(ZK_ERR_GENERIC, std::string(where) + ": " + hipGetErrorString(e));
+  }
+  virtual size_t fr_bytes() const = 0;
+  virtual size_t fq_bytes() const = 0;
+  virtual int pss_pack(const void* secrets, size_t nchunks, int order, uint64_t seed, bool det, void* shares,
+                       hipStream_t st) = 0;
+  virtual int pss_unpack(const void* shares, const uint32_t* parties, int np, size_t nchunks, bool two, void* secrets,
+                         hipStream_t st) = 0;
+  virtual int bitrev(void* x, int log_len, hipStream_t st) = 0;
+  virtual int vec_add(void* x, const void* y, size_t len, hipStream_t st) = 0;
+  virtual int vec_mul_sub(void* out, const void* a, const void* b, const void* c, size_t len, hipStream_t st) = 0;
+  virtual int fft1(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st) = 0;
+  virtual int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
+                        const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out,
+                        const void* out_mask, hipStream_t st) = 0;
+  virtual int fft_mask_sample(int rearrange, const void* g, int inverse, int log_m, uint64_t seed, void* in_mask,
+                              void* out_mask, hipStream_t st) = 0;
+  virtual int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
+                      hipStream_t st) = 0;
+  virtual int degred_mask_sample(size_t len, uint64_t seed, void* in_mask, void* out_mask, hipStream_t st) = 0;
+  virtual int d_pp(const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len,
+                   uint64_t seed, void* out, hipStream_t st) = 0;
+  virtual int msm(int group, const void* bases, size_t nb, const void* scalars, size_t ns, void* out,
+                  hipStream_t st) = 0;
+  virtual int d_msm(int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                    const void* out_mask, void* out, hipStream_t st) = 0;
+};
+
+IEngine* make_engine_bn254(int l, int device);
+IEngine* make_engine_bls381(int l, int device);
+IEngine* make_engine_bls377(int l, int device);
+
+#define ZK_HIP(expr)                                  \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return hip_fail(_e, #expr); \
+  } while (0)
+
+inline int ilog2(size_t x) {
+  int r = 0;
+  while (((size_t)1 << r) < x) r++;
+  return r;
+}
+
+// Simple device buffer owner.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t ensure(size_t b) {
+    if (b <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, b);
+    if (e == hipSuccess) bytes = b;
+    return e;
+  }
+};
+
+}  // namespace zk

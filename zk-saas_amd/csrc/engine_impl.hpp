@@ -1,0 +1,543 @@
+// Engine<Cfg>: per-curve implementation of IEngine (included by exactly one .hip file per curve).
+#pragma once
+#include <cstring>
+#include <memory>
+
+#include "engine.hpp"
+#include "msm.hpp"
+
+namespace zk {
+
+template <class F>
+__global__ void rand_fill_kernel(F* __restrict__ out, uint64_t seed, size_t count, uint32_t L, uint32_t transpose_lc_log) {
+  // out[i] = rand(seed, i); with transpose: value index v = k*L + s is stored at [s][k] (k < 2^log)
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  using P = typename F::Params;
+  F v = rand_fp<P>(seed, i);
+  size_t o = i;
+  if (transpose_lc_log != 0xffffffffu) {
+    size_t k = i / L, s = i % L;
+    o = (s << transpose_lc_log) + k;
+  }
+  store_elem(out + o, v);
+}
+
+template <class F>
+__global__ void vec_neg_kernel(F* __restrict__ out, const F* __restrict__ in, size_t len) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) store_elem(out + i, load_elem(in + i).neg());
+}
+
+template <class Cfg>
+class Engine : public IEngine {
+ public:
+  using FrP = typename Cfg::FrP;
+  using Fr = Fp<FrP>;
+  static constexpr int MAXL = 8;
+
+  Engine(int l_, int device_) {
+    l = l_;
+    t = l_;
+    n = 4 * l_;
+    device = device_;
+  }
+  ~Engine() override {
+    for (auto& kv : gentabs_) (void)hipFree(kv.second);
+    for (auto& kv : gtabs_) {
+      (void)hipFree(kv.second.tab);
+      (void)hipFree(kv.second.step);
+    }
+    for (auto& kv : umats_) (void)hipFree(kv.second);
+    if (pmat_) (void)hipFree(pmat_);
+    if (ident_) (void)hipFree(ident_);
+    if (err_flag_) (void)hipFree(err_flag_);
+  }
+
+  size_t fr_bytes() const override { return sizeof(Fr); }
+  size_t fq_bytes() const override { return sizeof(Fp<typename Cfg::FqP>); }
+
+  int init() {
+    ZK_HIP(hipSetDevice(device));
+    if (l != 1 && l != 2 && l != 4 && l != 8) return fail(ZK_ERR_BAD_INPUT, "packing factor l must be 1, 2, 4 or 8");
+    if (ilog2(n) > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large");
+    build_matrices();
+    ZK_HIP(hipMalloc(&err_flag_, sizeof(int)));
+    return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- field helpers (host)
+  static Fr root_of_unity(int log_size) {
+    Fr r = Fr::from_limbs(FrP::TWO_ADIC_ROOT);
+    for (int i = log_size; i < FrP::TWO_ADICITY; i++) r = r.sqr();
+    return r;
+  }
+  static Fr generator() { return Fr::from_limbs(FrP::GENERATOR); }
+
+  // ---------------------------------------------------------------- PSS matrices
+  // Points: share x_p = w_n^p; secret y_j = g w_{l+t}^j; secret2 z_j = g w_{2(l+t)}^j
+  // (secret-sharing/src/pss.rs:44-52).
+  void points(std::vector<Fr>& x, std::vector<Fr>& y, std::vector<Fr>& z) const {
+    Fr wn = root_of_unity(ilog2(n)), ws = root_of_unity(ilog2(l + t)), w2 = root_of_unity(ilog2(2 * (l + t)));
+    Fr g = generator();
+    x.resize(n);
+    y.resize(l + t);
+    z.resize(2 * (l + t));
+    Fr c = Fr::one();
+    for (int i = 0; i < n; i++) x[i] = c, c = c * wn;
+    c = g;
+    for (int i = 0; i < l + t; i++) y[i] = c, c = c * ws;
+    c = g;
+    for (int i = 0; i < 2 * (l + t); i++) z[i] = c, c = c * w2;
+  }
+
+  int upload(const std::vector<Fr>& h, Fr** d) {
+    ZK_HIP(hipMalloc((void**)d, h.size() * sizeof(Fr)));
+    ZK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    return ZK_OK;
+  }
+
+  void build_matrices() {
+    std::vector<Fr> x, y, z;
+    points(x, y, z);
+    int k = l + t;
+    // pack: P[p][j] = prod_{i != j} (x_p - y_i) / (y_j - y_i)       (pss.rs:90-122)
+    std::vector<Fr> Pm((size_t)n * k);
+    for (int p = 0; p < n; p++)
+      for (int j = 0; j < k; j++) {
+        Fr num = Fr::one(), den = Fr::one();
+        for (int i = 0; i < k; i++)
+          if (i != j) {
+            num = num * (x[p] - y[i]);
+            den = den * (y[j] - y[i]);
+          }
+        Pm[(size_t)p * k + j] = num * den.inverse();
+      }
+    (void)upload(Pm, &pmat_);
+    // unpack (pss.rs:125-138): IFFT_n, truncate to l+t coefficients, evaluate at y_k:
+    //   U1[k][p] = 1/n sum_{d < l+t} (y_k / x_p)^d
+    // unpack2 (pss.rs:141-166): U2[k][p] = 1/n sum_{d < n} (z_{2k} / x_p)^d
+    Fr ninv = Fr::from_u64((uint64_t)n).inverse();
+    std::vector<Fr> U1((size_t)l * n), U2((size_t)l * n);
+    for (int kk = 0; kk < l; kk++)
+      for (int p = 0; p < n; p++) {
+        Fr xi = x[p].inverse();
+        Fr r1 = y[kk] * xi, r2 = z[2 * kk] * xi;
+        Fr a1 = Fr::zero(), a2 = Fr::zero(), c1 = Fr::one(), c2 = Fr::one();
+        for (int d = 0; d < n; d++) {
+          if (d < k) a1 = a1 + c1;
+          a2 = a2 + c2;
+          c1 = c1 * r1;
+          c2 = c2 * r2;
+        }
+        U1[(size_t)kk * n + p] = a1 * ninv;
+        U2[(size_t)kk * n + p] = a2 * ninv;
+      }
+    Fr* d = nullptr;
+    (void)upload(U1, &d);
+    umats_[key_u(0xffffffffu, 1)] = d;
+    (void)upload(U2, &d);
+    umats_[key_u(full_mask(), 2)] = d;
+    // d_msm: king output = sum_k unpack2(shares)[k] = sum_p (sum_k U2[k][p]) * share_p  (dmsm/mod.rs:85-86)
+    std::vector<Fr> coef(n, Fr::zero());
+    for (int p = 0; p < n; p++)
+      for (int kk = 0; kk < l; kk++) coef[p] = coef[p] + U2[(size_t)kk * n + p];
+    (void)msm_.set_coefs(this, coef);
+    std::vector<Fr> I((size_t)l * l, Fr::zero());
+    for (int i = 0; i < l; i++) I[(size_t)i * l + i] = Fr::one();
+    (void)upload(I, &ident_);
+  }
+
+  uint32_t full_mask() const { return n >= 32 ? 0xffffffffu : ((1u << n) - 1); }
+  static uint64_t key_u(uint32_t mask, int kind) { return ((uint64_t)kind << 32) | mask; }
+
+  // unpack_missing_shares (pss.rs:210-221): unpack2 when all n present, else lagrange_unpack (:170-205):
+  //   U_S[k][i] = prod_{j in S, j != i} (z_{2k} - x_j) / (x_i - x_j)
+  int umat_for(const uint32_t* parties, int np, const Fr** out) {
+    if (np <= 0 || np > n) return fail(ZK_ERR_BAD_INPUT, "bad party count");
+    uint32_t mask = 0;
+    for (int i = 0; i < np; i++) {
+      uint32_t p = parties ? parties[i] : (uint32_t)i;
+      if (p >= (uint32_t)n || (i > 0 && parties && parties[i] <= parties[i - 1]))
+        return fail(ZK_ERR_BAD_INPUT, "party ids must be ascending and < n");
+      mask |= 1u << p;
+    }
+    if (np < n && np <= 2 * (t + l - 1))
+      return fail(ZK_ERR_PROTOCOL, "Not enough shares to reconstruct", 0);   // pss.rs:183-186
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = umats_.find(key_u(mask, 2));
+    if (it != umats_.end()) {
+      *out = it->second;
+      return ZK_OK;
+    }
+    std::vector<Fr> x, y, z;
+    points(x, y, z);
+    std::vector<Fr> U((size_t)l * np);
+    for (int kk = 0; kk < l; kk++)
+      for (int i = 0; i < np; i++) {
+        Fr num = Fr::one(), den = Fr::one();
+        for (int j = 0; j < np; j++)
+          if (j != i) {
+            num = num * (z[2 * kk] - x[parties[j]]);
+            den = den * (x[parties[i]] - x[parties[j]]);
+          }
+        U[(size_t)kk * np + i] = num * den.inverse();
+      }
+    Fr* d = nullptr;
+    int rc = upload(U, &d);
+    if (rc) return rc;
+    umats_[key_u(mask, 2)] = d;
+    *out = d;
+    return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- cached tables
+  // gentab(log_m, inverse)[e] = gen^e, e in [0, m]; gen = w_m or w_m^-1.
+  int gentab(int log_m, int inverse, hipStream_t st, const Fr** out) {
+    if (log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large for this field");
+    std::lock_guard<std::mutex> g(mu_);
+    int key = log_m * 2 + (inverse ? 1 : 0);
+    auto it = gentabs_.find(key);
+    if (it != gentabs_.end()) {
+      *out = it->second;
+      return ZK_OK;
+    }
+    Fr w = root_of_unity(log_m);
+    if (inverse) w = w.inverse();
+    size_t count = ((size_t)1 << log_m) + 1;
+    Fr* d = nullptr;
+    ZK_HIP(hipMalloc((void**)&d, count * sizeof(Fr)));
+    powers_kernel<Fr><<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st>>>(d, w, count, Fr::one());
+    ZK_HIP(hipGetLastError());
+    gentabs_[key] = d;
+    *out = d;
+    return ZK_OK;
+  }
+
+  struct GTab {
+    Fr* tab;
+    Fr* step;
+  };
+  // gtab[e] = c * g^e for e in [0, Lc]; step[e] = g^(Lc*e), e < l.  c = 1/m when scale.
+  int gtab(int log_m, const Fr& g, bool scale, hipStream_t st, GTab* out) {
+    std::string key((const char*)g.v, sizeof(Fr));
+    key.push_back((char)log_m);
+    key.push_back(scale ? 1 : 0);
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = gtabs_.find(key);
+    if (it != gtabs_.end()) {
+      *out = it->second;
+      return ZK_OK;
+    }
+    size_t Lc = ((size_t)1 << log_m) / l;
+    Fr c = Fr::one();
+    if (scale) c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+    GTab gt{};
+    ZK_HIP(hipMalloc((void**)&gt.tab, (Lc + 1) * sizeof(Fr)));
+    powers_kernel<Fr><<<dim3((unsigned)((Lc + 1 + 255) / 256)), dim3(256), 0, st>>>(gt.tab, g, Lc + 1, c);
+    ZK_HIP(hipGetLastError());
+    std::vector<Fr> step(l);
+    Fr gl = g.pow_u64(Lc), cur = Fr::one();
+    for (int e = 0; e < l; e++) step[e] = cur, cur = cur * gl;
+    ZK_HIP(hipMalloc((void**)&gt.step, l * sizeof(Fr)));
+    ZK_HIP(hipMemcpyAsync(gt.step, step.data(), l * sizeof(Fr), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipStreamSynchronize(st));   // `step` is a stack vector
+    gtabs_[key] = gt;
+    *out = gt;
+    return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- PSS entry points
+  template <int L>
+  int pack_l(const Fr* sec, size_t nch, int order, uint64_t seed, bool det, Fr* shares, hipStream_t st) {
+    dim3 grid((unsigned)((nch + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
+    if (det)
+      pss_pack_kernel<FrP, L, true><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, shares);
+    else
+      pss_pack_kernel<FrP, L, false><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, shares);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int pss_pack(const void* secrets, size_t nchunks, int order, uint64_t seed, bool det, void* shares,
+               hipStream_t st) override {
+    if (nchunks == 0) return ZK_OK;
+    if (!secrets || !shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const Fr* s = (const Fr*)secrets;
+    Fr* o = (Fr*)shares;
+    switch (l) {
+      case 1: return pack_l<1>(s, nchunks, order, seed, det, o, st);
+      case 2: return pack_l<2>(s, nchunks, order, seed, det, o, st);
+      case 4: return pack_l<4>(s, nchunks, order, seed, det, o, st);
+      default: return pack_l<8>(s, nchunks, order, seed, det, o, st);
+    }
+  }
+
+  template <int L>
+  int unpack_l(const Fr* sh, int np, size_t nch, const Fr* U, Fr* sec, hipStream_t st) {
+    dim3 grid((unsigned)((nch + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
+    pss_unpack_kernel<FrP, L><<<grid, block, 0, st>>>(sh, np, nch, U, sec);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int pss_unpack(const void* shares, const uint32_t* parties, int np, size_t nchunks, bool two, void* secrets,
+                 hipStream_t st) override {
+    if (nchunks == 0) return ZK_OK;
+    if (!secrets || !shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const Fr* U = nullptr;
+    if (!two) {
+      if (np != n) return fail(ZK_ERR_BAD_INPUT, "unpack needs all n shares");
+      U = umats_[key_u(0xffffffffu, 1)];
+    } else {
+      int rc = umat_for(parties, np, &U);
+      if (rc) return rc;
+    }
+    const Fr* s = (const Fr*)shares;
+    Fr* o = (Fr*)secrets;
+    switch (l) {
+      case 1: return unpack_l<1>(s, np, nchunks, U, o, st);
+      case 2: return unpack_l<2>(s, np, nchunks, U, o, st);
+      case 4: return unpack_l<4>(s, np, nchunks, U, o, st);
+      default: return unpack_l<8>(s, np, nchunks, U, o, st);
+    }
+  }
+
+  // ---------------------------------------------------------------- vector helpers
+  int bitrev(void* x, int log_len, hipStream_t st) override {
+    if (log_len < 0 || log_len > 40) return fail(ZK_ERR_BAD_INPUT, "bad length");
+    size_t len = (size_t)1 << log_len;
+    bitrev_kernel<Fr><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((Fr*)x, log_len);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int vec_add(void* x, const void* y, size_t len, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    vec_add_kernel<Fr><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((Fr*)x, (const Fr*)y, len);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int vec_mul_sub(void* out, const void* a, const void* b, const void* c, size_t len, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    vec_mul_sub_kernel<Fr><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((Fr*)out, (const Fr*)a,
+                                                                                     (const Fr*)b, (const Fr*)c, len);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- fft1 (dfft/mod.rs:178-208)
+  int fft1(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st) override {
+    int log_l = ilog2(l);
+    if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    int log_n = log_m - log_l;
+    if (batch == 0) return ZK_OK;
+    const Fr* tw = nullptr;
+    int rc = gentab(log_m, inverse, st, &tw);
+    if (rc) return rc;
+    Fr* data = (Fr*)shares;
+    size_t nvec = (size_t)1 << log_n;
+    if (log_n < NTT_TILE_BITS || force_simple_ntt) {
+      for (int s = 1; s <= log_n; s++) {
+        size_t work = (nvec / 2) * batch;
+        ntt_stage_simple_kernel<Fr><<<dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st>>>(data, log_n, s, tw,
+                                                                                                log_l, batch);
+        ZK_HIP(hipGetLastError());
+      }
+      if (add) return vec_add(shares, add, nvec * batch, st);
+      return ZK_OK;
+    }
+    NttPlan plan = make_ntt_plan(log_n);
+    for (int p = 0; p < plan.npass; p++) {
+      const NttPass& ps = plan.pass[p];
+      int rbits = ps.s1 - ps.s0;
+      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (NTT_TILE + ((size_t)1 << rbits) / 2 + 1);
+      static bool attr_set = false;
+      if (!attr_set) {
+        ZK_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((sizeof(Fr) / 16) * 16 * (NTT_TILE + NTT_TILE / 2 + 1))));
+        attr_set = true;
+      }
+      dim3 grid((unsigned)(nvec >> NTT_TILE_BITS), (unsigned)batch);
+      ntt_pass_kernel<Fr><<<grid, dim3(NTT_THREADS), lds, st>>>(data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l,
+                                                               p == plan.npass - 1 ? (const Fr*)add : nullptr);
+      ZK_HIP(hipGetLastError());
+    }
+    return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- king of d_fft (dfft/mod.rs:264-304)
+  template <int L>
+  int king_l(const Fr* in, const Fr* in_mask, int np, int log_lc, const Fr* U, const Fr* gen, const GTab* gt,
+             int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate, hipStream_t st) {
+    size_t Lc = (size_t)1 << log_lc;
+    size_t Wc = Lc < (size_t)KING_THREADS ? Lc : (size_t)KING_THREADS;
+    size_t lds = (size_t)L * Wc * sizeof(Fr);
+    dim3 grid((unsigned)(Lc / Wc)), block(KING_THREADS);
+    if (negate)
+      king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
+                                                               gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
+                                                               rearrange, seed, out, out_mask);
+    else
+      king_fft2_kernel<FrP, L, false><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
+                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
+                                                                rearrange, seed, out, out_mask);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int king_dispatch(const Fr* in, const Fr* in_mask, int np, int log_m, int inverse, const Fr* U, const void* g,
+                    int scale, int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate,
+                    hipStream_t st) {
+    int log_l = ilog2(l);
+    if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    const Fr* gen = nullptr;
+    int rc = gentab(log_m, inverse, st, &gen);
+    if (rc) return rc;
+    Fr gv = g ? Fr::from_limbs((const uint32_t*)g) : Fr::one();
+    GTab gt{};
+    bool need = scale || gv != Fr::one();
+    if (need) {
+      rc = gtab(log_m, gv, scale != 0, st, &gt);
+      if (rc) return rc;
+    }
+    int log_lc = log_m - log_l;
+    switch (l) {
+      case 1: return king_l<1>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
+      case 2: return king_l<2>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
+      case 4: return king_l<4>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
+      default: return king_l<8>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
+    }
+  }
+  int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
+                const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out, const void* out_mask,
+                hipStream_t st) override {
+    if (!in || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const Fr* U = nullptr;
+    int rc = umat_for(parties, np, &U);
+    if (rc) return rc;
+    return king_dispatch((const Fr*)in, (const Fr*)in_mask, np, log_m, inverse, U, g, scale_size_inv, rearrange, seed,
+                         (Fr*)out, (const Fr*)out_mask, false, st);
+  }
+
+  // FftMask::sample (dfft/mod.rs:30-85).  Streams: values = seed, in-mask randomness = seed ^ 0x1111,
+  // out-mask randomness = seed ^ 0x2222 (same convention as oracle/dist.py).
+  int fft_mask_sample(int rearrange, const void* g, int inverse, int log_m, uint64_t seed, void* in_mask,
+                      void* out_mask, hipStream_t st) override {
+    int log_l = ilog2(l);
+    if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    size_t m = (size_t)1 << log_m, Lc = m / l;
+    ZK_HIP(scratch_.ensure(m * sizeof(Fr)));
+    Fr* vals = (Fr*)scratch_.p;   // layout [l][Lc]: value k*l+s at [s][k]
+    rand_fill_kernel<Fr><<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st>>>(vals, seed, m, (uint32_t)l,
+                                                                                 (uint32_t)(log_m - log_l));
+    ZK_HIP(hipGetLastError());
+    int rc = pss_pack(vals, Lc, 1, seed ^ 0x1111, false, in_mask, st);
+    if (rc) return rc;
+    return king_dispatch(vals, nullptr, l, log_m, inverse, ident_, g, 0, rearrange, seed ^ 0x2222, (Fr*)out_mask,
+                         nullptr, true, st);
+  }
+
+  // ---------------------------------------------------------------- deg_red (deg_red.rs:80-126)
+  template <int L>
+  int degred_l(const Fr* in, const Fr* in_mask, int np, size_t len, const Fr* U, uint64_t seed, Fr* out,
+               const Fr* out_mask, hipStream_t st) {
+    dim3 grid((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
+    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, seed, out, out_mask);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int deg_red_np(const Fr* in, const Fr* in_mask, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
+                 const Fr* out_mask, hipStream_t st) {
+    if (!len) return ZK_OK;
+    const Fr* U = nullptr;
+    int rc = umat_for(parties, np, &U);
+    if (rc) return rc;
+    switch (l) {
+      case 1: return degred_l<1>(in, in_mask, np, len, U, seed, out, out_mask, st);
+      case 2: return degred_l<2>(in, in_mask, np, len, U, seed, out, out_mask, st);
+      case 4: return degred_l<4>(in, in_mask, np, len, U, seed, out, out_mask, st);
+      default: return degred_l<8>(in, in_mask, np, len, U, seed, out, out_mask, st);
+    }
+  }
+  int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed, hipStream_t st) override {
+    if (len && !x) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    return deg_red_np((const Fr*)x, (const Fr*)in_mask, nullptr, n, len, seed, (Fr*)x, (const Fr*)out_mask, st);
+  }
+  // DegRedMask::sample with gen = 1 (deg_red.rs:40-66)
+  int degred_mask_sample(size_t len, uint64_t seed, void* in_mask, void* out_mask, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    size_t cnt = len * l;
+    ZK_HIP(scratch_.ensure(cnt * sizeof(Fr)));
+    Fr* vals = (Fr*)scratch_.p;
+    rand_fill_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(vals, seed, cnt, (uint32_t)l,
+                                                                                   0xffffffffu);
+    ZK_HIP(hipGetLastError());
+    int rc = pss_pack(vals, len, 0, seed ^ 0x1111, false, in_mask, st);
+    if (rc) return rc;
+    vec_neg_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(vals, vals, cnt);
+    ZK_HIP(hipGetLastError());
+    return pss_pack(vals, len, 0, seed ^ 0x2222, false, out_mask, st);
+  }
+
+  // ---------------------------------------------------------------- d_pp (dpp/mod.rs:15-87)
+  int d_pp(const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
+           void* out, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!num || !den || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    size_t m = len * l;
+    ZK_HIP(scratch_.ensure(3 * m * sizeof(Fr)));
+    Fr* nu = (Fr*)scratch_.p;
+    Fr* de = nu + m;
+    Fr* x = de + m;
+    int rc = pss_unpack(num, nullptr, n, len, true, nu, st);
+    if (rc) return rc;
+    rc = pss_unpack(den, nullptr, n, len, true, de, st);
+    if (rc) return rc;
+    ZK_HIP(hipMemsetAsync(err_flag_, 0, sizeof(int), st));
+    size_t nthreads = (m + DPP_CHUNK - 1) / DPP_CHUNK;
+    dpp_div_kernel<Fr><<<dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, st>>>(nu, de, m, x, err_flag_);
+    ZK_HIP(hipGetLastError());
+    int herr = 0;
+    ZK_HIP(hipMemcpyAsync(&herr, err_flag_, sizeof(int), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (herr) return fail(ZK_ERR_GENERIC, "d_pp: zero denominator (reference panics: dpp/mod.rs:55)");
+    // inclusive prefix product
+    size_t nblocks = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (nblocks == 1) {
+      scan_block_kernel<Fr><<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(x, m, nullptr, nullptr);
+    } else {
+      Fr* bp = nu;   // numerators are dead now
+      scan_block_kernel<Fr><<<dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st>>>(x, m, bp, nullptr);
+      scan_carries_kernel<Fr><<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(bp, nblocks);
+      scan_block_kernel<Fr><<<dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st>>>(x, m, nullptr, bp);
+    }
+    ZK_HIP(hipGetLastError());
+    rc = pss_pack(x, len, 0, seed, false, out, st);
+    if (rc) return rc;
+    return deg_red_np((const Fr*)out, (const Fr*)in_mask, nullptr, n, len, seed ^ 0x3333, (Fr*)out,
+                      (const Fr*)out_mask, st);
+  }
+
+  // ---------------------------------------------------------------- MSM
+  int msm(int group, const void* bases, size_t nb, const void* scalars, size_t ns, void* out,
+          hipStream_t st) override {
+    if (nb != ns) {   // dmsm/mod.rs:73: G::msm returns Err(min len) -> MpcNetError::Generic(len.to_string())
+      return fail(ZK_ERR_GENERIC, std::to_string(nb < ns ? nb : ns));
+    }
+    return msm_.run(this, group, bases, scalars, nb, nullptr, 1, out, st);
+  }
+  int d_msm(int group, const void* bases, const void* scalars, size_t len, const void* in_mask, const void* out_mask,
+            void* out, hipStream_t st) override {
+    return msm_.d_msm(this, group, bases, scalars, len, in_mask, out_mask, out, st);
+  }
+
+  bool force_simple_ntt = false;
+  Fr* pmat_ = nullptr;
+  Fr* ident_ = nullptr;
+  int* err_flag_ = nullptr;
+  std::map<uint64_t, Fr*> umats_;
+  std::map<int, Fr*> gentabs_;
+  std::map<std::string, GTab> gtabs_;
+  std::mutex mu_;
+  DevBuf scratch_;
+  MsmRunner<Cfg> msm_;
+};
+
+}  // namespace zk

@@ -1,0 +1,251 @@
+// Prime-field arithmetic in Montgomery form for gfx950 (and the host side of the same library).
+//
+// Layout: N little-endian 32-bit limbs, value*R mod p with R = 2^(32N) -- bit-identical to
+// arkworks' in-memory `Fp<MontBackend, N/2>` ([u64; N/2] little-endian, R = 2^(64*N/2)), which is
+// what crosses the C ABI.  All values are kept fully reduced (< p).
+//
+// Replaces, on this path, ark-ff's `Fp::{mul,add,sub,neg,inverse,pow}` (reached from
+// secret-sharing/src/pss.rs, dist-primitives/src/dfft/mod.rs:159,196-206,222-233, dpp/mod.rs:55).
+//
+// The multiply is an operand-scanning CIOS written so that hipcc lowers every 32x32+64 step to one
+// v_mad_u64_u32 (D.u64 = S0.u32*S1.u32 + S2.u64).  There is no MFMA use: nothing here is a dense
+// contraction.
+#pragma once
+#include <stdint.h>
+#include "params.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_D __device__ __forceinline__
+#define ZK_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define ZK_HD inline
+#define ZK_D inline
+#define ZK_HD_NOINLINE __attribute__((noinline))
+#endif
+
+namespace zk {
+
+template <class P>
+struct Fp {
+  using Params = P;
+  static constexpr int N = P::N;
+  uint32_t v[N];
+
+  ZK_HD static Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = 0;
+    return r;
+  }
+  ZK_HD static Fp one() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = P::R1[i];
+    return r;
+  }
+  ZK_HD static Fp r2() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = P::R2[i];
+    return r;
+  }
+  ZK_HD bool is_zero() const {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) acc |= v[i];
+    return acc == 0;
+  }
+  ZK_HD bool operator==(const Fp& o) const {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) acc |= v[i] ^ o.v[i];
+    return acc == 0;
+  }
+  ZK_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+
+  // r = a - p if a >= p (a < 2p assumed); `carry` is the bit above limb N-1 of a.
+  ZK_HD static Fp reduce_once(const Fp& a, uint32_t carry = 0) {
+    Fp d;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)a.v[i] - P::MOD[i] - borrow;
+      d.v[i] = (uint32_t)t;
+      borrow = (uint32_t)(t >> 63);
+    }
+    // a >= p  <=>  carry set, or no borrow
+    bool ge = carry | (borrow ^ 1u);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = ge ? d.v[i] : a.v[i];
+    return r;
+  }
+
+  ZK_HD friend Fp operator+(const Fp& a, const Fp& b) {
+    Fp s;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
+      s.v[i] = (uint32_t)t;
+      c = (uint32_t)(t >> 32);
+    }
+    return reduce_once(s, c);
+  }
+
+  ZK_HD friend Fp operator-(const Fp& a, const Fp& b) {
+    Fp d;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
+      d.v[i] = (uint32_t)t;
+      borrow = (uint32_t)(t >> 63);
+    }
+    // add p back if we borrowed
+    uint32_t mask = 0u - borrow;
+    uint32_t c = 0;
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)d.v[i] + (P::MOD[i] & mask) + c;
+      r.v[i] = (uint32_t)t;
+      c = (uint32_t)(t >> 32);
+    }
+    return r;
+  }
+
+  ZK_HD Fp neg() const { return zero() - *this; }
+  ZK_HD Fp dbl() const { return *this + *this; }
+
+  // Montgomery product a*b*R^-1 mod p (CIOS, operand scanning, one row of a per outer step).
+  ZK_HD friend Fp operator*(const Fp& a, const Fp& b) {
+    uint32_t t[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 2; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t c = 0;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        uint64_t x = (uint64_t)a.v[i] * b.v[j] + t[j] + c;
+        t[j] = (uint32_t)x;
+        c = x >> 32;
+      }
+      uint64_t x = (uint64_t)t[N] + c;
+      t[N] = (uint32_t)x;
+      t[N + 1] = (uint32_t)(x >> 32);
+
+      uint32_t m = t[0] * P::N0INV;
+      x = (uint64_t)m * P::MOD[0] + t[0];
+      c = x >> 32;
+#pragma unroll
+      for (int j = 1; j < N; j++) {
+        x = (uint64_t)m * P::MOD[j] + t[j] + c;
+        t[j - 1] = (uint32_t)x;
+        c = x >> 32;
+      }
+      x = (uint64_t)t[N] + c;
+      t[N - 1] = (uint32_t)x;
+      t[N] = t[N + 1] + (uint32_t)(x >> 32);
+    }
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return reduce_once(r, t[N]);
+  }
+
+  // Out-of-line multiply for cold code (G2 tower, bucket reduction, l > 2 kernels): one copy per field
+  // instead of one per call site keeps code size and compile time bounded.
+  static ZK_HD_NOINLINE Fp mul_ni(const Fp& a, const Fp& b) { return a * b; }
+
+  ZK_HD Fp sqr() const { return *this * *this; }
+
+  ZK_HD Fp to_mont() const { return *this * r2(); }      // canonical integer -> Montgomery
+  ZK_HD Fp from_mont() const {                            // Montgomery -> canonical integer
+    Fp o = zero();
+    o.v[0] = 1;
+    return *this * o;
+  }
+
+  // this^e for a little-endian exponent of `nl` 32-bit limbs (square-and-multiply, MSB first).
+  ZK_HD Fp pow(const uint32_t* e, int nl) const {
+    Fp r = one();
+    bool started = false;
+    for (int i = nl - 1; i >= 0; i--) {
+      for (int b = 31; b >= 0; b--) {
+        if (started) r = mul_ni(r, r);
+        if ((e[i] >> b) & 1u) {
+          r = started ? mul_ni(r, *this) : *this;
+          started = true;
+        }
+      }
+    }
+    return r;
+  }
+  ZK_HD Fp pow_u64(uint64_t e) const {
+    uint32_t ee[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
+    return pow(ee, 2);
+  }
+  // Fermat inverse (this != 0): this^(p-2).
+  ZK_HD Fp inverse() const {
+    uint32_t e[N];
+    uint32_t borrow = 2;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)P::MOD[i] - borrow;
+      e[i] = (uint32_t)t;
+      borrow = (uint32_t)(t >> 63);
+    }
+    return pow(e, N);
+  }
+  ZK_HD static Fp from_u64(uint64_t x) {
+    Fp r = zero();
+    r.v[0] = (uint32_t)x;
+    r.v[1] = (uint32_t)(x >> 32);
+    return r.to_mont();
+  }
+  ZK_HD static Fp from_limbs(const uint32_t* p) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = p[i];
+    return r;
+  }
+};
+
+// Quadratic extension Fq2 = Fq[u]/(u^2 - NONRES) for G2 arithmetic; NONRES = -1 for BN254 and BLS12-381.
+template <class P>
+struct Fp2 {
+  using B = Fp<P>;
+  B c0, c1;
+  ZK_HD static Fp2 zero() { return {B::zero(), B::zero()}; }
+  ZK_HD static Fp2 one() { return {B::one(), B::zero()}; }
+  ZK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  ZK_HD bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+  ZK_HD bool operator!=(const Fp2& o) const { return !(*this == o); }
+  ZK_HD friend Fp2 operator+(const Fp2& a, const Fp2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+  ZK_HD friend Fp2 operator-(const Fp2& a, const Fp2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+  ZK_HD Fp2 neg() const { return {c0.neg(), c1.neg()}; }
+  ZK_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+  // (a0 + a1 u)(b0 + b1 u) with u^2 = -1, Karatsuba: 3 base multiplications.
+  ZK_HD friend Fp2 operator*(const Fp2& a, const Fp2& b) {
+    B v0 = B::mul_ni(a.c0, b.c0);
+    B v1 = B::mul_ni(a.c1, b.c1);
+    B s = B::mul_ni(a.c0 + a.c1, b.c0 + b.c1);
+    return {v0 - v1, s - v0 - v1};
+  }
+  // (a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u : 2 base multiplications.
+  ZK_HD Fp2 sqr() const {
+    B t = B::mul_ni(c0, c1);
+    return {B::mul_ni(c0 + c1, c0 - c1), t.dbl()};
+  }
+  ZK_HD Fp2 inverse() const {
+    B n = (B::mul_ni(c0, c0) + B::mul_ni(c1, c1)).inverse();
+    return {B::mul_ni(c0, n), B::mul_ni(c1, n).neg()};
+  }
+  static ZK_HD Fp2 mul_ni(const Fp2& a, const Fp2& b) { return a * b; }
+};
+
+}  // namespace zk

@@ -1,0 +1,340 @@
+// Packed-Shamir pack / unpack and the king-side kernels of d_fft, deg_red and d_pp.
+//
+// Reference: secret-sharing/src/pss.rs:69-221 (det_pack, pack, unpack, unpack2, lagrange_unpack),
+// dist-primitives/src/dfft/mod.rs:210-304 (fft2_in_place + king closure of fft2_with_rearrange),
+// dist-primitives/src/utils/deg_red.rs:103-111, dist-primitives/src/dpp/mod.rs:41-76.
+//
+// pack and unpack are fixed linear maps for a given l (DESIGN.md "PSS as matrices"):
+//   shares  = P (n x (l+t)) * [secrets ; randoms]          -- coset-IFFT on g*H_{l+t}, FFT on H_n
+//   secrets = U (l x n')    * shares                        -- IFFT on H_n, (coset-)FFT, truncation;
+//                                                              for a party subset the Lagrange form.
+// The matrices are built on the host with the same field code and live in HBM; their entries are
+// wave-uniform, so the compiler fetches them with scalar loads.
+#pragma once
+#include "field.hpp"
+#include "ntt.hpp"
+#include "prng.hpp"
+
+namespace zk {
+#if defined(__HIPCC__)
+
+constexpr int KING_THREADS = 256;
+
+// The l = 2 kernels (the configuration every reference example runs) inline their multiplies; larger
+// packing factors call the out-of-line one to keep code size bounded.
+template <int L, class F>
+ZK_D F mulsel(const F& a, const F& b) {
+  if constexpr (L <= 2) return a * b;
+  else return F::mul_ni(a, b);
+}
+
+// shares[p][j] for p < n from l secrets + t randoms.  One thread per chunk.
+//   order 0: secrets[j*l + i];  order 1: secrets[j + i*nchunks].
+template <class P, int L, bool DET>
+__global__ __launch_bounds__(KING_THREADS) void pss_pack_kernel(const Fp<P>* __restrict__ secrets, size_t nchunks,
+                                                               int order, uint64_t seed,
+                                                               const Fp<P>* __restrict__ Pm /* [n][l+t] */,
+                                                               Fp<P>* __restrict__ shares /* [n][nchunks] */) {
+  using F = Fp<P>;
+  constexpr int T = L, N = 4 * L;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nchunks) return;
+  F v[L + T];
+#pragma unroll
+  for (int i = 0; i < L; i++) v[i] = load_elem(secrets + (order ? j + (size_t)i * nchunks : j * L + i));
+  if (!DET) {
+#pragma unroll
+    for (int i = 0; i < T; i++) v[L + i] = rand_fp<P>(seed, j * T + i);
+  }
+#pragma unroll 1
+  for (int p = 0; p < N; p++) {
+    F acc = F::zero();
+#pragma unroll
+    for (int i = 0; i < (DET ? L : L + T); i++) acc = acc + mulsel<L>(Pm[p * (L + T) + i], v[i]);
+    store_elem(shares + (size_t)p * nchunks + j, acc);
+  }
+}
+
+// secrets[j*l + i] = sum_s U[i][s] * shares[s][j].
+template <class P, int L>
+__global__ __launch_bounds__(KING_THREADS) void pss_unpack_kernel(const Fp<P>* __restrict__ shares /* [np][nchunks] */,
+                                                                 int np, size_t nchunks,
+                                                                 const Fp<P>* __restrict__ U /* [l][np] */,
+                                                                 Fp<P>* __restrict__ secrets) {
+  using F = Fp<P>;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nchunks) return;
+  F acc[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) acc[i] = F::zero();
+#pragma unroll 1
+  for (int s = 0; s < np; s++) {
+    F x = load_elem(shares + (size_t)s * nchunks + j);
+#pragma unroll
+    for (int i = 0; i < L; i++) acc[i] = acc[i] + mulsel<L>(U[i * np + s], x);
+  }
+#pragma unroll
+  for (int i = 0; i < L; i++) store_elem(secrets + j * L + i, acc[i]);
+}
+
+// King closure of fft2_with_rearrange (dfft/mod.rs:264-304), fused:
+//   unpack_missing_shares per chunk -> fft2_in_place (log2 l stages inside the chunk, then the
+//   rotate_right(1)) -> *g^pos (and *1/m when `gtab` was built with it) -> [bit-reverse] -> pack.
+//
+// Index facts (DESIGN.md "king"): chunk k's in-place radix-l butterfly leaves element e at position
+// pos = (k + 1 + e*Lc) mod m, Lc = m/l; the stage pairing elements that differ in bit s' of e uses the
+// twiddle gen^((l >> (s'+1)) * (k + 1 + Lc*(e & (2^s'-1)))).  Output chunk q packs positions q*l..q*l+l-1
+// (rearrange: written to chunk bitrev(q), slot i taking position q*l + bitrev_l(i)).
+//
+// One workgroup handles Wc = min(256, Lc) input chunks k0-1 .. k0+Wc-2 (mod Lc), which produce exactly
+// the positions {h*Lc + k0 .. h*Lc + k0 + Wc - 1 : h < l}; these are exchanged through LDS and packed.
+//   in     : [np][Lc] (+ in_mask, optional)   out: [n][Lc] (+ out_mask, optional)
+//   gentab : gen^e, e in [0, m]               gtab: c*g^e, e in [0, Lc] or nullptr (g = 1, c = 1)
+//   gstep  : g^(Lc*e), e < l
+template <class P, int L, bool NEGATE>
+__global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
+    const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, uint32_t log_lc,
+    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
+    const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, int rearrange, uint64_t seed,
+    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
+  using F = Fp<P>;
+  constexpr int T = L, N = 4 * L;
+  constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
+  extern __shared__ uint4 smem[];
+  const uint32_t Lc = 1u << log_lc;
+  const uint32_t Wc = Lc < (uint32_t)KING_THREADS ? Lc : (uint32_t)KING_THREADS;
+  const uint32_t log_m = log_lc + LOGL;
+  LdsVec<F> lds{smem, (int)(L * Wc)};
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k0 = blockIdx.x * Wc;
+
+  if (tid < Wc) {
+    // ---- phase 1: chunk k = k0 - 1 + tid (mod Lc), i.e. k + 1 = k0 + tid (or Lc when that is 0)
+    uint32_t kp1 = k0 + tid;                 // k + 1 in [0, Lc)
+    bool wrapped = (kp1 == 0);               // k = Lc - 1
+    uint32_t k = wrapped ? Lc - 1 : kp1 - 1;
+    if (wrapped) kp1 = Lc;
+    F v[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) v[i] = F::zero();
+#pragma unroll 1
+    for (int s = 0; s < np; s++) {
+      F x = load_elem(in + ((size_t)s << log_lc) + k);
+      if (in_mask) x = x + load_elem(in_mask + ((size_t)s << log_lc) + k);
+#pragma unroll
+      for (int i = 0; i < L; i++) v[i] = v[i] + mulsel<L>(U[i * np + s], x);
+    }
+    // fft2 inside the chunk.  tk[s'] = gen^((l >> (s'+1)) * (k+1)); last stage uses gen^(k+1).
+    if (L > 1) {
+      F tk[LOGL > 0 ? LOGL : 1];
+      tk[LOGL - 1] = load_elem(gentab + kp1);
+#pragma unroll
+      for (int s = LOGL - 2; s >= 0; s--) tk[s] = tk[s + 1].sqr();
+#pragma unroll
+      for (int s = 0; s < LOGL; s++) {
+#pragma unroll
+        for (int e = 0; e < L; e++) {
+          if (e & (1 << s)) continue;
+          int elow = e & ((1 << s) - 1);
+          // gen^((l >> (s+1)) * Lc * elow) = gen^(m * elow / 2^(s+1))
+          F tw = tk[s];
+          if (elow) tw = mulsel<L>(tw, load_elem(gentab + ((size_t)elow << (log_m - s - 1))));
+          F y = mulsel<L>(v[e | (1 << s)], tw);
+          F x = v[e];
+          v[e] = x + y;
+          v[e | (1 << s)] = x - y;
+        }
+      }
+    }
+    // scale by g^pos and park in LDS at local position (region, offset)
+    F gk = gtab ? load_elem(gtab + kp1) : F::one();
+#pragma unroll
+    for (int e = 0; e < L; e++) {
+      F val = v[e];
+      uint32_t region = e;
+      if (wrapped) {
+        region = (e + 1) % L;
+        // pos = (e+1)*Lc mod m ; g^pos = gstep[(e+1) % L] (times c, folded into gtab[0])
+        if (gtab) val = val * load_elem(gtab + 0) * load_elem(gstep + region);
+      } else if (gtab) {
+        val = val * gk;
+        if (e) val = val * load_elem(gstep + e);
+      }
+      if (NEGATE) val = val.neg();   // FftMask::sample negates the mask values (dfft/mod.rs:56)
+      uint32_t off = wrapped ? 0 : tid;
+      lds.put(region * Wc + off, val);
+    }
+  }
+  __syncthreads();
+  if (tid < Wc) {
+    // ---- phase 2: one output chunk per thread
+    uint32_t q;
+    if (Wc == Lc) {
+      q = tid;
+    } else {
+      uint32_t per_region = Wc / L;
+      uint32_t h = tid / per_region, jj = tid % per_region;
+      q = (h * Lc + k0) / L + jj;
+    }
+    F sec[L + T];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      uint32_t src = rearrange ? bitrev32(i, LOGL) : i;
+      uint32_t pos = q * L + src;
+      uint32_t lp = (pos >> log_lc) * Wc + ((pos & (Lc - 1)) - k0);
+      sec[i] = lds.get(lp);
+    }
+    uint32_t j = rearrange ? bitrev32(q, log_lc) : q;
+#pragma unroll
+    for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
+#pragma unroll 1
+    for (int p = 0; p < N; p++) {
+      F acc = F::zero();
+#pragma unroll
+      for (int i = 0; i < L + T; i++) acc = acc + mulsel<L>(Pm[p * (L + T) + i], sec[i]);
+      size_t o = ((size_t)p << log_lc) + j;
+      if (out_mask) acc = acc + load_elem(out_mask + o);
+      store_elem(out + o, acc);
+    }
+  }
+}
+
+// King closure of deg_red (deg_red.rs:103-111): unpack_missing_shares then pack, per chunk.
+template <class P, int L>
+__global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
+    const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
+    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, uint64_t seed, Fp<P>* __restrict__ out,
+    const Fp<P>* __restrict__ out_mask) {
+  using F = Fp<P>;
+  constexpr int T = L, N = 4 * L;
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  F sec[L + T];
+#pragma unroll
+  for (int i = 0; i < L; i++) sec[i] = F::zero();
+#pragma unroll 1
+  for (int s = 0; s < np; s++) {
+    F x = load_elem(in + (size_t)s * len + j);
+    if (in_mask) x = x + load_elem(in_mask + (size_t)s * len + j);
+#pragma unroll
+    for (int i = 0; i < L; i++) sec[i] = sec[i] + mulsel<L>(U[i * np + s], x);
+  }
+#pragma unroll
+  for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
+#pragma unroll 1
+  for (int p = 0; p < N; p++) {
+    F acc = F::zero();
+#pragma unroll
+    for (int i = 0; i < L + T; i++) acc = acc + mulsel<L>(Pm[p * (L + T) + i], sec[i]);
+    size_t o = (size_t)p * len + j;
+    if (out_mask) acc = acc + load_elem(out_mask + o);
+    store_elem(out + o, acc);
+  }
+}
+
+// ---- d_pp king pieces (dpp/mod.rs:41-76) ------------------------------------------------------------
+// x[i] = num[i] / den[i] with one Fermat inversion per DPP_CHUNK elements (Montgomery's trick inside the
+// thread); zero denominators raise `*err`.
+constexpr int DPP_CHUNK = 32;
+template <class F>
+__global__ void dpp_div_kernel(const F* __restrict__ num, const F* __restrict__ den, size_t len, F* __restrict__ x,
+                               int* __restrict__ err) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t b = t * DPP_CHUNK;
+  if (b >= len) return;
+  size_t e = b + DPP_CHUNK < len ? b + DPP_CHUNK : len;
+  // prefix products of den into x (scratch), then walk back
+  F acc = F::one();
+  for (size_t i = b; i < e; i++) {
+    F d = load_elem(den + i);
+    if (d.is_zero()) {
+      atomicExch(err, 1);
+      return;
+    }
+    store_elem(x + i, acc);       // product of den[b..i)
+    acc = acc * d;
+  }
+  F inv = acc.inverse();           // 1 / prod den[b..e)
+  for (size_t i = e; i-- > b;) {
+    F d = load_elem(den + i);
+    F pre = load_elem(x + i);
+    store_elem(x + i, load_elem(num + i) * inv * pre);
+    inv = inv * d;
+  }
+}
+
+// Inclusive multiplicative scan in three launches: block products, scan of block products, apply.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
+
+template <class F>
+ZK_D F block_scan_exclusive(F v, F* sh /* [SCAN_THREADS] as F */, F* total) {
+  // Hillis-Steele over the block in shared memory (F values)
+  int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+    F t = sh[tid];
+    if (tid >= off) t = sh[tid - off] * t;
+    __syncthreads();
+    sh[tid] = t;
+    __syncthreads();
+  }
+  F ex = tid ? sh[tid - 1] : F::one();
+  if (total) *total = sh[SCAN_THREADS - 1];
+  return ex;
+}
+
+template <class F>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_kernel(F* __restrict__ x, size_t len,
+                                                                 F* __restrict__ block_prod, const F* __restrict__ carry) {
+  __shared__ F sh[SCAN_THREADS];
+  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+  F loc[SCAN_PER_THREAD];
+  F acc = F::one();
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; i++) {
+    loc[i] = base + i < len ? load_elem(x + base + i) : F::one();
+    acc = acc * loc[i];
+    loc[i] = acc;
+  }
+  F tot;
+  F ex = block_scan_exclusive(acc, sh, &tot);
+  if (carry) ex = ex * load_elem(carry + blockIdx.x);
+  if (block_prod) {
+    if (threadIdx.x == 0) store_elem(block_prod + blockIdx.x, tot);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; i++)
+    if (base + i < len) store_elem(x + base + i, ex * loc[i]);
+}
+
+// exclusive scan of up to SCAN_BLOCK block products by one workgroup (in place -> carries)
+template <class F>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_carries_kernel(F* __restrict__ bp, size_t nblocks) {
+  __shared__ F sh[SCAN_THREADS];
+  F running = F::one();
+  for (size_t base0 = 0; base0 < nblocks; base0 += SCAN_BLOCK) {
+    size_t base = base0 + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    F loc[SCAN_PER_THREAD];
+    F acc = F::one();
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; i++) {
+      F v = base + i < nblocks ? load_elem(bp + base + i) : F::one();
+      loc[i] = acc;               // exclusive within thread
+      acc = acc * v;
+    }
+    F tot;
+    F ex = block_scan_exclusive(acc, sh, &tot) * running;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; i++)
+      if (base + i < nblocks) store_elem(bp + base + i, ex * loc[i]);
+    running = running * tot;
+    __syncthreads();
+  }
+}
+
+#endif  // __HIPCC__
+}  // namespace zk
