@@ -82,18 +82,20 @@ int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, c
  *          `share + in_mask` of :254-258 fused into the last pass).
  * zk_fft2_king: the king closure of fft2_with_rearrange (:264-304): unpack_missing_shares per chunk ->
  *          fft2_in_place (:210-237) -> distribute_powers(g) (:278-280) -> (bit-reverse + stride) pack.
- *          in_d is [nparties][m/l], out_d is [n][m/l].  g (Montgomery Fr, host pointer) may be NULL for 1.
+ *          in_d is [nparties][m/l], out_d is [n][m/l] and must not alias in_d.  g (Montgomery Fr, host pointer) may be NULL for 1.
  *          scale_size_inv != 0 additionally multiplies by 1/m (d_ifft's :159 folded in).
- * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l] in place,
- *          masks [n][m/l] each or NULL for FftMask::zero. */
+ * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l] (clobbered: it
+ *          holds the fft1 output afterwards), masks [n][m/l] each or NULL for FftMask::zero.  The result is
+ *          written to out_d [n][m/l]; out_d == NULL or == shares_d returns it in shares_d (one extra device copy,
+ *          because the king step exchanges chunks between workgroups and cannot run in place). */
 int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream);
 int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int nparties, int log2_m, int inverse,
                  const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out_d,
                  const void* out_mask_d, void* stream);
 int zk_d_fft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange,
-             int log2_m, uint64_t seed, void* stream);
+             int log2_m, uint64_t seed, void* out_d, void* stream);
 int zk_d_ifft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange,
-              int log2_m, const void* g, uint64_t seed, void* stream);
+              int log2_m, const void* g, uint64_t seed, void* out_d, void* stream);
 /* FftMask::sample (:30-85): in_mask_d/out_mask_d are [n][m/l]. */
 int zk_fft_mask_sample(zk_ctx* ctx, int rearrange, const void* g, int inverse, int log2_m, uint64_t seed,
                        void* in_mask_d, void* out_mask_d, void* stream);

@@ -61,8 +61,8 @@ def load():
     lib.zk_vec_mul_sub.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     lib.zk_fft1.argtypes = [vp, vp, i32, i32, sz, vp, vp]
     lib.zk_fft2_king.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, i32, i32, vp, i32, i32, u64, vp, vp, vp]
-    lib.zk_d_fft.argtypes = [vp, vp, vp, vp, i32, i32, u64, vp]
-    lib.zk_d_ifft.argtypes = [vp, vp, vp, vp, i32, i32, vp, u64, vp]
+    lib.zk_d_fft.argtypes = [vp, vp, vp, vp, i32, i32, u64, vp, vp]
+    lib.zk_d_ifft.argtypes = [vp, vp, vp, vp, i32, i32, vp, u64, vp, vp]
     lib.zk_fft_mask_sample.argtypes = [vp, i32, vp, i32, i32, u64, vp, vp, vp]
     lib.zk_deg_red.argtypes = [vp, vp, vp, vp, sz, u64, vp]
     lib.zk_degred_mask_sample.argtypes = [vp, sz, u64, vp, vp, vp]

@@ -199,19 +199,19 @@ class MsmMask:
         return MsmMask(None, None)
 
 
-def d_fft(pp, shares_d, fft_mask, rearrange, log2_m, seed=0, stream=None):
-    """dfft/mod.rs:99-134 for all parties; shares_d [n][m/l] is transformed in place."""
+def d_fft(pp, shares_d, fft_mask, rearrange, log2_m, seed=0, out=None, stream=None):
+    """dfft/mod.rs:99-134 for all parties; shares_d [n][m/l].  Result in `out` (or back in shares_d if None)."""
     pp._check(pp.lib.zk_d_fft(pp.h, _ptr(shares_d), _ptr(fft_mask.in_mask), _ptr(fft_mask.out_mask), int(rearrange),
-                              log2_m, seed, stream))
-    return shares_d
+                              log2_m, seed, _ptr(out), stream))
+    return shares_d if out is None else out
 
 
-def d_ifft(pp, shares_d, fft_mask, rearrange, log2_m, g=None, seed=0, stream=None):
+def d_ifft(pp, shares_d, fft_mask, rearrange, log2_m, g=None, seed=0, out=None, stream=None):
     """dfft/mod.rs:137-175; g is an int (coset shift, 1 if None)."""
     garr = None if g is None else pp.fr.encode_one(g)
     pp._check(pp.lib.zk_d_ifft(pp.h, _ptr(shares_d), _ptr(fft_mask.in_mask), _ptr(fft_mask.out_mask), int(rearrange),
-                               log2_m, None if garr is None else garr.ctypes.data, seed, stream))
-    return shares_d
+                               log2_m, None if garr is None else garr.ctypes.data, seed, _ptr(out), stream))
+    return shares_d if out is None else out
 
 
 def deg_red(pp, x_d, mask, length, seed=0, stream=None):

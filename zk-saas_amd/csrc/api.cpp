@@ -136,26 +136,21 @@ int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int npa
                  const void* out_mask_d, void* stream) {
   CTX_OR_FAIL();
   if (!parties && nparties != e->n) return e->fail(ZK_ERR_BAD_INPUT, "parties list required when some are missing");
+  if (in_d == out_d) return e->fail(ZK_ERR_BAD_INPUT, "zk_fft2_king cannot run in place (workgroups exchange chunks)");
   return e->fft2_king(in_d, nullptr, parties, nparties, log2_m, inverse, g, scale_size_inv, rearrange, seed, out_d,
                       out_mask_d, S(stream));
 }
 // d_fft (dfft/mod.rs:99-134): fft1 on every party's vector, then the king closure with the mask adds fused.
 int zk_d_fft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange, int log2_m,
-             uint64_t seed, void* stream) {
+             uint64_t seed, void* out_d, void* stream) {
   CTX_OR_FAIL();
-  int rc = e->fft1(shares_d, log2_m, 0, (size_t)e->n, nullptr, S(stream));
-  if (rc) return rc;
-  return e->fft2_king(shares_d, in_mask_d, nullptr, e->n, log2_m, 0, nullptr, 0, rearrange, seed, shares_d,
-                      out_mask_d, S(stream));
+  return e->d_fft(shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 0, nullptr, seed, out_d, S(stream));
 }
 // d_ifft (dfft/mod.rs:137-175): the 1/m scaling of :159 is applied by the king together with g^i.
 int zk_d_ifft(zk_ctx* ctx, void* shares_d, const void* in_mask_d, const void* out_mask_d, int rearrange, int log2_m,
-              const void* g, uint64_t seed, void* stream) {
+              const void* g, uint64_t seed, void* out_d, void* stream) {
   CTX_OR_FAIL();
-  int rc = e->fft1(shares_d, log2_m, 1, (size_t)e->n, nullptr, S(stream));
-  if (rc) return rc;
-  return e->fft2_king(shares_d, in_mask_d, nullptr, e->n, log2_m, 1, g, 1, rearrange, seed, shares_d, out_mask_d,
-                      S(stream));
+  return e->d_fft(shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 1, g, seed, out_d, S(stream));
 }
 int zk_fft_mask_sample(zk_ctx* ctx, int rearrange, const void* g, int inverse, int log2_m, uint64_t seed,
                        void* in_mask_d, void* out_mask_d, void* stream) {

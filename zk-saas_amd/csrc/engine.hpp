@@ -49,6 +49,8 @@ class IEngine {
   virtual int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
                         const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out,
                         const void* out_mask, hipStream_t st) = 0;
+  virtual int d_fft(void* shares, const void* in_mask, const void* out_mask, int rearrange, int log_m, int inverse,
+                    const void* g, uint64_t seed, void* out, hipStream_t st) = 0;
   virtual int fft_mask_sample(int rearrange, const void* g, int inverse, int log_m, uint64_t seed, void* in_mask,
                               void* out_mask, hipStream_t st) = 0;
   virtual int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,

@@ -49,6 +49,7 @@ class Engine : public IEngine {
       (void)hipFree(kv.second.step);
     }
     for (auto& kv : umats_) (void)hipFree(kv.second);
+    for (auto& kv : sizeinv_) (void)hipFree(kv.second);
     if (pmat_) (void)hipFree(pmat_);
     if (ident_) (void)hipFree(ident_);
     if (err_flag_) (void)hipFree(err_flag_);
@@ -214,6 +215,23 @@ class Engine : public IEngine {
     return ZK_OK;
   }
 
+  // device copy of 1/m
+  int size_inv_dev(int log_m, hipStream_t st, const Fr** out) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = sizeinv_.find(log_m);
+    if (it != sizeinv_.end()) {
+      *out = it->second;
+      return ZK_OK;
+    }
+    Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+    Fr* d = nullptr;
+    ZK_HIP(hipMalloc((void**)&d, sizeof(Fr)));
+    ZK_HIP(hipMemcpy(d, &c, sizeof(Fr), hipMemcpyHostToDevice));
+    sizeinv_[log_m] = d;
+    *out = d;
+    return ZK_OK;
+  }
+
   struct GTab {
     Fr* tab;
     Fr* step;
@@ -366,7 +384,8 @@ class Engine : public IEngine {
   // ---------------------------------------------------------------- king of d_fft (dfft/mod.rs:264-304)
   template <int L>
   int king_l(const Fr* in, const Fr* in_mask, int np, int log_lc, const Fr* U, const Fr* gen, const GTab* gt,
-             int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate, hipStream_t st) {
+             const Fr* in_scale, int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate,
+             hipStream_t st) {
     size_t Lc = (size_t)1 << log_lc;
     size_t Wc = Lc < (size_t)KING_THREADS ? Lc : (size_t)KING_THREADS;
     size_t lds = (size_t)L * Wc * sizeof(Fr);
@@ -374,11 +393,11 @@ class Engine : public IEngine {
     if (negate)
       king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                               rearrange, seed, out, out_mask);
+                                                               in_scale, rearrange, seed, out, out_mask);
     else
       king_fft2_kernel<FrP, L, false><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                 gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                                rearrange, seed, out, out_mask);
+                                                                in_scale, rearrange, seed, out, out_mask);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -392,17 +411,24 @@ class Engine : public IEngine {
     if (rc) return rc;
     Fr gv = g ? Fr::from_limbs((const uint32_t*)g) : Fr::one();
     GTab gt{};
-    bool need = scale || gv != Fr::one();
+    // 1/m: folded into the g^i table when there is no in-mask, applied to the shares at load otherwise
+    bool fold = scale && !in_mask;
+    const Fr* in_scale = nullptr;
+    if (scale && in_mask) {
+      rc = size_inv_dev(log_m, st, &in_scale);
+      if (rc) return rc;
+    }
+    bool need = fold || gv != Fr::one();
     if (need) {
-      rc = gtab(log_m, gv, scale != 0, st, &gt);
+      rc = gtab(log_m, gv, fold, st, &gt);
       if (rc) return rc;
     }
     int log_lc = log_m - log_l;
     switch (l) {
-      case 1: return king_l<1>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
-      case 2: return king_l<2>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
-      case 4: return king_l<4>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
-      default: return king_l<8>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, rearrange, seed, out, out_mask, negate, st);
+      case 1: return king_l<1>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
+      case 2: return king_l<2>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
+      case 4: return king_l<4>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
+      default: return king_l<8>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
     }
   }
   int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
@@ -414,6 +440,29 @@ class Engine : public IEngine {
     if (rc) return rc;
     return king_dispatch((const Fr*)in, (const Fr*)in_mask, np, log_m, inverse, U, g, scale_size_inv, rearrange, seed,
                          (Fr*)out, (const Fr*)out_mask, false, st);
+  }
+
+  // d_fft / d_ifft for all n parties on this device (dfft/mod.rs:99-175).  The king kernel exchanges chunks
+  // between workgroups, so it never runs in place: with out == nullptr the result goes through a context-owned
+  // buffer and is copied back into `shares`.
+  int d_fft(void* shares, const void* in_mask, const void* out_mask, int rearrange, int log_m, int inverse,
+            const void* g, uint64_t seed, void* out, hipStream_t st) override {
+    if (!shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (out == shares) out = nullptr;
+    int log_l = ilog2(l);
+    if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    size_t bytes = (size_t)n * (((size_t)1 << log_m) / l) * sizeof(Fr);
+    int rc = fft1(shares, log_m, inverse, (size_t)n, nullptr, st);
+    if (rc) return rc;
+    void* dst = out;
+    if (!dst) {
+      ZK_HIP(king_tmp_.ensure(bytes));
+      dst = king_tmp_.p;
+    }
+    rc = fft2_king(shares, in_mask, nullptr, n, log_m, inverse, g, inverse ? 1 : 0, rearrange, seed, dst, out_mask, st);
+    if (rc) return rc;
+    if (!out) ZK_HIP(hipMemcpyAsync(shares, dst, bytes, hipMemcpyDeviceToDevice, st));
+    return ZK_OK;
   }
 
   // FftMask::sample (dfft/mod.rs:30-85).  Streams: values = seed, in-mask randomness = seed ^ 0x1111,
@@ -534,9 +583,11 @@ class Engine : public IEngine {
   int* err_flag_ = nullptr;
   std::map<uint64_t, Fr*> umats_;
   std::map<int, Fr*> gentabs_;
+  std::map<int, Fr*> sizeinv_;
   std::map<std::string, GTab> gtabs_;
   std::mutex mu_;
   DevBuf scratch_;
+  DevBuf king_tmp_;
   MsmRunner<Cfg> msm_;
 };
 

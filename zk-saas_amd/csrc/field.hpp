@@ -121,7 +121,13 @@ struct Fp {
   ZK_HD Fp dbl() const { return *this + *this; }
 
   // Montgomery product a*b*R^-1 mod p (CIOS, operand scanning, one row of a per outer step).
+  // 8-limb fields inline it at every call site; 12-limb fields (BLS12 base fields) always go through the
+  // out-of-line copy, which keeps kernels that chain dozens of them at a size the compiler handles well.
   ZK_HD friend Fp operator*(const Fp& a, const Fp& b) {
+    if constexpr (N > 8) return mul_ni(a, b);
+    else return mul_inline(a, b);
+  }
+  ZK_HD static Fp mul_inline(const Fp& a, const Fp& b) {
     uint32_t t[N + 2];
 #pragma unroll
     for (int i = 0; i < N + 2; i++) t[i] = 0;
@@ -159,7 +165,7 @@ struct Fp {
 
   // Out-of-line multiply for cold code (G2 tower, bucket reduction, l > 2 kernels): one copy per field
   // instead of one per call site keeps code size and compile time bounded.
-  static ZK_HD_NOINLINE Fp mul_ni(const Fp& a, const Fp& b) { return a * b; }
+  static ZK_HD_NOINLINE Fp mul_ni(const Fp& a, const Fp& b) { return mul_inline(a, b); }
 
   ZK_HD Fp sqr() const { return *this * *this; }
 

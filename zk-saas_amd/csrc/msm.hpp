@@ -18,6 +18,7 @@
 //                     (254 sequential doublings: latency-bound on any one lane, cheap on a CPU core).
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -214,11 +215,17 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __re
 //   S = sum bucket_b,   A = sum (b - base + 1) * bucket_b      (base = first bucket of the workgroup)
 template <class Fld>
 ZK_D XYZZ<Fld> block_reduce_sum(XYZZ<Fld> v, XYZZ<Fld>* sh) {
+  // Control flow is kept wave-uniform around the out-of-line group additions: every lane adds (idle lanes
+  // add the identity) and only the store is predicated.
   int tid = threadIdx.x;
   sh[tid] = v;
   __syncthreads();
   for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
-    if (tid < off) sh[tid] = xyzz_add_ni(sh[tid], sh[tid + off]);
+    XYZZ<Fld> a = sh[tid];
+    XYZZ<Fld> b = tid < off ? sh[tid + off] : XYZZ<Fld>::identity();
+    XYZZ<Fld> r = xyzz_add_ni(a, b);
+    __syncthreads();
+    if (tid < off) sh[tid] = r;
     __syncthreads();
   }
   XYZZ<Fld> r = sh[0];
@@ -240,29 +247,34 @@ __global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>
   XYZZ<Fld> run = XYZZ<Fld>::identity(), acc = XYZZ<Fld>::identity();
   for (int g = RED_G - 1; g >= 0; g--) {
     uint32_t b = base + tid * RED_G + g;
-    if (b < B) run = xyzz_add_ni(run, load_elem(wb + b));
+    XYZZ<Fld> bk = XYZZ<Fld>::identity();
+    if (b < B) bk = load_elem(wb + b);
+    run = xyzz_add_ni(run, bk);
     acc = xyzz_add_ni(acc, run);
   }
   // suffix scan of lane totals across the workgroup: suf[t] = sum_{t' >= t} run[t']
   sh[tid] = run;
   __syncthreads();
   for (int off = 1; off < RED_THREADS; off <<= 1) {
-    XYZZ<Fld> tv = sh[tid];
-    if (tid + off < RED_THREADS) tv = xyzz_add_ni(tv, sh[tid + off]);
+    XYZZ<Fld> a = sh[tid];
+    XYZZ<Fld> b = XYZZ<Fld>::identity();
+    if (tid + off < RED_THREADS) b = sh[tid + off];
+    XYZZ<Fld> tv = xyzz_add_ni(a, b);
     __syncthreads();
     sh[tid] = tv;
     __syncthreads();
   }
   XYZZ<Fld> S = sh[0];
   // sum_t t * run[t] = sum_{j >= 1} suf[j]; the lane weight is t*RED_G, so multiply by RED_G afterwards
-  XYZZ<Fld> mine = tid >= 1 ? sh[tid] : XYZZ<Fld>::identity();
+  XYZZ<Fld> mine = XYZZ<Fld>::identity();
+  if (tid >= 1) mine = sh[tid];
   __syncthreads();
   XYZZ<Fld> T = block_reduce_sum(mine, sh);
   XYZZ<Fld> Asum = block_reduce_sum(acc, sh);
+  XYZZ<Fld> TG = T;
+  for (int g = 1; g < RED_G; g <<= 1) TG = xyzz_dbl_ni(TG);
+  XYZZ<Fld> A = xyzz_add_ni(Asum, TG);
   if (tid == 0) {
-    XYZZ<Fld> TG = T;
-    for (int g = 1; g < RED_G; g <<= 1) TG = xyzz_dbl_ni(TG);
-    XYZZ<Fld> A = xyzz_add_ni(Asum, TG);
     store_elem(out + ((size_t)blockIdx.x) * 2, S);
     store_elem(out + ((size_t)blockIdx.x) * 2 + 1, A);
   }
@@ -336,22 +348,38 @@ class MsmRunner {
     hipError_t _e = (x);                                     \
     if (_e != hipSuccess) return eng->hip_fail(_e, #x);      \
   } while (0)
+    const bool dbg = getenv("ZK_DEBUG_SYNC") != nullptr;
+#define MSM_STAGE(name)                                                          \
+  do {                                                                           \
+    if (dbg) {                                                                   \
+      hipError_t _e = hipStreamSynchronize(st);                                  \
+      fprintf(stderr, "[zk msm] %s done (%s) npts=%zu c=%d nwin=%d\n", name,     \
+              hipGetErrorString(_e), npts, c, nwin);                             \
+      if (_e != hipSuccess) return eng->hip_fail(_e, name);                      \
+    }                                                                            \
+  } while (0)
     MSM_HIP(hipMemsetAsync(counts, 0, nkeys * 4, st));
     dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
     msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
                                                 counts, nullptr, nullptr);
+    MSM_STAGE("digits/count");
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
                                                                                      nullptr, 0);
     iscan_carry_kernel<<<dim3(1), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks);
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
                                                                                      offsets, 1);
+    MSM_STAGE("scan");
     msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs);
+    MSM_STAGE("expand");
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
                                                 nullptr, cursor, sorted);
+    MSM_STAGE("scatter");
     msm_accumulate_kernel<Fld><<<dim3((unsigned)((max_segs + 127) / 128)), dim3(128), 0, st>>>(
         (const Affine<Fld>*)bases, sorted, segs, offsets, nkeys, partial);
+    MSM_STAGE("accumulate");
     msm_finalize_kernel<Fld><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
                                                                                           buckets);
+    MSM_STAGE("finalize");
     size_t red_lds = RED_THREADS * sizeof(XYZZ<Fld>);
     static bool attr_set = false;
     if (!attr_set && red_lds > 48 * 1024) {
@@ -361,10 +389,12 @@ class MsmRunner {
     }
     msm_reduce_kernel<Fld><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
     MSM_HIP(hipGetLastError());
+    MSM_STAGE("reduce");
     std::vector<XYZZ<Fld>> h((size_t)nwin * bpw * 2);
     MSM_HIP(hipMemcpyAsync(h.data(), out, h.size() * sizeof(XYZZ<Fld>), hipMemcpyDeviceToHost, st));
     MSM_HIP(hipStreamSynchronize(st));
 #undef MSM_HIP
+#undef MSM_STAGE
     // host: window value = sum_blk (A_blk + blk*RED_THREADS*RED_G * S_blk); fold windows high -> low
     XYZZ<Fld> total = XYZZ<Fld>::identity();
     for (int w = nwin - 1; w >= 0; w--) {

@@ -90,13 +90,13 @@ __global__ __launch_bounds__(KING_THREADS) void pss_unpack_kernel(const Fp<P>* _
 // the positions {h*Lc + k0 .. h*Lc + k0 + Wc - 1 : h < l}; these are exchanged through LDS and packed.
 //   in     : [np][Lc] (+ in_mask, optional)   out: [n][Lc] (+ out_mask, optional)
 //   gentab : gen^e, e in [0, m]               gtab: c*g^e, e in [0, Lc] or nullptr (g = 1, c = 1)
-//   gstep  : g^(Lc*e), e < l
+//   gstep  : g^(Lc*e), e < l                  in_scale: optional factor applied to every input share
 template <class P, int L, bool NEGATE>
 __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, uint32_t log_lc,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
-    const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, int rearrange, uint64_t seed,
-    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
+    const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
+    int rearrange, uint64_t seed, Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
 #pragma unroll 1
     for (int s = 0; s < np; s++) {
       F x = load_elem(in + ((size_t)s << log_lc) + k);
+      // d_ifft scales the share by 1/m BEFORE the mask is added (dfft/mod.rs:159 then :254-258); without a
+      // mask the factor is folded into gtab instead.
+      if (in_scale) x = mulsel<L>(x, load_elem(in_scale));
       if (in_mask) x = x + load_elem(in_mask + ((size_t)s << log_lc) + k);
 #pragma unroll
       for (int i = 0; i < L; i++) v[i] = v[i] + mulsel<L>(U[i * np + s], x);
