@@ -122,6 +122,52 @@ int zk_msm(zk_ctx* ctx, int group, const void* bases_d, size_t len_bases, const 
 int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, const void* in_mask,
              const void* out_mask, void* out, void* stream);
 
+/* ---- dealer: fixed-base multiplication -----------------------------------------------------------------
+ * out_affine_d[i] = scalars_d[i] * Base for one affine base point (host pointer).  With the trapdoor this is how
+ * CRS elements are produced, and -- because det_pack is linear -- how PackedProvingKeyShare::
+ * pack_from_arkworks_proving_key (groth16/src/proving_key.rs:47-123) is evaluated: det_pack the discrete logs
+ * with zk_pss_det_pack, then multiply the base. */
+int zk_base_mul(zk_ctx* ctx, int group, const void* base_affine, const void* scalars_d, size_t len,
+                void* out_affine_d, void* stream);
+
+/* ---- Groth16 composition (groth16/src/ext_wit.rs, prove.rs, examples/sha256.rs:32-129) -------------------
+ * All n parties' shares live on this device.  Mask slots may be NULL (the *::zero() masks).
+ * fft masks 0..2: the three d_ifft (a, b, c), 3..5: the three d_fft (ext_wit.rs:127-170), each [n][m/l];
+ * degred: [n][m/l]; msm masks in the order A (S), B-in-G1 (H), B-in-G2 (V), C.w (W), C.u (U): n Jacobian
+ * points each, host memory (sha256.rs:226-291). */
+typedef struct zk_groth16_masks {
+  const void* fft_in[6];
+  const void* fft_out[6];
+  const void* degred_in;
+  const void* degred_out;
+  const void* msm_in[5];
+  const void* msm_out[5];
+} zk_groth16_masks;
+
+/* PackedProvingKeyShare for all parties (groth16/src/proving_key.rs:18-37): share vectors are device
+ * buffers [n][len] of affine points, the single elements are host affine points. */
+typedef struct zk_crs_share {
+  const void* s_d;   /* a_query[1..]      G1 [n][len_a] */
+  const void* h_d;   /* b_g1_query[1..]   G1 [n][len_a] */
+  const void* v_d;   /* b_g2_query[1..]   G2 [n][len_a] */
+  const void* w_d;   /* l_query           G1 [n][len_w] */
+  const void* u_d;   /* h_query           G1 [n][len_u], len_u = m/l */
+  size_t len_a, len_w, len_u;
+  const void *a_query0, *b_g1_query0, *delta_g1, *alpha_g1, *beta_g1; /* G1 */
+  const void *b_g2_query0, *delta_g2, *beta_g2;                       /* G2 */
+} zk_crs_share;
+
+/* circom_h (ext_wit.rs:104-181): qap_*_d [n][m/l] are not modified; h_d [n][m/l]. */
+int zk_circom_h(zk_ctx* ctx, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream);
+/* dsha256 (sha256.rs:32-129) for all parties: a_share_d [n][len_a] = shares of assignment[1..], ax_share_d
+ * [n][len_w] = shares of the aux assignment; r, s: Montgomery Fr (host) -- every party holds r and s in the
+ * clear.  pi_a / pi_c: n Jacobian G1 points, pi_b: n Jacobian G2 points (host). */
+int zk_groth16_prove(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                     const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r, const void* s,
+                     int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,180 @@
+"""ctypes front end of oracle/c/libzkref.so (the plain-C restatement; TEST INFRASTRUCTURE / CPU BASELINE ONLY)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .params import CURVES
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "c", "libzkref.so")
+_lib = None
+
+NL = 4
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.run(["make", "-C", os.path.join(_HERE, "c")], check=True)
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+class FieldT(C.Structure):
+    _fields_ = [("mod", C.c_uint64 * NL), ("n0inv", C.c_uint64), ("r1", C.c_uint64 * NL), ("r2", C.c_uint64 * NL)]
+
+
+class DomainT(C.Structure):
+    _fields_ = [("log_size", C.c_int), ("size", C.c_size_t)] + [(k, C.c_uint64 * NL) for k in
+                                                                 ("gen", "gen_inv", "size_inv", "offset", "offset_inv")]
+
+
+class PssT(C.Structure):
+    _fields_ = [("F", FieldT), ("l", C.c_int), ("t", C.c_int), ("n", C.c_int), ("share", DomainT),
+                ("secret", DomainT), ("secret2", DomainT)]
+
+
+def _limbs(v):
+    return (C.c_uint64 * NL)(*[(v >> (64 * i)) & ((1 << 64) - 1) for i in range(NL)])
+
+
+class Field:
+    """4-limb Montgomery field description + int <-> limb codecs."""
+
+    def __init__(self, p):
+        assert p.bit_length() <= 256
+        self.p = p
+        self.bits = p.bit_length()
+        self.R = 1 << 256
+        self.Rinv = pow(self.R, -1, p)
+        self.ct = FieldT(_limbs(p), (-pow(p, -1, 1 << 64)) % (1 << 64), _limbs(self.R % p), _limbs(self.R * self.R % p))
+
+    def mont(self, v):
+        return _limbs(v % self.p * self.R % self.p)
+
+    def enc(self, vals):
+        out = np.empty((len(vals), NL), dtype=np.uint64)
+        mask = (1 << 64) - 1
+        for i, v in enumerate(vals):
+            m = v % self.p * self.R % self.p
+            for k in range(NL):
+                out[i, k] = (m >> (64 * k)) & mask
+        return out
+
+    def dec(self, arr):
+        arr = np.asarray(arr, dtype=np.uint64).reshape(-1, NL)
+        out = []
+        for row in arr:
+            m = sum(int(row[k]) << (64 * k) for k in range(NL))
+            out.append(m * self.Rinv % self.p)
+        return out
+
+
+def _domain(fld, d):
+    return DomainT(d.log_size, d.size, fld.mont(d.group_gen), fld.mont(d.group_gen_inv), fld.mont(d.size_inv),
+                   fld.mont(d.offset), fld.mont(d.offset_inv))
+
+
+class CPss:
+    """PackedSharingParams for the C side, built from the Python oracle's domain constants."""
+
+    def __init__(self, curve_name, l):
+        from .pss import PackedSharingParams
+        self.curve = CURVES[curve_name]
+        self.opp = PackedSharingParams(self.curve, l)
+        self.fr = Field(self.curve.r)
+        self.fq = Field(self.curve.q) if self.curve.q.bit_length() <= 256 else None
+        o = self.opp
+        self.ct = PssT(self.fr.ct, o.l, o.t, o.n, _domain(self.fr, o.share), _domain(self.fr, o.secret),
+                       _domain(self.fr, o.secret2))
+        self.l, self.t, self.n = o.l, o.t, o.n
+
+    @staticmethod
+    def _p(arr):
+        return arr.ctypes.data_as(C.c_void_p)
+
+    def fft1(self, vec, gen):
+        a = self.fr.enc(vec)
+        lib().zkref_fft1(C.byref(self.ct), self._p(a), C.c_size_t(len(vec)), self.fr.mont(gen))
+        return self.fr.dec(a)
+
+    def d_fft_arrays(self, shares, mbyl, gen, size_inv, g, rearrange, in_mask, out_mask, seed):
+        """shares: uint64 array [n*mbyl][4] modified in place (gen, size_inv, g are ints)."""
+        lib().zkref_d_fft(C.byref(self.ct), self._p(shares), C.c_size_t(mbyl), self.fr.mont(gen),
+                          None if size_inv is None else self.fr.mont(size_inv), None if g is None else self.fr.mont(g),
+                          int(rearrange), None if in_mask is None else self._p(in_mask),
+                          None if out_mask is None else self._p(out_mask), C.c_uint64(seed), self.fr.bits)
+        return shares
+
+    def d_fft(self, shares, dom, rearrange, masks=None, seed=0, inverse=False, g=None):
+        """list-of-lists front end mirroring oracle.dist.d_fft / d_ifft."""
+        n, mbyl = len(shares), len(shares[0])
+        a = self.fr.enc([v for s in shares for v in s])
+        im = om = None
+        if masks is not None:
+            im = self.fr.enc([v for mk in masks for v in mk.in_mask])
+            om = self.fr.enc([v for mk in masks for v in mk.out_mask])
+        gen = dom.group_gen_inv if inverse else dom.group_gen
+        self.d_fft_arrays(a, mbyl, gen, dom.size_inv if inverse else None, g, rearrange, im, om, seed)
+        flat = self.fr.dec(a)
+        return [flat[i * mbyl:(i + 1) * mbyl] for i in range(n)]
+
+    def deg_red_arrays(self, x, ln, in_mask, out_mask, seed):
+        lib().zkref_deg_red(C.byref(self.ct), self._p(x), C.c_size_t(ln), None if in_mask is None else self._p(in_mask),
+                            None if out_mask is None else self._p(out_mask), C.c_uint64(seed), self.fr.bits)
+        return x
+
+    def deg_red(self, x, masks, seed):
+        n, ln = len(x), len(x[0])
+        a = self.fr.enc([v for s in x for v in s])
+        im = om = None
+        if masks is not None:
+            im = self.fr.enc([v for mk in masks for v in mk.in_mask])
+            om = self.fr.enc([v for mk in masks for v in mk.out_mask])
+        self.deg_red_arrays(a, ln, im, om, seed)
+        flat = self.fr.dec(a)
+        return [flat[i * ln:(i + 1) * ln] for i in range(n)]
+
+    def mul_sub_arrays(self, a, b, c):
+        out = np.empty_like(a)
+        lib().zkref_mul_sub(C.byref(self.fr.ct), self._p(a), self._p(b), self._p(c), C.c_size_t(a.shape[0]), self._p(out))
+        return out
+
+    # ---- group side (4-limb base fields only: BN254) ----
+    def msm_g1_arrays(self, bases, scalars, n, nthreads=1):
+        """bases uint64 [n][8] affine Montgomery, scalars uint64 [n][4]; returns uint64[12] Jacobian."""
+        out = np.zeros(12, dtype=np.uint64)
+        lib().zkref_msm_g1(C.byref(self.fr.ct), C.byref(self.fq.ct), self.fr.bits, self._p(bases), self._p(scalars),
+                           C.c_size_t(n), nthreads, self._p(out))
+        return out
+
+    def msm_g2_arrays(self, bases, scalars, n, nthreads=1):
+        out = np.zeros(24, dtype=np.uint64)
+        lib().zkref_msm_g2(C.byref(self.fr.ct), C.byref(self.fq.ct), self.fr.bits, self._p(bases), self._p(scalars),
+                           C.c_size_t(n), nthreads, self._p(out))
+        return out
+
+    def msm_g1(self, pts, scalars, nthreads=1):
+        b = self.fq.enc([c for p in pts for c in ((0, 0) if p is None else p)]).reshape(len(pts), 8)
+        s = self.fr.enc(scalars)
+        v = self.fq.dec(self.msm_g1_arrays(b, s, len(pts), nthreads))
+        return (v[0], v[1], v[2])
+
+    def msm_g2(self, pts, scalars, nthreads=1):
+        flat = []
+        for p in pts:
+            flat += [0, 0, 0, 0] if p is None else [p[0][0], p[0][1], p[1][0], p[1][1]]
+        b = self.fq.enc(flat).reshape(len(pts), 16)
+        s = self.fr.enc(scalars)
+        v = self.fq.dec(self.msm_g2_arrays(b, s, len(pts), nthreads))
+        return ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+
+    def doubling_chain_g1(self, p, n):
+        """affine uint64 [n][8]: 2^i * p"""
+        base = self.fq.enc(list(p)).reshape(-1)
+        out = np.zeros((n, 8), dtype=np.uint64)
+        lib().zkref_g1_doubling_chain(C.byref(self.fq.ct), self._p(base), C.c_size_t(n), self._p(out))
+        return out

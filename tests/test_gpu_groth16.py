@@ -1,0 +1,158 @@
+"""GPU parity for the Groth16 composition (groth16/src/ext_wit.rs, prove.rs, examples/sha256.rs)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import zksaas_amd as zk
+from zksaas_amd import groth16 as zg
+from zksaas_amd import sha256_circuit as sc
+from oracle import dist as od
+from oracle import groth16 as og
+from oracle import ser
+from oracle.curve import g1, g2, GroupOps
+from oracle.field import Domain
+from oracle.params import BN254
+from oracle.prng import rand_fp
+
+from gpu_util import ctx, opp, down_parties, up_parties, dec_jacobian, enc_jacobian
+from test_oracle_groth16 import small_r1cs
+
+P = BN254.r
+
+
+def _trapdoor(seed):
+    return [rand_fp(seed, i, P) for i in range(5)]
+
+
+def test_circom_h_matches_oracle():  # ext_wit.rs:419-538 (a = b = [0..m), c = a*b), masked
+    m, l = 1024, 2
+    pp, o = ctx("bn254", l), opp("bn254", l)
+    dom = Domain(BN254, m)
+    a = list(range(m))
+    c = [x * x % P for x in a]
+    qs = og.QAP(0, 0, a, a, c, dom).pss(o, 3)
+    w2m = Domain(BN254, 2 * m).element(1)
+    fm = ([od.FftMask.sample(True, w2m, dom.group_gen_inv, m, o, 40 + k) for k in range(3)]
+          + [od.FftMask.sample(False, 1, dom.group_gen, m, o, 50 + k) for k in range(3)])
+    dm = od.DegRedMask.sample(o, 1, m // l, 60)
+    want = og.circom_h(qs, fm, dm, o, dom, seed=4)
+    bufs = [up_parties(pp, [qs[i][k] for i in range(o.n)]) for k in range(3)]
+    keep = []
+    mk = zg.Masks()
+    for k in range(6):
+        bi = up_parties(pp, [x.in_mask for x in fm[k]])
+        bo = up_parties(pp, [x.out_mask for x in fm[k]])
+        keep += [bi, bo]
+        mk.fft_in[k], mk.fft_out[k] = bi.ptr, bo.ptr
+    di, do = up_parties(pp, [x.in_mask for x in dm]), up_parties(pp, [x.out_mask for x in dm])
+    mk.degred_in, mk.degred_out = di.ptr, do.ptr
+    h = pp.alloc_fr(o.n * (m // l))
+    pp._check(pp.lib.zk_circom_h(pp.h, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, 10, C.byref(mk), 4, h.ptr, None))
+    assert down_parties(pp, h, o.n, m // l) == want
+    # reconstructs to the in-test reference (ext_wit.rs:239-285) through unpack2
+    assert pp.download_fr(pp.unpack2(h, m // l)) == og.circom_ref(a, a, c, dom)
+
+
+def _reconstruct(o, G, ops, shares):
+    return o.unpack2(shares, ops)[0]          # sha256.rs:375-377
+
+
+@pytest.mark.parametrize("r_zero", [False, True])
+def test_small_circuit_proof_equals_oracle(r_zero):
+    """sha256.rs flow on a small R1CS: GPU (setup + dealing + prover) == oracle local prover == closed form."""
+    r1, w = small_r1cs()
+    pp, o = ctx("bn254", 2), opp("bn254", 2)
+    td = _trapdoor(42)
+    setup = zg.SetupScalars("bn254", r1, *td)
+    okey = og.setup_scalars(BN254, r1, og.Trapdoor(*td))
+    assert setup.a_query == okey.a_query and setup.b_query == okey.b_query
+    assert setup.l_query == okey.l_query and setup.h_query == okey.h_query
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bn254", r1, w, seed=5)
+    r = 0 if r_zero else rand_fp(43, 0, P)
+    s = rand_fp(43, 1, P)
+    pa, pb, pc = zg.prove(pp, crs, wit, r, s, seed=9)
+    G1, G2 = g1(BN254), g2(BN254)
+    o1, o2 = GroupOps(G1), GroupOps(G2)
+    A = _reconstruct(o, G1, o1, [dec_jacobian(pp, pa[i]) for i in range(o.n)])
+    B = _reconstruct(o, G2, o2, [dec_jacobian(pp, pb[i], True) for i in range(o.n)])
+    Cc = _reconstruct(o, G1, o1, [dec_jacobian(pp, pc[i]) for i in range(o.n)])
+    sa, sb, sc_ = og.prove_scalars(BN254, r1, okey, w, r, s)
+    assert og.verify_scalars(BN254, r1, okey, w, (sa, sb, sc_))
+    assert G1.eq(A, G1.mul(G1.from_affine(BN254.g1), sa))
+    assert G2.eq(B, G2.mul(G2.from_affine(BN254.g2), sb))
+    assert G1.eq(Cc, G1.mul(G1.from_affine(BN254.g1), sc_))
+    # identical compressed proof bytes vs the oracle's arkworks-style local prover
+    pk = og.proving_key_points(okey, G1, G2)
+    lA, lB, lC = og.create_proof_local(BN254, r1, pk, G1, G2, w, r, s)
+    enc = lambda a, b, c: ser.proof_compressed(G1.to_affine(a), G2.to_affine(b), G1.to_affine(c), BN254.q)
+    assert enc(A, B, Cc) == enc(lA, lB, lC)
+
+
+def test_small_circuit_with_all_masks():
+    r1, w = small_r1cs()
+    pp, o = ctx("bn254", 2), opp("bn254", 2)
+    td = _trapdoor(44)
+    setup = zg.SetupScalars("bn254", r1, *td)
+    okey = og.setup_scalars(BN254, r1, og.Trapdoor(*td))
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bn254", r1, w, seed=6)
+    m, l = setup.m, 2
+    dom = Domain(BN254, m)
+    G1, G2 = g1(BN254), g2(BN254)
+    o1, o2 = GroupOps(G1), GroupOps(G2)
+    keep = []
+    mk = zg.Masks()
+    for k in range(6):
+        fmk = zk.FftMask.sample(pp, k < 3, Domain(BN254, 2 * m).element(1) if k < 3 else None, 1 if k < 3 else 0,
+                                setup.log_m, 100 + k)
+        keep.append(fmk)
+        mk.fft_in[k], mk.fft_out[k] = fmk.in_mask.ptr, fmk.out_mask.ptr
+    dm = zk.DegRedMask.sample(pp, m // l, 200)
+    mk.degred_in, mk.degred_out = dm.in_mask.ptr, dm.out_mask.ptr
+    for k in range(5):
+        G, ops, is2 = (G2, o2, True) if k == 2 else (G1, o1, False)
+        om = od.MsmMask.sample(o, G, ops, 300 + k)
+        ai = np.stack([enc_jacobian(pp, x.in_mask, is2) for x in om])
+        ao = np.stack([enc_jacobian(pp, x.out_mask, is2) for x in om])
+        keep += [ai, ao]
+        mk.msm_in[k], mk.msm_out[k] = ai.ctypes.data, ao.ctypes.data
+    r, s = rand_fp(45, 0, P), rand_fp(45, 1, P)
+    pa, pb, pc = zg.prove(pp, crs, wit, r, s, masks=mk, seed=11)
+    A = _reconstruct(o, G1, o1, [dec_jacobian(pp, pa[i]) for i in range(o.n)])
+    B = _reconstruct(o, G2, o2, [dec_jacobian(pp, pb[i], True) for i in range(o.n)])
+    Cc = _reconstruct(o, G1, o1, [dec_jacobian(pp, pc[i]) for i in range(o.n)])
+    sa, sb, sc_ = og.prove_scalars(BN254, r1, okey, w, r, s)
+    assert G1.eq(A, G1.mul(G1.from_affine(BN254.g1), sa))
+    assert G2.eq(B, G2.mul(G2.from_affine(BN254.g2), sb))
+    assert G1.eq(Cc, G1.mul(G1.from_affine(BN254.g1), sc_))
+
+
+def test_sha256_fixture_proof():
+    """BASELINE configs 1/4: the SHA-256 circuit (a = 1, b = 2), m = 2^15, l = 2, n = 8."""
+    r1, w = sc.build(1, 2, P)
+    assert w[1] == 72587776472194017031617589674261467945970986113287823188107011979     # sha256.rs:392-393
+    pp, o = ctx("bn254", 2), opp("bn254", 2)
+    td = _trapdoor(42)
+    setup = zg.SetupScalars("bn254", r1, *td)
+    assert setup.log_m == 15
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bn254", r1, w, seed=7)
+    assert crs.len_u == 16384 and crs.len_a == (r1.num_variables - 1 + 1) // 2
+    r, s = rand_fp(43, 0, P), rand_fp(43, 1, P)
+    pa, pb, pc = zg.prove(pp, crs, wit, r, s, seed=13)
+    G1, G2 = g1(BN254), g2(BN254)
+    o1, o2 = GroupOps(G1), GroupOps(G2)
+    A = _reconstruct(o, G1, o1, [dec_jacobian(pp, pa[i]) for i in range(o.n)])
+    B = _reconstruct(o, G2, o2, [dec_jacobian(pp, pb[i], True) for i in range(o.n)])
+    Cc = _reconstruct(o, G1, o1, [dec_jacobian(pp, pc[i]) for i in range(o.n)])
+    R = og.R1CS(2, r1.num_witness_variables, r1.a, r1.b, r1.c)
+    okey = og.setup_scalars(BN254, R, og.Trapdoor(*td))
+    sa, sb, sc_ = og.prove_scalars(BN254, R, okey, w, r, s)
+    assert og.verify_scalars(BN254, R, okey, w, (sa, sb, sc_))          # the Groth16 equation holds
+    assert G1.eq(A, G1.mul(G1.from_affine(BN254.g1), sa))
+    assert G2.eq(B, G2.mul(G2.from_affine(BN254.g2), sb))
+    assert G1.eq(Cc, G1.mul(G1.from_affine(BN254.g1), sc_))

@@ -1,0 +1,99 @@
+"""The plain-C restatement (oracle/c/zkref.c) pinned against the Python big-int oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import dist as od
+from oracle.cref import CPss, Field, lib
+from oracle.curve import g1, g2
+from oracle.dist import transpose
+from oracle.field import Domain, bitrev_permute
+from oracle.params import CURVES, BN254
+from oracle.prng import rand_fp, rand_vec
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_377", "bls12_381"])
+def test_field_ops(name):
+    p = CURVES[name].r
+    F = Field(p)
+    a, b = rand_vec(1, 50, p), rand_vec(2, 50, p)
+    a[0], b[0], a[1] = 0, p - 1, p - 1
+    ea, eb = F.enc(a), F.enc(b)
+    out = np.zeros((1, 4), dtype=np.uint64)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    for i in range(50):
+        for fn, want in (("zkref_mul", a[i] * b[i] % p), ("zkref_add", (a[i] + b[i]) % p),
+                         ("zkref_sub", (a[i] - b[i]) % p)):
+            getattr(lib(), fn)(C.byref(F.ct), vp(ea[i]), vp(eb[i]), vp(out))
+            assert F.dec(out)[0] == want
+    lib().zkref_inv(C.byref(F.ct), vp(eb[3]), vp(out))
+    assert F.dec(out)[0] == pow(b[3], p - 2, p)
+
+
+@pytest.mark.parametrize("name,l,m,rearrange,inverse", [
+    ("bls12_377", 2, 8, False, False), ("bls12_377", 2, 1024, True, False), ("bn254", 4, 64, True, True),
+    ("bn254", 2, 256, False, True), ("bls12_381", 8, 64, False, False)])
+def test_d_fft_shares_equal_python_oracle(name, l, m, rearrange, inverse):
+    cp = CPss(name, l)
+    o = cp.opp
+    dom = Domain(CURVES[name], m)
+    x = rand_vec(3, m, o.p)
+    y = list(x)
+    bitrev_permute(y)
+    shares = transpose(od.stride_pack(y, o, 4))
+    g = Domain(CURVES[name], 2 * m).element(1) if inverse else 1
+    gen = dom.group_gen_inv if inverse else dom.group_gen
+    masks = od.FftMask.sample(rearrange, g, gen, m, o, 5)
+    if inverse:
+        want = od.d_ifft(shares, masks, rearrange, dom, g, o, seed=6)
+    else:
+        want = od.d_fft(shares, masks, rearrange, dom, o, seed=6)
+    got = cp.d_fft(shares, dom, rearrange, masks, seed=6, inverse=inverse, g=g if inverse else None)
+    assert got == want
+
+
+def test_fft1_and_deg_red():
+    cp = CPss("bn254", 2)
+    o = cp.opp
+    dom = Domain(BN254, 128)
+    v = rand_vec(7, 64, o.p)
+    assert cp.fft1(v, dom.group_gen) == od.fft1_in_place(list(v), o, dom.group_gen)
+    shares = transpose(od.pack_vec(rand_vec(8, 32, o.p), o, 9))
+    mul = [[a * a % o.p for a in s] for s in shares]
+    masks = od.DegRedMask.sample(o, 1, 16, 10)
+    assert cp.deg_red(mul, masks, 11) == od.deg_red(mul, masks, o, seed=11)
+
+
+@pytest.mark.parametrize("count,threads", [(1, 1), (31, 1), (200, 1), (200, 4)])
+def test_msm_g1(count, threads):
+    cp = CPss("bn254", 2)
+    G = g1(BN254)
+    gen = G.from_affine(G.gen)
+    pts = G.batch_to_affine([G.mul(gen, rand_fp(12, i, BN254.r)) for i in range(count)])
+    if count > 3:
+        pts[2] = None
+    sc = rand_vec(13, count, BN254.r)
+    if count > 5:
+        sc[4], sc[5] = 0, BN254.r - 1
+    assert G.eq(cp.msm_g1(pts, sc, threads), G.msm(pts, sc))
+
+
+def test_msm_g2():
+    cp = CPss("bn254", 2)
+    G = g2(BN254)
+    gen = G.from_affine(G.gen)
+    pts = G.batch_to_affine([G.mul(gen, rand_fp(14, i, BN254.r)) for i in range(40)])
+    sc = rand_vec(15, 40, BN254.r)
+    assert G.eq(cp.msm_g2(pts, sc), G.msm(pts, sc))
+
+
+def test_doubling_chain():
+    cp = CPss("bn254", 2)
+    G = g1(BN254)
+    chain = cp.doubling_chain_g1(BN254.g1, 6)
+    P = G.from_affine(BN254.g1)
+    for i in range(6):
+        aff = G.to_affine(P)
+        assert cp.fq.dec(chain[i]) == [aff[0], aff[1]]
+        P = G.double(P)

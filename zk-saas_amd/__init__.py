@@ -5,3 +5,4 @@ from . import fields  # noqa: F401
 from ._lib import LIB_PATH, SYMBOLS, ZkError, load  # noqa: F401
 from .api import (Context, DeviceBuffer, FftMask, DegRedMask, MsmMask, PackedSharingParams, d_fft, d_ifft, d_msm,  # noqa: F401
                   d_pp, deg_red)
+from . import groth16, sha256_circuit  # noqa: F401,E402

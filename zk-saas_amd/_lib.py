@@ -12,7 +12,7 @@ SYMBOLS = [
     "zk_fq_bytes", "zk_malloc", "zk_free", "zk_memcpy_h2d", "zk_memcpy_d2h", "zk_stream_sync", "zk_pss_pack",
     "zk_pss_det_pack", "zk_pss_unpack", "zk_pss_unpack2", "zk_bitrev", "zk_vec_add", "zk_vec_mul_sub", "zk_fft1",
     "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
-    "zk_msm", "zk_d_msm",
+    "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove",
 ]
 
 _lib = None
@@ -69,5 +69,8 @@ def load():
     lib.zk_d_pp.argtypes = [vp, vp, vp, vp, vp, sz, u64, vp, vp]
     lib.zk_msm.argtypes = [vp, i32, vp, sz, vp, sz, vp, vp]
     lib.zk_d_msm.argtypes = [vp, i32, vp, vp, sz, vp, vp, vp, vp]
+    lib.zk_base_mul.argtypes = [vp, i32, vp, vp, sz, vp, vp]
+    lib.zk_circom_h.argtypes = [vp, vp, vp, vp, i32, vp, u64, vp, vp]
+    lib.zk_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, vp, vp, vp]
     _lib = lib
     return lib

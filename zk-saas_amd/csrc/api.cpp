@@ -184,4 +184,23 @@ int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d,
   return e->d_msm(group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
 }
 
+int zk_base_mul(zk_ctx* ctx, int group, const void* base_affine, const void* scalars_d, size_t len,
+                void* out_affine_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->base_mul(group, base_affine, scalars_d, len, out_affine_d, S(stream));
+}
+int zk_circom_h(zk_ctx* ctx, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->circom_h(qap_a_d, qap_b_d, qap_c_d, log2_m, masks, seed, h_d, S(stream));
+}
+int zk_groth16_prove(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                     const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r, const void* s,
+                     int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
+                     void* stream) {
+  CTX_OR_FAIL();
+  return e->groth16_prove(crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed, pi_a,
+                          pi_b, pi_c, S(stream));
+}
+
 }  // extern "C"

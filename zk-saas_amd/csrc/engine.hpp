@@ -62,6 +62,14 @@ class IEngine {
                   hipStream_t st) = 0;
   virtual int d_msm(int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
                     const void* out_mask, void* out, hipStream_t st) = 0;
+  virtual int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
+                       hipStream_t st) = 0;
+  virtual int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* masks,
+                       uint64_t seed, void* h, hipStream_t st) = 0;
+  virtual int groth16_prove(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                            const void* a_share, const void* ax_share, const void* r, const void* s, int log_m,
+                            const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
+                            hipStream_t st) = 0;
 };
 
 IEngine* make_engine_bn254(int l, int device);

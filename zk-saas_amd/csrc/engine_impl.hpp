@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "engine.hpp"
+#include "groth16.hpp"
 #include "msm.hpp"
 
 namespace zk {
@@ -48,6 +49,7 @@ class Engine : public IEngine {
       (void)hipFree(kv.second.tab);
       (void)hipFree(kv.second.step);
     }
+    for (auto& kv : base_tables_) (void)hipFree(kv.second);
     for (auto& kv : umats_) (void)hipFree(kv.second);
     for (auto& kv : sizeinv_) (void)hipFree(kv.second);
     if (pmat_) (void)hipFree(pmat_);
@@ -577,7 +579,193 @@ class Engine : public IEngine {
     return msm_.d_msm(this, group, bases, scalars, len, in_mask, out_mask, out, st);
   }
 
+  // ---------------------------------------------------------------- fixed-base multiplication (dealer)
+  template <class Fld>
+  int base_mul_t(const void* base_affine, const void* scalars, size_t len, void* out_affine, hipStream_t st) {
+    if (!len) return ZK_OK;
+    if (!base_affine || !scalars || !out_affine) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const int nwin = (FrP::BITS + 7) / 8;
+    std::string key((const char*)base_affine, sizeof(Affine<Fld>));
+    Affine<Fld>* table = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = base_tables_.find(key);
+      if (it != base_tables_.end()) table = (Affine<Fld>*)it->second;
+    }
+    if (!table) {
+      // table[w][d-1] = d * 256^w * Base, built on the host
+      Affine<Fld> base;
+      memcpy(&base, base_affine, sizeof(base));
+      std::vector<Affine<Fld>> h((size_t)nwin * 255);
+      XYZZ<Fld> wbase = XYZZ<Fld>::from_affine(base);
+      for (int w = 0; w < nwin; w++) {
+        XYZZ<Fld> cur = wbase;
+        for (int d = 1; d <= 255; d++) {
+          h[(size_t)w * 255 + d - 1] = xyzz_to_affine(cur);
+          cur = xyzz_add_ni(cur, wbase);
+        }
+        wbase = cur;   // 256 * previous
+      }
+      ZK_HIP(hipMalloc((void**)&table, h.size() * sizeof(Affine<Fld>)));
+      ZK_HIP(hipMemcpy(table, h.data(), h.size() * sizeof(Affine<Fld>), hipMemcpyHostToDevice));
+      std::lock_guard<std::mutex> lk(mu_);
+      base_tables_[key] = table;
+    }
+    fixed_base_mul_kernel<FrP, Fld><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
+        (const Fr*)scalars, len, table, nwin, (Affine<Fld>*)out_affine);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
+               hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (group == ZK_G1) return base_mul_t<Fq>(base_affine, scalars, len, out_affine, st);
+    if (group == ZK_G2) {
+      if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+      return base_mul_t<Fq2>(base_affine, scalars, len, out_affine, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
+  }
+
+  // ---------------------------------------------------------------- circom_h (ext_wit.rs:104-181)
+  int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
+               void* h, hipStream_t st) override {
+    int log_l = ilog2(l);
+    if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large for this field");
+    if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    size_t Lc = ((size_t)1 << log_m) / l;
+    size_t per = (size_t)n * Lc;
+    ZK_HIP(hwork_.ensure(6 * per * sizeof(Fr)));
+    Fr* W0 = (Fr*)hwork_.p;
+    Fr* W1 = W0 + 3 * per;
+    const void* q[3] = {qa, qb, qc};
+    for (int k = 0; k < 3; k++)
+      ZK_HIP(hipMemcpyAsync(W0 + k * per, q[k], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    Fr w2m = root_of_unity(log_m + 1);     // Radix2EvaluationDomain::new(2m).element(1), ext_wit.rs:120-125
+    // 3 x d_ifft(rearrange = true, g = w_2m)   (ext_wit.rs:127-159)
+    int rc = fft1(W0, log_m, 1, 3 * (size_t)n, nullptr, st);
+    if (rc) return rc;
+    for (int k = 0; k < 3; k++) {
+      rc = fft2_king(W0 + k * per, mk ? mk->fft_in[k] : nullptr, nullptr, n, log_m, 1, &w2m, 1, 1, seed + k,
+                     W1 + k * per, mk ? mk->fft_out[k] : nullptr, st);
+      if (rc) return rc;
+    }
+    // 3 x d_fft(rearrange = false)             (ext_wit.rs:161-170)
+    rc = fft1(W1, log_m, 0, 3 * (size_t)n, nullptr, st);
+    if (rc) return rc;
+    for (int k = 0; k < 3; k++) {
+      rc = fft2_king(W1 + k * per, mk ? mk->fft_in[3 + k] : nullptr, nullptr, n, log_m, 0, nullptr, 0, 0, seed + 3 + k,
+                     W0 + k * per, mk ? mk->fft_out[3 + k] : nullptr, st);
+      if (rc) return rc;
+    }
+    // h = a*b - c share-wise, then deg_red     (ext_wit.rs:173-179)
+    rc = vec_mul_sub(h, W0, W0 + per, W0 + 2 * per, per, st);
+    if (rc) return rc;
+    return deg_red_np((const Fr*)h, mk ? (const Fr*)mk->degred_in : nullptr, nullptr, n, Lc, seed + 6, (Fr*)h,
+                      mk ? (const Fr*)mk->degred_out : nullptr, st);
+  }
+
+  // ---------------------------------------------------------------- prover (prove.rs, sha256.rs:32-129)
+  int groth16_prove(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
+                    const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
+                    uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    using P1 = XYZZ<Fq>;
+    using P2 = XYZZ<Fq2>;
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    if (!crs || !r_ || !s_ || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    size_t Lc = ((size_t)1 << log_m) / l;
+    if (crs->len_u != Lc) return fail(ZK_ERR_BAD_INPUT, "h_query share length must be m/l");   // dmsm/mod.rs:71
+    Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
+    auto aff1 = [](const void* p) {
+      Affine<Fq> a;
+      memcpy(&a, p, sizeof(a));
+      return P1::from_affine(a);
+    };
+    auto aff2 = [](const void* p) {
+      Affine<Fq2> a;
+      memcpy(&a, p, sizeof(a));
+      return P2::from_affine(a);
+    };
+    // scalar multiples of CRS constants do not depend on the device work: overlap them with it
+    P1 rN, sK, rsM;
+    P2 sK2;
+    std::thread host([&]() {
+      P1 d1 = aff1(crs->delta_g1);
+      rN = host_scalar_mul<FrP, Fq>(d1, r);
+      sK = host_scalar_mul<FrP, Fq>(d1, s);
+      rsM = host_scalar_mul<FrP, Fq>(d1, r * s);
+      sK2 = host_scalar_mul<FrP, Fq2>(aff2(crs->delta_g2), s);
+    });
+    struct Joiner {
+      std::thread& t;
+      ~Joiner() {
+        if (t.joinable()) t.join();
+      }
+    } joiner{host};
+
+    ZK_HIP(hshare_.ensure((size_t)n * Lc * sizeof(Fr)));
+    int rc = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, st);
+    if (rc) return rc;
+    P1 S, H, W, U;
+    P2 V;
+    const bool r_zero = r.is_zero();
+    rc = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S, st);
+    if (rc) return rc;
+    if (!r_zero) {
+      rc = msm_.template d_msm_sum_t<Fq>(this, crs->h_d, a_share, crs->len_a, mk ? mk->msm_in[1] : nullptr, &H, st);
+      if (rc) return rc;
+    }
+    rc = msm_.template d_msm_sum_t<Fq2>(this, crs->v_d, a_share, crs->len_a, mk ? mk->msm_in[2] : nullptr, &V, st);
+    if (rc) return rc;
+    rc = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W, st);
+    if (rc) return rc;
+    rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, st);
+    if (rc) return rc;
+    host.join();
+
+    // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party (shares differ only through the out-masks)
+    P1 cA = xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1));
+    P1 cB1 = xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1));
+    P2 cB2 = xyzz_add_ni(xyzz_add_ni(aff2(crs->b_g2_query0), sK2), aff2(crs->beta_g2));
+    auto om1 = [&](int k, int p, const P1& v) {
+      if (!mk || !mk->msm_out[k]) return v;
+      return xyzz_add_ni(v, jacobian_to_xyzz(((const Jacobian<Fq>*)mk->msm_out[k])[p]));
+    };
+    Jacobian<Fq>* oa = (Jacobian<Fq>*)pi_a;
+    Jacobian<Fq2>* ob = (Jacobian<Fq2>*)pi_b;
+    Jacobian<Fq>* oc = (Jacobian<Fq>*)pi_c;
+    const bool uniform = !mk || (!mk->msm_out[0] && !mk->msm_out[1] && !mk->msm_out[2] && !mk->msm_out[3] &&
+                                 !mk->msm_out[4]);
+    for (int p = 0; p < n; p++) {
+      if (uniform && p > 0) {
+        oa[p] = oa[0];
+        ob[p] = ob[0];
+        oc[p] = oc[0];
+        continue;
+      }
+      P1 A = xyzz_add_ni(cA, om1(0, p, S));
+      P1 B1 = r_zero ? P1::identity() : xyzz_add_ni(cB1, om1(1, p, H));
+      P2 Vp = V;
+      if (mk && mk->msm_out[2]) Vp = xyzz_add_ni(Vp, jacobian_to_xyzz(((const Jacobian<Fq2>*)mk->msm_out[2])[p]));
+      P2 B2 = xyzz_add_ni(cB2, Vp);
+      P1 C = xyzz_add_ni(host_scalar_mul<FrP, Fq>(A, s), host_scalar_mul<FrP, Fq>(B1, r));
+      C = xyzz_add_ni(C, rsM.neg());
+      C = xyzz_add_ni(C, om1(3, p, W));
+      C = xyzz_add_ni(C, om1(4, p, U));
+      oa[p] = xyzz_to_jacobian(A);
+      ob[p] = xyzz_to_jacobian(B2);
+      oc[p] = xyzz_to_jacobian(C);
+    }
+    return ZK_OK;
+  }
+
   bool force_simple_ntt = false;
+  std::map<std::string, void*> base_tables_;
+  DevBuf hwork_, hshare_;
   Fr* pmat_ = nullptr;
   Fr* ident_ = nullptr;
   int* err_flag_ = nullptr;

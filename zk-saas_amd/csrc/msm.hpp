@@ -454,30 +454,38 @@ class MsmRunner {
   //   king output = sum_k unpack2(c_shares)[k] = sum_p coef_p * (msm_p + in_mask_p),  coef_p = sum_k U2[k][p]
   // and sum_p coef_p * msm_p is ONE msm over the n*len points with scalars pre-multiplied by coef_p; the
   // n in-mask points ride along as extra bases with scalars coef_p.
+  // sum_p coef_p * (msm_p + in_mask_p): what the king reconstructs and sums (dmsm/mod.rs:85-86)
+  template <class Fld>
+  int d_msm_sum_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                  XYZZ<Fld>* result, hipStream_t st) {
+    const int n = eng->n;
+    XYZZ<Fld> r;
+    int rc = run_t<Fld>(eng, bases, scalars, (size_t)n * len, coef_d_, len, &r, st);
+    if (rc) return rc;
+    if (in_mask) {
+      // the n in-mask points contribute sum_p coef_p * mask_p (n host scalar multiplications)
+      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
+      std::vector<Affine<Fld>> aff(n);
+      for (int p = 0; p < n; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
+      std::vector<char> mt = host_lincomb<Fld>(aff);
+      r = xyzz_add_ni(r, *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
+    }
+    *result = r;
+    return ZK_OK;
+  }
+
   template <class Fld>
   int d_msm_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const void* in_mask,
               const void* out_mask, void* out, hipStream_t st) {
     const int n = eng->n;
     XYZZ<Fld> r;
-    size_t npts = (size_t)n * len;
-    const void* b = bases;
-    const void* s = scalars;
-    if (in_mask) {
-      // append n affine mask points and scalars 1 (their coefficient comes from coef[part])
-      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
-      std::vector<Affine<Fld>> aff(n);
-      for (int p = 0; p < n; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
-      // masks are folded on the host instead: sum_p coef_p * mask_p (n small scalar multiplications)
-      mask_term_ = host_lincomb<Fld>(aff);
-    }
-    int rc = run_t<Fld>(eng, b, s, npts, coef_d_, len, &r, st);
+    int rc = d_msm_sum_t<Fld>(eng, bases, scalars, len, in_mask, &r, st);
     if (rc) return rc;
-    if (in_mask) r = xyzz_add(r, *reinterpret_cast<XYZZ<Fld>*>(mask_term_.data()));
     const Jacobian<Fld>* om = (const Jacobian<Fld>*)out_mask;
     Jacobian<Fld>* o = (Jacobian<Fld>*)out;
     for (int p = 0; p < n; p++) {
       XYZZ<Fld> v = r;
-      if (om) v = xyzz_add(v, jacobian_to_xyzz(om[p]));
+      if (om) v = xyzz_add_ni(v, jacobian_to_xyzz(om[p]));
       o[p] = xyzz_to_jacobian(v);
     }
     return ZK_OK;
@@ -532,7 +540,6 @@ class MsmRunner {
   DevBuf ws_;
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;
-  std::vector<char> mask_term_;
 };
 
 }  // namespace zk
