@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- Groth16 proofs/s on the SHA-256 fixture circuit (BASELINE.json metric), MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one distributed Groth16 proof (n = 8 parties, l = 2, BN254, m = 2^15) of the SHA-256 circuit with
+every share (QAP, witness, packed CRS) already resident in HBM: circom_h (3 d_ifft + 3 d_fft + deg_red) and the
+five d_msm, ending with the parties' (A, B, C) shares on the host.  With N ranks the 8 parties are split over
+the ranks (king = rank 0) and the gather / scatter / broadcast of the star network run over RCCL.
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel's algorithmic bytes per launch
+over its average launch duration measured here with HIP events on the launching stream; `cpu_baseline` is the
+plain-C restatement of the reference's CPU path (oracle/c, kind "port") timed on this host on the same inputs,
+and its proof is compared with the GPU's.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# algorithmic bytes per unit of each timed slot (DESIGN.md "Measurement")
+#   ntt_pass      : one of P passes of fft1 over an element: (2 * 32 B) / P is charged per launch (see below)
+#   king_fft2     : per chunk, l = 2: n shares in + n shares out = 16 * 32 B
+#   msm accumulate: per point: affine base (2 |Fq|) + scalar (32 B)  -> 96 B (G1), 160 B (G2)
+SLOT_BYTES = {"king_fft2_kernel": 512.0, "msm_accumulate_kernel<G1>": 96.0, "msm_accumulate_kernel<G2>": 160.0,
+              "msm_digits+scan+expand": 32.0, "msm_finalize+reduce": 0.0, "king_degred_kernel": 512.0}
+
+
+def build_inputs(pp, zk, seed=42):
+    from zksaas_amd import groth16 as zg
+    from zksaas_amd import sha256_circuit as sc
+    from zksaas_amd.fields import FR
+    p = FR["bn254"]
+    r1, w = sc.build(1, 2, p)
+    assert w[1] == sc.expected_output(1, 2)
+    rng = np.random.default_rng(seed)
+    td = [int.from_bytes(rng.bytes(32), "little") % p for _ in range(5)]
+    setup = zg.SetupScalars("bn254", r1, *td)
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bn254", r1, w, seed=seed + 1)
+    r = int.from_bytes(rng.bytes(32), "little") % p
+    s = int.from_bytes(rng.bytes(32), "little") % p
+    return r1, w, setup, crs, wit, r, s
+
+
+def read_profile(pp):
+    lib = pp.lib
+    out = []
+    for slot in range(lib.zk_profile_slots()):
+        ms, units, calls = C.c_double(), C.c_double(), C.c_long()
+        pp._check(lib.zk_profile_read(pp.h, slot, C.byref(ms), C.byref(units), C.byref(calls)))
+        out.append({"kernel": lib.zk_profile_name(slot).decode(), "total_ms": ms.value, "units": units.value,
+                    "launches": calls.value})
+    return out
+
+
+def roofline_of(prof, ntt_passes):
+    best = max(prof, key=lambda e: e["total_ms"])
+    name = best["kernel"]
+    per_unit = SLOT_BYTES.get(name)
+    if name == "ntt_pass_kernel":
+        per_unit = 64.0 / max(1, ntt_passes)
+    if not best["launches"] or not per_unit:
+        return None
+    avg_ms = best["total_ms"] / best["launches"]
+    bytes_per_launch = per_unit * best["units"] / best["launches"]
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "launches": best["launches"]}
+
+
+def cpu_baseline(pp, crs, wit, r, s, seed, gpu_proof):
+    """Plain-C port of the CPU path on the same inputs (one proof), 8 threads = one per party."""
+    from oracle.cpu_prover import CpuProver
+    n, nl = pp.n, pp.fr.nl
+    Lc = (1 << wit.log_m) // pp.l
+    dl = lambda buf, *shape: buf.to_numpy().reshape(*shape)
+    inp = {
+        "qap": [dl(q, n * Lc, nl) for q in wit.qap], "log_m": wit.log_m, "seed": seed,
+        "a_share": dl(wit.a_share, n, wit.len_a, nl), "ax_share": dl(wit.ax_share, n, wit.len_w, nl),
+        "s": dl(crs.s, n, crs.len_a, 8), "h": dl(crs.h, n, crs.len_a, 8), "v": dl(crs.v, n, crs.len_a, 16),
+        "w": dl(crs.w, n, crs.len_w, 8), "u": dl(crs.u, n, crs.len_u, 8),
+        "a_query0": crs.s1[0], "b_g1_query0": crs.s1[1], "delta_g1": crs.s1[2], "alpha_g1": crs.s1[3],
+        "beta_g1": crs.s1[4], "b_g2_query0": crs.s2[0], "delta_g2": crs.s2[1], "beta_g2": crs.s2[2],
+        "r": r, "s_": s,
+    }
+    threads = min(8, os.cpu_count() or 1)
+    cpu = CpuProver("bn254", pp.l)
+    (A, B, Cc), tm = cpu.prove(inp, threads=threads)
+    ok = (cpu.affine(A) == cpu.affine(gpu_proof[0][0]) and cpu.affine(B, True) == cpu.affine(gpu_proof[1][0], True)
+          and cpu.affine(Cc) == cpu.affine(gpu_proof[2][0]))
+    return {"value": round(1.0 / tm["total_s"], 4), "unit": "proofs/s", "cores": threads, "kind": "port",
+            "sample": "1 proof of the same SHA-256 circuit shares (circom_h %.2fs + 8x5 MSM %.2fs + king/assembly %.2fs)"
+                      % (tm["circom_h_s"], tm["msm_s"], tm["king_assemble_s"]),
+            "host_cpus": os.cpu_count(), "proof_matches_gpu": bool(ok)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+
+    import torch
+    import zksaas_amd as zk
+    from zksaas_amd import groth16 as zg
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    if world > 1:
+        from zksaas_amd import multigpu
+        res = multigpu.bench(args, rank, local_rank, world)
+        if rank == 0:
+            print(json.dumps(res))
+        return
+
+    pp = zk.PackedSharingParams("bn254", 2, device=local_rank)
+    r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
+    seed = 1000
+    for _ in range(args.warmup):
+        proof = zg.prove(pp, crs, wit, r, s, seed=seed)
+    torch.cuda.synchronize()
+    pp._check(pp.lib.zk_profile_enable(pp.h, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = zg.prove(pp, crs, wit, r, s, seed=seed)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = read_profile(pp)
+    pp._check(pp.lib.zk_profile_enable(pp.h, 0))
+
+    proofs_per_s = args.steps / dt
+    res = {
+        "metric": "Groth16 proofs/sec (SHA-256 circuit)", "value": round(proofs_per_s, 3), "unit": "proofs/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)",
+        "data": "synthetic: SHA-256(a=1,b=2) circuit rebuilt from its semantics, seeded trapdoor CRS, seeded shares",
+        "config": {"workload": "BASELINE configs[3]: full distributed Groth16 on the SHA-256 circuit, BN254, l=2, "
+                               "n=8 parties on one GPU, zero masks", "constraints": r1.num_constraints,
+                   "wires": r1.num_variables, "domain": 1 << wit.log_m, "parties": pp.n, "packing_factor": pp.l},
+        "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
+        "roofline": roofline_of(prof, ntt_passes=2),
+        "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
+    }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(pp, crs, wit, r, s, seed, proof)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -168,6 +168,15 @@ int zk_groth16_prove(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, 
                      int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
                      void* stream);
 
+/* ---- per-kernel timing (measurement only) -----------------------------------------------------------------
+ * When enabled, HIP events are recorded on the launching stream around the kernels of each slot; zk_profile_read
+ * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the
+ * number of timed launches since zk_profile_enable. */
+int zk_profile_enable(zk_ctx* ctx, int on);
+int zk_profile_slots(void);
+const char* zk_profile_name(int slot);
+int zk_profile_read(zk_ctx* ctx, int slot, double* total_ms, double* units, long* calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,8 @@ SYMBOLS = [
     "zk_fq_bytes", "zk_malloc", "zk_free", "zk_memcpy_h2d", "zk_memcpy_d2h", "zk_stream_sync", "zk_pss_pack",
     "zk_pss_det_pack", "zk_pss_unpack", "zk_pss_unpack2", "zk_bitrev", "zk_vec_add", "zk_vec_mul_sub", "zk_fft1",
     "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
-    "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove",
+    "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove", "zk_profile_enable",
+    "zk_profile_slots", "zk_profile_name", "zk_profile_read",
 ]
 
 _lib = None
@@ -72,5 +73,10 @@ def load():
     lib.zk_base_mul.argtypes = [vp, i32, vp, vp, sz, vp, vp]
     lib.zk_circom_h.argtypes = [vp, vp, vp, vp, i32, vp, u64, vp, vp]
     lib.zk_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, vp, vp, vp]
+    lib.zk_profile_enable.argtypes = [vp, i32]
+    lib.zk_profile_slots.argtypes = []
+    lib.zk_profile_name.argtypes = [i32]
+    lib.zk_profile_name.restype = C.c_char_p
+    lib.zk_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     _lib = lib
     return lib

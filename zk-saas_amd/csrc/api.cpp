@@ -184,6 +184,28 @@ int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d,
   return e->d_msm(group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
 }
 
+// ---- profiling slots (bench.py roofline leg) ----
+static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king_fft2_kernel", "msm_accumulate_kernel<G1>",
+                                                         "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",
+                                                         "msm_finalize+reduce", "king_degred_kernel"};
+int zk_profile_enable(zk_ctx* ctx, int on) {
+  CTX_OR_FAIL();
+  e->prof.reset();
+  e->prof.on = on != 0;
+  return ZK_OK;
+}
+int zk_profile_slots(void) { return zk::PROF_NSLOTS; }
+const char* zk_profile_name(int slot) { return slot >= 0 && slot < zk::PROF_NSLOTS ? kSlotNames[slot] : ""; }
+int zk_profile_read(zk_ctx* ctx, int slot, double* total_ms, double* units, long* calls) {
+  CTX_OR_FAIL();
+  if (slot < 0 || slot >= zk::PROF_NSLOTS) return e->fail(ZK_ERR_BAD_INPUT, "bad slot");
+  e->prof.collect();
+  if (total_ms) *total_ms = e->prof.ms[slot];
+  if (units) *units = e->prof.units[slot];
+  if (calls) *calls = e->prof.calls[slot];
+  return ZK_OK;
+}
+
 int zk_base_mul(zk_ctx* ctx, int group, const void* base_affine, const void* scalars_d, size_t len,
                 void* out_affine_d, void* stream) {
   CTX_OR_FAIL();

@@ -21,10 +21,78 @@ struct Status {
   std::string msg;
 };
 
+// Per-kernel timing slots: HIP events recorded on the launching stream around selected kernels, so that a
+// host program can read a kernel's average launch duration over exactly its own timed region (bench.py).
+enum ProfSlot { PROF_NTT_PASS = 0, PROF_KING, PROF_MSM_ACC_G1, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE,
+                PROF_DEGRED, PROF_NSLOTS };
+
+struct Profiler {
+  bool on = false;
+  struct Rec {
+    hipEvent_t a, b;
+    int slot;
+    double units;
+  };
+  std::vector<Rec> recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  double ms[PROF_NSLOTS] = {0};
+  double units[PROF_NSLOTS] = {0};
+  long calls[PROF_NSLOTS] = {0};
+  hipEvent_t begin(hipStream_t st, hipEvent_t* end_out) {
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!pool.empty()) {
+      ev = pool.back();
+      pool.pop_back();
+    } else {
+      (void)hipEventCreate(&ev.first);
+      (void)hipEventCreate(&ev.second);
+    }
+    (void)hipEventRecord(ev.first, st);
+    *end_out = ev.second;
+    return ev.first;
+  }
+  void collect() {
+    for (auto& r : recs) {
+      (void)hipEventSynchronize(r.b);
+      float t = 0;
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+        ms[r.slot] += t;
+        units[r.slot] += r.units;
+        calls[r.slot]++;
+      }
+      pool.push_back({r.a, r.b});
+    }
+    recs.clear();
+  }
+  void reset() {
+    collect();
+    for (int i = 0; i < PROF_NSLOTS; i++) ms[i] = 0, units[i] = 0, calls[i] = 0;
+  }
+};
+
+// RAII scope: records the two events around the launches made inside it.
+struct ProfScope {
+  Profiler* p;
+  hipStream_t st;
+  hipEvent_t a, b;
+  int slot;
+  double units;
+  ProfScope(Profiler& pr, int slot_, hipStream_t st_, double units_) : p(pr.on ? &pr : nullptr), st(st_), slot(slot_), units(units_) {
+    if (p) a = p->begin(st, &b);
+  }
+  ~ProfScope() {
+    if (p) {
+      (void)hipEventRecord(b, st);
+      p->recs.push_back({a, b, slot, units});
+    }
+  }
+};
+
 // Abstract interface the C ABI dispatches to (one implementation per curve).
 class IEngine {
  public:
   virtual ~IEngine() {}
+  Profiler prof;
   int l = 0, n = 0, t = 0, device = 0;
   Status last;
   int fail(int code, const std::string& m, int party = -1) {

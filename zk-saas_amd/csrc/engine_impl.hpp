@@ -376,6 +376,7 @@ class Engine : public IEngine {
         attr_set = true;
       }
       dim3 grid((unsigned)(nvec >> NTT_TILE_BITS), (unsigned)batch);
+      ProfScope ps_(prof, PROF_NTT_PASS, st, (double)nvec * batch);
       ntt_pass_kernel<Fr><<<grid, dim3(NTT_THREADS), lds, st>>>(data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l,
                                                                p == plan.npass - 1 ? (const Fr*)add : nullptr);
       ZK_HIP(hipGetLastError());
@@ -392,6 +393,7 @@ class Engine : public IEngine {
     size_t Wc = Lc < (size_t)KING_THREADS ? Lc : (size_t)KING_THREADS;
     size_t lds = (size_t)L * Wc * sizeof(Fr);
     dim3 grid((unsigned)(Lc / Wc)), block(KING_THREADS);
+    ProfScope ps_(prof, PROF_KING, st, (double)Lc);
     if (negate)
       king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
@@ -490,6 +492,7 @@ class Engine : public IEngine {
   int degred_l(const Fr* in, const Fr* in_mask, int np, size_t len, const Fr* U, uint64_t seed, Fr* out,
                const Fr* out_mask, hipStream_t st) {
     dim3 grid((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
+    ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
     king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, seed, out, out_mask);
     ZK_HIP(hipGetLastError());
     return ZK_OK;

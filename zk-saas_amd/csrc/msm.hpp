@@ -360,6 +360,9 @@ class MsmRunner {
   } while (0)
     MSM_HIP(hipMemsetAsync(counts, 0, nkeys * 4, st));
     dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
+    constexpr bool IS_G2 = sizeof(Fld) != sizeof(Fq);
+    {
+    ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts);
     msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
                                                 counts, nullptr, nullptr);
     MSM_STAGE("digits/count");
@@ -373,10 +376,16 @@ class MsmRunner {
     MSM_STAGE("expand");
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
                                                 nullptr, cursor, sorted);
+    }
     MSM_STAGE("scatter");
+    {
+    ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts);
     msm_accumulate_kernel<Fld><<<dim3((unsigned)((max_segs + 127) / 128)), dim3(128), 0, st>>>(
         (const Affine<Fld>*)bases, sorted, segs, offsets, nkeys, partial);
+    }
     MSM_STAGE("accumulate");
+    {
+    ProfScope ps_(eng->prof, PROF_MSM_REDUCE, st, (double)npts);
     msm_finalize_kernel<Fld><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
                                                                                           buckets);
     MSM_STAGE("finalize");
@@ -388,6 +397,7 @@ class MsmRunner {
       attr_set = true;
     }
     msm_reduce_kernel<Fld><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
+    }
     MSM_HIP(hipGetLastError());
     MSM_STAGE("reduce");
     std::vector<XYZZ<Fld>> h((size_t)nwin * bpw * 2);
