@@ -28,6 +28,7 @@ enum ProfSlot { PROF_NTT_PASS = 0, PROF_KING, PROF_MSM_ACC_G1, PROF_MSM_ACC_G2, 
 
 struct Profiler {
   bool on = false;
+  std::mutex mu;
   struct Rec {
     hipEvent_t a, b;
     int slot;
@@ -39,6 +40,7 @@ struct Profiler {
   double units[PROF_NSLOTS] = {0};
   long calls[PROF_NSLOTS] = {0};
   hipEvent_t begin(hipStream_t st, hipEvent_t* end_out) {
+    std::lock_guard<std::mutex> lk(mu);
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!pool.empty()) {
       ev = pool.back();
@@ -51,7 +53,12 @@ struct Profiler {
     *end_out = ev.second;
     return ev.first;
   }
+  void push(const Rec& r) {
+    std::lock_guard<std::mutex> lk(mu);
+    recs.push_back(r);
+  }
   void collect() {
+    std::lock_guard<std::mutex> lk(mu);
     for (auto& r : recs) {
       (void)hipEventSynchronize(r.b);
       float t = 0;
@@ -83,7 +90,7 @@ struct ProfScope {
   ~ProfScope() {
     if (p) {
       (void)hipEventRecord(b, st);
-      p->recs.push_back({a, b, slot, units});
+      p->push({a, b, slot, units});
     }
   }
 };

@@ -710,25 +710,61 @@ class Engine : public IEngine {
       }
     } joiner{host};
 
+    // The four MSMs over the witness shares (S, H, V, W) do not depend on h: they run on their own streams
+    // (one host thread each, because every MSM ends with a small host-side fold) concurrently with circom_h;
+    // the reference gets the same overlap from tokio::try_join! (prove.rs:209-227).  U follows circom_h.
     ZK_HIP(hshare_.ensure((size_t)n * Lc * sizeof(Fr)));
-    int rc = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, st);
+    int rc = ensure_streams();
     if (rc) return rc;
     P1 S, H, W, U;
     P2 V;
     const bool r_zero = r.is_zero();
-    rc = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S, st);
-    if (rc) return rc;
-    if (!r_zero) {
-      rc = msm_.template d_msm_sum_t<Fq>(this, crs->h_d, a_share, crs->len_a, mk ? mk->msm_in[1] : nullptr, &H, st);
-      if (rc) return rc;
-    }
-    rc = msm_.template d_msm_sum_t<Fq2>(this, crs->v_d, a_share, crs->len_a, mk ? mk->msm_in[2] : nullptr, &V, st);
-    if (rc) return rc;
-    rc = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W, st);
-    if (rc) return rc;
-    rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, st);
-    if (rc) return rc;
+    int rcs[4] = {0, 0, 0, 0};
+    const int dev = device;
+    const bool serial = getenv("ZK_SERIAL_MSM") != nullptr;     // diagnostics: clean per-kernel timings
+    auto spawn = [&](auto fn) {
+      if (serial) {
+        fn();
+        return std::thread();
+      }
+      return std::thread(fn);
+    };
+    auto join = [](std::thread& t) {
+      if (t.joinable()) t.join();
+    };
+    std::thread tS = spawn([&]() {
+      (void)hipSetDevice(dev);
+      rcs[0] = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S,
+                                             streams_[0], 1);
+    });
+    std::thread tH = spawn([&]() {
+      (void)hipSetDevice(dev);
+      if (!r_zero)
+        rcs[1] = msm_.template d_msm_sum_t<Fq>(this, crs->h_d, a_share, crs->len_a, mk ? mk->msm_in[1] : nullptr, &H,
+                                               streams_[1], 2);
+    });
+    std::thread tV = spawn([&]() {
+      (void)hipSetDevice(dev);
+      rcs[2] = msm_.template d_msm_sum_t<Fq2>(this, crs->v_d, a_share, crs->len_a, mk ? mk->msm_in[2] : nullptr, &V,
+                                              streams_[2], 3);
+    });
+    std::thread tW = spawn([&]() {
+      (void)hipSetDevice(dev);
+      rcs[3] = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W,
+                                             streams_[3], 4);
+    });
+    rc = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, st);
+    if (!rc)
+      rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, st,
+                                         0);
+    join(tS);
+    join(tH);
+    join(tV);
+    join(tW);
     host.join();
+    if (rc) return rc;
+    for (int i = 0; i < 4; i++)
+      if (rcs[i]) return rcs[i];
 
     // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party (shares differ only through the out-masks)
     P1 cA = xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1));
@@ -766,6 +802,15 @@ class Engine : public IEngine {
     return ZK_OK;
   }
 
+  int ensure_streams() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (streams_ready_) return ZK_OK;
+    for (int i = 0; i < 4; i++) ZK_HIP(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+    streams_ready_ = true;
+    return ZK_OK;
+  }
+  hipStream_t streams_[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool streams_ready_ = false;
   bool force_simple_ntt = false;
   std::map<std::string, void*> base_tables_;
   DevBuf hwork_, hshare_;

@@ -128,6 +128,49 @@ struct Fp {
     else return mul_inline(a, b);
   }
   ZK_HD static Fp mul_inline(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host: same CIOS on 64-bit limbs with 128-bit products (the king-side folds and the dealer run here)
+    constexpr int M = N / 2;
+    static_assert(N % 2 == 0, "even limb count expected");
+    uint64_t A[M], B[M], Pm[M], t[M + 2];
+    for (int i = 0; i < M; i++) {
+      A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+      B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+      Pm[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+    }
+    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: x' = x (2 + p x)  (x = -p^-1 mod 2^32)
+    uint64_t x = P::N0INV;
+    x = x * (2 + Pm[0] * x);
+    for (int i = 0; i < M + 2; i++) t[i] = 0;
+    for (int i = 0; i < M; i++) {
+      uint64_t c = 0;
+      for (int j = 0; j < M; j++) {
+        unsigned __int128 z = (unsigned __int128)A[i] * B[j] + t[j] + c;
+        t[j] = (uint64_t)z;
+        c = (uint64_t)(z >> 64);
+      }
+      unsigned __int128 z = (unsigned __int128)t[M] + c;
+      t[M] = (uint64_t)z;
+      t[M + 1] = (uint64_t)(z >> 64);
+      uint64_t m = t[0] * x;
+      z = (unsigned __int128)m * Pm[0] + t[0];
+      c = (uint64_t)(z >> 64);
+      for (int j = 1; j < M; j++) {
+        z = (unsigned __int128)m * Pm[j] + t[j] + c;
+        t[j - 1] = (uint64_t)z;
+        c = (uint64_t)(z >> 64);
+      }
+      z = (unsigned __int128)t[M] + c;
+      t[M - 1] = (uint64_t)z;
+      t[M] = t[M + 1] + (uint64_t)(z >> 64);
+    }
+    Fp r;
+    for (int i = 0; i < M; i++) {
+      r.v[2 * i] = (uint32_t)t[i];
+      r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    return reduce_once(r, (uint32_t)t[M]);
+#else
     uint32_t t[N + 2];
 #pragma unroll
     for (int i = 0; i < N + 2; i++) t[i] = 0;
@@ -161,6 +204,7 @@ struct Fp {
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = t[i];
     return reduce_once(r, t[N]);
+#endif
   }
 
   // Out-of-line multiply for cold code (G2 tower, bucket reduction, l > 2 kernels): one copy per field

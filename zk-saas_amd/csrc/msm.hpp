@@ -29,9 +29,12 @@
 namespace zk {
 #if defined(__HIPCC__)
 
-constexpr int MSM_SEG = 64;           // max points per accumulate lane
-constexpr int RED_THREADS = 256;      // bucket-reduce workgroup
-constexpr int RED_G = 8;              // buckets per lane in bucket-reduce
+constexpr int MSM_SEG_MAX = 64;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
+// bucket-reduce workgroup: 256 lanes, 128 for the largest point types (two LDS planes must fit in 160 KiB)
+template <class Fld>
+constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
+constexpr int RED_G = 4;              // buckets per lane in bucket-reduce
+constexpr int MSM_WS = 6;             // independent workspaces (concurrent MSMs on separate streams)
 
 struct SegDesc {
   uint32_t bucket, start, end;
@@ -83,7 +86,7 @@ constexpr int ISCAN_THREADS = 256;
 constexpr int ISCAN_PER = 8;
 constexpr int ISCAN_BLOCK = ISCAN_THREADS * ISCAN_PER;
 
-ZK_D uint32_t nseg_of(uint32_t cnt) { return (cnt + MSM_SEG - 1) / MSM_SEG; }
+ZK_D uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
 
 ZK_D uint2 block_scan_u2(uint2 v, uint2* sh, uint2* total) {
   int tid = threadIdx.x;
@@ -108,7 +111,8 @@ ZK_D uint2 block_scan_u2(uint2 v, uint2* sh, uint2* total) {
 static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const uint32_t* __restrict__ counts, size_t len,
                                                                    uint2* __restrict__ block_tot,
                                                                    const uint2* __restrict__ carry,
-                                                                   uint2* __restrict__ offsets, int mode) {
+                                                                   uint2* __restrict__ offsets, int mode,
+                                                                   uint32_t seg) {
   __shared__ uint2 sh[ISCAN_THREADS];
   size_t base = (size_t)blockIdx.x * ISCAN_BLOCK + (size_t)threadIdx.x * ISCAN_PER;
   uint2 loc[ISCAN_PER];
@@ -118,7 +122,7 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const
     uint32_t cnt = base + i < len ? counts[base + i] : 0u;
     loc[i] = acc;
     acc.x += cnt;
-    acc.y += nseg_of(cnt);
+    acc.y += nseg_of(cnt, seg);
   }
   uint2 tot;
   uint2 ex = block_scan_u2(acc, sh, &tot);
@@ -162,14 +166,14 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint2
 
 // cursor[key] = offsets[key].x ; segment descriptors for every bucket
 static __global__ void msm_expand_kernel(const uint2* __restrict__ offsets, size_t nkeys, uint32_t* __restrict__ cursor,
-                                  SegDesc* __restrict__ segs) {
+                                  SegDesc* __restrict__ segs, uint32_t seg) {
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nkeys) return;
   uint2 o = offsets[k], o1 = offsets[k + 1];
   cursor[k] = o.x;
   uint32_t s = o.y;
-  for (uint32_t p = o.x; p < o1.x; p += MSM_SEG, s++) {
-    uint32_t e = p + MSM_SEG < o1.x ? p + MSM_SEG : o1.x;
+  for (uint32_t p = o.x; p < o1.x; p += seg, s++) {
+    uint32_t e = p + seg < o1.x ? p + seg : o1.x;
     segs[s] = {(uint32_t)k, p, e};
   }
 }
@@ -197,48 +201,90 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const Affine<Fld>* 
   store_elem(partial + s, acc);
 }
 
-template <class Fld>
+// Group additions in the cold kernels: inlined for 8-limb G1 (fast, compiles quickly), out of line otherwise.
+template <bool INL, class Fld>
+ZK_D XYZZ<Fld> add_sel(const XYZZ<Fld>& a, const XYZZ<Fld>& b) {
+  if constexpr (INL) return xyzz_add(a, b);
+  else return xyzz_add_ni(a, b);
+}
+template <bool INL, class Fld>
+ZK_D XYZZ<Fld> dbl_sel(const XYZZ<Fld>& a) {
+  if constexpr (INL) return xyzz_dbl(a);
+  else return xyzz_dbl_ni(a);
+}
+
+// One lane per bucket sums its segments when there are few; buckets with many segments (skewed digit
+// distributions: the sparsely used top window, degenerate scalars such as all ones) are queued on `heavy` and
+// summed by a whole workgroup each in msm_finalize_heavy_kernel, so no lane ever walks a long chain.
+constexpr uint32_t FIN_SEQ = 4;
+constexpr int FIN_HEAVY_THREADS = 128;
+
+template <class Fld, bool INL>
 __global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial,
                                                           const uint2* __restrict__ offsets, size_t nkeys,
-                                                          XYZZ<Fld>* __restrict__ buckets) {
+                                                          XYZZ<Fld>* __restrict__ buckets,
+                                                          uint32_t* __restrict__ heavy /* [0] = count */) {
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nkeys) return;
   uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
+  if (s1 - s0 > FIN_SEQ) {
+    uint32_t slot = atomicAdd(heavy, 1u);
+    heavy[1 + slot] = (uint32_t)k;
+    return;
+  }
   XYZZ<Fld> acc = XYZZ<Fld>::identity();
   if (s1 > s0) acc = load_elem(partial + s0);
-  for (uint32_t s = s0 + 1; s < s1; s++) acc = xyzz_add_ni(acc, load_elem(partial + s));
+  for (uint32_t s = s0 + 1; s < s1; s++) acc = add_sel<INL>(acc, load_elem(partial + s));
   store_elem(buckets + k, acc);
+}
+
+template <class Fld, bool INL>
+__global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
+    const XYZZ<Fld>* __restrict__ partial, const uint2* __restrict__ offsets, const uint32_t* __restrict__ heavy,
+    XYZZ<Fld>* __restrict__ buckets) {
+  extern __shared__ uint4 smem_fin[];
+  XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
+  const uint32_t nheavy = heavy[0];
+  const int tid = threadIdx.x;
+  for (uint32_t hbk = blockIdx.x; hbk < nheavy; hbk += gridDim.x) {
+    uint32_t k = heavy[1 + hbk];
+    uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
+    XYZZ<Fld> acc = XYZZ<Fld>::identity();
+    // uniform trip count across the workgroup; lanes past the end add the identity
+    uint32_t rounds = (s1 - s0 + FIN_HEAVY_THREADS - 1) / FIN_HEAVY_THREADS;
+    for (uint32_t r = 0; r < rounds; r++) {
+      uint32_t s = s0 + r * FIN_HEAVY_THREADS + tid;
+      XYZZ<Fld> v = XYZZ<Fld>::identity();
+      if (s < s1) v = load_elem(partial + s);
+      acc = add_sel<INL>(acc, v);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int off = FIN_HEAVY_THREADS / 2; off > 0; off >>= 1) {
+      XYZZ<Fld> a = sh[tid];
+      XYZZ<Fld> b = XYZZ<Fld>::identity();
+      if (tid < off) b = sh[tid + off];
+      XYZZ<Fld> rsum = add_sel<INL>(a, b);
+      __syncthreads();
+      if (tid < off) sh[tid] = rsum;
+      __syncthreads();
+    }
+    if (tid == 0) store_elem(buckets + k, sh[0]);
+    __syncthreads();
+  }
 }
 
 // -------------------------------------------------------------------------------------------------- reduce
 // Workgroup (w, blk) covers buckets [blk*RED_THREADS*RED_G, ...) of window w and emits
 //   S = sum bucket_b,   A = sum (b - base + 1) * bucket_b      (base = first bucket of the workgroup)
-template <class Fld>
-ZK_D XYZZ<Fld> block_reduce_sum(XYZZ<Fld> v, XYZZ<Fld>* sh) {
-  // Control flow is kept wave-uniform around the out-of-line group additions: every lane adds (idle lanes
-  // add the identity) and only the store is predicated.
-  int tid = threadIdx.x;
-  sh[tid] = v;
-  __syncthreads();
-  for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
-    XYZZ<Fld> a = sh[tid];
-    XYZZ<Fld> b = tid < off ? sh[tid + off] : XYZZ<Fld>::identity();
-    XYZZ<Fld> r = xyzz_add_ni(a, b);
-    __syncthreads();
-    if (tid < off) sh[tid] = r;
-    __syncthreads();
-  }
-  XYZZ<Fld> r = sh[0];
-  __syncthreads();
-  return r;
-}
-
-template <class Fld>
+// Control flow around the additions is wave-uniform (idle lanes add the identity); only stores are predicated.
+template <class Fld, bool INL, int RED_THREADS>
 __global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets, uint32_t B,
                                                                 uint32_t blocks_per_window,
                                                                 XYZZ<Fld>* __restrict__ out /* [nwin][bpw][2] */) {
   extern __shared__ uint4 smem_red[];
-  XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);
+  XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);      // [RED_THREADS]
+  XYZZ<Fld>* sh2 = sh + RED_THREADS;                            // [RED_THREADS]
   uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
   uint32_t base = blk * RED_THREADS * RED_G;
   int tid = threadIdx.x;
@@ -249,8 +295,8 @@ __global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>
     uint32_t b = base + tid * RED_G + g;
     XYZZ<Fld> bk = XYZZ<Fld>::identity();
     if (b < B) bk = load_elem(wb + b);
-    run = xyzz_add_ni(run, bk);
-    acc = xyzz_add_ni(acc, run);
+    run = add_sel<INL>(run, bk);
+    acc = add_sel<INL>(acc, run);
   }
   // suffix scan of lane totals across the workgroup: suf[t] = sum_{t' >= t} run[t']
   sh[tid] = run;
@@ -259,21 +305,40 @@ __global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>
     XYZZ<Fld> a = sh[tid];
     XYZZ<Fld> b = XYZZ<Fld>::identity();
     if (tid + off < RED_THREADS) b = sh[tid + off];
-    XYZZ<Fld> tv = xyzz_add_ni(a, b);
+    XYZZ<Fld> tv = add_sel<INL>(a, b);
     __syncthreads();
     sh[tid] = tv;
     __syncthreads();
   }
   XYZZ<Fld> S = sh[0];
-  // sum_t t * run[t] = sum_{j >= 1} suf[j]; the lane weight is t*RED_G, so multiply by RED_G afterwards
+  // sum_t t * run[t] = sum_{j >= 1} suf[j] (lane weight is t*RED_G: scaled afterwards); reduce it together
+  // with sum_t acc[t] in one tree (two independent additions per step)
   XYZZ<Fld> mine = XYZZ<Fld>::identity();
   if (tid >= 1) mine = sh[tid];
   __syncthreads();
-  XYZZ<Fld> T = block_reduce_sum(mine, sh);
-  XYZZ<Fld> Asum = block_reduce_sum(acc, sh);
-  XYZZ<Fld> TG = T;
-  for (int g = 1; g < RED_G; g <<= 1) TG = xyzz_dbl_ni(TG);
-  XYZZ<Fld> A = xyzz_add_ni(Asum, TG);
+  sh[tid] = mine;
+  sh2[tid] = acc;
+  __syncthreads();
+  for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
+    XYZZ<Fld> a1 = sh[tid], a2 = sh2[tid];
+    XYZZ<Fld> b1 = XYZZ<Fld>::identity(), b2 = XYZZ<Fld>::identity();
+    if (tid < off) {
+      b1 = sh[tid + off];
+      b2 = sh2[tid + off];
+    }
+    XYZZ<Fld> r1 = add_sel<INL>(a1, b1);
+    XYZZ<Fld> r2 = add_sel<INL>(a2, b2);
+    __syncthreads();
+    if (tid < off) {
+      sh[tid] = r1;
+      sh2[tid] = r2;
+    }
+    __syncthreads();
+  }
+  XYZZ<Fld> TG = sh[0];
+  XYZZ<Fld> Asum = sh2[0];
+  for (int g = 1; g < RED_G; g <<= 1) TG = dbl_sel<INL>(TG);
+  XYZZ<Fld> A = add_sel<INL>(Asum, TG);
   if (tid == 0) {
     store_elem(out + ((size_t)blockIdx.x) * 2, S);
     store_elem(out + ((size_t)blockIdx.x) * 2 + 1, A);
@@ -291,21 +356,41 @@ class MsmRunner {
   using Fq = Fp<typename Cfg::FqP>;
   using Fq2 = Fp2<typename Cfg::FqP>;
 
+  // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
+  // where nwin = ceil((BITS+1)/c) already prices a sparsely filled top window; ties go to the wider window
+  // (more buckets = more lanes with shorter chains).
   static int pick_c(size_t npts) {
     if (const char* e = getenv("ZK_MSM_C")) {
       int c = atoi(e);
       if (c >= 2 && c <= 20) return c;
     }
-    int lg = ilog2(npts ? npts : 1);
-    int c = lg - 4;
-    if (c < 4) c = 4;
-    if (c > 17) c = 17;
-    return c;
+    int best = 4;
+    double best_cost = 1e300;
+    for (int c = 4; c <= 17; c++) {
+      int nwin = (FrP::BITS + c) / c;
+      double cost = (double)nwin * ((double)npts + 4.0 * (double)((size_t)1 << (c - 1)));
+      if (cost <= best_cost) {
+        best_cost = cost;
+        best = c;
+      }
+    }
+    return best;
+  }
+
+  // points per accumulate lane (a bucket longer than this is cut into segments)
+  static uint32_t pick_seg(size_t npts, int nwin) {
+    if (const char* e = getenv("ZK_MSM_SEG")) {
+      int v = atoi(e);
+      if (v >= 1 && v <= 1024) return (uint32_t)v;
+    }
+    (void)npts;
+    (void)nwin;
+    return MSM_SEG_MAX;   // measured on MI355X: finer cuts cost more in finalize than they gain in accumulate
   }
 
   template <class Fld>
   int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-            XYZZ<Fld>* result, hipStream_t st) {
+            XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
 #if defined(__HIPCC__)
     *result = XYZZ<Fld>::identity();
     if (npts == 0) return ZK_OK;
@@ -315,7 +400,10 @@ class MsmRunner {
     const uint32_t B = 1u << (c - 1);
     const size_t nkeys = (size_t)nwin * B;
     const size_t max_sorted = npts * nwin;
-    const size_t max_segs = nkeys + max_sorted / MSM_SEG + 1;
+    const uint32_t seg = pick_seg(npts, nwin);
+    const size_t max_segs = nkeys + max_sorted / seg + 1;
+    constexpr bool INL = sizeof(Fld) == 32;     // 8-limb G1
+    constexpr int RED_THREADS = red_threads<Fld>();
     const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
     const size_t iscan_blocks = (nkeys + ISCAN_BLOCK - 1) / ISCAN_BLOCK;
 
@@ -329,10 +417,11 @@ class MsmRunner {
     size_t o_counts = take(nkeys * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
            o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
            o_partial = take(max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(nkeys * sizeof(XYZZ<Fld>)),
-           o_out = take((size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>));
-    hipError_t he = ws_.ensure(off);
+           o_out = take((size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
+    if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
+    hipError_t he = ws_[wslot].ensure(off);
     if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
-    char* ws = (char*)ws_.p;
+    char* ws = (char*)ws_[wslot].p;
     uint32_t* counts = (uint32_t*)(ws + o_counts);
     uint32_t* cursor = (uint32_t*)(ws + o_cursor);
     uint2* offsets = (uint2*)(ws + o_offsets);
@@ -342,6 +431,7 @@ class MsmRunner {
     XYZZ<Fld>* partial = (XYZZ<Fld>*)(ws + o_partial);
     XYZZ<Fld>* buckets = (XYZZ<Fld>*)(ws + o_buckets);
     XYZZ<Fld>* out = (XYZZ<Fld>*)(ws + o_out);
+    uint32_t* heavy = (uint32_t*)(ws + o_heavy);
 
 #define MSM_HIP(x)                                           \
   do {                                                       \
@@ -367,12 +457,12 @@ class MsmRunner {
                                                 counts, nullptr, nullptr);
     MSM_STAGE("digits/count");
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
-                                                                                     nullptr, 0);
+                                                                                     nullptr, 0, seg);
     iscan_carry_kernel<<<dim3(1), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks);
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
-                                                                                     offsets, 1);
+                                                                                     offsets, 1, seg);
     MSM_STAGE("scan");
-    msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs);
+    msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg);
     MSM_STAGE("expand");
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
                                                 nullptr, cursor, sorted);
@@ -386,17 +476,23 @@ class MsmRunner {
     MSM_STAGE("accumulate");
     {
     ProfScope ps_(eng->prof, PROF_MSM_REDUCE, st, (double)npts);
-    msm_finalize_kernel<Fld><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
-                                                                                          buckets);
+    MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
+    msm_finalize_kernel<Fld, INL><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
+                                                                                               buckets, heavy);
+    {
+      size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
+      msm_finalize_heavy_kernel<Fld, INL><<<dim3(512), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, offsets, heavy,
+                                                                                               buckets);
+    }
     MSM_STAGE("finalize");
-    size_t red_lds = RED_THREADS * sizeof(XYZZ<Fld>);
+    size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
     static bool attr_set = false;
     if (!attr_set && red_lds > 48 * 1024) {
-      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<Fld>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<Fld, INL, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)red_lds));
       attr_set = true;
     }
-    msm_reduce_kernel<Fld><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
+    msm_reduce_kernel<Fld, INL, RED_THREADS><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
     }
     MSM_HIP(hipGetLastError());
     MSM_STAGE("reduce");
@@ -467,10 +563,10 @@ class MsmRunner {
   // sum_p coef_p * (msm_p + in_mask_p): what the king reconstructs and sums (dmsm/mod.rs:85-86)
   template <class Fld>
   int d_msm_sum_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const void* in_mask,
-                  XYZZ<Fld>* result, hipStream_t st) {
+                  XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
     const int n = eng->n;
     XYZZ<Fld> r;
-    int rc = run_t<Fld>(eng, bases, scalars, (size_t)n * len, coef_d_, len, &r, st);
+    int rc = run_t<Fld>(eng, bases, scalars, (size_t)n * len, coef_d_, len, &r, st, wslot);
     if (rc) return rc;
     if (in_mask) {
       // the n in-mask points contribute sum_p coef_p * mask_p (n host scalar multiplications)
@@ -547,7 +643,7 @@ class MsmRunner {
     if (coef_d_) (void)hipFree(coef_d_);
   }
 
-  DevBuf ws_;
+  DevBuf ws_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;
 };
