@@ -168,6 +168,19 @@ int zk_groth16_prove(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, 
                      int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
                      void* stream);
 
+/* ---- multi-GPU building blocks (the n parties spread over several ranks, king = rank 0) ------------------
+ * zk_d_msm_local: this rank's share of d_msm's king step (dmsm/mod.rs:85-86): sum over its `nparties` parties
+ *   (ids first_party ..) of coef_p * (G::msm(bases_p, scalars_p) + in_mask_p), coef_p = sum_k unpack2 row k.
+ *   bases_d / scalars_d are [nparties][len]; in_mask: nparties Jacobian points (host) or NULL; out: one
+ *   Jacobian point (host).  Summing the ranks' outputs (zk_group_add) gives the king's broadcast value.
+ * zk_groth16_assemble: prove.rs:40-56, 99-110, 148-158, 229-235 from the five summed d_msm values
+ *   sums[0..4] = S, H, V (G2), W, U (Jacobian, host). */
+int zk_d_msm_local(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, int first_party,
+                   int nparties, const void* in_mask, void* out, void* stream);
+int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out);
+int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
+                        const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c);
+
 /* ---- per-kernel timing (measurement only) -----------------------------------------------------------------
  * When enabled, HIP events are recorded on the launching stream around the kernels of each slot; zk_profile_read
  * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the

@@ -156,3 +156,27 @@ def test_sha256_fixture_proof():
     assert G1.eq(A, G1.mul(G1.from_affine(BN254.g1), sa))
     assert G2.eq(B, G2.mul(G2.from_affine(BN254.g2), sb))
     assert G1.eq(Cc, G1.mul(G1.from_affine(BN254.g1), sc_))
+
+
+def test_sharded_code_path_on_one_rank():
+    """multigpu.DistProver + GpuBackend (zk_d_msm_local, zk_group_add, zk_groth16_assemble) with world = 1
+    must give the same shares as zk_groth16_prove."""
+    import torch
+    from zksaas_amd import multigpu as mg
+    r1, w = small_r1cs()
+    pp = ctx("bn254", 2)
+    setup = zg.SetupScalars("bn254", r1, *_trapdoor(46))
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bn254", r1, w, seed=8)
+    r, s = rand_fp(47, 0, P), rand_fp(47, 1, P)
+    want = zg.prove(pp, crs, wit, r, s, seed=21)
+    be = mg.GpuBackend(pp)
+    net = mg.StarNet(None, 0, 1)
+    prover = mg.DistProver(be, net, pp.n, pp.l, wit.log_m, zg._root_of_unity("bn254", wit.log_m + 1))
+    inp = mg._local_inputs(be, pp, crs, wit, 0, 1)
+    got = prover.prove(inp, r, s, 21)
+    G1, G2 = g1(BN254), g2(BN254)
+    for i in range(pp.n):
+        assert G1.eq(dec_jacobian(pp, got[0][i]), dec_jacobian(pp, want[0][i]))
+        assert G2.eq(dec_jacobian(pp, got[1][i], True), dec_jacobian(pp, want[1][i], True))
+        assert G1.eq(dec_jacobian(pp, got[2][i]), dec_jacobian(pp, want[2][i]))

@@ -184,6 +184,21 @@ int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d,
   return e->d_msm(group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
 }
 
+int zk_d_msm_local(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, int first_party,
+                   int nparties, const void* in_mask, void* out, void* stream) {
+  CTX_OR_FAIL();
+  return e->d_msm_local(group, bases_d, scalars_d, len, first_party, nparties, in_mask, out, S(stream));
+}
+int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out) {
+  CTX_OR_FAIL();
+  return e->group_add(group, a, b, out);
+}
+int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
+                        const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) {
+  CTX_OR_FAIL();
+  return e->groth16_assemble(crs, r, s, sums, masks, pi_a, pi_b, pi_c);
+}
+
 // ---- profiling slots (bench.py roofline leg) ----
 static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king_fft2_kernel", "msm_accumulate_kernel<G1>",
                                                          "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",

@@ -137,6 +137,11 @@ class IEngine {
                   hipStream_t st) = 0;
   virtual int d_msm(int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
                     const void* out_mask, void* out, hipStream_t st) = 0;
+  virtual int d_msm_local(int group, const void* bases, const void* scalars, size_t len, int first_party, int nparties,
+                          const void* in_mask, void* out, hipStream_t st) = 0;
+  virtual int group_add(int group, const void* a, const void* b, void* out) = 0;
+  virtual int groth16_assemble(const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
+                               const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
                        hipStream_t st) = 0;
   virtual int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* masks,

@@ -766,7 +766,27 @@ class Engine : public IEngine {
     for (int i = 0; i < 4; i++)
       if (rcs[i]) return rcs[i];
 
-    // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party (shares differ only through the out-masks)
+    return assemble_t(crs, r, s, rN, sK, rsM, sK2, S, H, V, W, U, mk, pi_a, pi_b, pi_c);
+  }
+
+  // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party (shares differ only through the out-masks)
+  template <class P1, class P2>
+  int assemble_t(const zk_crs_share* crs, const Fr& r, const Fr& s, const P1& rN, const P1& sK, const P1& rsM,
+                 const P2& sK2, const P1& S, const P1& H, const P2& V, const P1& W, const P1& U,
+                 const zk_groth16_masks* mk, void* pi_a, void* pi_b, void* pi_c) {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    auto aff1 = [](const void* p) {
+      Affine<Fq> a;
+      memcpy(&a, p, sizeof(a));
+      return P1::from_affine(a);
+    };
+    auto aff2 = [](const void* p) {
+      Affine<Fq2> a;
+      memcpy(&a, p, sizeof(a));
+      return P2::from_affine(a);
+    };
+    const bool r_zero = r.is_zero();
     P1 cA = xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1));
     P1 cB1 = xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1));
     P2 cB2 = xyzz_add_ni(xyzz_add_ni(aff2(crs->b_g2_query0), sK2), aff2(crs->beta_g2));
@@ -800,6 +820,83 @@ class Engine : public IEngine {
       oc[p] = xyzz_to_jacobian(C);
     }
     return ZK_OK;
+  }
+
+  // sum over the listed local parties of coef_p * (msm_p + in_mask_p): one rank's contribution to the king's
+  // unpack2 + sum (dmsm/mod.rs:85-86) when the n parties are spread over several GPUs.
+  int d_msm_local(int group, const void* bases, const void* scalars, size_t len, int first_party, int nparties,
+                  const void* in_mask, void* out, hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (first_party < 0 || nparties <= 0 || first_party + nparties > n) return fail(ZK_ERR_BAD_INPUT, "bad party range");
+    if (!out) return fail(ZK_ERR_BAD_INPUT, "null output");
+    if (group == ZK_G1) {
+      XYZZ<Fq> r;
+      int rc = msm_.template d_msm_range_t<Fq>(this, bases, scalars, len, first_party, nparties, in_mask, &r, st);
+      if (rc) return rc;
+      Jacobian<Fq> j = xyzz_to_jacobian(r);
+      memcpy(out, &j, sizeof(j));
+      return ZK_OK;
+    }
+    if (group == ZK_G2 && Cfg::HAS_G2) {
+      XYZZ<Fq2> r;
+      int rc = msm_.template d_msm_range_t<Fq2>(this, bases, scalars, len, first_party, nparties, in_mask, &r, st);
+      if (rc) return rc;
+      Jacobian<Fq2> j = xyzz_to_jacobian(r);
+      memcpy(out, &j, sizeof(j));
+      return ZK_OK;
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+  int group_add(int group, const void* a, const void* b, void* out) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (!a || !b || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (group == ZK_G1) {
+      Jacobian<Fq> x, y;
+      memcpy(&x, a, sizeof(x));
+      memcpy(&y, b, sizeof(y));
+      Jacobian<Fq> o = xyzz_to_jacobian(xyzz_add_ni(jacobian_to_xyzz(x), jacobian_to_xyzz(y)));
+      memcpy(out, &o, sizeof(o));
+      return ZK_OK;
+    }
+    if (group == ZK_G2 && Cfg::HAS_G2) {
+      Jacobian<Fq2> x, y;
+      memcpy(&x, a, sizeof(x));
+      memcpy(&y, b, sizeof(y));
+      Jacobian<Fq2> o = xyzz_to_jacobian(xyzz_add_ni(jacobian_to_xyzz(x), jacobian_to_xyzz(y)));
+      memcpy(out, &o, sizeof(o));
+      return ZK_OK;
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+  // A, B, C shares from the five d_msm king outputs (prove.rs) -- used when the MSMs were computed per rank.
+  int groth16_assemble(const zk_crs_share* crs, const void* r_, const void* s_, const void* const* sums,
+                       const zk_groth16_masks* mk, void* pi_a, void* pi_b, void* pi_c) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    using P1 = XYZZ<Fq>;
+    using P2 = XYZZ<Fq2>;
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    if (!crs || !r_ || !s_ || !sums || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
+    auto j1 = [](const void* p) {
+      Jacobian<Fq> j;
+      memcpy(&j, p, sizeof(j));
+      return jacobian_to_xyzz(j);
+    };
+    Jacobian<Fq2> jv;
+    memcpy(&jv, sums[2], sizeof(jv));
+    Affine<Fq> d1a;
+    memcpy(&d1a, crs->delta_g1, sizeof(d1a));
+    Affine<Fq2> d2a;
+    memcpy(&d2a, crs->delta_g2, sizeof(d2a));
+    P1 d1 = P1::from_affine(d1a);
+    P1 rN = host_scalar_mul<FrP, Fq>(d1, r), sK = host_scalar_mul<FrP, Fq>(d1, s),
+       rsM = host_scalar_mul<FrP, Fq>(d1, r * s);
+    P2 sK2 = host_scalar_mul<FrP, Fq2>(P2::from_affine(d2a), s);
+    return assemble_t<P1, P2>(crs, r, s, rN, sK, rsM, sK2, j1(sums[0]), j1(sums[1]), jacobian_to_xyzz(jv), j1(sums[3]),
+                              j1(sums[4]), mk, pi_a, pi_b, pi_c);
   }
 
   int ensure_streams() {

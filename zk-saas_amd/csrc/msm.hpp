@@ -580,6 +580,24 @@ class MsmRunner {
     return ZK_OK;
   }
 
+  // the same for a contiguous range of parties held by this rank (bases/scalars [nparties][len])
+  template <class Fld>
+  int d_msm_range_t(IEngine* eng, const void* bases, const void* scalars, size_t len, int first, int count,
+                    const void* in_mask, XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
+    XYZZ<Fld> r;
+    int rc = run_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, &r, st, wslot);
+    if (rc) return rc;
+    if (in_mask) {
+      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
+      std::vector<Affine<Fld>> aff(count);
+      for (int p = 0; p < count; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
+      std::vector<char> mt = host_lincomb<Fld>(aff, first);
+      r = xyzz_add_ni(r, *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
+    }
+    *result = r;
+    return ZK_OK;
+  }
+
   template <class Fld>
   int d_msm_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const void* in_mask,
               const void* out_mask, void* out, hipStream_t st) {
@@ -598,10 +616,10 @@ class MsmRunner {
   }
 
   template <class Fld>
-  std::vector<char> host_lincomb(const std::vector<Affine<Fld>>& pts) {
+  std::vector<char> host_lincomb(const std::vector<Affine<Fld>>& pts, int first = 0) {
     XYZZ<Fld> acc = XYZZ<Fld>::identity();
     for (size_t p = 0; p < pts.size(); p++) {
-      Fr k = coef_h_[p].from_mont();
+      Fr k = coef_h_[first + p].from_mont();
       XYZZ<Fld> base = XYZZ<Fld>::from_affine(pts[p]);
       XYZZ<Fld> r = XYZZ<Fld>::identity();
       for (int i = FrP::N - 1; i >= 0; i--)
