@@ -4,6 +4,12 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` may be imported by the
 product (`zk-saas_amd/`); only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` use it, and only as the checker.
 
+PARITY STATUS: pinned by every check the reference's own tests hold for this path (restated in
+tests/test_oracle_*.py: SURVEY.md 8c items 2-9), by the reference's SHA-256 public-output known answer and by the
+output of the reference's own wasm witness calculator run under node (tests/golden/).  Byte-level parity against an
+arkworks-PRODUCED proof is UNPINNED: the reference holds no expected proof / NTT / MSM bytes and cannot be built
+here (no Rust toolchain, arkworks not vendored) -- see DESIGN.md section 5.
+
 The arithmetic of the reference lives in third-party arkworks crates that are
 not vendored under /root/reference: ark-ff / ark-ec / ark-poly
 ``^0.4``, ark-bn254 / ark-bls12-377 ``^0.4.0``.  BLS12-381 is not a dependency
