@@ -27,6 +27,26 @@ class ZkError(RuntimeError):
         self.code, self.msg, self.party = code, msg, party
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, same as /opt/rocm's).  Two HIP
+    runtimes in one process do not coexist reliably (the second one to initialise may see no GPU), and bench.py /
+    multigpu.py hand torch tensors to this library, so when torch is installed its runtime is loaded first and the
+    dynamic loader then resolves this library's libamdhip64.so.7 dependency to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -34,6 +54,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libzksaas_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                           "there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, sz, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
     lib.zk_version.restype = C.c_char_p
