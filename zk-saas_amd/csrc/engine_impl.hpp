@@ -732,6 +732,28 @@ class Engine : public IEngine {
     auto join = [](std::thread& t) {
       if (t.joinable()) t.join();
     };
+    // V (G2) is the longest chain: it is issued first, on high-priority streams, as two halves of the party range
+    P2 V0, V1;
+    int rcv1 = 0;
+    const int nh = n / 2;
+    const size_t half_bytes_b = (size_t)nh * crs->len_a * sizeof(Affine<Fq2>);
+    const size_t half_bytes_s = (size_t)nh * crs->len_a * sizeof(Fr);
+    const bool split_v = (n >= 2) && !(mk && mk->msm_in[2]);
+    std::thread tV = spawn([&]() {
+      (void)hipSetDevice(dev);
+      if (split_v)
+        rcs[2] = msm_.template d_msm_range_t<Fq2>(this, crs->v_d, a_share, crs->len_a, 0, nh, nullptr, &V0, streams_[2], 3);
+      else
+        rcs[2] = msm_.template d_msm_sum_t<Fq2>(this, crs->v_d, a_share, crs->len_a, mk ? mk->msm_in[2] : nullptr, &V,
+                                                streams_[2], 3);
+    });
+    std::thread tV1 = spawn([&]() {
+      (void)hipSetDevice(dev);
+      if (split_v)
+        rcv1 = msm_.template d_msm_range_t<Fq2>(this, (const char*)crs->v_d + half_bytes_b,
+                                                (const char*)a_share + half_bytes_s, crs->len_a, nh, n - nh, nullptr,
+                                                &V1, streams_[4], 5);
+    });
     std::thread tS = spawn([&]() {
       (void)hipSetDevice(dev);
       rcs[0] = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S,
@@ -742,11 +764,6 @@ class Engine : public IEngine {
       if (!r_zero)
         rcs[1] = msm_.template d_msm_sum_t<Fq>(this, crs->h_d, a_share, crs->len_a, mk ? mk->msm_in[1] : nullptr, &H,
                                                streams_[1], 2);
-    });
-    std::thread tV = spawn([&]() {
-      (void)hipSetDevice(dev);
-      rcs[2] = msm_.template d_msm_sum_t<Fq2>(this, crs->v_d, a_share, crs->len_a, mk ? mk->msm_in[2] : nullptr, &V,
-                                              streams_[2], 3);
     });
     std::thread tW = spawn([&]() {
       (void)hipSetDevice(dev);
@@ -760,7 +777,10 @@ class Engine : public IEngine {
     join(tS);
     join(tH);
     join(tV);
+    join(tV1);
     join(tW);
+    if (split_v) V = xyzz_add_ni(V0, V1);
+    if (rcv1) return rcv1;
     host.join();
     if (rc) return rc;
     for (int i = 0; i < 4; i++)
@@ -902,11 +922,16 @@ class Engine : public IEngine {
   int ensure_streams() {
     std::lock_guard<std::mutex> lk(mu_);
     if (streams_ready_) return ZK_OK;
-    for (int i = 0; i < 4; i++) ZK_HIP(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     // hi = numerically lowest = highest priority
+    for (int i = 0; i < 5; i++) {
+      bool g2 = (i == 2 || i == 4);
+      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, g2 ? hi : lo));
+    }
     streams_ready_ = true;
     return ZK_OK;
   }
-  hipStream_t streams_[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t streams_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool streams_ready_ = false;
   bool force_simple_ntt = false;
   std::map<std::string, void*> base_tables_;

@@ -171,6 +171,12 @@ struct Fp {
     }
     return reduce_once(r, (uint32_t)t[M]);
 #else
+    return mul_pairs(a, b);
+#endif
+  }
+
+  // Reference device form (plain operand-scanning CIOS); kept for cross-checks (tools/mulbench.hip).
+  ZK_HD static Fp mul_ref(const Fp& a, const Fp& b) {
     uint32_t t[N + 2];
 #pragma unroll
     for (int i = 0; i < N + 2; i++) t[i] = 0;
@@ -204,6 +210,86 @@ struct Fp {
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = t[i];
     return reduce_once(r, t[N]);
+  }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  // X = a*b + add as one v_mad_u64_u32; the carry out of bit 63 is returned as a lane mask (SGPR pair).
+  static ZK_D uint64_t madc(uint32_t a, uint32_t b, uint64_t add, uint64_t* cy) {
+    uint64_t x, c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(x), "=s"(c) : "v"(a), "v"(b), "v"(add));
+    *cy = c;
+    return x;
+  }
+  static ZK_D uint64_t madc_k(uint32_t a, uint32_t k, uint64_t add, uint64_t* cy) {   // k: wave-uniform constant
+    uint64_t x, c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(x), "=s"(c) : "v"(a), "s"(k), "v"(add));
+    *cy = c;
+    return x;
+  }
+  // v + carry bit from a lane mask; the caller guarantees v <= 2^32 - 2
+  static ZK_D uint32_t add_cy(uint32_t v, uint64_t cy) {
+    uint32_t r;
+    asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(r) : "v"(v), "s"(cy) : "vcc");
+    return r;
+  }
+#endif
+
+  // Device multiply.  Per row of a: the even-indexed partial products take the limb PAIR (t[j+1]:t[j]) as the
+  // 64-bit addend of v_mad_u64_u32 (carry-out kept as a lane mask), the odd-indexed ones are plain products
+  // whose high word (<= 2^32-2) absorbs that carry bit; one add-with-carry chain recombines the two
+  // interleaved rows.  The Montgomery reduction row has the same shape.  Compared with the plain CIOS this
+  // removes the zero-extension moves and 64-bit adds the compiler otherwise emits (8 limbs: 128 v_mad_u64_u32
+  // + ~240 32-bit adds instead of + ~440 other VALU instructions).
+  ZK_HD static Fp mul_pairs(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(N % 2 == 0, "even limb count expected");
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int j = 0; j <= N; j++) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t X[N], cy[N / 2];
+#pragma unroll
+      for (int j = 0; j < N; j += 2) {
+        uint64_t add = ((uint64_t)t[j + 1] << 32) | t[j];
+        X[j] = madc(a.v[i], b.v[j], add, &cy[j / 2]);
+        X[j + 1] = (uint64_t)a.v[i] * b.v[j + 1];
+      }
+      uint32_t c, u[N + 1];
+      u[0] = (uint32_t)X[0];
+      u[1] = __builtin_addc((uint32_t)(X[0] >> 32), (uint32_t)X[1], 0u, &c);
+#pragma unroll
+      for (int k = 2; k < N; k++) {
+        uint32_t e = (k & 1) ? (uint32_t)(X[k - 1] >> 32) : (uint32_t)X[k];
+        uint32_t o = (k & 1) ? (uint32_t)X[k] : add_cy((uint32_t)(X[k - 1] >> 32), cy[k / 2 - 1]);
+        u[k] = __builtin_addc(e, o, c, &c);
+      }
+      u[N] = __builtin_addc(t[N], add_cy((uint32_t)(X[N - 1] >> 32), cy[N / 2 - 1]), c, &c);
+      uint32_t top = c;
+      uint32_t m = u[0] * P::N0INV;
+      uint64_t Y[N], dy[N / 2];
+#pragma unroll
+      for (int j = 0; j < N; j += 2) {
+        uint64_t add = ((uint64_t)u[j + 1] << 32) | u[j];
+        Y[j] = madc_k(m, P::MOD[j], add, &dy[j / 2]);
+        Y[j + 1] = (uint64_t)m * P::MOD[j + 1];
+      }
+      t[0] = __builtin_addc((uint32_t)(Y[0] >> 32), (uint32_t)Y[1], 0u, &c);
+#pragma unroll
+      for (int k = 2; k < N; k++) {
+        uint32_t e = (k & 1) ? (uint32_t)(Y[k - 1] >> 32) : (uint32_t)Y[k];
+        uint32_t o = (k & 1) ? (uint32_t)Y[k] : add_cy((uint32_t)(Y[k - 1] >> 32), dy[k / 2 - 1]);
+        t[k - 1] = __builtin_addc(e, o, c, &c);
+      }
+      t[N - 1] = __builtin_addc(u[N], add_cy((uint32_t)(Y[N - 1] >> 32), dy[N / 2 - 1]), c, &c);
+      t[N] = top + c;
+    }
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return reduce_once(r, t[N]);
+#else
+    return mul_ref(a, b);
 #endif
   }
 
@@ -270,6 +356,8 @@ template <class P>
 struct Fp2 {
   using B = Fp<P>;
   B c0, c1;
+  // base-field multiply used by the tower: Fp's operator* (inline for 8-limb fields, out of line for 12-limb)
+  static ZK_HD B bmul(const B& a, const B& b) { return a * b; }
   ZK_HD static Fp2 zero() { return {B::zero(), B::zero()}; }
   ZK_HD static Fp2 one() { return {B::one(), B::zero()}; }
   ZK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
@@ -281,15 +369,15 @@ struct Fp2 {
   ZK_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
   // (a0 + a1 u)(b0 + b1 u) with u^2 = -1, Karatsuba: 3 base multiplications.
   ZK_HD friend Fp2 operator*(const Fp2& a, const Fp2& b) {
-    B v0 = B::mul_ni(a.c0, b.c0);
-    B v1 = B::mul_ni(a.c1, b.c1);
-    B s = B::mul_ni(a.c0 + a.c1, b.c0 + b.c1);
+    B v0 = bmul(a.c0, b.c0);
+    B v1 = bmul(a.c1, b.c1);
+    B s = bmul(a.c0 + a.c1, b.c0 + b.c1);
     return {v0 - v1, s - v0 - v1};
   }
   // (a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u : 2 base multiplications.
   ZK_HD Fp2 sqr() const {
-    B t = B::mul_ni(c0, c1);
-    return {B::mul_ni(c0 + c1, c0 - c1), t.dbl()};
+    B t = bmul(c0, c1);
+    return {bmul(c0 + c1, c0 - c1), t.dbl()};
   }
   ZK_HD Fp2 inverse() const {
     B n = (B::mul_ni(c0, c0) + B::mul_ni(c1, c1)).inverse();

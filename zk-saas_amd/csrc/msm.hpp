@@ -190,13 +190,22 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const Affine<Fld>* 
   if (s >= nseg) return;
   SegDesc d = segs[s];
   XYZZ<Fld> acc = XYZZ<Fld>::identity();
+  // software pipeline: the next point's index and coordinates are in flight while the current one is added
+  uint32_t e = sorted[d.start];
+  Affine<Fld> pt = load_elem(bases + (e & 0x7fffffffu));
   for (uint32_t p = d.start; p < d.end; p++) {
-    uint32_t e = sorted[p];
-    uint32_t idx = e & 0x7fffffffu;
-    Affine<Fld> pt = load_elem(bases + idx);
-    if (pt.is_identity()) continue;
-    Fld y = (e >> 31) ? pt.y.neg() : pt.y;
-    acc = xyzz_madd(acc, pt.x, y);
+    uint32_t e_next = e;
+    Affine<Fld> pt_next = pt;
+    if (p + 1 < d.end) {
+      e_next = sorted[p + 1];
+      pt_next = load_elem(bases + (e_next & 0x7fffffffu));
+    }
+    if (!pt.is_identity()) {
+      Fld y = (e >> 31) ? pt.y.neg() : pt.y;
+      acc = xyzz_madd(acc, pt.x, y);
+    }
+    e = e_next;
+    pt = pt_next;
   }
   store_elem(partial + s, acc);
 }

@@ -111,7 +111,7 @@ struct LdsVec {
 //   pass 0 (s0 == 0) uses the shifted exponent k+1 and no pre-twiddle.
 //   add      : optional [batch][n] added at the final store (in_mask)
 template <class F>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0, int s1,
+__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0, int s1,
                                                               int cbits, const F* __restrict__ tw_full, int log_l,
                                                               const F* __restrict__ add) {
   extern __shared__ uint4 smem[];
