@@ -770,9 +770,15 @@ class Engine : public IEngine {
       rcs[3] = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W,
                                              streams_[3], 4);
     });
-    rc = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, st);
+    // circom_h and the U-MSM that depends on it form the longest dependent chain: they run on a high-priority
+    // internal stream (ordered after the caller's stream through an event) so that the bulk MSM kernels of the
+    // other streams cannot starve their small launches.
+    hipStream_t hs = streams_[5];
+    ZK_HIP(hipEventRecord(ev_in_, st));
+    ZK_HIP(hipStreamWaitEvent(hs, ev_in_, 0));
+    rc = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, hs);
     if (!rc)
-      rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, st,
+      rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, hs,
                                          0);
     join(tS);
     join(tH);
@@ -924,14 +930,16 @@ class Engine : public IEngine {
     if (streams_ready_) return ZK_OK;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     // hi = numerically lowest = highest priority
-    for (int i = 0; i < 5; i++) {
-      bool g2 = (i == 2 || i == 4);
-      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, g2 ? hi : lo));
+    for (int i = 0; i < 6; i++) {
+      bool prio = (i == 2 || i == 4 || i == 5);      // the two G2 halves and the circom_h -> U chain
+      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio ? hi : lo));
     }
+    ZK_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
     streams_ready_ = true;
     return ZK_OK;
   }
-  hipStream_t streams_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_in_ = nullptr;
   bool streams_ready_ = false;
   bool force_simple_ntt = false;
   std::map<std::string, void*> base_tables_;

@@ -29,7 +29,7 @@
 namespace zk {
 #if defined(__HIPCC__)
 
-constexpr int MSM_SEG_MAX = 64;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
+constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
 // bucket-reduce workgroup: 256 lanes, 128 for the largest point types (two LDS planes must fit in 160 KiB)
 template <class Fld>
 constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
@@ -225,7 +225,7 @@ ZK_D XYZZ<Fld> dbl_sel(const XYZZ<Fld>& a) {
 // One lane per bucket sums its segments when there are few; buckets with many segments (skewed digit
 // distributions: the sparsely used top window, degenerate scalars such as all ones) are queued on `heavy` and
 // summed by a whole workgroup each in msm_finalize_heavy_kernel, so no lane ever walks a long chain.
-constexpr uint32_t FIN_SEQ = 4;
+constexpr uint32_t FIN_SEQ = 16;
 constexpr int FIN_HEAVY_THREADS = 128;
 
 template <class Fld, bool INL>
@@ -378,6 +378,8 @@ class MsmRunner {
     for (int c = 4; c <= 17; c++) {
       int nwin = (FrP::BITS + c) / c;
       double cost = (double)nwin * ((double)npts + 4.0 * (double)((size_t)1 << (c - 1)));
+      int top_bits = FrP::BITS + 1 - (nwin - 1) * c;
+      if (2 * top_bits < c) cost *= 1.15;   // a sparsely used top window concentrates points in a few buckets
       if (cost <= best_cost) {
         best_cost = cost;
         best = c;
@@ -392,9 +394,11 @@ class MsmRunner {
       int v = atoi(e);
       if (v >= 1 && v <= 1024) return (uint32_t)v;
     }
-    (void)npts;
+    // Measured on MI355X (SHA-256 circuit, 111k-point MSMs): the accumulate kernel's duration is set by its
+    // longest lane chain, so short segments win (8.9 ms/proof at 16 vs 10.9 at 64); for multi-million-point MSMs
+    // the buckets are long anyway and 64 keeps the number of partial sums down.
     (void)nwin;
-    return MSM_SEG_MAX;   // measured on MI355X: finer cuts cost more in finalize than they gain in accumulate
+    return npts >= ((size_t)1 << 21) ? 64u : (uint32_t)MSM_SEG_MAX;
   }
 
   template <class Fld>
@@ -410,7 +414,7 @@ class MsmRunner {
     const size_t nkeys = (size_t)nwin * B;
     const size_t max_sorted = npts * nwin;
     const uint32_t seg = pick_seg(npts, nwin);
-    const size_t max_segs = nkeys + max_sorted / seg + 1;
+    const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
     constexpr bool INL = sizeof(Fld) == 32;     // 8-limb G1
     constexpr int RED_THREADS = red_threads<Fld>();
     const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
