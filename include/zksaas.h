@@ -178,6 +178,14 @@ int zk_groth16_prove(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, 
 int zk_d_msm_local(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, int first_party,
                    int nparties, const void* in_mask, void* out, void* stream);
 int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out);
+/* The five zk_d_msm_local of the prover for this rank's parties, overlapped: _begin starts S, H, V, W (they only
+ * need the witness shares; crs vectors are [nparties][len] here) on internal streams and returns; _finish runs U
+ * on `stream` once h_share_d [nparties][m/l] is available, joins, and writes out[0..4] = S, H, V(G2), W, U
+ * (Jacobian, host).  skip_h != 0 when r = 0 (prove.rs:96-98). */
+int zk_groth16_msms_begin(zk_ctx* ctx, const zk_crs_share* crs, const void* a_share_d, const void* ax_share_d,
+                          int first_party, int nparties, int skip_h);
+int zk_groth16_msms_finish(zk_ctx* ctx, const zk_crs_share* crs, const void* h_share_d, int first_party, int nparties,
+                           void* const* out, void* stream);
 int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                         const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c);
 

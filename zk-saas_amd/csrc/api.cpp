@@ -199,6 +199,17 @@ int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, con
   return e->groth16_assemble(crs, r, s, sums, masks, pi_a, pi_b, pi_c);
 }
 
+int zk_groth16_msms_begin(zk_ctx* ctx, const zk_crs_share* crs, const void* a_share_d, const void* ax_share_d,
+                          int first_party, int nparties, int skip_h) {
+  CTX_OR_FAIL();
+  return e->msms_begin(crs, a_share_d, ax_share_d, first_party, nparties, skip_h);
+}
+int zk_groth16_msms_finish(zk_ctx* ctx, const zk_crs_share* crs, const void* h_share_d, int first_party, int nparties,
+                           void* const* out, void* stream) {
+  CTX_OR_FAIL();
+  return e->msms_finish(crs, h_share_d, first_party, nparties, out, S(stream));
+}
+
 // ---- profiling slots (bench.py roofline leg) ----
 static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king_fft2_kernel", "msm_accumulate_kernel<G1>",
                                                          "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",

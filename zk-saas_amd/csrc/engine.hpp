@@ -142,6 +142,10 @@ class IEngine {
   virtual int group_add(int group, const void* a, const void* b, void* out) = 0;
   virtual int groth16_assemble(const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                                const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) = 0;
+  virtual int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count,
+                         int skip_h) = 0;
+  virtual int msms_finish(const zk_crs_share* crs, const void* h_share, int first, int count, void* const* out,
+                          hipStream_t st) = 0;
   virtual int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
                        hipStream_t st) = 0;
   virtual int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* masks,

@@ -925,6 +925,77 @@ class Engine : public IEngine {
                               j1(sums[4]), mk, pi_a, pi_b, pi_c);
   }
 
+  // ---- the five partial d_msm of one rank, concurrently (multi-GPU flow) ---------------------------------
+  // begin: S, H, V, W over this rank's parties start on internal streams; finish: U (needs h) runs, all join.
+  struct MsmJob {
+    std::thread th[4];
+    XYZZ<Fp<typename Cfg::FqP>> S, H, W, U;
+    XYZZ<Fp2<typename Cfg::FqP>> V;
+    int rc[4] = {0, 0, 0, 0};
+    bool active = false;
+  } job_;
+  int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count,
+                 int skip_h) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    if (job_.active) return fail(ZK_ERR_BAD_INPUT, "zk_groth16_msms_begin called twice");
+    if (first < 0 || count <= 0 || first + count > n) return fail(ZK_ERR_BAD_INPUT, "bad party range");
+    int rc = ensure_streams();
+    if (rc) return rc;
+    const int dev = device;
+    job_.active = true;
+    for (int i = 0; i < 4; i++) job_.rc[i] = 0;
+    job_.H = XYZZ<Fq>::identity();
+    job_.th[0] = std::thread([=]() {
+      (void)hipSetDevice(dev);
+      job_.rc[2] = msm_.template d_msm_range_t<Fq2>(this, crs->v_d, a_share, crs->len_a, first, count, nullptr, &job_.V,
+                                                    streams_[2], 3);
+    });
+    job_.th[1] = std::thread([=]() {
+      (void)hipSetDevice(dev);
+      job_.rc[0] = msm_.template d_msm_range_t<Fq>(this, crs->s_d, a_share, crs->len_a, first, count, nullptr, &job_.S,
+                                                   streams_[0], 1);
+    });
+    job_.th[2] = std::thread([=]() {
+      (void)hipSetDevice(dev);
+      if (!skip_h)
+        job_.rc[1] = msm_.template d_msm_range_t<Fq>(this, crs->h_d, a_share, crs->len_a, first, count, nullptr,
+                                                     &job_.H, streams_[1], 2);
+    });
+    job_.th[3] = std::thread([=]() {
+      (void)hipSetDevice(dev);
+      job_.rc[3] = msm_.template d_msm_range_t<Fq>(this, crs->w_d, ax_share, crs->len_w, first, count, nullptr, &job_.W,
+                                                   streams_[3], 4);
+    });
+    return ZK_OK;
+  }
+  int msms_finish(const zk_crs_share* crs, const void* h_share, int first, int count, void* const* out,
+                  hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (!job_.active) return fail(ZK_ERR_BAD_INPUT, "zk_groth16_msms_finish without begin");
+    int rc = msm_.template d_msm_range_t<Fq>(this, crs->u_d, h_share, crs->len_u, first, count, nullptr, &job_.U, st, 0);
+    for (int i = 0; i < 4; i++)
+      if (job_.th[i].joinable()) job_.th[i].join();
+    job_.active = false;
+    if (rc) return rc;
+    for (int i = 0; i < 4; i++)
+      if (job_.rc[i]) return job_.rc[i];
+    Jacobian<Fq> j;
+    j = xyzz_to_jacobian(job_.S);
+    memcpy(out[0], &j, sizeof(j));
+    j = xyzz_to_jacobian(job_.H);
+    memcpy(out[1], &j, sizeof(j));
+    Jacobian<Fq2> j2 = xyzz_to_jacobian(job_.V);
+    memcpy(out[2], &j2, sizeof(j2));
+    j = xyzz_to_jacobian(job_.W);
+    memcpy(out[3], &j, sizeof(j));
+    j = xyzz_to_jacobian(job_.U);
+    memcpy(out[4], &j, sizeof(j));
+    return ZK_OK;
+  }
+
   int ensure_streams() {
     std::lock_guard<std::mutex> lk(mu_);
     if (streams_ready_) return ZK_OK;

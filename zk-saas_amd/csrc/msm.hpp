@@ -30,9 +30,9 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
-// bucket-reduce workgroup: 256 lanes, 128 for the largest point types (two LDS planes must fit in 160 KiB)
+// bucket-reduce workgroup (one LDS plane of XYZZ points: 32..96 KiB)
 template <class Fld>
-constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
+constexpr int red_threads() { return 256; }
 constexpr int RED_G = 4;              // buckets per lane in bucket-reduce
 constexpr int MSM_WS = 6;             // independent workspaces (concurrent MSMs on separate streams)
 
@@ -293,7 +293,6 @@ __global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>
                                                                 XYZZ<Fld>* __restrict__ out /* [nwin][bpw][2] */) {
   extern __shared__ uint4 smem_red[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);      // [RED_THREADS]
-  XYZZ<Fld>* sh2 = sh + RED_THREADS;                            // [RED_THREADS]
   uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
   uint32_t base = blk * RED_THREADS * RED_G;
   int tid = threadIdx.x;
@@ -320,34 +319,25 @@ __global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>
     __syncthreads();
   }
   XYZZ<Fld> S = sh[0];
-  // sum_t t * run[t] = sum_{j >= 1} suf[j] (lane weight is t*RED_G: scaled afterwards); reduce it together
-  // with sum_t acc[t] in one tree (two independent additions per step)
+  // sum_b (b - base + 1) bucket_b = sum_t (acc[t] + RED_G * t * run[t]) and sum_t t * run[t] = sum_{j >= 1} suf[j]:
+  // each lane folds its suffix term into one value, then a single tree reduction (one addition per step)
   XYZZ<Fld> mine = XYZZ<Fld>::identity();
   if (tid >= 1) mine = sh[tid];
   __syncthreads();
-  sh[tid] = mine;
-  sh2[tid] = acc;
+  for (int g = 1; g < RED_G; g <<= 1) mine = dbl_sel<INL>(mine);
+  XYZZ<Fld> v = add_sel<INL>(acc, mine);
+  sh[tid] = v;
   __syncthreads();
   for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
-    XYZZ<Fld> a1 = sh[tid], a2 = sh2[tid];
-    XYZZ<Fld> b1 = XYZZ<Fld>::identity(), b2 = XYZZ<Fld>::identity();
-    if (tid < off) {
-      b1 = sh[tid + off];
-      b2 = sh2[tid + off];
-    }
+    XYZZ<Fld> a1 = sh[tid];
+    XYZZ<Fld> b1 = XYZZ<Fld>::identity();
+    if (tid < off) b1 = sh[tid + off];
     XYZZ<Fld> r1 = add_sel<INL>(a1, b1);
-    XYZZ<Fld> r2 = add_sel<INL>(a2, b2);
     __syncthreads();
-    if (tid < off) {
-      sh[tid] = r1;
-      sh2[tid] = r2;
-    }
+    if (tid < off) sh[tid] = r1;
     __syncthreads();
   }
-  XYZZ<Fld> TG = sh[0];
-  XYZZ<Fld> Asum = sh2[0];
-  for (int g = 1; g < RED_G; g <<= 1) TG = dbl_sel<INL>(TG);
-  XYZZ<Fld> A = add_sel<INL>(Asum, TG);
+  XYZZ<Fld> A = sh[0];
   if (tid == 0) {
     store_elem(out + ((size_t)blockIdx.x) * 2, S);
     store_elem(out + ((size_t)blockIdx.x) * 2 + 1, A);
@@ -498,7 +488,7 @@ class MsmRunner {
                                                                                                buckets);
     }
     MSM_STAGE("finalize");
-    size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
+    size_t red_lds = RED_THREADS * sizeof(XYZZ<Fld>);
     static bool attr_set = false;
     if (!attr_set && red_lds > 48 * 1024) {
       MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<Fld, INL, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,

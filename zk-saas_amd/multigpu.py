@@ -72,6 +72,26 @@ class GpuBackend:
                                         out.ctypes.data, self.stream()))
         return out
 
+    def msms_begin(self, inp, first, count, skip_h):
+        """start S, H, V, W for this rank's parties (overlaps the circom_h rounds)"""
+        pp = self.pp
+        self._local_crs = zg.CrsShare(inp["s"].data_ptr(), inp["h"].data_ptr(), inp["v"].data_ptr(),
+                                      inp["w"].data_ptr(), inp["u"].data_ptr(), inp["len_a"], inp["len_w"],
+                                      inp["u"].shape[1], *[getattr(inp["crs_ct"], f) for f in (
+                                          "a_query0", "b_g1_query0", "delta_g1", "alpha_g1", "beta_g1", "b_g2_query0",
+                                          "delta_g2", "beta_g2")])
+        pp._check(pp.lib.zk_groth16_msms_begin(pp.h, C.byref(self._local_crs), inp["a_share"].data_ptr(),
+                                               inp["ax_share"].data_ptr(), first, count, int(skip_h)))
+
+    def msms_finish(self, h, first, count):
+        pp = self.pp
+        nl = pp.fq.nl
+        outs = [np.zeros(3 * nl * (2 if i == 2 else 1), dtype=np.uint64) for i in range(5)]
+        arr = (C.c_void_p * 5)(*[x.ctypes.data for x in outs])
+        pp._check(pp.lib.zk_groth16_msms_finish(pp.h, C.byref(self._local_crs), h.data_ptr(), first, count, arr,
+                                                self.stream()))
+        return outs
+
     def group_add(self, group, a, b):
         pp = self.pp
         out = np.zeros_like(a)
@@ -181,17 +201,23 @@ class DistProver:
 
     def prove(self, inp, r, s, seed):
         be = self.be
-        h = self.circom_h(inp["qap"], seed)
         first, k = self.first, self.k
-        parts = [
-            be.msm_local(ZK_G1, inp["s"], inp["a_share"], inp["len_a"], first, k),
-            be.msm_local(ZK_G1, inp["h"], inp["a_share"], inp["len_a"], first, k) if r else None,
-            be.msm_local(ZK_G2, inp["v"], inp["a_share"], inp["len_a"], first, k),
-            be.msm_local(ZK_G1, inp["w"], inp["ax_share"], inp["len_w"], first, k),
-            be.msm_local(ZK_G1, inp["u"], h, self.Lc, first, k),
-        ]
-        if parts[1] is None:
-            parts[1] = np.zeros_like(parts[0])
+        if hasattr(be, "msms_begin"):
+            # the four MSMs over the witness shares overlap the king rounds of circom_h (prove.rs try_join!)
+            be.msms_begin(inp, first, k, skip_h=(r == 0))
+            h = self.circom_h(inp["qap"], seed)
+            parts = be.msms_finish(h, first, k)
+        else:
+            h = self.circom_h(inp["qap"], seed)
+            parts = [
+                be.msm_local(ZK_G1, inp["s"], inp["a_share"], inp["len_a"], first, k),
+                be.msm_local(ZK_G1, inp["h"], inp["a_share"], inp["len_a"], first, k) if r else None,
+                be.msm_local(ZK_G2, inp["v"], inp["a_share"], inp["len_a"], first, k),
+                be.msm_local(ZK_G1, inp["w"], inp["ax_share"], inp["len_w"], first, k),
+                be.msm_local(ZK_G1, inp["u"], h, self.Lc, first, k),
+            ]
+            if parts[1] is None:
+                parts[1] = np.zeros_like(parts[0])
         # d_msm's king: sum of the ranks' partial points, known to every rank afterwards (dmsm/mod.rs:85-92)
         flat = np.concatenate(parts)
         gathered = [be.tensor_to_points(t).reshape(-1) for t in self.net.all_gather(be.point_to_tensor(flat))]
