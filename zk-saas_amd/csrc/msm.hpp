@@ -30,9 +30,9 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
-// bucket-reduce workgroup (one LDS plane of XYZZ points: 32..96 KiB)
+// bucket-reduce workgroup: 256 lanes, 128 for the largest point type (two LDS planes must fit in 160 KiB)
 template <class Fld>
-constexpr int red_threads() { return 256; }
+constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
 constexpr int RED_G = 4;              // buckets per lane in bucket-reduce
 constexpr int MSM_WS = 6;             // independent workspaces (concurrent MSMs on separate streams)
 
@@ -210,25 +210,17 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const Affine<Fld>* 
   store_elem(partial + s, acc);
 }
 
-// Group additions in the cold kernels: inlined for 8-limb G1 (fast, compiles quickly), out of line otherwise.
-template <bool INL, class Fld>
-ZK_D XYZZ<Fld> add_sel(const XYZZ<Fld>& a, const XYZZ<Fld>& b) {
-  if constexpr (INL) return xyzz_add(a, b);
-  else return xyzz_add_ni(a, b);
-}
-template <bool INL, class Fld>
-ZK_D XYZZ<Fld> dbl_sel(const XYZZ<Fld>& a) {
-  if constexpr (INL) return xyzz_dbl(a);
-  else return xyzz_dbl_ni(a);
-}
-
 // One lane per bucket sums its segments when there are few; buckets with many segments (skewed digit
 // distributions: the sparsely used top window, degenerate scalars such as all ones) are queued on `heavy` and
 // summed by a whole workgroup each in msm_finalize_heavy_kernel, so no lane ever walks a long chain.
+//
+// Every kernel below has exactly ONE (inlined) group-addition call site inside a loop and keeps the lanes' running
+// values in LDS between iterations: an out-of-line addition would pass its 128..384-byte operands through scratch
+// memory (measured: 0.25 GB of scratch writes per G2 reduce launch), several inlined copies would blow up code size.
 constexpr uint32_t FIN_SEQ = 16;
 constexpr int FIN_HEAVY_THREADS = 128;
 
-template <class Fld, bool INL>
+template <class Fld>
 __global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial,
                                                           const uint2* __restrict__ offsets, size_t nkeys,
                                                           XYZZ<Fld>* __restrict__ buckets,
@@ -243,11 +235,11 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __re
   }
   XYZZ<Fld> acc = XYZZ<Fld>::identity();
   if (s1 > s0) acc = load_elem(partial + s0);
-  for (uint32_t s = s0 + 1; s < s1; s++) acc = add_sel<INL>(acc, load_elem(partial + s));
+  for (uint32_t s = s0 + 1; s < s1; s++) acc = xyzz_add(acc, load_elem(partial + s));
   store_elem(buckets + k, acc);
 }
 
-template <class Fld, bool INL>
+template <class Fld>
 __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
     const XYZZ<Fld>* __restrict__ partial, const uint2* __restrict__ offsets, const uint32_t* __restrict__ heavy,
     XYZZ<Fld>* __restrict__ buckets) {
@@ -255,27 +247,28 @@ __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
   const uint32_t nheavy = heavy[0];
   const int tid = threadIdx.x;
+  constexpr int LOGT = 7;
+  static_assert((1 << LOGT) == FIN_HEAVY_THREADS, "FIN_HEAVY_THREADS");
   for (uint32_t hbk = blockIdx.x; hbk < nheavy; hbk += gridDim.x) {
     uint32_t k = heavy[1 + hbk];
     uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
-    XYZZ<Fld> acc = XYZZ<Fld>::identity();
-    // uniform trip count across the workgroup; lanes past the end add the identity
-    uint32_t rounds = (s1 - s0 + FIN_HEAVY_THREADS - 1) / FIN_HEAVY_THREADS;
-    for (uint32_t r = 0; r < rounds; r++) {
-      uint32_t s = s0 + r * FIN_HEAVY_THREADS + tid;
-      XYZZ<Fld> v = XYZZ<Fld>::identity();
-      if (s < s1) v = load_elem(partial + s);
-      acc = add_sel<INL>(acc, v);
-    }
-    sh[tid] = acc;
-    __syncthreads();
-    for (int off = FIN_HEAVY_THREADS / 2; off > 0; off >>= 1) {
+    uint32_t rounds = (s1 - s0 + FIN_HEAVY_THREADS - 1) / FIN_HEAVY_THREADS;   // uniform across the workgroup
+    sh[tid] = XYZZ<Fld>::identity();
+    for (uint32_t it = 0; it < rounds + LOGT; it++) {
       XYZZ<Fld> a = sh[tid];
       XYZZ<Fld> b = XYZZ<Fld>::identity();
-      if (tid < off) b = sh[tid + off];
-      XYZZ<Fld> rsum = add_sel<INL>(a, b);
+      bool wr = true;
+      if (it < rounds) {                       // strided accumulation of the segments
+        uint32_t s = s0 + it * FIN_HEAVY_THREADS + tid;
+        if (s < s1) b = load_elem(partial + s);
+      } else {                                 // tree over the workgroup
+        int off = FIN_HEAVY_THREADS >> (it - rounds + 1);
+        wr = tid < off;
+        if (wr) b = sh[tid + off];
+      }
+      XYZZ<Fld> r = xyzz_add(a, b);
       __syncthreads();
-      if (tid < off) sh[tid] = rsum;
+      if (wr) sh[tid] = r;
       __syncthreads();
     }
     if (tid == 0) store_elem(buckets + k, sh[0]);
@@ -284,64 +277,75 @@ __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
 }
 
 // -------------------------------------------------------------------------------------------------- reduce
-// Workgroup (w, blk) covers buckets [blk*RED_THREADS*RED_G, ...) of window w and emits
+// Workgroup (w, blk) covers buckets [blk*RT*RED_G, ...) of window w and emits
 //   S = sum bucket_b,   A = sum (b - base + 1) * bucket_b      (base = first bucket of the workgroup)
-// Control flow around the additions is wave-uniform (idle lanes add the identity); only stores are predicated.
-template <class Fld, bool INL, int RED_THREADS>
-__global__ __launch_bounds__(RED_THREADS) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets, uint32_t B,
-                                                                uint32_t blocks_per_window,
-                                                                XYZZ<Fld>* __restrict__ out /* [nwin][bpw][2] */) {
+// as a fixed program of 2*RED_G + log RT + log RED_G + 1 + log RT addition steps over two LDS planes:
+//   [0, 2G)        per-lane suffix sums of its RED_G buckets: RUN += bucket_g ; ACC += RUN
+//   [.., +log RT)  suffix scan of RUN across the lanes (suf[t] = sum_{t' >= t} RUN[t'])  -> S = suf[0]
+//   [.., +log G)   sum_t t*RUN[t] = sum_{j>=1} suf[j]; lane weight is t*RED_G: RUN[t] <- RED_G * suf[t] (t >= 1)
+//   [.., +1)       ACC += RUN
+//   [.., +log RT)  tree sum of ACC -> A
+template <class Fld, int RT>
+__global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets, uint32_t B,
+                                                       uint32_t blocks_per_window,
+                                                       XYZZ<Fld>* __restrict__ out /* [nwin][bpw][2] */) {
   extern __shared__ uint4 smem_red[];
-  XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);      // [RED_THREADS]
-  uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
-  uint32_t base = blk * RED_THREADS * RED_G;
-  int tid = threadIdx.x;
+  XYZZ<Fld>* RUN = reinterpret_cast<XYZZ<Fld>*>(smem_red);
+  XYZZ<Fld>* ACC = RUN + RT;
+  constexpr int LOGT = RT == 256 ? 8 : 7;
+  static_assert((1 << LOGT) == RT, "RT must be 128 or 256");
+  constexpr int LOGG = RED_G == 1 ? 0 : RED_G == 2 ? 1 : RED_G == 4 ? 2 : 3;
+  static_assert((1 << LOGG) == RED_G, "RED_G must be 1, 2, 4 or 8");
+  const uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
+  const uint32_t base = blk * RT * RED_G;
+  const int tid = threadIdx.x;
   const XYZZ<Fld>* wb = buckets + (size_t)w * B;
-  // per-lane suffix sums over its RED_G buckets
-  XYZZ<Fld> run = XYZZ<Fld>::identity(), acc = XYZZ<Fld>::identity();
-  for (int g = RED_G - 1; g >= 0; g--) {
-    uint32_t b = base + tid * RED_G + g;
-    XYZZ<Fld> bk = XYZZ<Fld>::identity();
-    if (b < B) bk = load_elem(wb + b);
-    run = add_sel<INL>(run, bk);
-    acc = add_sel<INL>(acc, run);
-  }
-  // suffix scan of lane totals across the workgroup: suf[t] = sum_{t' >= t} run[t']
-  sh[tid] = run;
-  __syncthreads();
-  for (int off = 1; off < RED_THREADS; off <<= 1) {
-    XYZZ<Fld> a = sh[tid];
-    XYZZ<Fld> b = XYZZ<Fld>::identity();
-    if (tid + off < RED_THREADS) b = sh[tid + off];
-    XYZZ<Fld> tv = add_sel<INL>(a, b);
+  RUN[tid] = XYZZ<Fld>::identity();
+  ACC[tid] = XYZZ<Fld>::identity();
+  constexpr int P0 = 2 * RED_G, P1 = P0 + LOGT, P2 = P1 + LOGG, P3 = P2 + 1, P4 = P3 + LOGT;
+  for (int st = 0; st < P4; st++) {
+    XYZZ<Fld> a, b = XYZZ<Fld>::identity();
+    XYZZ<Fld>* dst = RUN + tid;
+    bool wr = true;
+    if (st < P0) {
+      if ((st & 1) == 0) {
+        uint32_t bi = base + tid * RED_G + (RED_G - 1 - st / 2);
+        a = RUN[tid];
+        if (bi < B) b = load_elem(wb + bi);
+      } else {
+        a = ACC[tid];
+        b = RUN[tid];
+        dst = ACC + tid;
+      }
+    } else if (st < P1) {
+      int off = 1 << (st - P0);
+      a = RUN[tid];
+      if (tid + off < RT) b = RUN[tid + off];
+    } else if (st < P2) {
+      if (st == P1) {                       // S is complete: emit it, then lane 0 drops out of the weighted sum
+        if (tid == 0) store_elem(out + ((size_t)blockIdx.x) * 2, RUN[0]);
+        a = tid == 0 ? XYZZ<Fld>::identity() : RUN[tid];
+      } else {
+        a = RUN[tid];
+      }
+      b = a;                                // doubling through the addition's equal-operands path
+    } else if (st < P3) {
+      a = ACC[tid];
+      b = (LOGG == 0 && tid == 0) ? XYZZ<Fld>::identity() : RUN[tid];
+      dst = ACC + tid;
+    } else {
+      int off = RT >> (st - P3 + 1);
+      a = ACC[tid];
+      wr = tid < off;
+      if (wr) b = ACC[tid + off];
+      dst = ACC + tid;
+    }
+    XYZZ<Fld> r = xyzz_add(a, b);
     __syncthreads();
-    sh[tid] = tv;
+    if (wr) *dst = r;
     __syncthreads();
   }
-  XYZZ<Fld> S = sh[0];
-  // sum_b (b - base + 1) bucket_b = sum_t (acc[t] + RED_G * t * run[t]) and sum_t t * run[t] = sum_{j >= 1} suf[j]:
-  // each lane folds its suffix term into one value, then a single tree reduction (one addition per step)
-  XYZZ<Fld> mine = XYZZ<Fld>::identity();
-  if (tid >= 1) mine = sh[tid];
-  __syncthreads();
-  for (int g = 1; g < RED_G; g <<= 1) mine = dbl_sel<INL>(mine);
-  XYZZ<Fld> v = add_sel<INL>(acc, mine);
-  sh[tid] = v;
-  __syncthreads();
-  for (int off = RED_THREADS / 2; off > 0; off >>= 1) {
-    XYZZ<Fld> a1 = sh[tid];
-    XYZZ<Fld> b1 = XYZZ<Fld>::identity();
-    if (tid < off) b1 = sh[tid + off];
-    XYZZ<Fld> r1 = add_sel<INL>(a1, b1);
-    __syncthreads();
-    if (tid < off) sh[tid] = r1;
-    __syncthreads();
-  }
-  XYZZ<Fld> A = sh[0];
-  if (tid == 0) {
-    store_elem(out + ((size_t)blockIdx.x) * 2, S);
-    store_elem(out + ((size_t)blockIdx.x) * 2 + 1, A);
-  }
+  if (tid == 0) store_elem(out + ((size_t)blockIdx.x) * 2 + 1, ACC[0]);
 }
 
 #endif  // __HIPCC__
@@ -405,7 +409,6 @@ class MsmRunner {
     const size_t max_sorted = npts * nwin;
     const uint32_t seg = pick_seg(npts, nwin);
     const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
-    constexpr bool INL = sizeof(Fld) == 32;     // 8-limb G1
     constexpr int RED_THREADS = red_threads<Fld>();
     const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
     const size_t iscan_blocks = (nkeys + ISCAN_BLOCK - 1) / ISCAN_BLOCK;
@@ -480,22 +483,22 @@ class MsmRunner {
     {
     ProfScope ps_(eng->prof, PROF_MSM_REDUCE, st, (double)npts);
     MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
-    msm_finalize_kernel<Fld, INL><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
+    msm_finalize_kernel<Fld><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
                                                                                                buckets, heavy);
     {
       size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
-      msm_finalize_heavy_kernel<Fld, INL><<<dim3(512), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, offsets, heavy,
+      msm_finalize_heavy_kernel<Fld><<<dim3(512), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, offsets, heavy,
                                                                                                buckets);
     }
     MSM_STAGE("finalize");
-    size_t red_lds = RED_THREADS * sizeof(XYZZ<Fld>);
+    size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
     static bool attr_set = false;
     if (!attr_set && red_lds > 48 * 1024) {
-      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<Fld, INL, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<Fld, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)red_lds));
       attr_set = true;
     }
-    msm_reduce_kernel<Fld, INL, RED_THREADS><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
+    msm_reduce_kernel<Fld, RED_THREADS><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
     }
     MSM_HIP(hipGetLastError());
     MSM_STAGE("reduce");
