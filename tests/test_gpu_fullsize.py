@@ -1,0 +1,118 @@
+"""Parity at BASELINE.json sizes (configs 2-3) against the plain-C oracle, plus size-independent properties for the
+curves the C oracle does not cover."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import zksaas_amd as zk
+from zksaas_amd.api import ZK_G1, msm
+from oracle.cref import CPss
+from oracle.curve import g1
+from oracle.field import Domain
+from oracle.params import CURVES, BN254
+
+from gpu_util import ctx, dec_jacobian
+
+
+def _rand_fr_array(count, seed, top_bits=60):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << top_bits) - 1)        # < r for all three scalar fields: valid Montgomery residues
+    return a
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_d_fft_2_20_shares_equal_c_oracle(inverse):
+    """Config 2: d_fft / d_ifft, m = 2^20, BN254, l = 2, n = 8: every output SHARE equals the C restatement's."""
+    pp = ctx("bn254", 2)
+    cp = CPss("bn254", 2)
+    log_m = 20
+    m = 1 << log_m
+    dom = Domain(BN254, m)
+    shares = _rand_fr_array(pp.n * (m // 2), 5)
+    g = Domain(BN254, 2 * m).element(1) if inverse else None
+    buf = zk.DeviceBuffer.from_numpy(pp, shares)
+    if inverse:
+        zk.d_ifft(pp, buf, zk.FftMask.zero(), True, log_m, g=g, seed=77)
+    else:
+        zk.d_fft(pp, buf, zk.FftMask.zero(), False, log_m, seed=77)
+    got = buf.to_numpy().reshape(-1, 4)
+    want = shares.copy()
+    cp.d_fft_arrays(want, m // 2, dom.group_gen_inv if inverse else dom.group_gen, dom.size_inv if inverse else None, g,
+                    inverse, None, None, 77)
+    assert np.array_equal(got, want)
+
+
+def test_msm_2_20_equals_c_oracle():
+    """Config 3 size: 2^20-point G1 MSM (doubling-chain bases as in local_groth_bench.rs:25-29, random scalars)."""
+    pp = ctx("bn254", 2)
+    cp = CPss("bn254", 2)
+    n = 1 << 20
+    bases = cp.doubling_chain_g1(BN254.g1, n)
+    scalars = _rand_fr_array(n, 6)
+    got = msm(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, bases), zk.DeviceBuffer.from_numpy(pp, scalars), n)
+    want = cp.msm_g1_arrays(bases, scalars, n, nthreads=8)
+    G = g1(BN254)
+    assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
+
+
+def test_d_msm_2_17_per_party_equals_c_oracle():
+    """d_msm with 2^17 points per party (8 parties, fused into one 2^20-point Pippenger on the GPU)."""
+    pp = ctx("bn254", 2)
+    cp = CPss("bn254", 2)
+    ln = 1 << 17
+    chain = cp.doubling_chain_g1(BN254.g1, pp.n * ln)
+    scalars = _rand_fr_array(pp.n * ln, 7)
+    out = zk.d_msm(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, chain), zk.DeviceBuffer.from_numpy(pp, scalars), ln)
+    G = g1(BN254)
+    o = cp.opp
+    # reference: per-party G::msm, king unpack2 + sum (dmsm/mod.rs:73-92)
+    from oracle.curve import GroupOps
+    parts = [dec_jacobian(pp, cp.msm_g1_arrays(chain[p * ln:(p + 1) * ln], scalars[p * ln:(p + 1) * ln], ln, 8))
+             for p in range(pp.n)]
+    want = G.sum(o.unpack2(parts, GroupOps(G)))
+    for p in range(pp.n):
+        assert G.eq(dec_jacobian(pp, out[p]), want)
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_msm_properties_on_12_limb_curves(curve):
+    """BLS12 base fields (12 limbs, no C oracle): msm(b, s) + msm(b, -s) = 0 and msm(b, s1) + msm(b, s2) = msm(b, s1+s2)
+    at 2^14 points, and a small exact comparison with the Python oracle."""
+    c = CURVES[curve]
+    pp = ctx(curve, 2)
+    G = g1(c)
+    n = 1 << 14
+    gen = G.from_affine(c.g1)
+    # bases: 64 distinct multiples of the generator, tiled
+    pts = G.batch_to_affine([G.mul(gen, 3 + 7 * i) for i in range(64)])
+    rows = np.stack([pp.fq.encode([p[0], p[1]]).reshape(-1) for p in pts])
+    bases = zk.DeviceBuffer.from_numpy(pp, np.tile(rows, (n // 64, 1)))
+    rng = np.random.default_rng(8)
+    s1 = [int.from_bytes(rng.bytes(32), "little") % c.r for _ in range(n)]
+    s2 = [int.from_bytes(rng.bytes(32), "little") % c.r for _ in range(n)]
+    up = lambda v: zk.DeviceBuffer.from_numpy(pp, pp.fr.encode(v))
+    m1 = dec_jacobian(pp, msm(pp, ZK_G1, bases, up(s1), n))
+    m1n = dec_jacobian(pp, msm(pp, ZK_G1, bases, up([(-x) % c.r for x in s1]), n))
+    m2 = dec_jacobian(pp, msm(pp, ZK_G1, bases, up(s2), n))
+    m12 = dec_jacobian(pp, msm(pp, ZK_G1, bases, up([(x + y) % c.r for x, y in zip(s1, s2)]), n))
+    assert G.is_identity(G.add(m1, m1n))
+    assert G.eq(G.add(m1, m2), m12)
+    # exact: sum_i s_i * P_(i mod 64) = sum_j (sum_{i = j mod 64} s_i) * P_j
+    agg = [sum(s1[j::64]) % c.r for j in range(64)]
+    assert G.eq(m1, G.msm(pts, agg))
+
+
+def test_d_fft_roundtrip_bls12_381_2_18():
+    """Config 5 curve at a moderate size: d_ifft(rearrange) o d_fft is the identity on the reconstructed secrets."""
+    pp = ctx("bls12_381", 2)
+    log_m = 18
+    m = 1 << log_m
+    sec = _rand_fr_array(m, 9)
+    sec_d = zk.DeviceBuffer.from_numpy(pp, sec)
+    pp._check(pp.lib.zk_bitrev(pp.h, sec_d.ptr, log_m, None))
+    shares = pp.pack(sec_d, m // 2, seed=9, order=1)
+    zk.d_ifft(pp, shares, zk.FftMask.zero(), True, log_m, seed=10)
+    zk.d_fft(pp, shares, zk.FftMask.zero(), False, log_m, seed=11)
+    assert np.array_equal(pp.unpack(shares, m // 2).to_numpy().reshape(m, 4), sec)
