@@ -73,6 +73,8 @@ int zk_pss_unpack2(zk_ctx* ctx, const void* shares_d, const uint32_t* parties, i
 /* ---- vector helpers ------------------------------------------------------------------------------ */
 int zk_bitrev(zk_ctx* ctx, void* x_d, int log2_len, void* stream);  /* dfft/mod.rs:322-335 fft_in_place_rearrange */
 int zk_vec_add(zk_ctx* ctx, void* x_d, const void* y_d, size_t len, void* stream);              /* x += y      */
+int zk_vec_scale(zk_ctx* ctx, void* x_d, const void* k, size_t len, void* stream);   /* x *= k (k: Montgomery Fr, host);
+                                                                    the 1/Z(g) factor of libsnark_h, ext_wit.rs:78-87 */
 int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, const void* c_d, size_t len,
                    void* stream);                                   /* out = a*b - c, groth16/src/ext_wit.rs:173-177 */
 
@@ -104,6 +106,12 @@ int zk_fft_mask_sample(zk_ctx* ctx, int rearrange, const void* g, int inverse, i
  * x_d [n][len] in place; masks [n][len] or NULL. */
 int zk_deg_red(zk_ctx* ctx, void* x_d, const void* in_mask_d, const void* out_mask_d, size_t len, uint64_t seed,
                void* stream);
+/* The same when only `nparties` parties' vectors reached the king (mpc-net/src/ser_net.rs:57-94): x_d is
+ * [nparties][len] for the listed ascending ids (masks, if any, in the same order for in_mask and [n][len] for
+ * out_mask); the king reconstructs through lagrange_unpack (pss.rs:170-221) and every one of the n parties gets a
+ * fresh share in out_d [n][len]. */
+int zk_deg_red_parties(zk_ctx* ctx, const void* x_d, const uint32_t* parties, int nparties, const void* in_mask_d,
+                       const void* out_mask_d, size_t len, uint64_t seed, void* out_d, void* stream);
 int zk_degred_mask_sample(zk_ctx* ctx, size_t len, uint64_t seed, void* in_mask_d, void* out_mask_d,
                           void* stream);                              /* deg_red.rs:40-66 with gen = 1 */
 /* num_d, den_d [n][len]; out_d [n][len].  Returns ZK_ERR_GENERIC if a reconstructed denominator is zero
@@ -197,6 +205,12 @@ int zk_profile_enable(zk_ctx* ctx, int on);
 int zk_profile_slots(void);
 const char* zk_profile_name(int slot);
 int zk_profile_read(zk_ctx* ctx, int slot, double* total_ms, double* units, long* calls);
+
+/* d_msm when some parties dropped out: bases_d / scalars_d / in_mask hold the `nparties` surviving parties (ascending
+ * ids); out (n Jacobian points) as zk_d_msm. */
+int zk_d_msm_parties(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len,
+                     const uint32_t* parties, int nparties, const void* in_mask, const void* out_mask, void* out,
+                     void* stream);
 
 #ifdef __cplusplus
 }

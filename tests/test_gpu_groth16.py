@@ -180,3 +180,22 @@ def test_sharded_code_path_on_one_rank():
         assert G1.eq(dec_jacobian(pp, got[0][i]), dec_jacobian(pp, want[0][i]))
         assert G2.eq(dec_jacobian(pp, got[1][i], True), dec_jacobian(pp, want[1][i], True))
         assert G1.eq(dec_jacobian(pp, got[2][i]), dec_jacobian(pp, want[2][i]))
+
+
+def test_libsnark_h_matches_oracle():  # ext_wit.rs:287-417 (m = 32, masked)
+    m, l = 32, 2
+    pp, o = ctx("bn254", l), opp("bn254", l)
+    dom = Domain(BN254, m)
+    a = list(range(m))
+    c = [x * x % P for x in a]
+    qs = og.QAP(0, 0, a, a, c, dom).pss(o, 3)
+    co = dom.get_coset(BN254.r_gen)
+    fm = ([od.FftMask.sample(True, co.offset, dom.group_gen_inv, m, o, 10 + k) for k in range(3)]
+          + [od.FftMask.sample(True, 1, dom.group_gen, m, o, 20 + k) for k in range(3)]
+          + [od.FftMask.sample(False, co.offset_inv, dom.group_gen_inv, m, o, 30)])
+    want = og.libsnark_h(qs, fm, o, dom, seed=2)
+    bufs = [up_parties(pp, [qs[i][k] for i in range(o.n)]) for k in range(3)]
+    masks = [zk.FftMask(up_parties(pp, [x.in_mask for x in f]), up_parties(pp, [x.out_mask for x in f])) for f in fm]
+    h = zg.libsnark_h(pp, bufs, masks, 5, seed=2)
+    assert down_parties(pp, h, o.n, m // l) == want
+    assert pp.download_fr(pp.unpack2(h, m // l)) == og.libsnark_ref(a, a, c, dom)

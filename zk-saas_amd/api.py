@@ -249,3 +249,37 @@ def d_msm(pp, group, bases_d, scalars_d, length, msm_mask=None, stream=None):
                               None if im is None else im.ctypes.data, None if om is None else om.ctypes.data,
                               out.ctypes.data, stream))
     return out
+
+
+def deg_red_parties(pp, x_d, parties, mask, length, seed=0, out=None, stream=None):
+    """deg_red when only `parties` reached the king (ser_net.rs:57-94 -> pss.rs:170-221); x_d [len(parties)][length]."""
+    out = out or pp.alloc_fr(pp.n * length)
+    arr = (C.c_uint32 * len(parties))(*parties)
+    pp._check(pp.lib.zk_deg_red_parties(pp.h, _ptr(x_d), arr, len(parties), _ptr(mask.in_mask), _ptr(mask.out_mask),
+                                        length, seed, _ptr(out), stream))
+    return out
+
+
+def d_msm_parties(pp, group, bases_d, scalars_d, length, parties, msm_mask=None, stream=None):
+    """d_msm when only `parties` reached the king; bases_d / scalars_d [len(parties)][length]."""
+    msm_mask = msm_mask or MsmMask.zero()
+    nl = pp.fq.nl * (2 if group == ZK_G2 else 1)
+    out = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
+    arr = (C.c_uint32 * len(parties))(*parties)
+    im = None if msm_mask.in_mask is None else np.ascontiguousarray(msm_mask.in_mask, dtype=np.uint64)
+    om = None if msm_mask.out_mask is None else np.ascontiguousarray(msm_mask.out_mask, dtype=np.uint64)
+    pp._check(pp.lib.zk_d_msm_parties(pp.h, group, _ptr(bases_d), _ptr(scalars_d), length, arr, len(parties),
+                                      None if im is None else im.ctypes.data, None if om is None else om.ctypes.data,
+                                      out.ctypes.data, stream))
+    return out
+
+
+def vec_scale(pp, x_d, k, length, stream=None):
+    karr = pp.fr.encode_one(k)
+    pp._check(pp.lib.zk_vec_scale(pp.h, _ptr(x_d), karr.ctypes.data, length, stream))
+    return x_d
+
+
+def vec_mul_sub(pp, out_d, a_d, b_d, c_d, length, stream=None):
+    pp._check(pp.lib.zk_vec_mul_sub(pp.h, _ptr(out_d), _ptr(a_d), _ptr(b_d), _ptr(c_d), length, stream))
+    return out_d

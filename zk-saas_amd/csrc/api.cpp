@@ -121,6 +121,21 @@ int zk_vec_add(zk_ctx* ctx, void* x_d, const void* y_d, size_t len, void* stream
   CTX_OR_FAIL();
   return e->vec_add(x_d, y_d, len, S(stream));
 }
+int zk_vec_scale(zk_ctx* ctx, void* x_d, const void* k, size_t len, void* stream) {
+  CTX_OR_FAIL();
+  return e->vec_scale(x_d, k, len, S(stream));
+}
+int zk_deg_red_parties(zk_ctx* ctx, const void* x_d, const uint32_t* parties, int nparties, const void* in_mask_d,
+                       const void* out_mask_d, size_t len, uint64_t seed, void* out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->deg_red_parties(x_d, parties, nparties, in_mask_d, out_mask_d, len, seed, out_d, S(stream));
+}
+int zk_d_msm_parties(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len,
+                     const uint32_t* parties, int nparties, const void* in_mask, const void* out_mask, void* out,
+                     void* stream) {
+  CTX_OR_FAIL();
+  return e->d_msm_parties(group, bases_d, scalars_d, len, parties, nparties, in_mask, out_mask, out, S(stream));
+}
 int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, const void* c_d, size_t len,
                    void* stream) {
   CTX_OR_FAIL();

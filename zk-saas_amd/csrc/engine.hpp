@@ -119,6 +119,7 @@ class IEngine {
                          hipStream_t st) = 0;
   virtual int bitrev(void* x, int log_len, hipStream_t st) = 0;
   virtual int vec_add(void* x, const void* y, size_t len, hipStream_t st) = 0;
+  virtual int vec_scale(void* x, const void* k, size_t len, hipStream_t st) = 0;
   virtual int vec_mul_sub(void* out, const void* a, const void* b, const void* c, size_t len, hipStream_t st) = 0;
   virtual int fft1(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st) = 0;
   virtual int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
@@ -130,6 +131,10 @@ class IEngine {
                               void* out_mask, hipStream_t st) = 0;
   virtual int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
                       hipStream_t st) = 0;
+  virtual int deg_red_parties(const void* x, const uint32_t* parties, int np, const void* in_mask,
+                              const void* out_mask, size_t len, uint64_t seed, void* out, hipStream_t st) = 0;
+  virtual int d_msm_parties(int group, const void* bases, const void* scalars, size_t len, const uint32_t* parties,
+                            int np, const void* in_mask, const void* out_mask, void* out, hipStream_t st) = 0;
   virtual int degred_mask_sample(size_t len, uint64_t seed, void* in_mask, void* out_mask, hipStream_t st) = 0;
   virtual int d_pp(const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len,
                    uint64_t seed, void* out, hipStream_t st) = 0;

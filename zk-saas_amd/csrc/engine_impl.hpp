@@ -194,6 +194,34 @@ class Engine : public IEngine {
     return ZK_OK;
   }
 
+  // coef_i = sum_k U_S[k][i] for a party subset S (the king's unpack_missing_shares + sum of d_msm as one
+  // linear form over the surviving parties, dmsm/mod.rs:85-86 with pss.rs:170-221)
+  int coefs_for(const uint32_t* parties, int np, std::vector<Fr>& coef) {
+    if (np <= 0 || np > n || !parties) return fail(ZK_ERR_BAD_INPUT, "bad party list");
+    for (int i = 0; i < np; i++)
+      if (parties[i] >= (uint32_t)n || (i > 0 && parties[i] <= parties[i - 1]))
+        return fail(ZK_ERR_BAD_INPUT, "party ids must be ascending and < n");
+    if (np < n && np <= 2 * (t + l - 1)) return fail(ZK_ERR_PROTOCOL, "Not enough shares to reconstruct", 0);
+    std::vector<Fr> x, y, z;
+    points(x, y, z);
+    coef.assign(np, Fr::zero());
+    if (np == n) {
+      coef = msm_.coef_h_;
+      return ZK_OK;
+    }
+    for (int kk = 0; kk < l; kk++)
+      for (int i = 0; i < np; i++) {
+        Fr num = Fr::one(), den = Fr::one();
+        for (int j = 0; j < np; j++)
+          if (j != i) {
+            num = num * (z[2 * kk] - x[parties[j]]);
+            den = den * (x[parties[i]] - x[parties[j]]);
+          }
+        coef[i] = coef[i] + num * den.inverse();
+      }
+    return ZK_OK;
+  }
+
   // ---------------------------------------------------------------- cached tables
   // gentab(log_m, inverse)[e] = gen^e, e in [0, m]; gen = w_m or w_m^-1.
   int gentab(int log_m, int inverse, hipStream_t st, const Fr** out) {
@@ -332,6 +360,14 @@ class Engine : public IEngine {
   int vec_add(void* x, const void* y, size_t len, hipStream_t st) override {
     if (!len) return ZK_OK;
     vec_add_kernel<Fr><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((Fr*)x, (const Fr*)y, len);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int vec_scale(void* x, const void* k, size_t len, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!x || !k) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    vec_scale_kernel<Fr><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((Fr*)x, Fr::from_limbs((const uint32_t*)k),
+                                                                                 len);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -513,6 +549,25 @@ class Engine : public IEngine {
   int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed, hipStream_t st) override {
     if (len && !x) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     return deg_red_np((const Fr*)x, (const Fr*)in_mask, nullptr, n, len, seed, (Fr*)x, (const Fr*)out_mask, st);
+  }
+  int deg_red_parties(const void* x, const uint32_t* parties, int np, const void* in_mask, const void* out_mask,
+                      size_t len, uint64_t seed, void* out, hipStream_t st) override {
+    if (len && (!x || !out)) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (np != n && x == out) return fail(ZK_ERR_BAD_INPUT, "in-place deg_red needs all n parties");
+    return deg_red_np((const Fr*)x, (const Fr*)in_mask, parties, np, len, seed, (Fr*)out, (const Fr*)out_mask, st);
+  }
+  // d_msm when only the listed parties' contributions reached the king (ser_net.rs:57-94): bases/scalars [np][len]
+  int d_msm_parties(int group, const void* bases, const void* scalars, size_t len, const uint32_t* parties, int np,
+                    const void* in_mask, const void* out_mask, void* out, hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    std::vector<Fr> coef;
+    int rc = coefs_for(parties, np, coef);
+    if (rc) return rc;
+    if (group == ZK_G1) return msm_.template d_msm_coef_t<Fq>(this, bases, scalars, len, coef, in_mask, out_mask, out, st);
+    if (group == ZK_G2 && Cfg::HAS_G2)
+      return msm_.template d_msm_coef_t<Fq2>(this, bases, scalars, len, coef, in_mask, out_mask, out, st);
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
   }
   // DegRedMask::sample with gen = 1 (deg_red.rs:40-66)
   int degred_mask_sample(size_t len, uint64_t seed, void* in_mask, void* out_mask, hipStream_t st) override {

@@ -653,6 +653,45 @@ class MsmRunner {
     return eng->fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
   }
 
+  // d_msm with explicit per-contributor coefficients (party subsets): bases/scalars [coef.size()][len]; every one
+  // of the n parties receives the king's value plus its own out-mask.
+  template <class Fld>
+  int d_msm_coef_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const std::vector<Fr>& coef,
+                   const void* in_mask, const void* out_mask, void* out, hipStream_t st) {
+    if (!out) return eng->fail(ZK_ERR_BAD_INPUT, "null output");
+    const int np = (int)coef.size();
+    Fr* cd = nullptr;
+    hipError_t he = hipMalloc((void**)&cd, np * sizeof(Fr));
+    if (he != hipSuccess) return eng->hip_fail(he, "hipMalloc coef");
+    he = hipMemcpy(cd, coef.data(), np * sizeof(Fr), hipMemcpyHostToDevice);
+    XYZZ<Fld> r;
+    int rc = he == hipSuccess ? run_t<Fld>(eng, bases, scalars, (size_t)np * len, cd, len, &r, st) : eng->hip_fail(he, "memcpy");
+    (void)hipFree(cd);
+    if (rc) return rc;
+    if (in_mask) {
+      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
+      for (int p = 0; p < np; p++) {
+        XYZZ<Fld> mp = jacobian_to_xyzz(jm[p]);
+        Fr k = coef[p].from_mont();
+        XYZZ<Fld> acc = XYZZ<Fld>::identity();
+        for (int i = FrP::N - 1; i >= 0; i--)
+          for (int b = 31; b >= 0; b--) {
+            acc = xyzz_dbl_ni(acc);
+            if ((k.v[i] >> b) & 1) acc = xyzz_add_ni(acc, mp);
+          }
+        r = xyzz_add_ni(r, acc);
+      }
+    }
+    const Jacobian<Fld>* om = (const Jacobian<Fld>*)out_mask;
+    Jacobian<Fld>* o = (Jacobian<Fld>*)out;
+    for (int p = 0; p < eng->n; p++) {
+      XYZZ<Fld> v = r;
+      if (om) v = xyzz_add_ni(v, jacobian_to_xyzz(om[p]));
+      o[p] = xyzz_to_jacobian(v);
+    }
+    return ZK_OK;
+  }
+
   // coef_p = sum_k U2[k][p]  (set by the engine once the PSS matrices exist)
   int set_coefs(IEngine* eng, const std::vector<Fr>& coef) {
     coef_h_ = coef;

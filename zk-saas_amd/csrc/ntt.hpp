@@ -279,6 +279,12 @@ __global__ void vec_add_kernel(F* __restrict__ x, const F* __restrict__ y, size_
 }
 
 template <class F>
+__global__ void vec_scale_kernel(F* __restrict__ x, F k, size_t len) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) store_elem(x + i, load_elem(x + i) * k);
+}
+
+template <class F>
 __global__ void vec_mul_sub_kernel(F* __restrict__ out, const F* __restrict__ a, const F* __restrict__ b,
                                    const F* __restrict__ c, size_t len) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
