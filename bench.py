@@ -65,6 +65,28 @@ def read_profile(pp):
     return out
 
 
+PMC_KERNEL = {"msm_accumulate_kernel<G1>": "msm_accumulate_kernel<Fp<", "msm_accumulate_kernel<G2>": "msm_accumulate_kernel<Fp2<",
+              "ntt_pass_kernel": "ntt_pass_kernel", "king_fft2_kernel": "king_fft2_kernel",
+              "king_degred_kernel": "king_degred_kernel"}
+
+
+def pmc_traffic(slot_name):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01_final_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, KB units;
+    no 2x streaming-read correction is applied because the accesses are 64-byte gathers)."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.json")
+    prefix = PMC_KERNEL.get(slot_name)
+    if not prefix or not os.path.exists(path):
+        return None
+    try:
+        for k in json.load(open(path))["kernels"]:
+            if k["kernel"].startswith(prefix):
+                return int((k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024)
+    except (ValueError, KeyError):
+        return None
+    return None
+
+
 def roofline_of(prof, ntt_passes):
     # the dominant STREAMING kernel: the sort and the bucket finalize/reduce helpers are latency-bound tree
     # kernels without a per-unit byte figure in SURVEY.md 8d; they are listed under "kernels"
@@ -85,9 +107,51 @@ def roofline_of(prof, ntt_passes):
     # ALU view of the same launch: a mixed addition is 10 (G1) / 28 (G2) base-field Montgomery multiplies
     # per point and window -- the figure that actually bounds this kernel
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
             "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "launches": best["launches"]}
+
+
+def primitives(pp, zk):
+    """GPU-side timings of BASELINE configs 2 (d_fft, m = 2^20) and 3-like (d_msm, 8 x 2^17 points) with the
+    achieved fraction of HBM bandwidth on SURVEY.md 8d's algorithmic bytes (the CPU side of these two is in
+    profiles/r01_primitives_c2_c3.json; here only a few milliseconds of GPU time are spent)."""
+    from zksaas_amd.api import ZK_G1
+    rng = np.random.default_rng(3)
+
+    def rand_fr(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return zk.DeviceBuffer.from_numpy(pp, a)
+
+    def med(fn, reps):
+        fn()
+        pp.sync()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            pp.sync()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    out = {}
+    log_m = 20
+    m = 1 << log_m
+    sh, dst = rand_fr(pp.n * m // 2), pp.alloc_fr(pp.n * m // 2)
+    t = med(lambda: zk.d_fft(pp, sh, zk.FftMask.zero(), False, log_m, seed=3, out=dst), 10)
+    alg = 32 * m * 32
+    out["d_fft_m2^20_bn254_l2_n8"] = {"ms": round(t * 1e3, 3), "algorithmic_bytes": alg,
+                                      "achieved_GBps": round(alg / t / 1e9, 1), "frac_hbm": round(alg / t / 8e12, 4)}
+    ln = 1 << 17
+    g1 = pp.fq.encode([1, 2]).reshape(-1)
+    bases = zk.DeviceBuffer.from_numpy(pp, np.tile(g1, (pp.n * ln, 1)))
+    sc = rand_fr(pp.n * ln)
+    t = med(lambda: zk.d_msm(pp, ZK_G1, bases, sc, ln), 5)
+    alg = pp.n * ln * 96
+    out["d_msm_g1_8x2^17_bn254"] = {"ms": round(t * 1e3, 3), "algorithmic_bytes": alg,
+                                    "achieved_GBps": round(alg / t / 1e9, 1), "frac_hbm": round(alg / t / 8e12, 5)}
+    return out
 
 
 def cpu_baseline(pp, crs, wit, r, s, seed, gpu_proof):
@@ -122,6 +186,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-primitives", action="store_true", help="skip the d_fft / d_msm side measurements "
+                    "(used for the rocprofv3 runs so that every profiled launch belongs to the proof loop)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +239,8 @@ def main():
         "roofline": roofline_of(prof, ntt_passes=2),
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
+    if not args.no_primitives:
+        res["primitives"] = primitives(pp, zk)
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(pp, crs, wit, r, s, seed, proof)
     print(json.dumps(res))
