@@ -53,6 +53,7 @@ class Engine : public IEngine {
     for (auto& kv : umats_) (void)hipFree(kv.second);
     for (auto& kv : sizeinv_) (void)hipFree(kv.second);
     if (pmat_) (void)hipFree(pmat_);
+    if (pack2_) (void)hipFree(pack2_);
     if (ident_) (void)hipFree(ident_);
     if (err_flag_) (void)hipFree(err_flag_);
   }
@@ -117,6 +118,19 @@ class Engine : public IEngine {
         Pm[(size_t)p * k + j] = num * den.inverse();
       }
     (void)upload(Pm, &pmat_);
+    if (l == 2) {
+      // constants of the FFT-structured pack (pss.hpp pack_chunk): secret domain g*H_4, share domain H_8
+      Fr w4 = root_of_unity(2), w8 = root_of_unity(3), g = generator();
+      PackL2<Fr> k;
+      k.w4inv = w4.inverse();
+      Fr ginv = g.inverse(), quarter = Fr::from_u64(4).inverse(), cur = quarter;
+      for (int i = 0; i < 4; i++) k.kc[i] = cur, cur = cur * ginv;
+      k.w8 = w8;
+      k.w4 = w4;
+      k.w8_3 = w8 * w8 * w8;
+      if (hipMalloc((void**)&pack2_, sizeof(k)) == hipSuccess)
+        (void)hipMemcpy(pack2_, &k, sizeof(k), hipMemcpyHostToDevice);
+    }
     // unpack (pss.rs:125-138): IFFT_n, truncate to l+t coefficients, evaluate at y_k:
     //   U1[k][p] = 1/n sum_{d < l+t} (y_k / x_p)^d
     // unpack2 (pss.rs:141-166): U2[k][p] = 1/n sum_{d < n} (z_{2k} / x_p)^d
@@ -300,9 +314,9 @@ class Engine : public IEngine {
   int pack_l(const Fr* sec, size_t nch, int order, uint64_t seed, bool det, Fr* shares, hipStream_t st) {
     dim3 grid((unsigned)((nch + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
     if (det)
-      pss_pack_kernel<FrP, L, true><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, shares);
+      pss_pack_kernel<FrP, L, true><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, pack2_, shares);
     else
-      pss_pack_kernel<FrP, L, false><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, shares);
+      pss_pack_kernel<FrP, L, false><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, pack2_, shares);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -433,11 +447,11 @@ class Engine : public IEngine {
     if (negate)
       king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                               in_scale, rearrange, seed, out, out_mask);
+                                                               in_scale, pack2_, rearrange, seed, out, out_mask);
     else
       king_fft2_kernel<FrP, L, false><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                 gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                                in_scale, rearrange, seed, out, out_mask);
+                                                                in_scale, pack2_, rearrange, seed, out, out_mask);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -529,7 +543,7 @@ class Engine : public IEngine {
                const Fr* out_mask, hipStream_t st) {
     dim3 grid((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
     ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
-    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, seed, out, out_mask);
+    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, seed, out, out_mask);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -1071,6 +1085,7 @@ class Engine : public IEngine {
   std::map<std::string, void*> base_tables_;
   DevBuf hwork_, hshare_;
   Fr* pmat_ = nullptr;
+  PackL2<Fr>* pack2_ = nullptr;
   Fr* ident_ = nullptr;
   int* err_flag_ = nullptr;
   std::map<uint64_t, Fr*> umats_;

@@ -28,12 +28,62 @@ ZK_D F mulsel(const F& a, const F& b) {
   else return F::mul_ni(a, b);
 }
 
+// Constants of the FFT-structured pack for l = 2 (n = 8, secret domain g*H_4), built on the host:
+//   w4inv = w_4^-1, kc[i] = g^-i / 4, w8 = w_8, w4 = w_4, w8_3 = w_8^3
+template <class F>
+struct PackL2 {
+  F w4inv, kc[4], w8, w4, w8_3;
+};
+
+// pack (secret-sharing/src/pss.rs:90-122) for one chunk: v = [secrets ; randoms] -> n shares.
+// l = 2 follows the reference's own structure -- 4-point coset IFFT on the secret domain, zero-padded 8-point
+// FFT on the share domain -- which costs 10 multiplications instead of the 32 of the dense 8 x 4 matrix
+// (same linear map, so the shares are bit-identical).  Other packing factors use the dense matrix.
+template <class P, int L, int NV>
+ZK_D void pack_chunk(const Fp<P>* v, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2,
+                     Fp<P>* out /* [4L] */) {
+  using F = Fp<P>;
+  if constexpr (L == 2) {
+    F v2 = NV > 2 ? v[2] : F::zero(), v3 = NV > 2 ? v[3] : F::zero();
+    F w4inv = k2->w4inv;
+    // 4-point inverse DFT (unscaled)
+    F e0 = v[0] + v2, e1 = v[0] - v2, o0 = v[1] + v3, o1 = (v[1] - v3) * w4inv;
+    F c0 = (e0 + o0) * k2->kc[0], c1 = (e1 + o1) * k2->kc[1], c2 = (e0 - o0) * k2->kc[2], c3 = (e1 - o1) * k2->kc[3];
+    // 8-point DFT of (c0, c1, c2, c3, 0, 0, 0, 0): even outputs = DFT_4(c), odd outputs = DFT_4(c_i w_8^i)
+    F w4 = k2->w4;
+    F b1 = c1 * k2->w8, b2 = c2 * w4, b3 = c3 * k2->w8_3;
+    {
+      F t0 = c0 + c2, t1 = c0 - c2, u0 = c1 + c3, u1 = (c1 - c3) * w4;
+      out[0] = t0 + u0;
+      out[4] = t0 - u0;
+      out[2] = t1 + u1;
+      out[6] = t1 - u1;
+    }
+    {
+      F t0 = c0 + b2, t1 = c0 - b2, u0 = b1 + b3, u1 = (b1 - b3) * w4;
+      out[1] = t0 + u0;
+      out[5] = t0 - u0;
+      out[3] = t1 + u1;
+      out[7] = t1 - u1;
+    }
+  } else {
+#pragma unroll 1
+    for (int p = 0; p < 4 * L; p++) {
+      F acc = F::zero();
+#pragma unroll
+      for (int i = 0; i < NV; i++) acc = acc + mulsel<L>(Pm[p * (2 * L) + i], v[i]);
+      out[p] = acc;
+    }
+  }
+}
+
 // shares[p][j] for p < n from l secrets + t randoms.  One thread per chunk.
 //   order 0: secrets[j*l + i];  order 1: secrets[j + i*nchunks].
 template <class P, int L, bool DET>
 __global__ __launch_bounds__(KING_THREADS) void pss_pack_kernel(const Fp<P>* __restrict__ secrets, size_t nchunks,
                                                                int order, uint64_t seed,
                                                                const Fp<P>* __restrict__ Pm /* [n][l+t] */,
+                                                               const PackL2<Fp<P>>* __restrict__ k2,
                                                                Fp<P>* __restrict__ shares /* [n][nchunks] */) {
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
@@ -46,13 +96,10 @@ __global__ __launch_bounds__(KING_THREADS) void pss_pack_kernel(const Fp<P>* __r
 #pragma unroll
     for (int i = 0; i < T; i++) v[L + i] = rand_fp<P>(seed, j * T + i);
   }
-#pragma unroll 1
-  for (int p = 0; p < N; p++) {
-    F acc = F::zero();
+  F sh[N];
+  pack_chunk<P, L, (DET ? L : L + T)>(v, Pm, k2, sh);
 #pragma unroll
-    for (int i = 0; i < (DET ? L : L + T); i++) acc = acc + mulsel<L>(Pm[p * (L + T) + i], v[i]);
-    store_elem(shares + (size_t)p * nchunks + j, acc);
-  }
+  for (int p = 0; p < N; p++) store_elem(shares + (size_t)p * nchunks + j, sh[p]);
 }
 
 // secrets[j*l + i] = sum_s U[i][s] * shares[s][j].
@@ -96,7 +143,8 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, uint32_t log_lc,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
     const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
-    int rearrange, uint64_t seed, Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
+    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, uint64_t seed, Fp<P>* __restrict__ out,
+    const Fp<P>* __restrict__ out_mask) {
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
@@ -190,12 +238,12 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     uint32_t j = rearrange ? bitrev32(q, log_lc) : q;
 #pragma unroll
     for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
-#pragma unroll 1
-    for (int p = 0; p < N; p++) {
-      F acc = F::zero();
+    F sh[N];
+    pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
-      for (int i = 0; i < L + T; i++) acc = acc + mulsel<L>(Pm[p * (L + T) + i], sec[i]);
+    for (int p = 0; p < N; p++) {
       size_t o = ((size_t)p << log_lc) + j;
+      F acc = sh[p];
       if (out_mask) acc = acc + load_elem(out_mask + o);
       store_elem(out + o, acc);
     }
@@ -206,8 +254,8 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
 template <class P, int L>
 __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
-    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, uint64_t seed, Fp<P>* __restrict__ out,
-    const Fp<P>* __restrict__ out_mask) {
+    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, uint64_t seed,
+    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,12 +272,12 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
   }
 #pragma unroll
   for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
-#pragma unroll 1
-  for (int p = 0; p < N; p++) {
-    F acc = F::zero();
+  F sh[N];
+  pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
-    for (int i = 0; i < L + T; i++) acc = acc + mulsel<L>(Pm[p * (L + T) + i], sec[i]);
+  for (int p = 0; p < N; p++) {
     size_t o = (size_t)p * len + j;
+    F acc = sh[p];
     if (out_mask) acc = acc + load_elem(out_mask + o);
     store_elem(out + o, acc);
   }
