@@ -135,6 +135,12 @@ int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d,
  * CRS elements are produced, and -- because det_pack is linear -- how PackedProvingKeyShare::
  * pack_from_arkworks_proving_key (groth16/src/proving_key.rs:47-123) is evaluated: det_pack the discrete logs
  * with zk_pss_det_pack, then multiply the base. */
+/* pack / det_pack over GROUP elements (pss.rs:69-122 with T = curve point): points_d is [nchunks][points_per_chunk]
+ * affine with points_per_chunk = l (det_pack: PackedProvingKeyShare::pack_from_arkworks_proving_key,
+ * proving_key.rs:72-86) or l + t (pack with caller-supplied random points: MsmMask::sample, dmsm/mod.rs:34-38);
+ * shares_d is [n][nchunks] affine.  No trapdoor is needed (compare zk_base_mul). */
+int zk_pss_pack_points(zk_ctx* ctx, int group, const void* points_d, size_t nchunks, int points_per_chunk,
+                       void* shares_d, void* stream);
 int zk_base_mul(zk_ctx* ctx, int group, const void* base_affine, const void* scalars_d, size_t len,
                 void* out_affine_d, void* stream);
 

@@ -199,3 +199,45 @@ def test_libsnark_h_matches_oracle():  # ext_wit.rs:287-417 (m = 32, masked)
     h = zg.libsnark_h(pp, bufs, masks, 5, seed=2)
     assert down_parties(pp, h, o.n, m // l) == want
     assert pp.download_fr(pp.unpack2(h, m // l)) == og.libsnark_ref(a, a, c, dom)
+
+
+def test_crs_packing_over_group_elements_equals_trapdoor_path():
+    """proving_key.rs:47-123: det_pack over the curve points (zk_pss_pack_points, no trapdoor) must give exactly the
+    shares obtained from packing the discrete logs (zk_pss_det_pack + zk_base_mul), point for point."""
+    r1, w = small_r1cs()
+    pp = ctx("bn254", 2)
+    setup = zg.SetupScalars("bn254", r1, *_trapdoor(48))
+    crs = zg.Crs(pp, setup, keep_unpacked=True)
+    pk = {k: (v, n_) for (k, v), n_ in zip(crs.unpacked.items(), (len(setup.a_query), len(setup.b_query),
+                                                                   len(setup.b_query), len(setup.l_query),
+                                                                   len(setup.h_query)))}
+    crs2 = zg.crs_from_proving_key(pp, pk, crs)
+    assert (crs2.len_a, crs2.len_w, crs2.len_u) == (crs.len_a, crs.len_w, crs.len_u)
+    for name in ("s", "h", "v", "w", "u"):
+        assert np.array_equal(getattr(crs2, name).to_numpy(), getattr(crs, name).to_numpy()), name
+    # and the prover accepts it
+    wit = zg.Witness(pp, "bn254", r1, w, seed=8)
+    r, s = rand_fp(49, 0, P), rand_fp(49, 1, P)
+    a1 = zg.prove(pp, crs, wit, r, s, seed=3)
+    a2 = zg.prove(pp, crs2, wit, r, s, seed=3)
+    G1 = g1(BN254)
+    assert G1.eq(dec_jacobian(pp, a1[2][0]), dec_jacobian(pp, a2[2][0]))
+
+
+def test_pack_points_with_random_points_reconstructs():
+    """pss.rs:90-122 on group elements (dmsm/mod.rs:127-137 pack_unpack_test): unpack(pack(points)) == points."""
+    pp, o = ctx("bn254", 2), opp("bn254", 2)
+    G1 = g1(BN254)
+    ops = GroupOps(G1)
+    gen = G1.from_affine(BN254.g1)
+    nch = 5
+    pts = [G1.mul(gen, rand_fp(50, i, P)) for i in range(nch * 4)]        # per chunk: l secrets + t randoms
+    aff = G1.batch_to_affine(pts)
+    from gpu_util import enc_affine
+    sh = zg.pack_points(pp, zk.api.ZK_G1, zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, aff)), nch, 4)
+    rows = sh.to_numpy().reshape(o.n, nch, 8)
+    for j in range(nch):
+        want = o.pack(pts[4 * j:4 * j + 2], pts[4 * j + 2:4 * j + 4], ops)
+        for p_ in range(o.n):
+            v = pp.fq.decode(rows[p_, j].reshape(2, 4))
+            assert (v[0], v[1]) == G1.to_affine(want[p_])

@@ -14,7 +14,7 @@ SYMBOLS = [
     "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
     "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove", "zk_profile_enable",
     "zk_profile_slots", "zk_profile_name", "zk_profile_read", "zk_d_msm_local", "zk_group_add", "zk_groth16_assemble",
-    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties",
+    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load():
     lib.zk_vec_scale.argtypes = [vp, vp, vp, sz, vp]
     lib.zk_deg_red_parties.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, vp, vp, sz, u64, vp, vp]
     lib.zk_d_msm_parties.argtypes = [vp, i32, vp, vp, sz, C.POINTER(C.c_uint32), i32, vp, vp, vp, vp]
+    lib.zk_pss_pack_points.argtypes = [vp, i32, vp, sz, i32, vp, vp]
     lib.zk_profile_enable.argtypes = [vp, i32]
     lib.zk_profile_slots.argtypes = []
     lib.zk_profile_name.argtypes = [i32]

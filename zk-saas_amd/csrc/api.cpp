@@ -247,6 +247,11 @@ int zk_profile_read(zk_ctx* ctx, int slot, double* total_ms, double* units, long
   return ZK_OK;
 }
 
+int zk_pss_pack_points(zk_ctx* ctx, int group, const void* points_d, size_t nchunks, int points_per_chunk,
+                       void* shares_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->pss_pack_points(group, points_d, nchunks, points_per_chunk, shares_d, S(stream));
+}
 int zk_base_mul(zk_ctx* ctx, int group, const void* base_affine, const void* scalars_d, size_t len,
                 void* out_affine_d, void* stream) {
   CTX_OR_FAIL();

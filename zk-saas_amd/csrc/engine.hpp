@@ -151,6 +151,7 @@ class IEngine {
                          int skip_h) = 0;
   virtual int msms_finish(const zk_crs_share* crs, const void* h_share, int first, int count, void* const* out,
                           hipStream_t st) = 0;
+  virtual int pss_pack_points(int group, const void* points, size_t nchunks, int nv, void* shares, hipStream_t st) = 0;
   virtual int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
                        hipStream_t st) = 0;
   virtual int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* masks,

@@ -53,6 +53,7 @@ class Engine : public IEngine {
     for (auto& kv : umats_) (void)hipFree(kv.second);
     for (auto& kv : sizeinv_) (void)hipFree(kv.second);
     if (pmat_) (void)hipFree(pmat_);
+    for (auto& kv : pcoef_) (void)hipFree(kv.second);
     if (pack2_) (void)hipFree(pack2_);
     if (ident_) (void)hipFree(ident_);
     if (err_flag_) (void)hipFree(err_flag_);
@@ -118,6 +119,7 @@ class Engine : public IEngine {
         Pm[(size_t)p * k + j] = num * den.inverse();
       }
     (void)upload(Pm, &pmat_);
+    pmat_host_ = Pm;
     if (l == 2) {
       // constants of the FFT-structured pack (pss.hpp pack_chunk): secret domain g*H_4, share domain H_8
       Fr w4 = root_of_unity(2), w8 = root_of_unity(3), g = generator();
@@ -700,6 +702,46 @@ class Engine : public IEngine {
     return fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
   }
 
+  // ---------------------------------------------------------------- PSS over group elements
+  template <class Fld>
+  int pack_points_t(const void* points, size_t nchunks, int nv, void* shares, hipStream_t st) {
+    if (!nchunks) return ZK_OK;
+    if (!points || !shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (nv != l && nv != l + t) return fail(ZK_ERR_BAD_INPUT, "points per chunk must be l (det_pack) or l+t (pack)");
+    // canonical (non-Montgomery) copies of the first nv columns of P, [n][nv]
+    Fr* coef = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = pcoef_.find(nv);
+      if (it != pcoef_.end()) coef = it->second;
+    }
+    if (!coef) {
+      std::vector<Fr> h((size_t)n * nv);
+      for (int p = 0; p < n; p++)
+        for (int i = 0; i < nv; i++) h[(size_t)p * nv + i] = pmat_host_[(size_t)p * (l + t) + i].from_mont();
+      int rc = upload(h, &coef);
+      if (rc) return rc;
+      std::lock_guard<std::mutex> lk(mu_);
+      pcoef_[nv] = coef;
+    }
+    size_t total = nchunks * (size_t)n;
+    dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    const Affine<Fld>* in = (const Affine<Fld>*)points;
+    Affine<Fld>* out = (Affine<Fld>*)shares;
+    if (nv == 2) pss_pack_points_kernel<FrP, Fld, 2><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
+    else if (nv == 4) pss_pack_points_kernel<FrP, Fld, 4><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
+    else return fail(ZK_ERR_BAD_INPUT, "point packing is built for 2 or 4 points per chunk (l = 2, or det_pack at l = 4)");
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int pss_pack_points(int group, const void* points, size_t nchunks, int nv, void* shares, hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (group == ZK_G1) return pack_points_t<Fq>(points, nchunks, nv, shares, st);
+    if (group == ZK_G2 && Cfg::HAS_G2) return pack_points_t<Fq2>(points, nchunks, nv, shares, st);
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
   // ---------------------------------------------------------------- circom_h (ext_wit.rs:104-181)
   int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
                void* h, hipStream_t st) override {
@@ -1085,6 +1127,8 @@ class Engine : public IEngine {
   std::map<std::string, void*> base_tables_;
   DevBuf hwork_, hshare_;
   Fr* pmat_ = nullptr;
+  std::vector<Fr> pmat_host_;
+  std::map<int, Fr*> pcoef_;
   PackL2<Fr>* pack2_ = nullptr;
   Fr* ident_ = nullptr;
   int* err_flag_ = nullptr;

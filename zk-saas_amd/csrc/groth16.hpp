@@ -35,6 +35,40 @@ __global__ __launch_bounds__(128) void fixed_base_mul_kernel(const Fp<FrP>* __re
   store_elem(out + i, xyzz_to_affine(acc));
 }
 
+// PSS pack / det_pack over GROUP elements (secret-sharing/src/pss.rs:69-122 with T = curve point, as used by
+// PackedProvingKeyShare::pack_from_arkworks_proving_key, groth16/src/proving_key.rs:72-86, and MsmMask::sample,
+// dist-primitives/src/dmsm/mod.rs:34-38): share_p = sum_i P[p][i] * point_i.  One lane per (chunk, party):
+// interleaved double-and-add over the NV scalars (canonical integers, `coef` = [n][NV]), affine output.
+//   points: [nchunks][NV] affine (order 0)     shares: [n][nchunks] affine
+template <class FrP, class Fld, int NV>
+__global__ __launch_bounds__(128) void pss_pack_points_kernel(const Affine<Fld>* __restrict__ points, size_t nchunks,
+                                                             int n, const Fp<FrP>* __restrict__ coef,
+                                                             Affine<Fld>* __restrict__ shares) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks * (size_t)n) return;
+  size_t j = t % nchunks;
+  int p = (int)(t / nchunks);
+  Affine<Fld> pt[NV];
+  Fp<FrP> k[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    pt[i] = load_elem(points + j * NV + i);
+    k[i] = load_elem(coef + (size_t)p * NV + i);
+  }
+  XYZZ<Fld> acc = XYZZ<Fld>::identity();
+  constexpr int N = FrP::N;
+  for (int w = N - 1; w >= 0; w--) {
+    for (int b = 31; b >= 0; b--) {
+      acc = xyzz_dbl(acc);
+      // one inlined mixed addition per loop body (NV > 2 is not unrolled: code size)
+#pragma unroll(NV <= 2 ? NV : 1)
+      for (int i = 0; i < NV; i++)
+        if (((k[i].v[w] >> b) & 1u) && !pt[i].is_identity()) acc = xyzz_madd(acc, pt[i].x, pt[i].y);
+    }
+  }
+  store_elem(shares + t, xyzz_to_affine(acc));
+}
+
 #endif  // __HIPCC__
 
 // Host-side scalar multiplication k * P (k in Montgomery form), plain double-and-add over XYZZ.

@@ -350,6 +350,16 @@ __global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restr
 
 #endif  // __HIPCC__
 
+// Field type the device kernels are instantiated with: the inline tower for G2 over 8-limb base fields.
+template <class Fld>
+struct KernelField {
+  using type = Fld;
+};
+template <class P>
+struct KernelField<Fp2T<P, false>> {
+  using type = Fp2T<P, (P::N <= 8)>;
+};
+
 // ---------------------------------------------------------------------------------------------------- host
 template <class Cfg>
 class MsmRunner {
@@ -434,9 +444,11 @@ class MsmRunner {
     uint2* bt = (uint2*)(ws + o_bt);
     uint32_t* sorted = (uint32_t*)(ws + o_sorted);
     SegDesc* segs = (SegDesc*)(ws + o_segs);
-    XYZZ<Fld>* partial = (XYZZ<Fld>*)(ws + o_partial);
-    XYZZ<Fld>* buckets = (XYZZ<Fld>*)(ws + o_buckets);
-    XYZZ<Fld>* out = (XYZZ<Fld>*)(ws + o_out);
+    using KF = typename KernelField<Fld>::type;     // same layout as Fld
+    static_assert(sizeof(KF) == sizeof(Fld), "kernel field layout");
+    XYZZ<KF>* partial = (XYZZ<KF>*)(ws + o_partial);
+    XYZZ<KF>* buckets = (XYZZ<KF>*)(ws + o_buckets);
+    XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
     uint32_t* heavy = (uint32_t*)(ws + o_heavy);
 
 #define MSM_HIP(x)                                           \
@@ -476,29 +488,29 @@ class MsmRunner {
     MSM_STAGE("scatter");
     {
     ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts);
-    msm_accumulate_kernel<Fld><<<dim3((unsigned)((max_segs + 127) / 128)), dim3(128), 0, st>>>(
-        (const Affine<Fld>*)bases, sorted, segs, offsets, nkeys, partial);
+    msm_accumulate_kernel<KF><<<dim3((unsigned)((max_segs + 127) / 128)), dim3(128), 0, st>>>(
+        (const Affine<KF>*)bases, sorted, segs, offsets, nkeys, partial);
     }
     MSM_STAGE("accumulate");
     {
     ProfScope ps_(eng->prof, PROF_MSM_REDUCE, st, (double)npts);
     MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
-    msm_finalize_kernel<Fld><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
+    msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
                                                                                                buckets, heavy);
     {
       size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
-      msm_finalize_heavy_kernel<Fld><<<dim3(512), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, offsets, heavy,
+      msm_finalize_heavy_kernel<KF><<<dim3(512), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, offsets, heavy,
                                                                                                buckets);
     }
     MSM_STAGE("finalize");
     size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
     static bool attr_set = false;
     if (!attr_set && red_lds > 48 * 1024) {
-      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<Fld, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<KF, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)red_lds));
       attr_set = true;
     }
-    msm_reduce_kernel<Fld, RED_THREADS><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
+    msm_reduce_kernel<KF, RED_THREADS><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
     }
     MSM_HIP(hipGetLastError());
     MSM_STAGE("reduce");

@@ -183,6 +183,14 @@ def base_points(pp, group, scalars_d, count):
     return out
 
 
+def pack_points(pp, group, points_d, nchunks, points_per_chunk):
+    """pss.rs:69-122 over curve points: [nchunks][points_per_chunk] affine -> [n][nchunks] affine shares."""
+    width = (4 if group == ZK_G2 else 2) * pp.fq.nl * 8
+    out = DeviceBuffer(pp, pp.n * nchunks * width)
+    pp._check(pp.lib.zk_pss_pack_points(pp.h, group, _ptr(points_d), nchunks, points_per_chunk, out.ptr, None))
+    return out
+
+
 class Crs:
     """Device-resident PackedProvingKeyShare for all parties + the unpacked proving key (for the local prover)."""
 
@@ -214,6 +222,9 @@ class Crs:
             self.unpacked = {"a_query": q(setup.a_query, ZK_G1), "b_g1_query": q(setup.b_query, ZK_G1),
                              "b_g2_query": q(setup.b_query, ZK_G2), "l_query": q(setup.l_query, ZK_G1),
                              "h_query": q(setup.h_query, ZK_G1)}
+        self._make_ct()
+
+    def _make_ct(self):
         self.ct = CrsShare(self.s.ptr, self.h.ptr, self.v.ptr, self.w.ptr, self.u.ptr, self.len_a, self.len_w,
                            self.len_u, self.s1[0].ctypes.data, self.s1[1].ctypes.data, self.s1[2].ctypes.data,
                            self.s1[3].ctypes.data, self.s1[4].ctypes.data, self.s2[0].ctypes.data,
@@ -277,3 +288,32 @@ def libsnark_h(pp, qap, fft_masks, log_m, seed=0):
     zinv = pow((pow(g, m, p) - 1) % p, p - 2, p)            # 1 / Z(g), Z(x) = x^m - 1  (ext_wit.rs:78-81)
     api.vec_scale(pp, h, zinv, cnt)
     return api.d_ifft(pp, h, fft_masks[6], False, log_m, g=pow(g, p - 2, p), seed=seed + 6, out=pp.alloc_fr(cnt))
+
+
+def crs_from_proving_key(pp, pk, singles_from):
+    """PackedProvingKeyShare::pack_from_arkworks_proving_key (proving_key.rs:47-123) WITHOUT a trapdoor: `pk` maps
+    "a_query", "b_g1_query", "b_g2_query", "l_query", "h_query" to (device affine buffer, count); every l-chunk of
+    a_query[1..], h_query, l_query, b_g1_query[1..], b_g2_query[1..] is det_pack'ed over the group elements on the GPU.
+    `singles_from`: a Crs whose single elements (a_query[0], delta, alpha, ...) are reused."""
+    l = pp.l
+    nl = pp.fq.nl
+
+    def packed(name, group, skip_first):
+        buf, count = pk[name]
+        width = (4 if group == ZK_G2 else 2) * nl
+        arr = buf.to_numpy().reshape(count, width)[1 if skip_first else 0:]
+        if arr.shape[0] % l:                                   # det_pack zero-pads a short last chunk (pss.rs:78)
+            arr = np.concatenate([arr, np.zeros((l - arr.shape[0] % l, width), dtype=np.uint64)])
+        nch = arr.shape[0] // l
+        return pack_points(pp, group, DeviceBuffer.from_numpy(pp, arr), nch, l), nch
+
+    crs = Crs.__new__(Crs)
+    crs.pp, crs.setup, crs.unpacked = pp, None, None
+    crs.s, crs.len_a = packed("a_query", ZK_G1, True)
+    crs.h, _ = packed("b_g1_query", ZK_G1, True)
+    crs.v, _ = packed("b_g2_query", ZK_G2, True)
+    crs.w, crs.len_w = packed("l_query", ZK_G1, False)
+    crs.u, crs.len_u = packed("h_query", ZK_G1, False)
+    crs.s1, crs.s2 = singles_from.s1, singles_from.s2
+    crs._make_ct()
+    return crs
