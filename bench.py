@@ -202,6 +202,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if os.environ.get("ZK_DIST_VIA_CPU"):
+        local_rank = 0           # debugging mode: every rank drives GPU 0 (see multigpu.StarNet)
     torch.cuda.set_device(local_rank)
 
     if world > 1 or os.environ.get("ZK_BENCH_FORCE_SHARDED"):

@@ -121,15 +121,28 @@ class GpuBackend:
 
 
 class StarNet:
-    """gather-to-king / scatter-from-king over torch.distributed (rank 0 hosts the king)."""
+    """gather-to-king / scatter-from-king over torch.distributed (rank 0 hosts the king).
 
-    def __init__(self, dist, rank, world):
-        self.dist, self.rank, self.world = dist, rank, world
+    `via_cpu` stages every collective through host tensors (gloo): a debugging mode that lets two ranks share ONE
+    GPU (RCCL refuses duplicate devices), used to exercise the complete multi-rank GPU code path on a 1-GPU box."""
+
+    def __init__(self, dist, rank, world, via_cpu=False):
+        self.dist, self.rank, self.world, self.via_cpu = dist, rank, world, via_cpu
 
     def gather(self, local, full):
         """local [k, ...] from every rank -> full [n, ...] on rank 0 (party-major = rank-major)."""
         if self.world == 1:
             full.copy_(local)
+            return
+        if self.via_cpu:
+            loc = local.cpu()
+            if self.rank == 0:
+                parts = [loc.new_empty(loc.shape) for _ in range(self.world)]
+                self.dist.gather(loc, gather_list=parts, dst=0)
+                for dst, src in zip(full.chunk(self.world, dim=0), parts):
+                    dst.copy_(src)
+            else:
+                self.dist.gather(loc, dst=0)
             return
         if self.rank == 0:
             parts = list(full.chunk(self.world, dim=0))
@@ -142,6 +155,14 @@ class StarNet:
         if self.world == 1:
             local.copy_(full)
             return
+        if self.via_cpu:
+            loc = local.cpu()
+            if self.rank == 0:
+                self.dist.scatter(loc, scatter_list=[p.cpu().contiguous() for p in full.chunk(self.world, dim=0)], src=0)
+            else:
+                self.dist.scatter(loc, src=0)
+            local.copy_(loc)
+            return
         if self.rank == 0:
             parts = [p.contiguous() for p in full.chunk(self.world, dim=0)]
             self.dist.scatter(local, scatter_list=parts, src=0)
@@ -151,6 +172,11 @@ class StarNet:
     def all_gather(self, local):
         if self.world == 1:
             return [local]
+        if self.via_cpu:
+            loc = local.cpu()
+            outs = [loc.new_empty(loc.shape) for _ in range(self.world)]
+            self.dist.all_gather(outs, loc)
+            return outs
         outs = [local.new_empty(local.shape) for _ in range(self.world)]
         self.dist.all_gather(outs, local)
         return outs
@@ -257,15 +283,19 @@ def bench(args, rank, local_rank, world):
     import zksaas_amd as zk
     from bench import build_inputs
 
+    via_cpu = bool(os.environ.get("ZK_DIST_VIA_CPU"))      # debugging: several ranks on one GPU, gloo collectives
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if via_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     pp = zk.PackedSharingParams("bn254", 2, device=local_rank)
     if pp.n % world:
         raise SystemExit("the number of GPUs must divide n = %d parties" % pp.n)
     r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
     be = GpuBackend(pp)
-    net = StarNet(dist, rank, world)
+    net = StarNet(dist, rank, world, via_cpu=via_cpu)
     w2m = zg._root_of_unity("bn254", wit.log_m + 1)
     prover = DistProver(be, net, pp.n, pp.l, wit.log_m, w2m)
     inp = _local_inputs(be, pp, crs, wit, rank, world)
@@ -282,7 +312,7 @@ def bench(args, rank, local_rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=be.device)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else be.device)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
