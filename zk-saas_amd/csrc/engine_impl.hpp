@@ -807,12 +807,18 @@ class Engine : public IEngine {
     // scalar multiples of CRS constants do not depend on the device work: overlap them with it
     P1 rN, sK, rsM;
     P2 sK2;
+    CPre<P1> pre;
+    const bool uniform = !mk || (!mk->msm_out[0] && !mk->msm_out[1] && !mk->msm_out[2] && !mk->msm_out[3] &&
+                                 !mk->msm_out[4]);
     std::thread host([&]() {
       P1 d1 = aff1(crs->delta_g1);
       rN = host_scalar_mul<FrP, Fq>(d1, r);
       sK = host_scalar_mul<FrP, Fq>(d1, s);
       rsM = host_scalar_mul<FrP, Fq>(d1, r * s);
       sK2 = host_scalar_mul<FrP, Fq2>(aff2(crs->delta_g2), s);
+      // s*(A - S) and r*(B1 - H): the part of C that does not wait for any MSM (prove.rs:229-235, linearity)
+      pre.s_cA = host_scalar_mul<FrP, Fq>(xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1)), s);
+      pre.r_cB1 = host_scalar_mul<FrP, Fq>(xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1)), r);
     });
     struct Joiner {
       std::thread& t;
@@ -833,6 +839,15 @@ class Engine : public IEngine {
     int rcs[4] = {0, 0, 0, 0};
     const int dev = device;
     const bool serial = getenv("ZK_SERIAL_MSM") != nullptr;     // diagnostics: clean per-kernel timings
+    // circom_h and the U-MSM that depends on it form a long dependent chain: they run on a high-priority internal
+    // stream (ordered after the caller's stream through an event).  Holding the other MSM streams (or only their
+    // accumulate launches) back until circom_h has finished was measured and rejected: 8.6-8.8 ms per proof against
+    // 6.9 ms when everything is issued at once.
+    hipStream_t hs = streams_[5];
+    ZK_HIP(hipEventRecord(ev_in_, st));
+    ZK_HIP(hipStreamWaitEvent(hs, ev_in_, 0));
+    int rc_h = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, hs);
+    if (rc_h) return rc_h;
     auto spawn = [&](auto fn) {
       if (serial) {
         fn();
@@ -869,28 +884,22 @@ class Engine : public IEngine {
       (void)hipSetDevice(dev);
       rcs[0] = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S,
                                              streams_[0], 1);
+      if (!rcs[0] && uniform) pre.sS = host_scalar_mul<FrP, Fq>(S, s);     // off the tail: S finishes early
     });
     std::thread tH = spawn([&]() {
       (void)hipSetDevice(dev);
       if (!r_zero)
         rcs[1] = msm_.template d_msm_sum_t<Fq>(this, crs->h_d, a_share, crs->len_a, mk ? mk->msm_in[1] : nullptr, &H,
                                                streams_[1], 2);
+      if (!r_zero && !rcs[1] && uniform) pre.rH = host_scalar_mul<FrP, Fq>(H, r);
     });
     std::thread tW = spawn([&]() {
       (void)hipSetDevice(dev);
       rcs[3] = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W,
                                              streams_[3], 4);
     });
-    // circom_h and the U-MSM that depends on it form the longest dependent chain: they run on a high-priority
-    // internal stream (ordered after the caller's stream through an event) so that the bulk MSM kernels of the
-    // other streams cannot starve their small launches.
-    hipStream_t hs = streams_[5];
-    ZK_HIP(hipEventRecord(ev_in_, st));
-    ZK_HIP(hipStreamWaitEvent(hs, ev_in_, 0));
-    rc = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, hs);
-    if (!rc)
-      rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, hs,
-                                         0);
+    // the U-MSM (needs h) follows circom_h on the same high-priority stream
+    rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, hs, 0);
     join(tS);
     join(tH);
     join(tV);
@@ -903,14 +912,22 @@ class Engine : public IEngine {
     for (int i = 0; i < 4; i++)
       if (rcs[i]) return rcs[i];
 
-    return assemble_t(crs, r, s, rN, sK, rsM, sK2, S, H, V, W, U, mk, pi_a, pi_b, pi_c);
+    pre.valid = uniform;
+    return assemble_t(crs, r, s, rN, sK, rsM, sK2, S, H, V, W, U, mk, pi_a, pi_b, pi_c, &pre);
   }
+
+  // precomputed pieces of C = s*A + r*B1 - rs*delta + W + U for the case without out-masks (all parties equal)
+  template <class P1>
+  struct CPre {
+    bool valid = false;
+    P1 s_cA = P1::identity(), r_cB1 = P1::identity(), sS = P1::identity(), rH = P1::identity();
+  };
 
   // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party (shares differ only through the out-masks)
   template <class P1, class P2>
   int assemble_t(const zk_crs_share* crs, const Fr& r, const Fr& s, const P1& rN, const P1& sK, const P1& rsM,
                  const P2& sK2, const P1& S, const P1& H, const P2& V, const P1& W, const P1& U,
-                 const zk_groth16_masks* mk, void* pi_a, void* pi_b, void* pi_c) {
+                 const zk_groth16_masks* mk, void* pi_a, void* pi_b, void* pi_c, const CPre<P1>* pre = nullptr) {
     using Fq = Fp<typename Cfg::FqP>;
     using Fq2 = Fp2<typename Cfg::FqP>;
     auto aff1 = [](const void* p) {
@@ -948,7 +965,13 @@ class Engine : public IEngine {
       P2 Vp = V;
       if (mk && mk->msm_out[2]) Vp = xyzz_add_ni(Vp, jacobian_to_xyzz(((const Jacobian<Fq2>*)mk->msm_out[2])[p]));
       P2 B2 = xyzz_add_ni(cB2, Vp);
-      P1 C = xyzz_add_ni(host_scalar_mul<FrP, Fq>(A, s), host_scalar_mul<FrP, Fq>(B1, r));
+      P1 C;
+      if (pre && pre->valid && uniform) {
+        C = xyzz_add_ni(pre->s_cA, pre->sS);
+        if (!r_zero) C = xyzz_add_ni(C, xyzz_add_ni(pre->r_cB1, pre->rH));
+      } else {
+        C = xyzz_add_ni(host_scalar_mul<FrP, Fq>(A, s), host_scalar_mul<FrP, Fq>(B1, r));
+      }
       C = xyzz_add_ni(C, rsM.neg());
       C = xyzz_add_ni(C, om1(3, p, W));
       C = xyzz_add_ni(C, om1(4, p, U));

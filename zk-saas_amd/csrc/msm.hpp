@@ -164,18 +164,61 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint2
   }
 }
 
-// cursor[key] = offsets[key].x ; segment descriptors for every bucket
-static __global__ void msm_expand_kernel(const uint2* __restrict__ offsets, size_t nkeys, uint32_t* __restrict__ cursor,
-                                  SegDesc* __restrict__ segs, uint32_t seg) {
+// cursor[key] = offsets[key].x ; segment descriptors for every bucket; histogram of the segment lengths
+constexpr int SEG_BINS = 65;
+__device__ __forceinline__ uint32_t seg_bin(uint32_t len, uint32_t seg) { return (len * 64u + seg - 1) / seg; }
+
+static __global__ __launch_bounds__(256) void msm_expand_kernel(const uint2* __restrict__ offsets, size_t nkeys,
+                                                                uint32_t* __restrict__ cursor,
+                                                                SegDesc* __restrict__ segs, uint32_t seg,
+                                                                uint32_t* __restrict__ lenhist) {
+  __shared__ uint32_t lh[SEG_BINS];
+  if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
+  __syncthreads();
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nkeys) return;
-  uint2 o = offsets[k], o1 = offsets[k + 1];
-  cursor[k] = o.x;
-  uint32_t s = o.y;
-  for (uint32_t p = o.x; p < o1.x; p += seg, s++) {
-    uint32_t e = p + seg < o1.x ? p + seg : o1.x;
-    segs[s] = {(uint32_t)k, p, e};
+  if (k < nkeys) {
+    uint2 o = offsets[k], o1 = offsets[k + 1];
+    cursor[k] = o.x;
+    uint32_t s = o.y;
+    uint32_t full = (o1.x - o.x) / seg, rem = (o1.x - o.x) % seg;
+    for (uint32_t p = o.x; p < o1.x; p += seg, s++) {
+      uint32_t e = p + seg < o1.x ? p + seg : o1.x;
+      segs[s] = {(uint32_t)k, p, e};
+    }
+    if (full) atomicAdd(&lh[64], full);
+    if (rem) atomicAdd(&lh[seg_bin(rem, seg)], 1u);
   }
+  __syncthreads();
+  if (threadIdx.x < SEG_BINS && lh[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], lh[threadIdx.x]);
+}
+
+// order[] = the segment indices sorted by descending length (counting sort over SEG_BINS length classes), so that
+// the 64 lanes of an accumulate wave walk chains of equal length: bucket sizes are Poisson-like and an unsorted
+// launch idles ~25% of its lanes (every wave runs for its longest lane).
+static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __restrict__ segs,
+                                                               const uint2* __restrict__ offsets, size_t nkeys,
+                                                               uint32_t seg, const uint32_t* __restrict__ lenhist,
+                                                               uint32_t* __restrict__ bincur,
+                                                               uint32_t* __restrict__ order) {
+  __shared__ uint32_t lh[SEG_BINS], base[SEG_BINS];
+  if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t nseg = offsets[nkeys].y;
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t bin = 0, r = 0;
+  if (s < nseg) {
+    SegDesc d = segs[s];
+    bin = seg_bin(d.end - d.start, seg);
+    r = atomicAdd(&lh[bin], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < SEG_BINS) {
+    uint32_t b = threadIdx.x, before = 0;
+    for (uint32_t j = b + 1; j < SEG_BINS; j++) before += lenhist[j];
+    base[b] = before + (lh[b] ? atomicAdd(&bincur[b], lh[b]) : 0u);
+  }
+  __syncthreads();
+  if (s < nseg) order[base[bin] + r] = s;
 }
 
 // -------------------------------------------------------------------------------------------------- accumulate
@@ -184,10 +227,12 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const Affine<Fld>* 
                                                             const uint32_t* __restrict__ sorted,
                                                             const SegDesc* __restrict__ segs,
                                                             const uint2* __restrict__ offsets, size_t nkeys,
+                                                            const uint32_t* __restrict__ order,
                                                             XYZZ<Fld>* __restrict__ partial) {
-  size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t nseg = offsets[nkeys].y;
-  if (s >= nseg) return;
+  if (t >= nseg) return;
+  const uint32_t s = order[t];
   SegDesc d = segs[s];
   XYZZ<Fld> acc = XYZZ<Fld>::identity();
   // software pipeline: the next point's index and coordinates are in flight while the current one is added
@@ -372,7 +417,12 @@ class MsmRunner {
   // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
   // where nwin = ceil((BITS+1)/c) already prices a sparsely filled top window; ties go to the wider window
   // (more buckets = more lanes with shorter chains).
-  static int pick_c(size_t npts) {
+  static int pick_c(size_t npts, bool g2 = false) {
+    if (g2)
+      if (const char* e = getenv("ZK_MSM_C_G2")) {
+        int c = atoi(e);
+        if (c >= 2 && c <= 20) return c;
+      }
     if (const char* e = getenv("ZK_MSM_C")) {
       int c = atoi(e);
       if (c >= 2 && c <= 20) return c;
@@ -393,7 +443,12 @@ class MsmRunner {
   }
 
   // points per accumulate lane (a bucket longer than this is cut into segments)
-  static uint32_t pick_seg(size_t npts, int nwin) {
+  static uint32_t pick_seg(size_t npts, int nwin, bool g2 = false) {
+    if (g2)
+      if (const char* e = getenv("ZK_MSM_SEG_G2")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 1024) return (uint32_t)v;
+      }
     if (const char* e = getenv("ZK_MSM_SEG")) {
       int v = atoi(e);
       if (v >= 1 && v <= 1024) return (uint32_t)v;
@@ -412,12 +467,13 @@ class MsmRunner {
     *result = XYZZ<Fld>::identity();
     if (npts == 0) return ZK_OK;
     if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
-    const int c = pick_c(npts);
+    constexpr bool G2FLD = sizeof(Fld) != sizeof(Fq);
+    const int c = pick_c(npts, G2FLD);
     const int nwin = (FrP::BITS + c) / c;          // ceil((BITS+1)/c): room for the signed-digit carry
     const uint32_t B = 1u << (c - 1);
     const size_t nkeys = (size_t)nwin * B;
     const size_t max_sorted = npts * nwin;
-    const uint32_t seg = pick_seg(npts, nwin);
+    const uint32_t seg = pick_seg(npts, nwin, G2FLD);
     const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
     constexpr int RED_THREADS = red_threads<Fld>();
     const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
@@ -430,7 +486,7 @@ class MsmRunner {
       off += (bytes + 255) & ~(size_t)255;
       return o;
     };
-    size_t o_counts = take(nkeys * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
+    size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
            o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
            o_partial = take(max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(nkeys * sizeof(XYZZ<Fld>)),
            o_out = take((size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
@@ -439,6 +495,8 @@ class MsmRunner {
     if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
     char* ws = (char*)ws_[wslot].p;
     uint32_t* counts = (uint32_t*)(ws + o_counts);
+    uint32_t* lenhist = (uint32_t*)(ws + o_lenhist);   // [SEG_BINS] histogram, [SEG_BINS] cursors
+    uint32_t* order = (uint32_t*)(ws + o_order);
     uint32_t* cursor = (uint32_t*)(ws + o_cursor);
     uint2* offsets = (uint2*)(ws + o_offsets);
     uint2* bt = (uint2*)(ws + o_bt);
@@ -466,7 +524,7 @@ class MsmRunner {
       if (_e != hipSuccess) return eng->hip_fail(_e, name);                      \
     }                                                                            \
   } while (0)
-    MSM_HIP(hipMemsetAsync(counts, 0, nkeys * 4, st));
+    MSM_HIP(hipMemsetAsync(counts, 0, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
     dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
     constexpr bool IS_G2 = sizeof(Fld) != sizeof(Fq);
     {
@@ -480,7 +538,10 @@ class MsmRunner {
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
                                                                                      offsets, 1, seg);
     MSM_STAGE("scan");
-    msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg);
+    msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg,
+                                                                                   lenhist);
+    msm_order_kernel<<<dim3((unsigned)((max_segs + 255) / 256)), dim3(256), 0, st>>>(segs, offsets, nkeys, seg, lenhist,
+                                                                                     lenhist + SEG_BINS, order);
     MSM_STAGE("expand");
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
                                                 nullptr, cursor, sorted);
@@ -489,7 +550,7 @@ class MsmRunner {
     {
     ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts);
     msm_accumulate_kernel<KF><<<dim3((unsigned)((max_segs + 127) / 128)), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, sorted, segs, offsets, nkeys, partial);
+        (const Affine<KF>*)bases, sorted, segs, offsets, nkeys, order, partial);
     }
     MSM_STAGE("accumulate");
     {
