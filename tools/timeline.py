@@ -1,0 +1,43 @@
+"""Per-stream kernel timeline of one proof from a rocprofv3 --kernel-trace csv (diagnostics).
+
+usage: python tools/timeline.py gpurun_out/prof/p_kernel_trace.csv [proof_index_from_end]
+A proof starts at each launch of the first kernel of circom_h's stream-independent prefix (msm_digits on any stream
+after a gap); here simply: split the trace at every `king_degred_kernel` end (one per proof).
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(n):
+    n = re.sub(r"^void zk::", "", n)
+    m = re.match(r"(\w+)", n)
+    s = m.group(1) if m else n
+    if "Fp2" in n:
+        s += "<G2>"
+    return s
+# proof boundaries: gaps > 150 us with no kernel running
+bounds, end = [0], 0
+for i, r in enumerate(rows):
+    st = int(r["Start_Timestamp"])
+    if i and st - end > 150_000:
+        bounds.append(i)
+    end = max(end, int(r["End_Timestamp"]))
+bounds.append(len(rows))
+lo, hi = bounds[-1 - back], bounds[-back]
+sel = rows[lo:hi]
+t0 = int(sel[0]["Start_Timestamp"])
+print(f"proof window: {len(sel)} launches, {(max(int(r['End_Timestamp']) for r in sel) - t0) / 1e6:.3f} ms busy, "
+      f"period {(int(rows[hi]['Start_Timestamp']) - t0) / 1e6 if hi < len(rows) else float('nan'):.3f} ms")
+by = defaultdict(list)
+for r in sel:
+    by[r.get("Stream_Id", r.get("Queue_Id"))].append(r)
+for q, rs in sorted(by.items(), key=lambda kv: int(kv[1][0]["Start_Timestamp"])):
+    print(f"-- stream/queue {q}")
+    for r in rs:
+        s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+        if e - s >= 0.03:
+            print(f"   {s:7.3f} -> {e:7.3f}  ({e - s:6.3f})  {short(r['Kernel_Name'])}  grid={r.get('Grid_Size_X', r.get('Grid_Size'))}")

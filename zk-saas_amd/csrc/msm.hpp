@@ -44,7 +44,8 @@ struct SegDesc {
 // pass 0: histogram; pass 1: scatter.  coef (optional): per-part multiplier, part = i / part_len.
 template <class FrP, int PASS>
 __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t npts, const Fp<FrP>* __restrict__ coef,
-                                  size_t part_len, int c, int nwin, uint32_t* __restrict__ counts /* [nwin*B] */,
+                                  size_t part_len, int c, int nwin, int wide /* windows [0, wide) have c bits, the rest
+                                  c-1 */, uint32_t* __restrict__ counts /* [nwin*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
@@ -55,14 +56,15 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
   uint32_t carry = 0;
   constexpr int N = FrP::N;
   for (int w = 0; w < nwin; w++) {
-    // low c bits, then shift the whole scalar right by c (static limb indices: stays in registers)
-    uint32_t val = s.v[0] & ((1u << c) - 1);
+    // low cw bits, then shift the whole scalar right by cw (static limb indices: stays in registers)
+    const int cw = w < wide ? c : c - 1;
+    uint32_t val = s.v[0] & ((1u << cw) - 1);
 #pragma unroll
-    for (int q = 0; q < N - 1; q++) s.v[q] = (s.v[q] >> c) | (s.v[q + 1] << (32 - c));
-    s.v[N - 1] >>= c;
+    for (int q = 0; q < N - 1; q++) s.v[q] = (s.v[q] >> cw) | (s.v[q + 1] << (32 - cw));
+    s.v[N - 1] >>= cw;
     int32_t d = (int32_t)(val + carry);
-    if ((uint32_t)d > B) {
-      d -= (int32_t)(1u << c);
+    if ((uint32_t)d > (1u << (cw - 1))) {
+      d -= (int32_t)(1u << cw);
       carry = 1;
     } else {
       carry = 0;
@@ -113,6 +115,7 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const
                                                                    const uint2* __restrict__ carry,
                                                                    uint2* __restrict__ offsets, int mode,
                                                                    uint32_t seg) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   __shared__ uint2 sh[ISCAN_THREADS];
   size_t base = (size_t)blockIdx.x * ISCAN_BLOCK + (size_t)threadIdx.x * ISCAN_PER;
   uint2 loc[ISCAN_PER];
@@ -139,6 +142,7 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const
 }
 
 static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint2* __restrict__ bt, size_t nblocks) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   __shared__ uint2 sh[ISCAN_THREADS];
   uint2 running = make_uint2(0, 0);
   for (size_t b0 = 0; b0 < nblocks; b0 += ISCAN_BLOCK) {
@@ -172,6 +176,7 @@ static __global__ __launch_bounds__(256) void msm_expand_kernel(const uint2* __r
                                                                 uint32_t* __restrict__ cursor,
                                                                 SegDesc* __restrict__ segs, uint32_t seg,
                                                                 uint32_t* __restrict__ lenhist) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   __shared__ uint32_t lh[SEG_BINS];
   if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
   __syncthreads();
@@ -200,6 +205,7 @@ static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __
                                                                uint32_t seg, const uint32_t* __restrict__ lenhist,
                                                                uint32_t* __restrict__ bincur,
                                                                uint32_t* __restrict__ order) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   __shared__ uint32_t lh[SEG_BINS], base[SEG_BINS];
   if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
   __syncthreads();
@@ -270,6 +276,7 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __re
                                                           const uint2* __restrict__ offsets, size_t nkeys,
                                                           XYZZ<Fld>* __restrict__ buckets,
                                                           uint32_t* __restrict__ heavy /* [0] = count */) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nkeys) return;
   uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
@@ -288,6 +295,7 @@ template <class Fld>
 __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
     const XYZZ<Fld>* __restrict__ partial, const uint2* __restrict__ offsets, const uint32_t* __restrict__ heavy,
     XYZZ<Fld>* __restrict__ buckets) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
   const uint32_t nheavy = heavy[0];
@@ -334,6 +342,7 @@ template <class Fld, int RT>
 __global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets, uint32_t B,
                                                        uint32_t blocks_per_window,
                                                        XYZZ<Fld>* __restrict__ out /* [nwin][bpw][2] */) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   extern __shared__ uint4 smem_red[];
   XYZZ<Fld>* RUN = reinterpret_cast<XYZZ<Fld>*>(smem_red);
   XYZZ<Fld>* ACC = RUN + RT;
@@ -415,7 +424,7 @@ class MsmRunner {
   using Fq2 = Fp2<typename Cfg::FqP>;
 
   // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
-  // where nwin = ceil((BITS+1)/c) already prices a sparsely filled top window; ties go to the wider window
+  // with nwin = ceil((BITS+1)/c) windows of evenly spread width (see run_t); ties go to the wider window
   // (more buckets = more lanes with shorter chains).
   static int pick_c(size_t npts, bool g2 = false) {
     if (g2)
@@ -431,9 +440,8 @@ class MsmRunner {
     double best_cost = 1e300;
     for (int c = 4; c <= 17; c++) {
       int nwin = (FrP::BITS + c) / c;
-      double cost = (double)nwin * ((double)npts + 4.0 * (double)((size_t)1 << (c - 1)));
-      int top_bits = FrP::BITS + 1 - (nwin - 1) * c;
-      if (2 * top_bits < c) cost *= 1.15;   // a sparsely used top window concentrates points in a few buckets
+      int ceff = (FrP::BITS + nwin) / nwin;          // widest window after spreading BITS+1 bits over nwin windows
+      double cost = (double)nwin * ((double)npts + 4.0 * (double)((size_t)1 << (ceff - 1)));
       if (cost <= best_cost) {
         best_cost = cost;
         best = c;
@@ -468,8 +476,14 @@ class MsmRunner {
     if (npts == 0) return ZK_OK;
     if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
     constexpr bool G2FLD = sizeof(Fld) != sizeof(Fq);
-    const int c = pick_c(npts, G2FLD);
-    const int nwin = (FrP::BITS + c) / c;          // ceil((BITS+1)/c): room for the signed-digit carry
+    const int c_req = pick_c(npts, G2FLD);
+    // BITS+1 bits (room for the signed-digit carry) are spread EVENLY over the windows: `wide` windows of c bits and
+    // nwin-wide of c-1.  A plain c-bit split leaves a top window of a few bits (254 = 19*13 + 7) whose 64 buckets
+    // each receive npts/64 points: hot atomics in the sort, long chains, and a heavy-bucket pass in every MSM.
+    const int T = FrP::BITS + 1;
+    const int nwin = (T + c_req - 1) / c_req;
+    const int c = (T + nwin - 1) / nwin;            // widest window
+    const int wide = T - nwin * (c - 1);            // 1 <= wide <= nwin
     const uint32_t B = 1u << (c - 1);
     const size_t nkeys = (size_t)nwin * B;
     const size_t max_sorted = npts * nwin;
@@ -530,7 +544,7 @@ class MsmRunner {
     {
     ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts);
     msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
-                                                counts, nullptr, nullptr);
+                                                wide, counts, nullptr, nullptr);
     MSM_STAGE("digits/count");
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
                                                                                      nullptr, 0, seg);
@@ -544,7 +558,7 @@ class MsmRunner {
                                                                                      lenhist + SEG_BINS, order);
     MSM_STAGE("expand");
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, part_len ? part_len : npts, c, nwin,
-                                                nullptr, cursor, sorted);
+                                                wide, nullptr, cursor, sorted);
     }
     MSM_STAGE("scatter");
     {
@@ -583,7 +597,7 @@ class MsmRunner {
     // host: window value = sum_blk (A_blk + blk*RED_THREADS*RED_G * S_blk); fold windows high -> low
     XYZZ<Fld> total = XYZZ<Fld>::identity();
     for (int w = nwin - 1; w >= 0; w--) {
-      for (int i = 0; i < c; i++) total = xyzz_dbl_ni(total);
+      for (int i = 0; i < (w < wide ? c : c - 1); i++) total = xyzz_dbl_ni(total);
       XYZZ<Fld> wsum = XYZZ<Fld>::identity();
       XYZZ<Fld> run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
       for (int blk = (int)bpw - 1; blk >= 0; blk--) {

@@ -114,6 +114,7 @@ template <class F>
 __global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0, int s1,
                                                               int cbits, const F* __restrict__ tw_full, int log_l,
                                                               const F* __restrict__ add) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   extern __shared__ uint4 smem[];
   constexpr int H = sizeof(F) / 16;
   const int rbits = s1 - s0;

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
     const PackL2<Fp<P>>* __restrict__ k2, int rearrange, uint64_t seed, Fp<P>* __restrict__ out,
     const Fp<P>* __restrict__ out_mask) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, uint64_t seed,
     Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
