@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 #   ntt_pass      : one of P passes of fft1 over an element: (2 * 32 B) / P is charged per launch (see below)
 #   king_fft2     : per chunk, l = 2: n shares in + n shares out = 16 * 32 B
 #   msm accumulate: per point: affine base (2 |Fq|) + scalar (32 B)  -> 96 B (G1), 160 B (G2)
+MUL_PEAK_G = 93.0   # measured on MI355X with tools/mulbench.hip (profiles/r01_mulbench.txt)
 SLOT_BYTES = {"king_fft2_kernel": 512.0, "msm_accumulate_kernel<G1>": 96.0, "msm_accumulate_kernel<G2>": 160.0,
               "msm_digits+scan+expand": 32.0, "msm_finalize+reduce": 0.0, "king_degred_kernel": 512.0}
 
@@ -87,7 +88,7 @@ def pmc_traffic(slot_name):
     return None
 
 
-def roofline_of(prof, ntt_passes):
+def roofline_of(prof, ntt_passes, pp=None):
     # the dominant STREAMING kernel: the sort and the bucket finalize/reduce helpers are latency-bound tree
     # kernels without a per-unit byte figure in SURVEY.md 8d; they are listed under "kernels"
     cands = [e for e in prof if e["launches"] and (SLOT_BYTES.get(e["kernel"]) or e["kernel"] == "ntt_pass_kernel")
@@ -104,9 +105,19 @@ def roofline_of(prof, ntt_passes):
     avg_ms = best["total_ms"] / best["launches"]
     bytes_per_launch = per_unit * best["units"] / best["launches"]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    # ALU view of the same launch: a mixed addition is 10 (G1) / 28 (G2) base-field Montgomery multiplies
-    # per point and window -- the figure that actually bounds this kernel
-    return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # ALU view of the same launch: a mixed addition is 10 (G1) / 28 (G2) base-field Montgomery
+    # multiplications per point and window -- the figure that actually bounds this kernel.  The peak is the measured
+    # chip-wide rate of independent 256-bit Montgomery multiplications (tools/mulbench.hip, v_mad_u64_u32 bound).
+    alu = None
+    if pp is not None and name.startswith("msm_accumulate"):
+        from zksaas_amd.api import ZK_G1, ZK_G2, msm_plan
+        pts = int(best["units"] / best["launches"])
+        plan = msm_plan(pp, ZK_G2 if "G2" in name else ZK_G1, pts)
+        muls = pts * plan["windows"] * plan["muls_per_add"]
+        rate = muls / (avg_ms * 1e-3) / 1e9
+        alu = {"achieved": round(rate, 2), "peak": MUL_PEAK_G, "unit": "G modmul/s (256-bit Montgomery)",
+               "frac": round(rate / MUL_PEAK_G, 3), "plan": plan}
+    return {"bound": "hbm", "alu": alu, "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
             "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "launches": best["launches"]}
@@ -238,7 +249,7 @@ def main():
                                "n=8 parties on one GPU, zero masks", "constraints": r1.num_constraints,
                    "wires": r1.num_variables, "domain": 1 << wit.log_m, "parties": pp.n, "packing_factor": pp.l},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
-        "roofline": roofline_of(prof, ntt_passes=2),
+        "roofline": roofline_of(prof, ntt_passes=2, pp=pp),
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
     if not args.no_primitives:

@@ -192,6 +192,11 @@ int zk_groth16_prove(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, 
 int zk_d_msm_local(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, int first_party,
                    int nparties, const void* in_mask, void* out, void* stream);
 int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out);
+/* Introspection (no reference counterpart; ark-ec picks its window inside VariableBaseMSM::msm): the Pippenger plan
+ * zk_msm uses for `len` points of `group`: plan[0] = widest window in bits, plan[1] = number of windows,
+ * plan[2] = points per accumulate lane, plan[3] = base-field multiplications per mixed addition (10 for G1,
+ * 28 for G2 over Fq2).  Benchmarks use it to turn a launch duration into multiplications per second. */
+int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
 /* The five zk_d_msm_local of the prover for this rank's parties, overlapped: _begin starts S, H, V, W (they only
  * need the witness shares; crs vectors are [nparties][len] here) on internal streams and returns; _finish runs U
  * on `stream` once h_share_d [nparties][m/l] is available, joins, and writes out[0..4] = S, H, V(G2), W, U

@@ -14,7 +14,7 @@ SYMBOLS = [
     "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
     "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove", "zk_profile_enable",
     "zk_profile_slots", "zk_profile_name", "zk_profile_read", "zk_d_msm_local", "zk_group_add", "zk_groth16_assemble",
-    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points",
+    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def load():
     lib.zk_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, vp, vp, vp]
     lib.zk_d_msm_local.argtypes = [vp, i32, vp, vp, sz, i32, i32, vp, vp, vp]
     lib.zk_group_add.argtypes = [vp, i32, vp, vp, vp]
+    lib.zk_msm_plan.argtypes = [vp, i32, C.c_size_t, C.POINTER(C.c_int)]
     lib.zk_groth16_assemble.argtypes = [vp, vp, vp, vp, C.POINTER(vp), vp, vp, vp, vp]
     lib.zk_groth16_msms_begin.argtypes = [vp, vp, vp, vp, i32, i32, i32]
     lib.zk_groth16_msms_finish.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp), vp]

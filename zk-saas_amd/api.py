@@ -102,6 +102,12 @@ class Context:
     def upload_fr(self, vals):
         return DeviceBuffer.from_numpy(self, self.fr.encode(vals))
 
+    def upload_u32(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint32)
+        if arr.size == 0:
+            arr = np.zeros(1, dtype=np.uint32)
+        return DeviceBuffer.from_numpy(self, arr)
+
     def download_fr(self, buf, count=None):
         arr = buf.to_numpy()
         if count is not None:
@@ -235,6 +241,14 @@ def msm(pp, group, bases_d, scalars_d, length, len_scalars=None, stream=None):
     ls = length if len_scalars is None else len_scalars
     pp._check(pp.lib.zk_msm(pp.h, group, _ptr(bases_d), length, _ptr(scalars_d), ls, out.ctypes.data, stream))
     return out
+
+
+def msm_plan(pp, group, length):
+    """The Pippenger plan zk_msm uses for `length` points: dict(window_bits, windows, lane_points, muls_per_add)."""
+    import ctypes as C
+    plan = (C.c_int * 4)()
+    pp._check(pp.lib.zk_msm_plan(pp.h, group, length, plan))
+    return {"window_bits": plan[0], "windows": plan[1], "lane_points": plan[2], "muls_per_add": plan[3]}
 
 
 def d_msm(pp, group, bases_d, scalars_d, length, msm_mask=None, stream=None):

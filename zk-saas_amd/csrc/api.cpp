@@ -208,6 +208,10 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
   CTX_OR_FAIL();
   return e->group_add(group, a, b, out);
 }
+int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]) {
+  CTX_OR_FAIL();
+  return e->msm_plan(group, len, plan);
+}
 int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                         const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) {
   CTX_OR_FAIL();

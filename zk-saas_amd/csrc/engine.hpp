@@ -145,6 +145,7 @@ class IEngine {
   virtual int d_msm_local(int group, const void* bases, const void* scalars, size_t len, int first_party, int nparties,
                           const void* in_mask, void* out, hipStream_t st) = 0;
   virtual int group_add(int group, const void* a, const void* b, void* out) = 0;
+  virtual int msm_plan(int group, size_t len, int* plan) = 0;
   virtual int groth16_assemble(const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                                const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count,

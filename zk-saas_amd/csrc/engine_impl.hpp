@@ -1008,6 +1008,12 @@ class Engine : public IEngine {
     }
     return fail(ZK_ERR_BAD_INPUT, "bad group");
   }
+  int msm_plan(int group, size_t len, int* plan) override {
+    if (!plan || (group != ZK_G1 && group != ZK_G2)) return fail(ZK_ERR_BAD_INPUT, "bad argument");
+    if (group == ZK_G2 && !Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    msm_.plan(len, group == ZK_G2, plan);
+    return ZK_OK;
+  }
   int group_add(int group, const void* a, const void* b, void* out) override {
     using Fq = Fp<typename Cfg::FqP>;
     using Fq2 = Fp2<typename Cfg::FqP>;

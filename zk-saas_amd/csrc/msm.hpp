@@ -228,37 +228,46 @@ static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __
 }
 
 // -------------------------------------------------------------------------------------------------- accumulate
+// Waves per SIMD the accumulate kernel is compiled for.  The inlined Fq2 mixed addition takes 256 VGPRs + ~200 AGPR
+// spill slots = one wave per SIMD.  Forcing two waves (256 registers, ~600 B of scratch per lane, scheduling barriers
+// between the field multiplications to shorten live ranges) was measured and rejected: 0.96 ms against 0.73 ms per
+// 52k-point launch -- with so few waves the multiplier needs the instruction-level parallelism across independent
+// field multiplications more than it needs a second wave.
 template <class Fld>
-__global__ __launch_bounds__(128) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases,
+constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : 3;
+template <class Fld>
+__global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases,
                                                             const uint32_t* __restrict__ sorted,
                                                             const SegDesc* __restrict__ segs,
                                                             const uint2* __restrict__ offsets, size_t nkeys,
                                                             const uint32_t* __restrict__ order,
                                                             XYZZ<Fld>* __restrict__ partial) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nseg = offsets[nkeys].y;
-  if (t >= nseg) return;
-  const uint32_t s = order[t];
-  SegDesc d = segs[s];
-  XYZZ<Fld> acc = XYZZ<Fld>::identity();
-  // software pipeline: the next point's index and coordinates are in flight while the current one is added
-  uint32_t e = sorted[d.start];
-  Affine<Fld> pt = load_elem(bases + (e & 0x7fffffffu));
-  for (uint32_t p = d.start; p < d.end; p++) {
-    uint32_t e_next = e;
-    Affine<Fld> pt_next = pt;
-    if (p + 1 < d.end) {
-      e_next = sorted[p + 1];
-      pt_next = load_elem(bases + (e_next & 0x7fffffffu));
+  // bounded grid + grid-stride loop: every workgroup of the launch is resident at once, so the launch does not sit
+  // in its hardware queue waiting for wave slots (which stalls every other stream mapped to the same pipe)
+  const uint32_t nseg = offsets[nkeys].y;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nseg; t += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t s = order[t];
+    SegDesc d = segs[s];
+    XYZZ<Fld> acc = XYZZ<Fld>::identity();
+    // software pipeline: the next point's index and coordinates are in flight while the current one is added
+    uint32_t e = sorted[d.start];
+    Affine<Fld> pt = load_elem(bases + (e & 0x7fffffffu));
+    for (uint32_t p = d.start; p < d.end; p++) {
+      uint32_t e_next = e;
+      Affine<Fld> pt_next = pt;
+      if (p + 1 < d.end) {
+        e_next = sorted[p + 1];
+        pt_next = load_elem(bases + (e_next & 0x7fffffffu));
+      }
+      if (!pt.is_identity()) {
+        Fld y = (e >> 31) ? pt.y.neg() : pt.y;
+        acc = xyzz_madd(acc, pt.x, y);
+      }
+      e = e_next;
+      pt = pt_next;
     }
-    if (!pt.is_identity()) {
-      Fld y = (e >> 31) ? pt.y.neg() : pt.y;
-      acc = xyzz_madd(acc, pt.x, y);
-    }
-    e = e_next;
-    pt = pt_next;
+    store_elem(partial + s, acc);
   }
-  store_elem(partial + s, acc);
 }
 
 // One lane per bucket sums its segments when there are few; buckets with many segments (skewed digit
@@ -468,6 +477,17 @@ class MsmRunner {
     return npts >= ((size_t)1 << 21) ? 64u : (uint32_t)MSM_SEG_MAX;
   }
 
+  // the window split run_t uses (see there)
+  static void plan(size_t npts, bool g2, int* out) {
+    const int c_req = pick_c(npts ? npts : 1, g2);
+    const int T = FrP::BITS + 1;
+    const int nwin = (T + c_req - 1) / c_req;
+    out[0] = (T + nwin - 1) / nwin;
+    out[1] = nwin;
+    out[2] = (int)pick_seg(npts, nwin, g2);
+    out[3] = g2 ? 28 : 10;
+  }
+
   template <class Fld>
   int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
             XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
@@ -563,7 +583,14 @@ class MsmRunner {
     MSM_STAGE("scatter");
     {
     ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts);
-    msm_accumulate_kernel<KF><<<dim3((unsigned)((max_segs + 127) / 128)), dim3(128), 0, st>>>(
+    size_t acc_wgs = (max_segs + 127) / 128;
+    {
+      static const int cap_g1 = getenv("ZK_ACC_WGS_G1") ? atoi(getenv("ZK_ACC_WGS_G1")) : 0;
+      static const int cap_g2 = getenv("ZK_ACC_WGS_G2") ? atoi(getenv("ZK_ACC_WGS_G2")) : 0;
+      const int cap = IS_G2 ? cap_g2 : cap_g1;
+      if (cap > 0 && acc_wgs > (size_t)cap) acc_wgs = (size_t)cap;
+    }
+    msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs), dim3(128), 0, st>>>(
         (const Affine<KF>*)bases, sorted, segs, offsets, nkeys, order, partial);
     }
     MSM_STAGE("accumulate");
