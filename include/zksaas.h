@@ -197,6 +197,27 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
  * plan[2] = points per accumulate lane, plan[3] = base-field multiplications per mixed addition (10 for G1,
  * 28 for G2 over Fq2).  Benchmarks use it to turn a launch duration into multiplications per second. */
 int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
+/* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value
+ * -(sum), both packed with t random group elements each (streams seed^0x1111, seed^0x2222; a random group element
+ * is a random multiple of gen).  gen_affine: the group generator (host, affine Montgomery); in_mask / out_mask
+ * (HOST) receive n Jacobian points each. */
+int zk_msm_mask_sample(zk_ctx* ctx, int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask);
+
+/* ---- circom front end (what the reference takes from ark-circom + groth16/src/qap.rs) ------------------
+ * zk_r1cs_qap: qap.rs:42-89 (`qap::<F, D>()` for the circom reduction): A and B as CSR on the device
+ *   (row_ptr [num_constraints+1] u32, col u32 wire indices, val Montgomery Fr), w_d the full assignment
+ *   [num_variables]; writes a, b, c [2^log_m] in natural order: a_i = <A_i,w>, b_i = <B_i,w>, c_i = a_i*b_i,
+ *   a[nc .. nc+ni) = w[0 .. ni), zero padding.  2^log_m < nc + ni -> ZK_ERR_BAD_INPUT; a wire index
+ *   >= num_variables -> ZK_ERR_GENERIC.
+ * zk_fr_to_bytes / zk_fr_from_bytes: ark-serialize CanonicalSerialize / CanonicalDeserialize of Fr elements
+ *   (little-endian canonical integers, the payload of mpc-net frames, ser_net.rs:24-25) for device vectors;
+ *   from_bytes returns ZK_ERR_GENERIC when an element is >= the modulus (arkworks: InvalidData). */
+int zk_r1cs_qap(zk_ctx* ctx, const void* a_row_ptr_d, const void* a_col_d, const void* a_val_d,
+                const void* b_row_ptr_d, const void* b_col_d, const void* b_val_d, const void* w_d,
+                size_t num_variables, size_t num_constraints, size_t num_instance, int log_m, void* a_out_d,
+                void* b_out_d, void* c_out_d, void* stream);
+int zk_fr_to_bytes(zk_ctx* ctx, const void* x_d, size_t len, void* bytes_out_d, void* stream);
+int zk_fr_from_bytes(zk_ctx* ctx, const void* bytes_d, size_t len, void* x_out_d, void* stream);
 /* The five zk_d_msm_local of the prover for this rank's parties, overlapped: _begin starts S, H, V, W (they only
  * need the witness shares; crs vectors are [nparties][len] here) on internal streams and returns; _finish runs U
  * on `stream` once h_share_d [nparties][m/l] is available, joins, and writes out[0..4] = S, H, V(G2), W, U

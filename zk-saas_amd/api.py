@@ -204,6 +204,18 @@ class MsmMask:
     def zero():
         return MsmMask(None, None)
 
+    @staticmethod
+    def sample(pp, group, gen_affine, seed):
+        """MsmMask::sample (dmsm/mod.rs:21-47); gen_affine: the group generator as Montgomery limbs (uint64 array)."""
+        nl = pp.fq.nl * (2 if group == ZK_G2 else 1)
+        gen = np.ascontiguousarray(gen_affine, dtype=np.uint64).reshape(-1)
+        if gen.size != 2 * nl:
+            raise ValueError("generator must be an affine point (%d limbs)" % (2 * nl))
+        im = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
+        om = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
+        pp._check(pp.lib.zk_msm_mask_sample(pp.h, group, gen.ctypes.data, seed, im.ctypes.data, om.ctypes.data))
+        return MsmMask(im, om)
+
 
 def d_fft(pp, shares_d, fft_mask, rearrange, log2_m, seed=0, out=None, stream=None):
     """dfft/mod.rs:99-134 for all parties; shares_d [n][m/l].  Result in `out` (or back in shares_d if None)."""
@@ -240,6 +252,28 @@ def msm(pp, group, bases_d, scalars_d, length, len_scalars=None, stream=None):
     out = np.zeros(3 * nl, dtype=np.uint64)
     ls = length if len_scalars is None else len_scalars
     pp._check(pp.lib.zk_msm(pp.h, group, _ptr(bases_d), length, _ptr(scalars_d), ls, out.ctypes.data, stream))
+    return out
+
+
+def fr_to_bytes(pp, x_d, count, stream=None):
+    """ark-serialize CanonicalSerialize of `count` Fr elements of a device vector: bytes (32 or 48 per element,
+    little-endian canonical integers) -- the payload of an mpc-net frame (ser_net.rs:24-25)."""
+    out = pp.alloc_fr(count)
+    pp._check(pp.lib.zk_fr_to_bytes(pp.h, _ptr(x_d), count, out.ptr, stream))
+    pp.sync(stream)
+    return out.to_numpy(dtype=np.uint8)[: count * pp.fr.nbytes].tobytes()
+
+
+def fr_from_bytes(pp, data, stream=None):
+    """CanonicalDeserialize of a byte string of Fr elements into a device vector (Montgomery form); raises if an
+    element is not below the modulus, as arkworks does."""
+    nb = pp.fr.nbytes
+    if len(data) % nb:
+        raise ValueError("byte length is not a multiple of the element size")
+    count = len(data) // nb
+    raw = DeviceBuffer.from_numpy(pp, np.frombuffer(data, dtype=np.uint8))
+    out = pp.alloc_fr(max(count, 1))
+    pp._check(pp.lib.zk_fr_from_bytes(pp.h, raw.ptr, count, out.ptr, stream))
     return out
 
 

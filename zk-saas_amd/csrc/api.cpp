@@ -212,6 +212,26 @@ int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]) {
   CTX_OR_FAIL();
   return e->msm_plan(group, len, plan);
 }
+int zk_msm_mask_sample(zk_ctx* ctx, int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) {
+  CTX_OR_FAIL();
+  return e->msm_mask_sample(group, gen_affine, seed, in_mask, out_mask);
+}
+int zk_r1cs_qap(zk_ctx* ctx, const void* a_row_ptr_d, const void* a_col_d, const void* a_val_d,
+                const void* b_row_ptr_d, const void* b_col_d, const void* b_val_d, const void* w_d,
+                size_t num_variables, size_t num_constraints, size_t num_instance, int log_m, void* a_out_d,
+                void* b_out_d, void* c_out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->r1cs_qap(a_row_ptr_d, a_col_d, a_val_d, b_row_ptr_d, b_col_d, b_val_d, w_d, num_variables,
+                     num_constraints, num_instance, log_m, a_out_d, b_out_d, c_out_d, S(stream));
+}
+int zk_fr_to_bytes(zk_ctx* ctx, const void* x_d, size_t len, void* bytes_out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->fr_bytes(x_d, len, bytes_out_d, 0, S(stream));
+}
+int zk_fr_from_bytes(zk_ctx* ctx, const void* bytes_d, size_t len, void* x_out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->fr_bytes(bytes_d, len, x_out_d, 1, S(stream));
+}
 int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                         const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) {
   CTX_OR_FAIL();

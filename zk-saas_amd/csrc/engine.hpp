@@ -146,6 +146,11 @@ class IEngine {
                           const void* in_mask, void* out, hipStream_t st) = 0;
   virtual int group_add(int group, const void* a, const void* b, void* out) = 0;
   virtual int msm_plan(int group, size_t len, int* plan) = 0;
+  virtual int msm_mask_sample(int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) = 0;
+  virtual int r1cs_qap(const void* pa, const void* ca, const void* va, const void* pb, const void* cb, const void* vb,
+                       const void* w, size_t nvars, size_t nc, size_t ni, int log_m, void* a, void* b, void* c,
+                       hipStream_t st) = 0;
+  virtual int fr_bytes(const void* in, size_t len, void* out, int from_bytes, hipStream_t st) = 0;
   virtual int groth16_assemble(const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                                const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count,

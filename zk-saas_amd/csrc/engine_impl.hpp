@@ -5,6 +5,7 @@
 
 #include "engine.hpp"
 #include "groth16.hpp"
+#include "qap.hpp"
 #include "msm.hpp"
 
 namespace zk {
@@ -1008,6 +1009,89 @@ class Engine : public IEngine {
     }
     return fail(ZK_ERR_BAD_INPUT, "bad group");
   }
+  // MsmMask::sample (dmsm/mod.rs:21-47); scalar form: shares of (x_0..x_{l-1} | t random) times the generator
+  template <class Fld>
+  int msm_mask_sample_t(const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) {
+    Affine<Fld> g;
+    memcpy(&g, gen_affine, sizeof(g));
+    XYZZ<Fld> gen = XYZZ<Fld>::from_affine(g);
+    const int k = l + t;
+    std::vector<Fr> sec_in(k), sec_out(k);
+    Fr sum = Fr::zero();
+    for (int i = 0; i < l; i++) {
+      sec_in[i] = rand_fp<FrP>(seed, (uint64_t)i);
+      sum = sum + sec_in[i];
+    }
+    for (int i = 0; i < l; i++) sec_out[i] = sum.neg();
+    for (int i = 0; i < t; i++) {
+      sec_in[l + i] = rand_fp<FrP>(seed ^ 0x1111ull, (uint64_t)i);
+      sec_out[l + i] = rand_fp<FrP>(seed ^ 0x2222ull, (uint64_t)i);
+    }
+    Jacobian<Fld>* oi = (Jacobian<Fld>*)in_mask;
+    Jacobian<Fld>* oo = (Jacobian<Fld>*)out_mask;
+    for (int p = 0; p < n; p++) {
+      Fr si = Fr::zero(), so = Fr::zero();
+      for (int j = 0; j < k; j++) {
+        si = si + pmat_host_[(size_t)p * k + j] * sec_in[j];
+        so = so + pmat_host_[(size_t)p * k + j] * sec_out[j];
+      }
+      oi[p] = xyzz_to_jacobian(host_scalar_mul<FrP, Fld>(gen, si));
+      oo[p] = xyzz_to_jacobian(host_scalar_mul<FrP, Fld>(gen, so));
+    }
+    return ZK_OK;
+  }
+  int msm_mask_sample(int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (!gen_affine || !in_mask || !out_mask) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (group == ZK_G1) return msm_mask_sample_t<Fq>(gen_affine, seed, in_mask, out_mask);
+    if (group == ZK_G2 && Cfg::HAS_G2) return msm_mask_sample_t<Fq2>(gen_affine, seed, in_mask, out_mask);
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
+  // ---------------------------------------------------------------- circom front end (qap.rs:42-89)
+  int r1cs_qap(const void* pa, const void* ca, const void* va, const void* pb, const void* cb, const void* vb,
+               const void* w, size_t nvars, size_t nc, size_t ni, int log_m, void* a, void* b, void* c,
+               hipStream_t st) override {
+    if (!pa || !pb || !w || !a || !b || !c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (log_m < 0 || log_m > 30) return fail(ZK_ERR_BAD_INPUT, "bad domain size");
+    const size_t m = (size_t)1 << log_m;
+    if (nc + ni > m) return fail(ZK_ERR_BAD_INPUT, "domain smaller than num_constraints + num_inputs");   // qap.rs:52-56
+    if (ni > nvars || nvars >= ((size_t)1 << 32) || nc >= ((size_t)1 << 32))
+      return fail(ZK_ERR_BAD_INPUT, "bad R1CS dimensions");
+    ZK_HIP(flag_.ensure(4));
+    ZK_HIP(hipMemsetAsync(flag_.p, 0, 4, st));
+    r1cs_qap_kernel<Fr><<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st>>>(
+        (const uint32_t*)pa, (const uint32_t*)ca, (const Fr*)va, (const uint32_t*)pb, (const uint32_t*)cb,
+        (const Fr*)vb, (const Fr*)w, (uint32_t)nvars, (uint32_t)nc, (uint32_t)ni, m, (Fr*)a, (Fr*)b, (Fr*)c,
+        (uint32_t*)flag_.p);
+    ZK_HIP(hipGetLastError());
+    uint32_t bad = 0;
+    ZK_HIP(hipMemcpyAsync(&bad, flag_.p, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (bad) return fail(ZK_ERR_GENERIC, "R1CS wire index out of range");
+    return ZK_OK;
+  }
+  int fr_bytes(const void* in, size_t len, void* out, int from_bytes, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!in || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    dim3 g((unsigned)((len + 255) / 256)), b(256);
+    if (!from_bytes) {
+      fr_to_bytes_kernel<Fr><<<g, b, 0, st>>>((const Fr*)in, len, (Fr*)out);
+      ZK_HIP(hipGetLastError());
+      return ZK_OK;
+    }
+    ZK_HIP(flag_.ensure(4));
+    ZK_HIP(hipMemsetAsync(flag_.p, 0, 4, st));
+    fr_from_bytes_kernel<Fr><<<g, b, 0, st>>>((const Fr*)in, len, (Fr*)out, (uint32_t*)flag_.p);
+    ZK_HIP(hipGetLastError());
+    uint32_t bad = 0;
+    ZK_HIP(hipMemcpyAsync(&bad, flag_.p, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (bad) return fail(ZK_ERR_GENERIC, "field element not below the modulus (InvalidData)");
+    return ZK_OK;
+  }
+
   int msm_plan(int group, size_t len, int* plan) override {
     if (!plan || (group != ZK_G1 && group != ZK_G2)) return fail(ZK_ERR_BAD_INPUT, "bad argument");
     if (group == ZK_G2 && !Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
@@ -1157,6 +1241,7 @@ class Engine : public IEngine {
   DevBuf hwork_, hshare_;
   Fr* pmat_ = nullptr;
   std::vector<Fr> pmat_host_;
+  DevBuf flag_;   // 4-byte device flag for the validating kernels
   std::map<int, Fr*> pcoef_;
   PackL2<Fr>* pack2_ = nullptr;
   Fr* ident_ = nullptr;

@@ -64,6 +64,15 @@ struct Fp {
     return acc == 0;
   }
   ZK_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+  // limbs, read as a plain integer, are below the modulus
+  ZK_HD bool is_canonical() const {
+    uint32_t borrow = 0;
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)v[i] - P::MOD[i] - borrow;
+      borrow = (uint32_t)(t >> 63);
+    }
+    return borrow != 0;
+  }
 
   // r = a - p if a >= p (a < 2p assumed); `carry` is the bit above limb N-1 of a.
   ZK_HD static Fp reduce_once(const Fp& a, uint32_t carry = 0) {

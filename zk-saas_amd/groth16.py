@@ -101,21 +101,6 @@ def _ntt(vals, root, p):
     return a
 
 
-def qap_vectors(curve, r1cs, w):
-    """groth16/src/qap.rs:42-89: a_i = <A_i, w>, b_i = <B_i, w>, a[nc..nc+ni] = w[..ni], c_i = a_i b_i."""
-    p = fields.FR[curve]
-    ni, nc = r1cs.num_instance_variables, r1cs.num_constraints
-    log_m = max(0, (nc + ni - 1).bit_length())
-    m = 1 << log_m
-    a, b, c = [0] * m, [0] * m, [0] * m
-    for i in range(nc):
-        a[i] = sum(co * w[j] for co, j in r1cs.a[i]) % p
-        b[i] = sum(co * w[j] for co, j in r1cs.b[i]) % p
-        c[i] = a[i] * b[i] % p
-    a[nc:nc + ni] = [x % p for x in w[:ni]]
-    return a, b, c, log_m
-
-
 class SetupScalars:
     """Discrete logs of the CRS for a given trapdoor (what `circuit_specific_setup` computes before the
     fixed-base multiplications): LibsnarkReduction::instance_map_with_evaluation + CircomReduction::h_query_scalars."""
@@ -234,15 +219,18 @@ class Crs:
 class Witness:
     """QAP::pss (qap.rs:91-135) and pack_from_witness (sha256.rs:131-156) on the device."""
 
-    def __init__(self, pp, curve, r1cs, w, seed):
-        a, b, c, log_m = qap_vectors(curve, r1cs, w)
-        self.log_m = log_m
+    def __init__(self, pp, curve, r1cs, w, seed, dev_r1cs=None):
+        from .circom import DeviceR1cs
+        dev_r1cs = dev_r1cs or DeviceR1cs(pp, r1cs)
+        w_d = w if isinstance(w, DeviceBuffer) else pp.upload_fr(w)
+        self.log_m = log_m = dev_r1cs.log_m
         m = 1 << log_m
         self.qap = []
-        for k, v in enumerate((a, b, c)):
-            d = pp.upload_fr(v)
+        for k, d in enumerate(dev_r1cs.qap(w_d)):              # qap.rs:42-89 on the device
             pp._check(pp.lib.zk_bitrev(pp.h, d.ptr, log_m, None))
             self.qap.append(pp.pack(d, m // pp.l, seed + k, order=1))
+        if isinstance(w, DeviceBuffer):
+            w = pp.download_fr(w, r1cs.num_variables)
         ni = r1cs.num_instance_variables
 
         def deal(vals, sd):
