@@ -221,7 +221,9 @@ int zk_fr_from_bytes(zk_ctx* ctx, const void* bytes_d, size_t len, void* x_out_d
 /* The five zk_d_msm_local of the prover for this rank's parties, overlapped: _begin starts S, H, V, W (they only
  * need the witness shares; crs vectors are [nparties][len] here) on internal streams and returns; _finish runs U
  * on `stream` once h_share_d [nparties][m/l] is available, joins, and writes out[0..4] = S, H, V(G2), W, U
- * (Jacobian, host).  skip_h != 0 when r = 0 (prove.rs:96-98). */
+ * (Jacobian, host).  skip_h != 0 when r = 0 (prove.rs:96-98).  Stream ordering: _begin's internal streams wait
+ * for everything already queued on the legacy default stream (it has no stream argument); zk_groth16_prove's
+ * internal streams wait for everything already queued on its `stream`. */
 int zk_groth16_msms_begin(zk_ctx* ctx, const zk_crs_share* crs, const void* a_share_d, const void* ax_share_d,
                           int first_party, int nparties, int skip_h);
 int zk_groth16_msms_finish(zk_ctx* ctx, const zk_crs_share* crs, const void* h_share_d, int first_party, int nparties,

@@ -116,3 +116,53 @@ def test_d_fft_roundtrip_bls12_381_2_18():
     zk.d_ifft(pp, shares, zk.FftMask.zero(), True, log_m, seed=10)
     zk.d_fft(pp, shares, zk.FftMask.zero(), False, log_m, seed=11)
     assert np.array_equal(pp.unpack(shares, m // 2).to_numpy().reshape(m, 4), sec)
+
+
+@pytest.mark.parametrize("curve,log_m", [("bn254", 20), ("bls12_381", 18)])
+def test_synthetic_prover_distributed_equals_local_and_ignores_share_randomness(curve, log_m):
+    """Size-independent properties of the whole prover on a synthetic instance built on the device
+    (zksaas_amd/synthetic.py; SURVEY.md 8d C5 at a size that runs in seconds; tools/c5_bls381.py runs 2^24):
+    * dealing the same witness again (new share randomness) and proving IMMEDIATELY after the dealing kernels were
+      queued gives the same proof -- also the regression test for the stream-ordering bug where the MSM streams read
+      the shares before the caller's stream had written them;
+    * distributed == local: zk_groth16_assemble over five plain zk_msm's of the public query elements."""
+    import ctypes as C
+    from zksaas_amd import synthetic, wire
+    from zksaas_amd import groth16 as zg
+    from zksaas_amd.api import ZK_G2
+    pp = ctx(curve, 2)
+    inst = synthetic.SyntheticInstance(pp, log_m, seed=3)
+    r, s = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321
+
+    def norm(pf):
+        return (wire.jacobian_to_affine(pp, pf[0][0], False), wire.jacobian_to_affine(pp, pf[1][0], True),
+                wire.jacobian_to_affine(pp, pf[2][0], False))
+    wit = inst.witness(seed=100)
+    pp.sync()
+    ref = norm(zg.prove(pp, inst.crs, wit, r, s, seed=7))
+    for ws in (900, 901, 902):
+        w2 = inst.witness(seed=ws)                      # kernels still in flight on the default stream
+        assert norm(zg.prove(pp, inst.crs, w2, r, s, seed=ws)) == ref
+        del w2
+    m, l, eb = inst.m, pp.l, pp.fr.nbytes
+    hsh = pp.alloc_fr(pp.n * (m // l))
+    pp._check(pp.lib.zk_circom_h(pp.h, wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr, log_m, None, 7, hsh.ptr, None))
+    h_pub = pp.unpack(hsh, m // l)
+    sums = []
+    for name, group, scal, count in (("a", ZK_G1, inst.w.view(eb), l * inst.len_a), ("b", ZK_G1, inst.w.view(eb), l * inst.len_a),
+                                     ("b", ZK_G2, inst.w.view(eb), l * inst.len_a),
+                                     ("l", ZK_G1, inst.w.view(inst.ni * eb), l * inst.len_w), ("h", ZK_G1, h_pub, m)):
+        pts = inst.unpacked_points(name, group)
+        sums.append(msm(pp, group, pts, scal, count))
+        pts.free()
+    nl = pp.fq.nl
+    pa, pb, pc = (np.zeros((pp.n, 3 * nl), dtype=np.uint64), np.zeros((pp.n, 6 * nl), dtype=np.uint64),
+                  np.zeros((pp.n, 3 * nl), dtype=np.uint64))
+    rr, ss = pp.fr.encode_one(r), pp.fr.encode_one(s)
+    arr = (C.c_void_p * 5)(*[x.ctypes.data for x in sums])
+    pp._check(pp.lib.zk_groth16_assemble(pp.h, C.byref(inst.crs.ct), rr.ctypes.data, ss.ctypes.data, arr, None,
+                                         pa.ctypes.data, pb.ctypes.data, pc.ctypes.data))
+    assert norm((pa, pb, pc)) == ref
+    # the proof survives the ark-compressed wire format
+    blob = wire.proof_to_bytes(pp, pa[0], pb[0], pc[0])
+    assert wire.proof_from_bytes(pp, blob, curve) == ref

@@ -48,7 +48,20 @@ class DeviceBuffer:
             self.ctx._check(self.ctx.lib.zk_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, self.nbytes, None))
         return out.reshape(shape) if shape is not None else out
 
+    def view(self, offset_bytes, nbytes=None):
+        """A non-owning window into this buffer (keeps the parent alive)."""
+        v = DeviceBuffer.__new__(DeviceBuffer)
+        v.ctx, v.parent, v.owner = self.ctx, self, False
+        v.nbytes = self.nbytes - offset_bytes if nbytes is None else int(nbytes)
+        if offset_bytes < 0 or v.nbytes < 0 or offset_bytes + v.nbytes > self.nbytes:
+            raise ValueError("view outside the buffer")
+        v.ptr = self.ptr + offset_bytes
+        return v
+
     def free(self):
+        if not getattr(self, "owner", True):
+            self.ptr = None
+            return
         if self.ptr:
             self.ctx.lib.zk_free(self.ctx.h, self.ptr)
             self.ptr = None
@@ -268,10 +281,12 @@ def fr_from_bytes(pp, data, stream=None):
     """CanonicalDeserialize of a byte string of Fr elements into a device vector (Montgomery form); raises if an
     element is not below the modulus, as arkworks does."""
     nb = pp.fr.nbytes
-    if len(data) % nb:
+    host = (np.ascontiguousarray(data).view(np.uint8).reshape(-1) if isinstance(data, np.ndarray)
+            else np.frombuffer(data, dtype=np.uint8))
+    if host.size % nb:
         raise ValueError("byte length is not a multiple of the element size")
-    count = len(data) // nb
-    raw = DeviceBuffer.from_numpy(pp, np.frombuffer(data, dtype=np.uint8))
+    count = host.size // nb
+    raw = DeviceBuffer.from_numpy(pp, host)
     out = pp.alloc_fr(max(count, 1))
     pp._check(pp.lib.zk_fr_from_bytes(pp.h, raw.ptr, count, out.ptr, stream))
     return out

@@ -18,6 +18,7 @@ import struct
 
 import numpy as np
 
+from .api import DeviceBuffer
 from .sha256_circuit import R1CS
 
 R1CS_MAGIC = b"r1cs"
@@ -179,6 +180,24 @@ class DeviceR1cs:
             ptr_d = pp.upload_u32(ptr)
             vals_d = pp.upload_fr(vals) if vals else pp.alloc_fr(1)
             self._mats.append((ptr_d, cols_d, vals_d))
+
+    @classmethod
+    def from_csr(cls, pp, num_constraints, num_instance_variables, num_variables, a_csr, b_csr):
+        """a_csr / b_csr = (row_ptr uint32 [nc+1], cols uint32, vals uint64 [nnz][limbs] in Montgomery form):
+        for matrices that are produced as arrays (synthetic circuits at scale) rather than Python lists."""
+        self = cls.__new__(cls)
+        self.pp = pp
+        self.num_constraints, self.num_instance_variables = num_constraints, num_instance_variables
+        self.num_variables = num_variables
+        self.log_m = max(0, (num_constraints + num_instance_variables - 1).bit_length())
+        self._mats = []
+        for ptr, cols, vals in (a_csr, b_csr):
+            if len(ptr) != num_constraints + 1 or int(ptr[-1]) != len(cols):
+                raise ValueError("inconsistent CSR arrays")
+            self._mats.append((pp.upload_u32(ptr), pp.upload_u32(cols),
+                               DeviceBuffer.from_numpy(pp, np.ascontiguousarray(vals, dtype=np.uint64))
+                               if len(cols) else pp.alloc_fr(1)))
+        return self
 
     def qap(self, w_d, stream=None):
         """qap.rs:42-89: returns device vectors (a, b, c) of length m = 2^log_m in natural order."""

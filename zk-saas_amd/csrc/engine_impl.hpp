@@ -845,8 +845,11 @@ class Engine : public IEngine {
     // accumulate launches) back until circom_h has finished was measured and rejected: 8.6-8.8 ms per proof against
     // 6.9 ms when everything is issued at once.
     hipStream_t hs = streams_[5];
+    // every internal stream is ordered after the work already queued on the caller's stream (the shares may still
+    // be in flight there: found by tools/c5_bls381.py, where the a_share pack kernel of a 2^22 witness was still
+    // running when the S/H/V MSMs started reading it)
     ZK_HIP(hipEventRecord(ev_in_, st));
-    ZK_HIP(hipStreamWaitEvent(hs, ev_in_, 0));
+    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_, 0));
     int rc_h = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, hs);
     if (rc_h) return rc_h;
     auto spawn = [&](auto fn) {
@@ -1168,6 +1171,9 @@ class Engine : public IEngine {
     int rc = ensure_streams();
     if (rc) return rc;
     const int dev = device;
+    // no stream argument: the inputs are ordered after everything queued on the legacy default stream
+    ZK_HIP(hipEventRecord(ev_in_, nullptr));
+    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_, 0));
     job_.active = true;
     for (int i = 0; i < 4; i++) job_.rc[i] = 0;
     job_.H = XYZZ<Fq>::identity();
