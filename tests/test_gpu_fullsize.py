@@ -166,3 +166,17 @@ def test_synthetic_prover_distributed_equals_local_and_ignores_share_randomness(
     # the proof survives the ark-compressed wire format
     blob = wire.proof_to_bytes(pp, pa[0], pb[0], pc[0])
     assert wire.proof_from_bytes(pp, blob, curve) == ref
+
+
+def test_d_pp_telescopes_bls12_381_2_18():
+    """d_pp (dpp/mod.rs:15-87) at 2^18 on the config-5 curve: num_i = x_(i+1), den_i = x_i  =>  prefix product_i
+    times x_0 equals x_(i+1) (size-independent property; the small exact comparison is in test_gpu_dfft.py)."""
+    from zksaas_amd import synthetic
+    pp = ctx("bls12_381", 2)
+    m, l, eb, nl = 1 << 18, 2, pp.fr.nbytes, pp.fr.nl
+    x = synthetic.rand_fr_device(pp, m + 1, 77)
+    num_sh, den_sh = pp.pack(x.view(eb), m // l, 78), pp.pack(x, m // l, 79)
+    res = zk.d_pp(pp, num_sh, den_sh, zk.DegRedMask.zero(), m // l, seed=80)
+    prod = pp.unpack(res, m // l)
+    zk.api.vec_scale(pp, prod, pp.download_fr(x, 1)[0], m)
+    assert np.array_equal(prod.to_numpy()[: m * nl], x.to_numpy()[nl:(m + 1) * nl])

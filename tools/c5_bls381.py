@@ -2,6 +2,7 @@
 16.7 M constraints, n = 8 parties, l = 2, all parties on ONE GPU), synthetic instance built on the device
 (zksaas_amd/synthetic.py).  Prints one JSON line with timings and two size-independent checks:
   * the proof does not depend on the share randomness (two dealings of the same witness);
+  * d_pp at the same size telescopes (num_i = x_(i+1), den_i = x_i  =>  product_i * x_0 = x_(i+1));
   * distributed == local: zk_groth16_assemble over five PLAIN zk_msm's of the public query elements and the public
     witness (h taken from the unpacked zk_circom_h output) is the same proof.
 usage: python tools/c5_bls381.py [LOG_M] > gpurun_out/c5.json"""
@@ -76,6 +77,20 @@ arr = (C.c_void_p * 5)(*[x.ctypes.data for x in sums])
 pp._check(pp.lib.zk_groth16_assemble(pp.h, C.byref(inst.crs.ct), rr.ctypes.data, ss.ctypes.data, arr, None,
                                      pa.ctypes.data, pb.ctypes.data, pc.ctypes.data))
 out["distributed_equals_local"] = norm((pa, pb, pc)) == ref
+# (3) d_pp at the same size (dpp/mod.rs:15-87): num_i = x_(i+1), den_i = x_i  =>  prefix product_i = x_(i+1) / x_0
+del wit, hsh, h_pub
+x = synthetic.rand_fr_device(pp, m + 1, 77)
+num_sh, den_sh = pp.pack(x.view(eb), m // l, 78), pp.pack(x, m // l, 79)
+zk.d_pp(pp, num_sh, den_sh, zk.DegRedMask.zero(), m // l, seed=80).free()      # warm-up (tables, workspaces)
+pp.sync()
+t0 = time.perf_counter()
+res = zk.d_pp(pp, num_sh, den_sh, zk.DegRedMask.zero(), m // l, seed=80)
+pp.sync()
+out["d_pp_s"] = round(time.perf_counter() - t0, 4)
+prod = pp.unpack(res, m // l)
+x0 = pp.download_fr(x, 1)[0]
+zk.api.vec_scale(pp, prod, x0, m)
+out["d_pp_telescopes"] = bool(np.array_equal(prod.to_numpy()[: m * pp.fr.nl], x.to_numpy()[pp.fr.nl:(m + 1) * pp.fr.nl]))
 out["proof_compressed_hex"] = wire.proof_to_bytes(pp, proof[0][0], proof[1][0], proof[2][0]).hex()
 print(json.dumps(out))
-sys.exit(0 if (out["independent_of_share_randomness"] and out["distributed_equals_local"]) else 1)
+sys.exit(0 if (out["independent_of_share_randomness"] and out["distributed_equals_local"] and out["d_pp_telescopes"]) else 1)
