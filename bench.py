@@ -66,7 +66,7 @@ def read_profile(pp):
     return out
 
 
-PMC_KERNEL = {"msm_accumulate_kernel<G1>": "msm_accumulate_kernel<Fp<", "msm_accumulate_kernel<G2>": "msm_accumulate_kernel<Fp2<",
+PMC_KERNEL = {"msm_accumulate_kernel<G1>": "msm_accumulate_kernel<Fp<", "msm_accumulate_kernel<G2>": "msm_accumulate_kernel<Fp2",
               "ntt_pass_kernel": "ntt_pass_kernel", "king_fft2_kernel": "king_fft2_kernel",
               "king_degred_kernel": "king_degred_kernel"}
 
