@@ -439,39 +439,44 @@ class Engine : public IEngine {
 
   // ---------------------------------------------------------------- king of d_fft (dfft/mod.rs:264-304)
   template <int L>
-  int king_l(const Fr* in, const Fr* in_mask, int np, int log_lc, const Fr* U, const Fr* gen, const GTab* gt,
-             const Fr* in_scale, int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate,
-             hipStream_t st) {
+  int king_l(const Fr* in, const KingBatch<Fr>& kb, int batch, int np, int log_lc, const Fr* U, const Fr* gen,
+             const GTab* gt, const Fr* in_scale, int rearrange, uint64_t seed, Fr* out, bool negate, hipStream_t st) {
     size_t Lc = (size_t)1 << log_lc;
     size_t Wc = Lc < (size_t)KING_THREADS ? Lc : (size_t)KING_THREADS;
     size_t lds = (size_t)L * Wc * sizeof(Fr);
-    dim3 grid((unsigned)(Lc / Wc)), block(KING_THREADS);
-    ProfScope ps_(prof, PROF_KING, st, (double)Lc);
+    dim3 grid((unsigned)(Lc / Wc), (unsigned)batch), block(KING_THREADS);
+    ProfScope ps_(prof, PROF_KING, st, (double)Lc * batch);
     if (negate)
-      king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
+      king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, kb, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                               in_scale, pack2_, rearrange, seed, out, out_mask);
+                                                               in_scale, pack2_, rearrange, seed, out);
     else
-      king_fft2_kernel<FrP, L, false><<<grid, block, lds, st>>>(in, in_mask, np, (uint32_t)log_lc, U, pmat_, gen,
+      king_fft2_kernel<FrP, L, false><<<grid, block, lds, st>>>(in, kb, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                 gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                                in_scale, pack2_, rearrange, seed, out, out_mask);
+                                                                in_scale, pack2_, rearrange, seed, out);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
-  int king_dispatch(const Fr* in, const Fr* in_mask, int np, int log_m, int inverse, const Fr* U, const void* g,
-                    int scale, int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate,
-                    hipStream_t st) {
+  // `batch` vectors at in + y * stride -> out + y * stride, masks per item (all in-masks present or all absent),
+  // share randomness seed + y
+  int king_dispatch_batch(const Fr* in, const KingBatch<Fr>& kb, int batch, int np, int log_m, int inverse,
+                          const Fr* U, const void* g, int scale, int rearrange, uint64_t seed, Fr* out, bool negate,
+                          hipStream_t st) {
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (batch < 1 || batch > KING_BATCH) return fail(ZK_ERR_BAD_INPUT, "bad king batch");
+    const bool has_in_mask = kb.in_mask[0] != nullptr;
+    for (int y = 1; y < batch; y++)
+      if ((kb.in_mask[y] != nullptr) != has_in_mask) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in one batch");
     const Fr* gen = nullptr;
     int rc = gentab(log_m, inverse, st, &gen);
     if (rc) return rc;
     Fr gv = g ? Fr::from_limbs((const uint32_t*)g) : Fr::one();
     GTab gt{};
     // 1/m: folded into the g^i table when there is no in-mask, applied to the shares at load otherwise
-    bool fold = scale && !in_mask;
+    bool fold = scale && !has_in_mask;
     const Fr* in_scale = nullptr;
-    if (scale && in_mask) {
+    if (scale && has_in_mask) {
       rc = size_inv_dev(log_m, st, &in_scale);
       if (rc) return rc;
     }
@@ -482,11 +487,20 @@ class Engine : public IEngine {
     }
     int log_lc = log_m - log_l;
     switch (l) {
-      case 1: return king_l<1>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
-      case 2: return king_l<2>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
-      case 4: return king_l<4>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
-      default: return king_l<8>(in, in_mask, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, out_mask, negate, st);
+      case 1: return king_l<1>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
+      case 2: return king_l<2>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
+      case 4: return king_l<4>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
+      default: return king_l<8>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
     }
+  }
+  int king_dispatch(const Fr* in, const Fr* in_mask, int np, int log_m, int inverse, const Fr* U, const void* g,
+                    int scale, int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate,
+                    hipStream_t st) {
+    KingBatch<Fr> kb{};
+    kb.in_mask[0] = in_mask;
+    kb.out_mask[0] = out_mask;
+    kb.stride = 0;
+    return king_dispatch_batch(in, kb, 1, np, log_m, inverse, U, g, scale, rearrange, seed, out, negate, st);
   }
   int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
                 const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out, const void* out_mask,
@@ -744,6 +758,31 @@ class Engine : public IEngine {
   }
 
   // ---------------------------------------------------------------- circom_h (ext_wit.rs:104-181)
+  // the king step of three d_fft / d_ifft (a, b, c at in + k * per; masks mk->fft_*[first + k]; randomness seed + k):
+  // one batched launch when the in-masks are all present or all absent, three launches otherwise
+  int king3(const Fr* in, const zk_groth16_masks* mk, int first, int log_m, int inverse, const void* g, int scale,
+            int rearrange, uint64_t seed, Fr* out, size_t per, hipStream_t st) {
+    const Fr* U = nullptr;
+    int rc = umat_for(nullptr, n, &U);
+    if (rc) return rc;
+    KingBatch<Fr> kb{};
+    kb.stride = per;
+    bool any = false, all = true;
+    for (int k = 0; k < 3; k++) {
+      kb.in_mask[k] = mk ? (const Fr*)mk->fft_in[first + k] : nullptr;
+      kb.out_mask[k] = mk ? (const Fr*)mk->fft_out[first + k] : nullptr;
+      any = any || kb.in_mask[k];
+      all = all && kb.in_mask[k];
+    }
+    if (any == all)
+      return king_dispatch_batch(in, kb, 3, n, log_m, inverse, U, g, scale, rearrange, seed, out, false, st);
+    for (int k = 0; k < 3; k++) {
+      rc = king_dispatch(in + k * per, kb.in_mask[k], n, log_m, inverse, U, g, scale, rearrange, seed + k,
+                         out + k * per, kb.out_mask[k], false, st);
+      if (rc) return rc;
+    }
+    return ZK_OK;
+  }
   int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
                void* h, hipStream_t st) override {
     int log_l = ilog2(l);
@@ -762,19 +801,13 @@ class Engine : public IEngine {
     // 3 x d_ifft(rearrange = true, g = w_2m)   (ext_wit.rs:127-159)
     int rc = fft1(W0, log_m, 1, 3 * (size_t)n, nullptr, st);
     if (rc) return rc;
-    for (int k = 0; k < 3; k++) {
-      rc = fft2_king(W0 + k * per, mk ? mk->fft_in[k] : nullptr, nullptr, n, log_m, 1, &w2m, 1, 1, seed + k,
-                     W1 + k * per, mk ? mk->fft_out[k] : nullptr, st);
-      if (rc) return rc;
-    }
+    rc = king3(W0, mk, 0, log_m, 1, &w2m, 1, 1, seed, W1, per, st);
+    if (rc) return rc;
     // 3 x d_fft(rearrange = false)             (ext_wit.rs:161-170)
     rc = fft1(W1, log_m, 0, 3 * (size_t)n, nullptr, st);
     if (rc) return rc;
-    for (int k = 0; k < 3; k++) {
-      rc = fft2_king(W1 + k * per, mk ? mk->fft_in[3 + k] : nullptr, nullptr, n, log_m, 0, nullptr, 0, 0, seed + 3 + k,
-                     W0 + k * per, mk ? mk->fft_out[3 + k] : nullptr, st);
-      if (rc) return rc;
-    }
+    rc = king3(W1, mk, 3, log_m, 0, nullptr, 0, 0, seed + 3, W0, per, st);
+    if (rc) return rc;
     // h = a*b - c share-wise, then deg_red     (ext_wit.rs:173-179)
     rc = vec_mul_sub(h, W0, W0 + per, W0 + 2 * per, per, st);
     if (rc) return rc;
@@ -884,19 +917,26 @@ class Engine : public IEngine {
                                                 (const char*)a_share + half_bytes_s, crs->len_a, nh, n - nh, nullptr,
                                                 &V1, streams_[4], 5);
     });
+    // S and H multiply two base vectors by the same witness shares: one sort, shared launches (msm.hpp run_t)
     std::thread tS = spawn([&]() {
       (void)hipSetDevice(dev);
-      rcs[0] = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S,
-                                             streams_[0], 1);
-      if (!rcs[0] && uniform) pre.sS = host_scalar_mul<FrP, Fq>(S, s);     // off the tail: S finishes early
+      if (r_zero) {
+        rcs[0] = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S,
+                                               streams_[0], 1);
+      } else {
+        rcs[0] = msm_.template d_msm_sum2_t<Fq>(this, crs->s_d, crs->h_d, a_share, crs->len_a,
+                                                mk ? mk->msm_in[0] : nullptr, mk ? mk->msm_in[1] : nullptr, &S, &H,
+                                                streams_[0], 1);
+      }
+      if (!rcs[0] && uniform) {                                     // off the tail: these finish early
+        std::thread th([&]() {
+          if (!r_zero) pre.rH = host_scalar_mul<FrP, Fq>(H, r);
+        });
+        pre.sS = host_scalar_mul<FrP, Fq>(S, s);
+        th.join();
+      }
     });
-    std::thread tH = spawn([&]() {
-      (void)hipSetDevice(dev);
-      if (!r_zero)
-        rcs[1] = msm_.template d_msm_sum_t<Fq>(this, crs->h_d, a_share, crs->len_a, mk ? mk->msm_in[1] : nullptr, &H,
-                                               streams_[1], 2);
-      if (!r_zero && !rcs[1] && uniform) pre.rH = host_scalar_mul<FrP, Fq>(H, r);
-    });
+    std::thread tH;
     std::thread tW = spawn([&]() {
       (void)hipSetDevice(dev);
       rcs[3] = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W,

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "ec.hpp"
@@ -236,12 +237,16 @@ static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __
 template <class Fld>
 constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : 3;
 template <class Fld>
-__global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases,
+__global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases0,
+                                                            const Affine<Fld>* __restrict__ bases1, size_t pstride,
                                                             const uint32_t* __restrict__ sorted,
                                                             const SegDesc* __restrict__ segs,
                                                             const uint2* __restrict__ offsets, size_t nkeys,
                                                             const uint32_t* __restrict__ order,
-                                                            XYZZ<Fld>* __restrict__ partial) {
+                                                            XYZZ<Fld>* __restrict__ partial0) {
+  // blockIdx.y: which of the (up to two) base vectors that share this scalar vector -- and therefore the sort
+  const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
+  XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
   // bounded grid + grid-stride loop: every workgroup of the launch is resident at once, so the launch does not sit
   // in its hardware queue waiting for wave slots (which stalls every other stream mapped to the same pipe)
   const uint32_t nseg = offsets[nkeys].y;
@@ -281,17 +286,21 @@ constexpr uint32_t FIN_SEQ = 16;
 constexpr int FIN_HEAVY_THREADS = 128;
 
 template <class Fld>
-__global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial,
+__global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
                                                           const uint2* __restrict__ offsets, size_t nkeys,
-                                                          XYZZ<Fld>* __restrict__ buckets,
+                                                          XYZZ<Fld>* __restrict__ buckets0,
                                                           uint32_t* __restrict__ heavy /* [0] = count */) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
+  XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nkeys) return;
   uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
   if (s1 - s0 > FIN_SEQ) {
-    uint32_t slot = atomicAdd(heavy, 1u);
-    heavy[1 + slot] = (uint32_t)k;
+    if (blockIdx.y == 0) {             // the heavy list depends on the sort only: built once, used for every y
+      uint32_t slot = atomicAdd(heavy, 1u);
+      heavy[1 + slot] = (uint32_t)k;
+    }
     return;
   }
   XYZZ<Fld> acc = XYZZ<Fld>::identity();
@@ -302,9 +311,11 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __re
 
 template <class Fld>
 __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
-    const XYZZ<Fld>* __restrict__ partial, const uint2* __restrict__ offsets, const uint32_t* __restrict__ heavy,
-    XYZZ<Fld>* __restrict__ buckets) {
+    const XYZZ<Fld>* __restrict__ partial0, size_t pstride, const uint2* __restrict__ offsets, size_t nkeys,
+    const uint32_t* __restrict__ heavy, XYZZ<Fld>* __restrict__ buckets0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
+  XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
   const uint32_t nheavy = heavy[0];
@@ -348,10 +359,12 @@ __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
 //   [.., +1)       ACC += RUN
 //   [.., +log RT)  tree sum of ACC -> A
 template <class Fld, int RT>
-__global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets, uint32_t B,
-                                                       uint32_t blocks_per_window,
-                                                       XYZZ<Fld>* __restrict__ out /* [nwin][bpw][2] */) {
+__global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets0, size_t nkeys,
+                                                       uint32_t B, uint32_t blocks_per_window,
+                                                       XYZZ<Fld>* __restrict__ out0 /* [y][nwin][bpw][2] */) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  const XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
+  XYZZ<Fld>* __restrict__ out = out0 + (size_t)blockIdx.y * gridDim.x * 2;
   extern __shared__ uint4 smem_red[];
   XYZZ<Fld>* RUN = reinterpret_cast<XYZZ<Fld>*>(smem_red);
   XYZZ<Fld>* ACC = RUN + RT;
@@ -489,10 +502,15 @@ class MsmRunner {
   }
 
   template <class Fld>
+  // bases2 / result2 (optional): a second base vector multiplied by the SAME scalars (Groth16's a_query and
+  // b_g1_query over the witness shares): one sort, and every later launch covers both through blockIdx.y.
   int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-            XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
+            XYZZ<Fld>* result, hipStream_t st, int wslot = 0, const void* bases2 = nullptr,
+            XYZZ<Fld>* result2 = nullptr) {
 #if defined(__HIPCC__)
     *result = XYZZ<Fld>::identity();
+    if (result2) *result2 = XYZZ<Fld>::identity();
+    const unsigned NB = (bases2 && result2) ? 2u : 1u;
     if (npts == 0) return ZK_OK;
     if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
     constexpr bool G2FLD = sizeof(Fld) != sizeof(Fq);
@@ -522,8 +540,8 @@ class MsmRunner {
     };
     size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
            o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
-           o_partial = take(max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(nkeys * sizeof(XYZZ<Fld>)),
-           o_out = take((size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
+           o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
+           o_out = take(NB * (size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     hipError_t he = ws_[wslot].ensure(off);
     if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
@@ -582,7 +600,7 @@ class MsmRunner {
     }
     MSM_STAGE("scatter");
     {
-    ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts);
+    ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB);
     size_t acc_wgs = (max_segs + 127) / 128;
     {
       static const int cap_g1 = getenv("ZK_ACC_WGS_G1") ? atoi(getenv("ZK_ACC_WGS_G1")) : 0;
@@ -590,19 +608,19 @@ class MsmRunner {
       const int cap = IS_G2 ? cap_g2 : cap_g1;
       if (cap > 0 && acc_wgs > (size_t)cap) acc_wgs = (size_t)cap;
     }
-    msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, sorted, segs, offsets, nkeys, order, partial);
+    msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
+        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
     }
     MSM_STAGE("accumulate");
     {
     ProfScope ps_(eng->prof, PROF_MSM_REDUCE, st, (double)npts);
     MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
-    msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + 127) / 128)), dim3(128), 0, st>>>(partial, offsets, nkeys,
-                                                                                               buckets, heavy);
+    msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + 127) / 128), NB), dim3(128), 0, st>>>(
+        partial, max_segs, offsets, nkeys, buckets, heavy);
     {
       size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
-      msm_finalize_heavy_kernel<KF><<<dim3(512), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, offsets, heavy,
-                                                                                               buckets);
+      msm_finalize_heavy_kernel<KF><<<dim3(512, NB), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, max_segs, offsets,
+                                                                                               nkeys, heavy, buckets);
     }
     MSM_STAGE("finalize");
     size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
@@ -612,37 +630,78 @@ class MsmRunner {
                                   (int)red_lds));
       attr_set = true;
     }
-    msm_reduce_kernel<KF, RED_THREADS><<<dim3((unsigned)(nwin * bpw)), dim3(RED_THREADS), red_lds, st>>>(buckets, B, bpw, out);
+    msm_reduce_kernel<KF, RED_THREADS><<<dim3((unsigned)(nwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
+        buckets, nkeys, B, bpw, out);
     }
     MSM_HIP(hipGetLastError());
     MSM_STAGE("reduce");
-    std::vector<XYZZ<Fld>> h((size_t)nwin * bpw * 2);
-    MSM_HIP(hipMemcpyAsync(h.data(), out, h.size() * sizeof(XYZZ<Fld>), hipMemcpyDeviceToHost, st));
+    std::vector<XYZZ<Fld>> hall(NB * (size_t)nwin * bpw * 2);
+    MSM_HIP(hipMemcpyAsync(hall.data(), out, hall.size() * sizeof(XYZZ<Fld>), hipMemcpyDeviceToHost, st));
     MSM_HIP(hipStreamSynchronize(st));
 #undef MSM_HIP
 #undef MSM_STAGE
-    // host: window value = sum_blk (A_blk + blk*RED_THREADS*RED_G * S_blk); fold windows high -> low
+    // host: window value X_w = sum_blk A_blk + K * sum_blk blk * S_blk with K = RED_THREADS * RED_G = 2^kbits, then
+    // Horner over the windows from the top.  The factor K costs nothing: the weighted sum enters the Horner chain
+    // kbits doublings before X_w's own addition.  The per-window block sums are independent; for extension-field
+    // points (1.1 us per host addition) they are spread over a few host threads.
+    auto fold = [&](const XYZZ<Fld>* h) -> XYZZ<Fld> {
+    std::vector<XYZZ<Fld>> wsum((size_t)nwin, XYZZ<Fld>::identity()), wts((size_t)nwin, XYZZ<Fld>::identity());
+    auto block_sums = [&](int w0, int w1) {
+      for (int w = w0; w < w1; w++) {
+        XYZZ<Fld> acc = XYZZ<Fld>::identity(), run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
+        for (int blk = (int)bpw - 1; blk >= 0; blk--) {
+          acc = xyzz_add_ni(acc, h[((size_t)w * bpw + blk) * 2 + 1]);
+          if (blk >= 1) {
+            run = xyzz_add_ni(run, h[((size_t)w * bpw + blk) * 2]);   // sum_{blk' >= blk} S
+            wt = xyzz_add_ni(wt, run);                                 // accumulates sum blk * S_blk
+          }
+        }
+        wsum[(size_t)w] = acc;
+        wts[(size_t)w] = wt;
+      }
+    };
+    const int fold_threads = (G2FLD && bpw > 1 && nwin >= 8) ? 4 : 1;
+    if (fold_threads > 1) {
+      std::thread th[3];
+      const int per_t = (nwin + fold_threads - 1) / fold_threads;
+      for (int i = 1; i < fold_threads; i++)
+        th[i - 1] = std::thread(block_sums, std::min(nwin, i * per_t), std::min(nwin, (i + 1) * per_t));
+      block_sums(0, std::min(nwin, per_t));
+      for (int i = 1; i < fold_threads; i++) th[i - 1].join();
+    } else {
+      block_sums(0, nwin);
+    }
+    constexpr uint64_t KBLK = (uint64_t)RED_THREADS * RED_G;
+    int kbits = 0;
+    while (((uint64_t)1 << kbits) < KBLK) kbits++;
+    static_assert((KBLK & (KBLK - 1)) == 0, "RED_THREADS * RED_G must be a power of two");
     XYZZ<Fld> total = XYZZ<Fld>::identity();
     for (int w = nwin - 1; w >= 0; w--) {
-      for (int i = 0; i < (w < wide ? c : c - 1); i++) total = xyzz_dbl_ni(total);
-      XYZZ<Fld> wsum = XYZZ<Fld>::identity();
-      XYZZ<Fld> run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
-      for (int blk = (int)bpw - 1; blk >= 0; blk--) {
-        const XYZZ<Fld>& S = h[((size_t)w * bpw + blk) * 2];
-        const XYZZ<Fld>& A = h[((size_t)w * bpw + blk) * 2 + 1];
-        wsum = xyzz_add_ni(wsum, A);
-        if (blk >= 1) {
-          run = xyzz_add_ni(run, S);      // sum_{blk' >= blk} S
-          wt = xyzz_add_ni(wt, run);      // accumulates sum blk * S_blk
-        }
+      const int cw = w < wide ? c : c - 1;
+      if (bpw > 1 && kbits <= cw) {
+        for (int i = 0; i < cw - kbits; i++) total = xyzz_dbl_ni(total);
+        total = xyzz_add_ni(total, wts[(size_t)w]);
+        for (int i = 0; i < kbits; i++) total = xyzz_dbl_ni(total);
+      } else {
+        for (int i = 0; i < cw; i++) total = xyzz_dbl_ni(total);
+        if (bpw > 1) total = xyzz_add_ni(total, xyzz_mul_small(wts[(size_t)w], KBLK));
       }
-      if (bpw > 1) wsum = xyzz_add_ni(wsum, xyzz_mul_small(wt, (uint64_t)RED_THREADS * RED_G));
-      total = xyzz_add_ni(total, wsum);
+      total = xyzz_add_ni(total, wsum[(size_t)w]);
     }
-    *result = total;
+    return total;
+    };
+    if (NB == 2) {
+      // the second fold runs beside the first (both are short dependent chains on the host)
+      std::thread t2([&]() { *result2 = fold(hall.data() + (size_t)nwin * bpw * 2); });
+      *result = fold(hall.data());
+      t2.join();
+    } else {
+      *result = fold(hall.data());
+    }
     return ZK_OK;
 #else
     (void)eng; (void)bases; (void)scalars; (void)npts; (void)coef_d; (void)part_len; (void)result; (void)st;
+    (void)bases2; (void)result2;
     return ZK_ERR_GENERIC;
 #endif
   }
@@ -697,6 +756,30 @@ class MsmRunner {
       r = xyzz_add_ni(r, *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
     }
     *result = r;
+    return ZK_OK;
+  }
+
+  // two base vectors over the same scalar shares (S and H of the prover): one sort, shared launches
+  template <class Fld>
+  int d_msm_sum2_t(IEngine* eng, const void* bases_a, const void* bases_b, const void* scalars, size_t len,
+                   const void* in_mask_a, const void* in_mask_b, XYZZ<Fld>* result_a, XYZZ<Fld>* result_b,
+                   hipStream_t st, int wslot = 0) {
+    const int n = eng->n;
+    XYZZ<Fld> ra, rb;
+    int rc = run_t<Fld>(eng, bases_a, scalars, (size_t)n * len, coef_d_, len, &ra, st, wslot, bases_b, &rb);
+    if (rc) return rc;
+    const void* masks[2] = {in_mask_a, in_mask_b};
+    XYZZ<Fld>* rs[2] = {&ra, &rb};
+    for (int k = 0; k < 2; k++)
+      if (masks[k]) {
+        const Jacobian<Fld>* jm = (const Jacobian<Fld>*)masks[k];
+        std::vector<Affine<Fld>> aff(n);
+        for (int p = 0; p < n; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
+        std::vector<char> mt = host_lincomb<Fld>(aff);
+        *rs[k] = xyzz_add_ni(*rs[k], *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
+      }
+    *result_a = ra;
+    *result_b = rb;
     return ZK_OK;
   }
 

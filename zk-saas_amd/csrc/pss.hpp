@@ -138,15 +138,29 @@ __global__ __launch_bounds__(KING_THREADS) void pss_unpack_kernel(const Fp<P>* _
 //   in     : [np][Lc] (+ in_mask, optional)   out: [n][Lc] (+ out_mask, optional)
 //   gentab : gen^e, e in [0, m]               gtab: c*g^e, e in [0, Lc] or nullptr (g = 1, c = 1)
 //   gstep  : g^(Lc*e), e < l                  in_scale: optional factor applied to every input share
+// Batched form: blockIdx.y selects one of up to KING_BATCH independent vectors (the a, b, c polynomials of
+// circom_h): input / output at y * stride, masks per item, share randomness stream seed + y.
+constexpr int KING_BATCH = 3;
+template <class F>
+struct KingBatch {
+  const F* in_mask[KING_BATCH];
+  const F* out_mask[KING_BATCH];
+  size_t stride;
+};
+
 template <class P, int L, bool NEGATE>
 __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
-    const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, uint32_t log_lc,
+    const Fp<P>* __restrict__ in0, KingBatch<Fp<P>> kb, int np, uint32_t log_lc,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
     const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
-    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, uint64_t seed, Fp<P>* __restrict__ out,
-    const Fp<P>* __restrict__ out_mask) {
+    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, uint64_t seed0, Fp<P>* __restrict__ out0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
+  const F* __restrict__ in = in0 + blockIdx.y * kb.stride;
+  F* __restrict__ out = out0 + blockIdx.y * kb.stride;
+  const F* __restrict__ in_mask = kb.in_mask[blockIdx.y];
+  const F* __restrict__ out_mask = kb.out_mask[blockIdx.y];
+  const uint64_t seed = seed0 + blockIdx.y;
   constexpr int T = L, N = 4 * L;
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
   extern __shared__ uint4 smem[];
