@@ -619,8 +619,11 @@ class MsmRunner {
         partial, max_segs, offsets, nkeys, buckets, heavy);
     {
       size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
-      msm_finalize_heavy_kernel<KF><<<dim3(512, NB), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, max_segs, offsets,
-                                                                                               nkeys, heavy, buckets);
+      // small fixed grid (it strides over the heavy list, which is empty for well-spread scalars): a launch of many
+      // workgroups of this register-hungry kernel would wait for whole SIMDs to drain just to find nothing to do
+      static const unsigned heavy_wgs = getenv("ZK_FIN_HEAVY_WGS") ? (unsigned)atoi(getenv("ZK_FIN_HEAVY_WGS")) : 48u;
+      msm_finalize_heavy_kernel<KF><<<dim3(heavy_wgs ? heavy_wgs : 48u, NB), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, max_segs, offsets,
+                                                                                              nkeys, heavy, buckets);
     }
     MSM_STAGE("finalize");
     size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
