@@ -241,3 +241,29 @@ def test_pack_points_with_random_points_reconstructs():
         for p_ in range(o.n):
             v = pp.fq.decode(rows[p_, j].reshape(2, 4))
             assert (v[0], v[1]) == G1.to_affine(want[p_])
+
+
+def test_two_ranks_sharing_the_gpu_give_the_single_rank_proof():
+    """The multi-rank flow of bench.py --gpus 2 (party sharding, partial MSM sums, king rounds through
+    gather/scatter/all-gather) launched exactly as the driver launches it, with both ranks on the one GPU of this box
+    and the collectives staged through host memory over gloo (ZK_DIST_VIA_CPU=1; RCCL needs one GPU per rank).
+    bench.py itself compares the sharded proof with the single-context proof."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, ZK_DIST_VIA_CPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["proof_matches_single_gpu"] is True
+    assert res["config"]["parties_per_gpu"] == 4
