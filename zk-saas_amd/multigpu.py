@@ -281,7 +281,7 @@ def bench(args, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     import zksaas_amd as zk
-    from bench import build_inputs
+    from bench import build_inputs, read_profile, roofline_of
 
     via_cpu = bool(os.environ.get("ZK_DIST_VIA_CPU"))      # debugging: several ranks on one GPU, gloo collectives
     if world > 1 and not dist.is_initialized():
@@ -305,6 +305,7 @@ def bench(args, rank, local_rank, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    pp._check(pp.lib.zk_profile_enable(pp.h, 1))        # HIP-event kernel slots of THIS rank (rank 0 reports its own)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proof = prover.prove(inp, r, s, seed)
@@ -316,6 +317,8 @@ def bench(args, rank, local_rank, world):
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    prof = read_profile(pp)
+    pp._check(pp.lib.zk_profile_enable(pp.h, 0))
     # untimed cross-check on rank 0 against the single-GPU prover on the full dealing
     ok = None
     if rank == 0:
@@ -336,6 +339,8 @@ def bench(args, rank, local_rank, world):
                    "parties": pp.n, "parties_per_gpu": pp.n // world, "packing_factor": pp.l},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
         "proof_matches_single_gpu": ok,
+        "roofline": roofline_of(prof, ntt_passes=2, pp=pp),       # rank 0's dominant streaming kernel
+        "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
 
 
