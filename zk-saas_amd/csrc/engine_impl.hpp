@@ -1224,14 +1224,12 @@ class Engine : public IEngine {
     });
     job_.th[1] = std::thread([=]() {
       (void)hipSetDevice(dev);
-      job_.rc[0] = msm_.template d_msm_range_t<Fq>(this, crs->s_d, a_share, crs->len_a, first, count, nullptr, &job_.S,
-                                                   streams_[0], 1);
-    });
-    job_.th[2] = std::thread([=]() {
-      (void)hipSetDevice(dev);
-      if (!skip_h)
-        job_.rc[1] = msm_.template d_msm_range_t<Fq>(this, crs->h_d, a_share, crs->len_a, first, count, nullptr,
-                                                     &job_.H, streams_[1], 2);
+      if (skip_h)
+        job_.rc[0] = msm_.template d_msm_range_t<Fq>(this, crs->s_d, a_share, crs->len_a, first, count, nullptr, &job_.S,
+                                                     streams_[0], 1);
+      else        // S and H share the scalars: one sort (msm.hpp run_t with two base vectors)
+        job_.rc[0] = msm_.template d_msm_range2_t<Fq>(this, crs->s_d, crs->h_d, a_share, crs->len_a, first, count,
+                                                      &job_.S, &job_.H, streams_[0], 1);
     });
     job_.th[3] = std::thread([=]() {
       (void)hipSetDevice(dev);
