@@ -197,6 +197,10 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
  * plan[2] = points per accumulate lane, plan[3] = base-field multiplications per mixed addition (10 for G1,
  * 28 for G2 over Fq2).  Benchmarks use it to turn a launch duration into multiplications per second. */
 int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
+/* Tunables of this context (no reference counterpart).  "msm_bigsort_min": point count from which zk_msm sorts with
+ * the two-level LDS counting sort instead of global atomics (default 65536; tests force both paths with it).
+ * Unknown name -> ZK_ERR_BAD_INPUT. */
+int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
 /* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value
  * -(sum), both packed with t random group elements each (streams seed^0x1111, seed^0x2222; a random group element
  * is a random multiple of gen).  gen_affine: the group generator (host, affine Montgomery); in_mask / out_mask

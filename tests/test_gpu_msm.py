@@ -202,3 +202,56 @@ def test_deg_red_and_d_msm_with_dropout():
     ref = od.d_msm([G.batch_to_affine(v) for v in x_sh], y_sh, [od.MsmMask.zero(G)] * o.n, o, G, ops, parties=parties)
     for i in range(pp.n):
         assert G.eq(dec_jacobian(pp, out[i]), ref[i]) and G.eq(dec_jacobian(pp, out[i]), want)
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", ZK_G1), ("bn254", ZK_G2), ("bls12_381", ZK_G1)])
+def test_msm_both_sort_paths_agree_and_match_oracle(curve, group):
+    """The two-level LDS counting sort (default from 2^16 points) and the global-atomics sort are forced in turn on the
+    same inputs through zk_ctx_set_option: random scalars (exact against the oracle), ragged length (not a multiple
+    of the 4096-point tile), zeros, r-1, all ones (one heavy bucket per window) and a duplicated base."""
+    c = CURVES[curve]
+    pp = zk.PackedSharingParams(curve, 2)          # own context: the option must not leak into other tests
+    is2 = group == ZK_G2
+    G = g2(c) if is2 else g1(c)
+    n = 4096 + 777
+    distinct = _points(G, c, 48, 64)
+    pts = [distinct[i % 48] for i in range(n)]
+    pts[5] = None                                  # an identity base
+    bases = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts, is2))
+    cases = {
+        "random": rand_vec(65, n, c.r),
+        "edge": [0, 1, c.r - 1, 2, c.r - 2] * (n // 5) + [1] * (n % 5),
+        "ones": [1] * n,
+    }
+    for name, sc in cases.items():
+        sc_d = up(pp, sc)
+        outs = []
+        for big_min in (0, 1 << 40):
+            pp.set_option("msm_bigsort_min", big_min)
+            outs.append(dec_jacobian(pp, msm(pp, group, bases, sc_d, n), is2))
+        assert G.eq(outs[0], outs[1]), name
+        agg = [0] * 48                                   # sum_i s_i * P_(i mod 48), identity base skipped
+        for i, s in enumerate(sc):
+            if i != 5:
+                agg[i % 48] = (agg[i % 48] + s) % c.r
+        assert G.eq(outs[0], G.msm(distinct, agg)), name
+    with pytest.raises(zk.ZkError):
+        pp.set_option("no_such_option", 1)
+
+
+def test_d_msm_big_sort_path_with_party_coefficients():
+    """The fused d_msm (scalars pre-multiplied by the per-party unpack2 coefficients inside the sort kernels) through
+    the two-level sort, against the global-atomics path."""
+    pp = zk.PackedSharingParams("bn254", 2)
+    c = CURVES["bn254"]
+    G = g1(c)
+    ln = 2500
+    distinct = _points(G, c, 32, 66)
+    bases = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, [distinct[i % 32] for i in range(pp.n * ln)]))
+    sc = up(pp, rand_vec(67, pp.n * ln, c.r))
+    res = []
+    for big_min in (0, 1 << 40):
+        pp.set_option("msm_bigsort_min", big_min)
+        res.append(zk.d_msm(pp, ZK_G1, bases, sc, ln))
+    for p in range(pp.n):
+        assert G.eq(dec_jacobian(pp, res[0][p]), dec_jacobian(pp, res[1][p]))

@@ -111,6 +111,10 @@ class Context:
             self.lib.zk_ctx_destroy(self.h)
             self.h = None
 
+    def set_option(self, name, value):
+        """zk_ctx_set_option: context tunables ("msm_bigsort_min")."""
+        self._check(self.lib.zk_ctx_set_option(self.h, name.encode(), int(value)))
+
     # --- marshalling helpers ---------------------------------------------------------------------
     def upload_fr(self, vals):
         return DeviceBuffer.from_numpy(self, self.fr.encode(vals))

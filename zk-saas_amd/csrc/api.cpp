@@ -208,6 +208,10 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
   CTX_OR_FAIL();
   return e->group_add(group, a, b, out);
 }
+int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value) {
+  CTX_OR_FAIL();
+  return e->set_option(name, value);
+}
 int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]) {
   CTX_OR_FAIL();
   return e->msm_plan(group, len, plan);

@@ -1135,6 +1135,15 @@ class Engine : public IEngine {
     return ZK_OK;
   }
 
+  int set_option(const char* name, long long value) override {
+    if (!name) return fail(ZK_ERR_BAD_INPUT, "null option name");
+    if (!strcmp(name, "msm_bigsort_min")) {
+      if (value < 0) return fail(ZK_ERR_BAD_INPUT, "msm_bigsort_min must be >= 0");
+      msm_.bigsort_min = (size_t)value;
+      return ZK_OK;
+    }
+    return fail(ZK_ERR_BAD_INPUT, "unknown option");
+  }
   int msm_plan(int group, size_t len, int* plan) override {
     if (!plan || (group != ZK_G1 && group != ZK_G2)) return fail(ZK_ERR_BAD_INPUT, "bad argument");
     if (group == ZK_G2 && !Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");

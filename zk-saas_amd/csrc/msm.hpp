@@ -735,7 +735,7 @@ class MsmRunner {
            o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
            o_out = take(NB * (size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
     // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
-    static const size_t big_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)1 << 16);
+    const size_t big_min = bigsort_min;
     const int lo_bits = c - 1 - BIG_HI;
     const bool big = npts >= big_min && lo_bits >= 1 && lo_bits <= 10;
     size_t o_bins = 0, o_tmp = 0;
@@ -1135,6 +1135,8 @@ class MsmRunner {
     if (coef_d_) (void)hipFree(coef_d_);
   }
 
+  // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min"; env ZK_MSM_BIGSORT_MIN at start)
+  size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)1 << 16);
   DevBuf ws_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;
