@@ -34,7 +34,12 @@ constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller
 // bucket-reduce workgroup: 256 lanes, 128 for the largest point type (two LDS planes must fit in 160 KiB)
 template <class Fld>
 constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
-constexpr int RED_G = 4;              // buckets per lane in bucket-reduce
+// buckets per lane in the bucket reduction: the reduction is a chain of 2G + 2 log RT + log G + 1 dependent group
+// additions.  G = 2 (22 steps instead of 27) pays only where the launch is latency-bound, i.e. has few waves: the
+// extension-field MSMs of a proof.  For base-field points it was measured and rejected (twice the lanes for 24/27 of
+// the steps is more total work: d_msm 8 x 2^17 went from 5.0 to 5.65 ms).
+template <class Fld>
+constexpr int red_g() { return sizeof(XYZZ<Fld>) == 256 ? 2 : 4; }
 constexpr int MSM_WS = 6;             // independent workspaces (concurrent MSMs on separate streams)
 
 struct SegDesc {
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
 //   [.., +log G)   sum_t t*RUN[t] = sum_{j>=1} suf[j]; lane weight is t*RED_G: RUN[t] <- RED_G * suf[t] (t >= 1)
 //   [.., +1)       ACC += RUN
 //   [.., +log RT)  tree sum of ACC -> A
-template <class Fld, int RT>
+template <class Fld, int RT, int RED_G>
 __global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets0, size_t nkeys,
                                                        uint32_t B, uint32_t blocks_per_window,
                                                        XYZZ<Fld>* __restrict__ out0 /* [y][nwin][bpw][2] */) {
@@ -551,8 +556,8 @@ __global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restr
   extern __shared__ uint4 smem_red[];
   XYZZ<Fld>* RUN = reinterpret_cast<XYZZ<Fld>*>(smem_red);
   XYZZ<Fld>* ACC = RUN + RT;
-  constexpr int LOGT = RT == 256 ? 8 : 7;
-  static_assert((1 << LOGT) == RT, "RT must be 128 or 256");
+  constexpr int LOGT = RT == 512 ? 9 : RT == 256 ? 8 : 7;
+  static_assert((1 << LOGT) == RT, "RT must be 128, 256 or 512");
   constexpr int LOGG = RED_G == 1 ? 0 : RED_G == 2 ? 1 : RED_G == 4 ? 2 : 3;
   static_assert((1 << LOGG) == RED_G, "RED_G must be 1, 2, 4 or 8");
   const uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
@@ -720,6 +725,7 @@ class MsmRunner {
     }
     const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
     constexpr int RED_THREADS = red_threads<Fld>();
+    constexpr int RED_G = red_g<Fld>();
     const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
     const size_t iscan_blocks = (nkeys + ISCAN_BLOCK - 1) / ISCAN_BLOCK;
 
@@ -850,11 +856,11 @@ class MsmRunner {
     size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
     static bool attr_set = false;
     if (!attr_set && red_lds > 48 * 1024) {
-      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<KF, RED_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<KF, RED_THREADS, RED_G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)red_lds));
       attr_set = true;
     }
-    msm_reduce_kernel<KF, RED_THREADS><<<dim3((unsigned)(nwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
+    msm_reduce_kernel<KF, RED_THREADS, RED_G><<<dim3((unsigned)(nwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
         buckets, nkeys, B, bpw, out);
     }
     MSM_HIP(hipGetLastError());
