@@ -198,7 +198,7 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
  * 28 for G2 over Fq2).  Benchmarks use it to turn a launch duration into multiplications per second. */
 int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
 /* Tunables of this context (no reference counterpart).  "msm_bigsort_min": point count from which zk_msm sorts with
- * the two-level LDS counting sort instead of global atomics (default 65536; tests force both paths with it).
+ * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
  * Unknown name -> ZK_ERR_BAD_INPUT. */
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
 /* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value

@@ -1142,7 +1142,7 @@ class MsmRunner {
   }
 
   // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min"; env ZK_MSM_BIGSORT_MIN at start)
-  size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)1 << 16);
+  size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)3 << 16);
   DevBuf ws_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;
