@@ -88,7 +88,7 @@ def pmc_traffic(slot_name):
     return None
 
 
-def roofline_of(prof, ntt_passes, pp=None):
+def roofline_of(prof, ntt_passes, pp=None, table_windows=None):
     # the dominant STREAMING kernel: the sort and the bucket finalize/reduce helpers are latency-bound tree
     # kernels without a per-unit byte figure in SURVEY.md 8d; they are listed under "kernels"
     cands = [e for e in prof if e["launches"] and (SLOT_BYTES.get(e["kernel"]) or e["kernel"] == "ntt_pass_kernel")
@@ -113,6 +113,8 @@ def roofline_of(prof, ntt_passes, pp=None):
         from zksaas_amd.api import ZK_G1, ZK_G2, msm_plan
         pts = int(best["units"] / best["launches"])
         plan = msm_plan(pp, ZK_G2 if "G2" in name else ZK_G1, pts)
+        if table_windows:           # fixed-base tables: every MSM runs with the table's window layout
+            plan["windows"], plan["window_bits"], plan["fixed_base_table"] = table_windows, 16, True
         muls = pts * plan["windows"] * plan["muls_per_add"]
         rate = muls / (avg_ms * 1e-3) / 1e9
         alu = {"achieved": round(rate, 2), "peak": MUL_PEAK_G, "unit": "G modmul/s (256-bit Montgomery)",
@@ -165,12 +167,14 @@ def primitives(pp, zk):
     return out
 
 
-def pipelined(zk, zg, pp, crs, wit, r, s, device, total):
+def pipelined(zk, zg, pp, crs, wit, r, s, device, total, tables):
     """Informational, outside the timed K steps: the same proofs with TWO in flight (a second context = second set of
     workspaces and streams, its own host thread; CRS and witness shares are shared read-only).  A prover service
     would run like this; `value` above stays the one-proof-at-a-time rate."""
     import threading
     ctxs = [pp, zk.PackedSharingParams("bn254", 2, device=device)]
+    if tables:
+        crs.precompute(ctxs[1])
     for c in ctxs:
         zg.prove(c, crs, wit, r, s, seed=1)
     per = total // len(ctxs)
@@ -221,6 +225,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tables", action="store_true", help="prove without the fixed-base tables of the CRS "
+                    "(zk_msm_precompute); default: tables built once at setup, as a prover service would")
     ap.add_argument("--no-primitives", action="store_true", help="skip the d_fft / d_msm side measurements "
                     "(used for the rocprofv3 runs so that every profiled launch belongs to the proof loop)")
     args = ap.parse_args()
@@ -250,6 +256,11 @@ def main():
 
     pp = zk.PackedSharingParams("bn254", 2, device=local_rank)
     r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
+    table_windows = None
+    if not args.no_tables:
+        from zksaas_amd import api
+        crs.precompute()
+        table_windows = api.msm_table_info(pp, api.ZK_G1, crs.s)["windows"]
     seed = 1000
     for _ in range(args.warmup):
         proof = zg.prove(pp, crs, wit, r, s, seed=seed)
@@ -271,14 +282,16 @@ def main():
         "data": "synthetic: SHA-256(a=1,b=2) circuit rebuilt from its semantics, seeded trapdoor CRS, seeded shares",
         "config": {"workload": "BASELINE configs[3]: full distributed Groth16 on the SHA-256 circuit, BN254, l=2, "
                                "n=8 parties on one GPU, zero masks", "constraints": r1.num_constraints,
-                   "wires": r1.num_variables, "domain": 1 << wit.log_m, "parties": pp.n, "packing_factor": pp.l},
+                   "wires": r1.num_variables, "domain": 1 << wit.log_m, "parties": pp.n, "packing_factor": pp.l,
+                   "fixed_base_tables": not args.no_tables},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
-        "roofline": roofline_of(prof, ntt_passes=2, pp=pp),
+        "roofline": roofline_of(prof, ntt_passes=2, pp=pp, table_windows=table_windows),
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
     if not args.no_primitives:
         res["primitives"] = primitives(pp, zk)
-        res["pipelined"] = pipelined(zk, zg, pp, crs, wit, r, s, local_rank, max(8, args.steps // 2 * 2))
+        res["pipelined"] = pipelined(zk, zg, pp, crs, wit, r, s, local_rank, max(8, args.steps // 2 * 2),
+                                     not args.no_tables)
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(pp, crs, wit, r, s, seed, proof)
     print(json.dumps(res))

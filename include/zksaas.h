@@ -197,6 +197,17 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
  * plan[2] = points per accumulate lane, plan[3] = base-field multiplications per mixed addition (10 for G1,
  * 28 for G2 over Fq2).  Benchmarks use it to turn a launch duration into multiplications per second. */
 int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
+/* Fixed-base tables (no reference counterpart; arkworks has FixedBase::msm for setup only).  A prover service proves
+ * many witnesses against one CRS: zk_msm_precompute builds, for the affine vector bases_d [len] (e.g. one query of
+ * zk_crs_share, all parties: len = n * len_a), the multiples 2^(16 j) * P_i, j < 16, owned by the context (16 x the
+ * size of the vector).  Every later zk_msm / zk_d_msm / zk_groth16_prove whose base pointer lies inside a registered
+ * vector uses its table: all windows then share one bucket set (one bucket reduction, no doublings in the final
+ * fold, 16 instead of 20-22 mixed additions per point).  Results are the same group elements.
+ * zk_msm_forget drops the table of bases_d (returns ZK_ERR_BAD_INPUT if there is none); zk_msm_table_info writes
+ * info[0] = window bits, info[1] = digit windows of the table that covers bases_d (zeros if none). */
+int zk_msm_precompute(zk_ctx* ctx, int group, const void* bases_d, size_t len, void* stream);
+int zk_msm_forget(zk_ctx* ctx, const void* bases_d);
+int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
 /* Tunables of this context (no reference counterpart).  "msm_bigsort_min": point count from which zk_msm sorts with
  * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
  * Unknown name -> ZK_ERR_BAD_INPUT. */

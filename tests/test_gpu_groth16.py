@@ -267,3 +267,21 @@ def test_two_ranks_sharing_the_gpu_give_the_single_rank_proof():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["proof_matches_single_gpu"] is True
     assert res["config"]["parties_per_gpu"] == 4
+
+
+def test_proof_with_fixed_base_tables_equals_proof_without():
+    """Crs.precompute() (zk_msm_precompute on the five query vectors): the SHA-256 circuit proof is the same group
+    elements with and without the tables, for r = 0 as well (H skipped, S alone)."""
+    import zksaas_amd as zk
+    from zksaas_amd import wire
+    from bench import build_inputs
+    pp = zk.PackedSharingParams("bn254", 2)
+    r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
+
+    def norm(pf):
+        return (wire.jacobian_to_affine(pp, pf[0][0], False), wire.jacobian_to_affine(pp, pf[1][0], True),
+                wire.jacobian_to_affine(pp, pf[2][0], False))
+    plain = [norm(zg.prove(pp, crs, wit, rr, s, seed=5)) for rr in (r, 0)]
+    crs.precompute()
+    tabled = [norm(zg.prove(pp, crs, wit, rr, s, seed=5)) for rr in (r, 0)]
+    assert plain == tabled

@@ -255,3 +255,54 @@ def test_d_msm_big_sort_path_with_party_coefficients():
         res.append(zk.d_msm(pp, ZK_G1, bases, sc, ln))
     for p in range(pp.n):
         assert G.eq(dec_jacobian(pp, res[0][p]), dec_jacobian(pp, res[1][p]))
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", ZK_G1), ("bn254", ZK_G2), ("bls12_381", ZK_G1)])
+def test_fixed_base_table_gives_the_same_msm(curve, group):
+    """zk_msm_precompute: MSMs over a registered base vector (whole vector, a sub-range starting inside it, the fused
+    d_msm over all parties) equal the table-free results and the oracle; zk_msm_forget restores the plain path."""
+    from zksaas_amd import api
+    c = CURVES[curve]
+    pp = zk.PackedSharingParams(curve, 2)
+    is2 = group == ZK_G2
+    G = g2(c) if is2 else g1(c)
+    n = 1500
+    distinct = _points(G, c, 40, 68)
+    pts = [distinct[i % 40] for i in range(n)]
+    pts[7] = None
+    rows = enc_affine(pp, pts, is2)
+    bases = zk.DeviceBuffer.from_numpy(pp, rows)
+    sc = rand_vec(69, n, c.r)
+    sc[3], sc[4], sc[11] = 0, c.r - 1, 1
+    sc_d = up(pp, sc)
+    plain = dec_jacobian(pp, msm(pp, group, bases, sc_d, n), is2)
+    assert api.msm_table_info(pp, group, bases)["windows"] == 0
+    api.msm_precompute(pp, group, bases, n)
+    assert api.msm_table_info(pp, group, bases) == {"window_bits": 16, "windows": 16}
+    agg = [0] * 40
+    for i, s in enumerate(sc):
+        if i != 7:
+            agg[i % 40] = (agg[i % 40] + s) % c.r
+    want = G.msm(distinct, agg)
+    with_table = dec_jacobian(pp, msm(pp, group, bases, sc_d, n), is2)
+    assert G.eq(with_table, plain) and G.eq(with_table, want)
+    # a sub-range that starts inside the registered vector (the prover's party halves do this)
+    off, cnt = 520, 700
+    sub = bases.view(off * rows.shape[1] * 8)
+    sub_sc = up(pp, sc[off:off + cnt])
+    got = dec_jacobian(pp, msm(pp, group, sub, sub_sc, cnt), is2)
+    agg = [0] * 40
+    for i in range(off, off + cnt):
+        if i != 7:
+            agg[i % 40] = (agg[i % 40] + sc[i]) % c.r
+    assert G.eq(got, G.msm(distinct, agg))
+    # fused d_msm over all parties: [n_parties][len] is one registered vector
+    ln = 150
+    d_with = zk.d_msm(pp, group, bases, sc_d, ln)
+    api.msm_forget(pp, bases)
+    assert api.msm_table_info(pp, group, bases)["windows"] == 0
+    d_plain = zk.d_msm(pp, group, bases, sc_d, ln)
+    for p in range(pp.n):
+        assert G.eq(dec_jacobian(pp, d_with[p], is2), dec_jacobian(pp, d_plain[p], is2))
+    with pytest.raises(zk.ZkError):
+        api.msm_forget(pp, bases)

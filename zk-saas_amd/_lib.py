@@ -15,7 +15,7 @@ SYMBOLS = [
     "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove", "zk_profile_enable",
     "zk_profile_slots", "zk_profile_name", "zk_profile_read", "zk_d_msm_local", "zk_group_add", "zk_groth16_assemble",
     "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
-    "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option",
+    "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
 ]
 
 _lib = None
@@ -100,6 +100,9 @@ def load():
     lib.zk_group_add.argtypes = [vp, i32, vp, vp, vp]
     lib.zk_msm_plan.argtypes = [vp, i32, C.c_size_t, C.POINTER(C.c_int)]
     lib.zk_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
+    lib.zk_msm_precompute.argtypes = [vp, i32, vp, sz, vp]
+    lib.zk_msm_forget.argtypes = [vp, vp]
+    lib.zk_msm_table_info.argtypes = [vp, i32, vp, C.POINTER(C.c_int)]
     lib.zk_msm_mask_sample.argtypes = [vp, i32, vp, u64, vp, vp]
     lib.zk_r1cs_qap.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, sz, i32, vp, vp, vp, vp]
     lib.zk_fr_to_bytes.argtypes = [vp, vp, sz, vp, vp]

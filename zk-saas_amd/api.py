@@ -296,6 +296,22 @@ def fr_from_bytes(pp, data, stream=None):
     return out
 
 
+def msm_precompute(pp, group, bases_d, length, stream=None):
+    """zk_msm_precompute: fixed-base table for the affine vector bases_d [length]; later MSMs over it use the table."""
+    pp._check(pp.lib.zk_msm_precompute(pp.h, group, _ptr(bases_d), length, stream))
+
+
+def msm_forget(pp, bases_d):
+    pp._check(pp.lib.zk_msm_forget(pp.h, _ptr(bases_d)))
+
+
+def msm_table_info(pp, group, bases_d):
+    import ctypes as C
+    info = (C.c_int * 2)()
+    pp._check(pp.lib.zk_msm_table_info(pp.h, group, _ptr(bases_d), info))
+    return {"window_bits": info[0], "windows": info[1]}
+
+
 def msm_plan(pp, group, length):
     """The Pippenger plan zk_msm uses for `length` points: dict(window_bits, windows, lane_points, muls_per_add)."""
     import ctypes as C

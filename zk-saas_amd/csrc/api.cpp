@@ -208,6 +208,18 @@ int zk_group_add(zk_ctx* ctx, int group, const void* a, const void* b, void* out
   CTX_OR_FAIL();
   return e->group_add(group, a, b, out);
 }
+int zk_msm_precompute(zk_ctx* ctx, int group, const void* bases_d, size_t len, void* stream) {
+  CTX_OR_FAIL();
+  return e->msm_precompute(group, bases_d, len, S(stream));
+}
+int zk_msm_forget(zk_ctx* ctx, const void* bases_d) {
+  CTX_OR_FAIL();
+  return e->msm_forget(bases_d);
+}
+int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]) {
+  CTX_OR_FAIL();
+  return e->msm_table_info(group, bases_d, info);
+}
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value) {
   CTX_OR_FAIL();
   return e->set_option(name, value);

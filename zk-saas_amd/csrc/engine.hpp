@@ -147,6 +147,9 @@ class IEngine {
   virtual int group_add(int group, const void* a, const void* b, void* out) = 0;
   virtual int msm_plan(int group, size_t len, int* plan) = 0;
   virtual int set_option(const char* name, long long value) = 0;
+  virtual int msm_precompute(int group, const void* bases, size_t len, hipStream_t st) = 0;
+  virtual int msm_forget(const void* bases) = 0;
+  virtual int msm_table_info(int group, const void* bases, int* info) = 0;
   virtual int msm_mask_sample(int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) = 0;
   virtual int r1cs_qap(const void* pa, const void* ca, const void* va, const void* pb, const void* cb, const void* vb,
                        const void* w, size_t nvars, size_t nc, size_t ni, int log_m, void* a, void* b, void* c,

@@ -1135,6 +1135,23 @@ class Engine : public IEngine {
     return ZK_OK;
   }
 
+  int msm_precompute(int group, const void* bases, size_t len, hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (group == ZK_G1) return msm_.template precompute_t<Fq>(this, bases, len, st);
+    if (group == ZK_G2 && Cfg::HAS_G2) return msm_.template precompute_t<Fq2>(this, bases, len, st);
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+  int msm_forget(const void* bases) override {
+    return msm_.forget_table(bases) ? ZK_OK : fail(ZK_ERR_BAD_INPUT, "no table registered for this base vector");
+  }
+  int msm_table_info(int group, const void* bases, int* info) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    using Fq2 = Fp2<typename Cfg::FqP>;
+    if (!info || !bases || (group != ZK_G1 && group != ZK_G2)) return fail(ZK_ERR_BAD_INPUT, "bad argument");
+    msm_.table_info(bases, group == ZK_G2 ? sizeof(Affine<Fq2>) : sizeof(Affine<Fq>), info);
+    return ZK_OK;
+  }
   int set_option(const char* name, long long value) override {
     if (!name) return fail(ZK_ERR_BAD_INPUT, "null option name");
     if (!strcmp(name, "msm_bigsort_min")) {

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -51,7 +53,9 @@ struct SegDesc {
 template <class FrP, int PASS>
 __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t npts, const Fp<FrP>* __restrict__ coef,
                                   size_t part_len, int c, int nwin, int wide /* windows [0, wide) have c bits, the rest
-                                  c-1 */, uint32_t* __restrict__ counts /* [nwin*B] */,
+                                  c-1 */, uint32_t pre_stride /* fixed-base table: rows of this many points, one per
+                                  window; all windows share ONE bucket set; 0 = no table */, uint32_t pre_off,
+                                  uint32_t* __restrict__ counts /* [nwin*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
@@ -78,12 +82,13 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
     if (d == 0) continue;
     uint32_t neg = d < 0 ? 1u : 0u;
     uint32_t b = (uint32_t)(neg ? -d : d) - 1;
-    uint32_t key = (uint32_t)w * B + b;
+    uint32_t key = pre_stride ? b : (uint32_t)w * B + b;
     if (PASS == 0) {
       atomicAdd(counts + key, 1u);
     } else {
       uint32_t pos = atomicAdd(cursor + key, 1u);
-      sorted[pos] = (uint32_t)i | (neg << 31);
+      uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + (uint32_t)i : (uint32_t)i;
+      sorted[pos] = idx | (neg << 31);
     }
   }
 }
@@ -612,6 +617,33 @@ __global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restr
   if (tid == 0) store_elem(out + ((size_t)blockIdx.x) * 2 + 1, ACC[0]);
 }
 
+// Fixed-base table (zk_msm_precompute): row w holds 2^(start of window w) * P_i in affine form, so that every window's
+// digit of a scalar selects a point of its own row and ALL windows share one bucket set: no per-window bucket
+// reduction, no doublings in the final fold, and the window can be wider (fewer mixed additions per point).
+template <class Fld>
+__global__ __launch_bounds__(128) void msm_table_kernel(const Affine<Fld>* __restrict__ bases, size_t len, int c,
+                                                       int nwin, int wide, Affine<Fld>* __restrict__ table) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  Affine<Fld> p = load_elem(bases + i);
+  if (p.is_identity()) {
+    for (int w = 0; w < nwin; w++) store_elem(table + (size_t)w * len + i, p);
+    return;
+  }
+  XYZZ<Fld> acc = XYZZ<Fld>::from_affine(p);
+  int left = 0;
+  for (int w = 0; w < nwin;) {                       // one inlined doubling / one inlined inversion call site
+    if (left == 0) {
+      store_elem(table + (size_t)w * len + i, xyzz_to_affine(acc));
+      left = w < wide ? c : c - 1;
+      w++;
+      if (w == nwin) break;
+    }
+    acc = xyzz_dbl(acc);
+    left--;
+  }
+}
+
 #endif  // __HIPCC__
 
 // Field type the device kernels are instantiated with: the inline tower for G2 over 8-limb base fields.
@@ -702,7 +734,16 @@ class MsmRunner {
     if (npts == 0) return ZK_OK;
     if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
     constexpr bool G2FLD = sizeof(Fld) != sizeof(Fq);
-    const int c_req = pick_c(npts, G2FLD);
+    // fixed-base table registered for this base vector (and the same window layout / offset for the second one)?
+    size_t toff = 0, toff2 = 0;
+    const Table* tab = find_table(bases, npts, sizeof(Affine<Fld>), &toff);
+    if (tab && NB == 2) {
+      const Table* tab2 = find_table(bases2, npts, sizeof(Affine<Fld>), &toff2);
+      if (!tab2 || tab2->len != tab->len || toff2 != toff || tab2->c != tab->c) tab = nullptr;
+      else bases2 = tab2->data.p;
+    }
+    if (tab) bases = tab->data.p;
+    const int c_req = tab ? tab->c : pick_c(npts, G2FLD);
     // BITS+1 bits (room for the signed-digit carry) are spread EVENLY over the windows: `wide` windows of c bits and
     // nwin-wide of c-1.  A plain c-bit split leaves a top window of a few bits (254 = 19*13 + 7) whose 64 buckets
     // each receive npts/64 points: hot atomics in the sort, long chains, and a heavy-bucket pass in every MSM.
@@ -711,13 +752,15 @@ class MsmRunner {
     const int c = (T + nwin - 1) / nwin;            // widest window
     const int wide = T - nwin * (c - 1);            // 1 <= wide <= nwin
     const uint32_t B = 1u << (c - 1);
-    const size_t nkeys = (size_t)nwin * B;
+    const int kwin = tab ? 1 : nwin;                // bucket sets: with a table all windows share one
+    const size_t nkeys = (size_t)kwin * B;
     const size_t max_sorted = npts * nwin;
+    const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
     uint32_t seg = pick_seg(npts, nwin, G2FLD);
     {
       // keep the average bucket at no more than ~4 segments: with 2^26 points and 2^16 buckets per window a 64-point
       // segment would leave 16 partial sums per bucket, i.e. every bucket on the slow heavy-bucket path
-      const size_t avg = npts >> (c - 1);
+      const size_t avg = (tab ? npts * nwin : npts) >> (c - 1);
       uint32_t want = 1;
       while ((size_t)want * 4 < avg && want < 1024) want <<= 1;
       const bool overridden = getenv("ZK_MSM_SEG") || (G2FLD && getenv("ZK_MSM_SEG_G2"));
@@ -739,11 +782,11 @@ class MsmRunner {
     size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
            o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
            o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
-           o_out = take(NB * (size_t)nwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
+           o_out = take(NB * (size_t)kwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
     // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
     const size_t big_min = bigsort_min;
     const int lo_bits = c - 1 - BIG_HI;
-    const bool big = npts >= big_min && lo_bits >= 1 && lo_bits <= 10;
+    const bool big = !tab && npts >= big_min && lo_bits >= 1 && lo_bits <= 10;
     size_t o_bins = 0, o_tmp = 0;
     if (big) {
       o_bins = take((3 * ((size_t)nwin << BIG_HI) + 1) * 4);
@@ -806,8 +849,8 @@ class MsmRunner {
                                                                      sorted);
       MSM_STAGE("big sort");
     } else {
-      msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, counts, nullptr,
-                                                  nullptr);
+      msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
+                                                  pre_off, counts, nullptr, nullptr);
       MSM_STAGE("digits/count");
     }
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
@@ -822,8 +865,8 @@ class MsmRunner {
                                                                                      lenhist + SEG_BINS, order);
     MSM_STAGE("expand");
     if (!big)
-      msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, nullptr, cursor,
-                                                  sorted);
+      msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
+                                                  pre_off, nullptr, cursor, sorted);
     }
     MSM_STAGE("scatter");
     {
@@ -860,12 +903,12 @@ class MsmRunner {
                                   (int)red_lds));
       attr_set = true;
     }
-    msm_reduce_kernel<KF, RED_THREADS, RED_G><<<dim3((unsigned)(nwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
+    msm_reduce_kernel<KF, RED_THREADS, RED_G><<<dim3((unsigned)(kwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
         buckets, nkeys, B, bpw, out);
     }
     MSM_HIP(hipGetLastError());
     MSM_STAGE("reduce");
-    std::vector<XYZZ<Fld>> hall(NB * (size_t)nwin * bpw * 2);
+    std::vector<XYZZ<Fld>> hall(NB * (size_t)kwin * bpw * 2);
     MSM_HIP(hipMemcpyAsync(hall.data(), out, hall.size() * sizeof(XYZZ<Fld>), hipMemcpyDeviceToHost, st));
     MSM_HIP(hipStreamSynchronize(st));
 #undef MSM_HIP
@@ -875,7 +918,7 @@ class MsmRunner {
     // kbits doublings before X_w's own addition.  The per-window block sums are independent; for extension-field
     // points (1.1 us per host addition) they are spread over a few host threads.
     auto fold = [&](const XYZZ<Fld>* h) -> XYZZ<Fld> {
-    std::vector<XYZZ<Fld>> wsum((size_t)nwin, XYZZ<Fld>::identity()), wts((size_t)nwin, XYZZ<Fld>::identity());
+    std::vector<XYZZ<Fld>> wsum((size_t)kwin, XYZZ<Fld>::identity()), wts((size_t)kwin, XYZZ<Fld>::identity());
     auto block_sums = [&](int w0, int w1) {
       for (int w = w0; w < w1; w++) {
         XYZZ<Fld> acc = XYZZ<Fld>::identity(), run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
@@ -890,23 +933,23 @@ class MsmRunner {
         wts[(size_t)w] = wt;
       }
     };
-    const int fold_threads = (G2FLD && bpw > 1 && nwin >= 8) ? 4 : 1;
+    const int fold_threads = (G2FLD && bpw > 1 && kwin >= 8) ? 4 : 1;
     if (fold_threads > 1) {
       std::thread th[3];
-      const int per_t = (nwin + fold_threads - 1) / fold_threads;
+      const int per_t = (kwin + fold_threads - 1) / fold_threads;
       for (int i = 1; i < fold_threads; i++)
-        th[i - 1] = std::thread(block_sums, std::min(nwin, i * per_t), std::min(nwin, (i + 1) * per_t));
-      block_sums(0, std::min(nwin, per_t));
+        th[i - 1] = std::thread(block_sums, std::min(kwin, i * per_t), std::min(kwin, (i + 1) * per_t));
+      block_sums(0, std::min(kwin, per_t));
       for (int i = 1; i < fold_threads; i++) th[i - 1].join();
     } else {
-      block_sums(0, nwin);
+      block_sums(0, kwin);
     }
     constexpr uint64_t KBLK = (uint64_t)RED_THREADS * RED_G;
     int kbits = 0;
     while (((uint64_t)1 << kbits) < KBLK) kbits++;
     static_assert((KBLK & (KBLK - 1)) == 0, "RED_THREADS * RED_G must be a power of two");
     XYZZ<Fld> total = XYZZ<Fld>::identity();
-    for (int w = nwin - 1; w >= 0; w--) {
+    for (int w = kwin - 1; w >= 0; w--) {
       const int cw = w < wide ? c : c - 1;
       if (bpw > 1 && kbits <= cw) {
         for (int i = 0; i < cw - kbits; i++) total = xyzz_dbl_ni(total);
@@ -922,7 +965,7 @@ class MsmRunner {
     };
     if (NB == 2) {
       // the second fold runs beside the first (both are short dependent chains on the host)
-      std::thread t2([&]() { *result2 = fold(hall.data() + (size_t)nwin * bpw * 2); });
+      std::thread t2([&]() { *result2 = fold(hall.data() + (size_t)kwin * bpw * 2); });
       *result = fold(hall.data());
       t2.join();
     } else {
@@ -1139,6 +1182,79 @@ class MsmRunner {
   }
   ~MsmRunner() {
     if (coef_d_) (void)hipFree(coef_d_);
+  }
+
+  // ---- fixed-base tables (zk_msm_precompute): looked up by the address range of the base vector
+  struct Table {
+    const char* base = nullptr;     // the registered affine vector [len]
+    size_t len = 0, elem = 0;
+    int c = 0, nwin = 0, wide = 0;
+    DevBuf data;                    // [nwin][len] affine
+  };
+  std::vector<std::unique_ptr<Table>> tables_;
+  std::mutex tmu_;
+  static constexpr int TABLE_C = 16;
+  const Table* find_table(const void* p, size_t npts, size_t elem, size_t* offset) {
+    std::lock_guard<std::mutex> g(tmu_);
+    const char* q = (const char*)p;
+    for (auto& t : tables_)
+      if (t->elem == elem && q >= t->base && q + npts * elem <= t->base + t->len * elem && (q - t->base) % elem == 0) {
+        *offset = (size_t)(q - t->base) / elem;
+        return t.get();
+      }
+    return nullptr;
+  }
+  template <class Fld>
+  int precompute_t(IEngine* eng, const void* bases, size_t len, hipStream_t st) {
+#if defined(__HIPCC__)
+    if (!bases || !len) return eng->fail(ZK_ERR_BAD_INPUT, "null base vector");
+    const int T = FrP::BITS + 1;
+    const int nwin = (T + TABLE_C - 1) / TABLE_C;
+    const int c = (T + nwin - 1) / nwin;
+    if ((size_t)nwin * len >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "base vector too long for a table");
+    auto t = std::make_unique<Table>();
+    t->base = (const char*)bases;
+    t->len = len;
+    t->elem = sizeof(Affine<Fld>);
+    t->c = c;
+    t->nwin = nwin;
+    t->wide = T - nwin * (c - 1);
+    hipError_t he = t->data.ensure((size_t)nwin * len * sizeof(Affine<Fld>));
+    if (he != hipSuccess) return eng->hip_fail(he, "msm table");
+    using KF = typename KernelField<Fld>::type;
+    msm_table_kernel<KF><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
+        (const Affine<KF>*)bases, len, c, nwin, t->wide, (Affine<KF>*)t->data.p);
+    he = hipGetLastError();
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) return eng->hip_fail(he, "msm_table_kernel");
+    std::lock_guard<std::mutex> g(tmu_);
+    for (auto it = tables_.begin(); it != tables_.end(); ++it)
+      if ((*it)->base == t->base) {
+        tables_.erase(it);
+        break;
+      }
+    tables_.push_back(std::move(t));
+    return ZK_OK;
+#else
+    (void)eng; (void)bases; (void)len; (void)st;
+    return ZK_ERR_GENERIC;
+#endif
+  }
+  int forget_table(const void* bases) {
+    std::lock_guard<std::mutex> g(tmu_);
+    for (auto it = tables_.begin(); it != tables_.end(); ++it)
+      if ((*it)->base == (const char*)bases) {
+        tables_.erase(it);
+        return 1;
+      }
+    return 0;
+  }
+  // [window bits, digit windows] of the table registered for `bases`, or zeros
+  void table_info(const void* bases, size_t elem, int* out) {
+    size_t off;
+    const Table* t = find_table(bases, 1, elem, &off);
+    out[0] = t ? t->c : 0;
+    out[1] = t ? t->nwin : 0;
   }
 
   // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min"; env ZK_MSM_BIGSORT_MIN at start)

@@ -209,6 +209,17 @@ class Crs:
                              "h_query": q(setup.h_query, ZK_G1)}
         self._make_ct()
 
+    def precompute(self, pp=None):
+        """Fixed-base tables for the five query vectors (zk_msm_precompute): for a service that proves many witnesses
+        against this CRS.  16 x the size of the packed CRS shares in HBM.  Tables belong to a context: pass `pp` to
+        build them for another context that proves against the same CRS buffers."""
+        from . import api
+        pp = pp or self.pp
+        for buf, grp, ln in ((self.s, ZK_G1, self.len_a), (self.h, ZK_G1, self.len_a), (self.v, ZK_G2, self.len_a),
+                             (self.w, ZK_G1, self.len_w), (self.u, ZK_G1, self.len_u)):
+            api.msm_precompute(pp, grp, buf, pp.n * ln)
+        return self
+
     def _make_ct(self):
         self.ct = CrsShare(self.s.ptr, self.h.ptr, self.v.ptr, self.w.ptr, self.u.ptr, self.len_a, self.len_w,
                            self.len_u, self.s1[0].ctypes.data, self.s1[1].ctypes.data, self.s1[2].ctypes.data,
