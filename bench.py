@@ -114,7 +114,7 @@ def roofline_of(prof, ntt_passes, pp=None, table_windows=None):
         pts = int(best["units"] / best["launches"])
         plan = msm_plan(pp, ZK_G2 if "G2" in name else ZK_G1, pts)
         if table_windows:           # fixed-base tables: every MSM runs with the table's window layout
-            plan["windows"], plan["window_bits"], plan["fixed_base_table"] = table_windows, 16, True
+            plan["windows"], plan["window_bits"], plan["fixed_base_table"] = table_windows, -(-256 // table_windows), True
         muls = pts * plan["windows"] * plan["muls_per_add"]
         rate = muls / (avg_ms * 1e-3) / 1e9
         alu = {"achieved": round(rate, 2), "peak": MUL_PEAK_G, "unit": "G modmul/s (256-bit Montgomery)",
@@ -259,6 +259,8 @@ def main():
     table_windows = None
     if not args.no_tables:
         from zksaas_amd import api
+        if os.environ.get("ZK_TABLE_C"):
+            pp.set_option("msm_table_c", int(os.environ["ZK_TABLE_C"]))
         crs.precompute()
         table_windows = api.msm_table_info(pp, api.ZK_G1, crs.s)["windows"]
     seed = 1000

@@ -210,6 +210,7 @@ int zk_msm_forget(zk_ctx* ctx, const void* bases_d);
 int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
 /* Tunables of this context (no reference counterpart).  "msm_bigsort_min": point count from which zk_msm sorts with
  * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
+ * "msm_table_c": window bits (8..20, default 16) of tables built by later zk_msm_precompute calls.
  * Unknown name -> ZK_ERR_BAD_INPUT. */
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
 /* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value

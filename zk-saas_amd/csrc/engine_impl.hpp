@@ -1159,6 +1159,11 @@ class Engine : public IEngine {
       msm_.bigsort_min = (size_t)value;
       return ZK_OK;
     }
+    if (!strcmp(name, "msm_table_c")) {
+      if (value < 8 || value > 20) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be in 8..20");
+      msm_.table_c = (int)value;
+      return ZK_OK;
+    }
     return fail(ZK_ERR_BAD_INPUT, "unknown option");
   }
   int msm_plan(int group, size_t len, int* plan) override {

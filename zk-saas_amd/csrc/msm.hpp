@@ -1193,7 +1193,7 @@ class MsmRunner {
   };
   std::vector<std::unique_ptr<Table>> tables_;
   std::mutex tmu_;
-  static constexpr int TABLE_C = 16;
+  int table_c = 16;               // window bits of new tables (zk_ctx_set_option "msm_table_c")
   const Table* find_table(const void* p, size_t npts, size_t elem, size_t* offset) {
     std::lock_guard<std::mutex> g(tmu_);
     const char* q = (const char*)p;
@@ -1209,7 +1209,7 @@ class MsmRunner {
 #if defined(__HIPCC__)
     if (!bases || !len) return eng->fail(ZK_ERR_BAD_INPUT, "null base vector");
     const int T = FrP::BITS + 1;
-    const int nwin = (T + TABLE_C - 1) / TABLE_C;
+    const int nwin = (T + table_c - 1) / table_c;
     const int c = (T + nwin - 1) / nwin;
     if ((size_t)nwin * len >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "base vector too long for a table");
     auto t = std::make_unique<Table>();
