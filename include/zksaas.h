@@ -203,6 +203,8 @@ int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
  * size of the vector).  Every later zk_msm / zk_d_msm / zk_groth16_prove whose base pointer lies inside a registered
  * vector uses its table: all windows then share one bucket set (one bucket reduction, no doublings in the final
  * fold, 16 instead of 20-22 mixed additions per point).  Results are the same group elements.
+ * zk_free drops the tables of vectors inside the freed allocation; for memory the caller frees itself (e.g. a torch
+ * tensor) call zk_msm_forget first -- tables are found by address.
  * zk_msm_forget drops the table of bases_d (returns ZK_ERR_BAD_INPUT if there is none); zk_msm_table_info writes
  * info[0] = window bits, info[1] = digit windows of the table that covers bases_d (zeros if none). */
 int zk_msm_precompute(zk_ctx* ctx, int group, const void* bases_d, size_t len, void* stream);

@@ -306,3 +306,34 @@ def test_fixed_base_table_gives_the_same_msm(curve, group):
         assert G.eq(dec_jacobian(pp, d_with[p], is2), dec_jacobian(pp, d_plain[p], is2))
     with pytest.raises(zk.ZkError):
         api.msm_forget(pp, bases)
+
+
+def test_fixed_base_table_is_dropped_with_its_vector_and_errors():
+    """Tables are found by address: freeing the base vector through zk_free must drop its table (a later allocation at
+    the same address would otherwise be multiplied through a stale table); argument errors of the table API."""
+    from zksaas_amd import api
+    c = CURVES["bn254"]
+    pp = zk.PackedSharingParams("bn254", 2)
+    G = g1(c)
+    n = 300
+    pts_a, pts_b = _points(G, c, n, 70), _points(G, c, n, 71)
+    sc = rand_vec(72, n, c.r)
+    sc_d = up(pp, sc)
+    a = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts_a))
+    api.msm_precompute(pp, ZK_G1, a, n)
+    addr = a.ptr
+    a.free()
+    b = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts_b))        # very likely the same address again
+    if b.ptr == addr:
+        assert api.msm_table_info(pp, ZK_G1, b)["windows"] == 0
+    assert G.eq(dec_jacobian(pp, msm(pp, ZK_G1, b, sc_d, n)), G.msm(pts_b, sc))
+    with pytest.raises(zk.ZkError):
+        api.msm_precompute(pp, ZK_G1, None, n)
+    with pytest.raises(zk.ZkError):
+        api.msm_precompute(pp, 7, b, n)
+    with pytest.raises(zk.ZkError):
+        pp.set_option("msm_table_c", 40)
+    pp.set_option("msm_table_c", 12)                                  # another window width: 22 digit windows
+    api.msm_precompute(pp, ZK_G1, b, n)
+    assert api.msm_table_info(pp, ZK_G1, b) == {"window_bits": 12, "windows": 22}
+    assert G.eq(dec_jacobian(pp, msm(pp, ZK_G1, b, sc_d, n)), G.msm(pts_b, sc))

@@ -72,6 +72,16 @@ int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
 }
 int zk_free(zk_ctx* ctx, void* p_d) {
   CTX_OR_FAIL();
+  // a fixed-base table is found by the ADDRESS of its base vector: drop the tables of vectors inside this allocation,
+  // or a later allocation at the same address would silently be multiplied through a stale table
+  if (p_d) {
+    hipDeviceptr_t abase = nullptr;
+    size_t asize = 0;
+    if (hipMemGetAddressRange(&abase, &asize, (hipDeviceptr_t)p_d) == hipSuccess && asize)
+      e->msm_forget_range(abase, asize);
+    else
+      e->msm_forget_range(p_d, 1);
+  }
   hipError_t h = hipFree(p_d);
   return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipFree");
 }

@@ -149,6 +149,7 @@ class IEngine {
   virtual int set_option(const char* name, long long value) = 0;
   virtual int msm_precompute(int group, const void* bases, size_t len, hipStream_t st) = 0;
   virtual int msm_forget(const void* bases) = 0;
+  virtual void msm_forget_range(const void* base, size_t bytes) = 0;
   virtual int msm_table_info(int group, const void* bases, int* info) = 0;
   virtual int msm_mask_sample(int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) = 0;
   virtual int r1cs_qap(const void* pa, const void* ca, const void* va, const void* pb, const void* cb, const void* vb,

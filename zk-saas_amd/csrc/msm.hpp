@@ -1249,6 +1249,14 @@ class MsmRunner {
       }
     return 0;
   }
+  // drop every table whose base vector starts inside [base, base + bytes) (the allocation is being freed)
+  void forget_range(const void* base, size_t bytes) {
+    std::lock_guard<std::mutex> g(tmu_);
+    const char* lo = (const char*)base;
+    for (auto it = tables_.begin(); it != tables_.end();)
+      if ((*it)->base >= lo && (*it)->base < lo + bytes) it = tables_.erase(it);
+      else ++it;
+  }
   // [window bits, digit windows] of the table registered for `bases`, or zeros
   void table_info(const void* bases, size_t elem, int* out) {
     size_t off;
