@@ -257,7 +257,8 @@ def test_d_msm_big_sort_path_with_party_coefficients():
         assert G.eq(dec_jacobian(pp, res[0][p]), dec_jacobian(pp, res[1][p]))
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", ZK_G1), ("bn254", ZK_G2), ("bls12_381", ZK_G1)])
+@pytest.mark.parametrize("curve,group", [("bn254", ZK_G1), ("bn254", ZK_G2), ("bls12_381", ZK_G1),
+                                         ("bls12_381", ZK_G2)])
 def test_fixed_base_table_gives_the_same_msm(curve, group):
     """zk_msm_precompute: MSMs over a registered base vector (whole vector, a sub-range starting inside it, the fused
     d_msm over all parties) equal the table-free results and the oracle; zk_msm_forget restores the plain path."""
