@@ -66,8 +66,9 @@ class CpuProver:
         return self.cp.fq.enc(vals).reshape(-1)
 
     # ---- prover ----
-    def circom_h(self, qap, log_m, seed):
-        """qap: 3 arrays [n*Lc][4] (copied); returns h shares [n*Lc][4]  (ext_wit.rs:104-181, zero masks)."""
+    def circom_h(self, qap, log_m, seed, fft_masks=None, degred_mask=None):
+        """qap: 3 arrays [n*Lc][4] (copied); returns h shares [n*Lc][4]  (ext_wit.rs:104-181).  fft_masks: six
+        (in_mask, out_mask) array pairs [n*Lc][4] or None; degred_mask: one pair or None."""
         cp = self.cp
         m = 1 << log_m
         dom = Domain(cp.curve, m)
@@ -76,29 +77,33 @@ class CpuProver:
         ev = []
         for k in range(3):
             x = qap[k].copy()
-            cp.d_fft_arrays(x, Lc, dom.group_gen_inv, dom.size_inv, w2m, True, None, None, seed + k)
-            cp.d_fft_arrays(x, Lc, dom.group_gen, None, None, False, None, None, seed + 3 + k)
+            mi, mf = (fft_masks[k], fft_masks[3 + k]) if fft_masks else ((None, None), (None, None))
+            cp.d_fft_arrays(x, Lc, dom.group_gen_inv, dom.size_inv, w2m, True, mi[0], mi[1], seed + k)
+            cp.d_fft_arrays(x, Lc, dom.group_gen, None, None, False, mf[0], mf[1], seed + 3 + k)
             ev.append(x)
         h = cp.mul_sub_arrays(ev[0], ev[1], ev[2])
-        cp.deg_red_arrays(h, Lc, None, None, seed + 6)
+        dm = degred_mask or (None, None)
+        cp.deg_red_arrays(h, Lc, dm[0], dm[1], seed + 6)
         return h
 
-    def prove(self, inp, threads=8):
-        """inp: dict of numpy arrays (see bench.py); returns (A, B, C) Jacobian uint64 arrays and timing."""
+    def prove(self, inp, threads=8, msm_threads=1):
+        """inp: dict of numpy arrays (see bench.py); returns (A, B, C) Jacobian uint64 arrays and timing.
+        threads: parties proved concurrently; msm_threads: window-parallel threads inside each G::msm."""
         cp = self.cp
         n = cp.n
         t0 = time.perf_counter()
-        h = self.circom_h(inp["qap"], inp["log_m"], inp["seed"])
+        h = self.circom_h(inp["qap"], inp["log_m"], inp["seed"], inp.get("fft_masks"), inp.get("degred_mask"))
         t1 = time.perf_counter()
         Lc = h.shape[0] // n
 
         def party(p):
             sa = inp["a_share"][p]
-            S = cp.msm_g1_arrays(inp["s"][p], sa, sa.shape[0])
-            H = cp.msm_g1_arrays(inp["h"][p], sa, sa.shape[0])
-            V = cp.msm_g2_arrays(inp["v"][p], sa, sa.shape[0])
-            W = cp.msm_g1_arrays(inp["w"][p], inp["ax_share"][p], inp["ax_share"][p].shape[0])
-            U = cp.msm_g1_arrays(inp["u"][p], h[p * Lc:(p + 1) * Lc], Lc)
+            mt = msm_threads
+            S = cp.msm_g1_arrays(inp["s"][p], sa, sa.shape[0], mt)
+            H = cp.msm_g1_arrays(inp["h"][p], sa, sa.shape[0], mt)
+            V = cp.msm_g2_arrays(inp["v"][p], sa, sa.shape[0], mt)
+            W = cp.msm_g1_arrays(inp["w"][p], inp["ax_share"][p], inp["ax_share"][p].shape[0], mt)
+            U = cp.msm_g1_arrays(inp["u"][p], h[p * Lc:(p + 1) * Lc], Lc, mt)
             return S, H, V, W, U
 
         with ThreadPoolExecutor(max_workers=threads) as ex:

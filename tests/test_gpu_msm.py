@@ -87,8 +87,8 @@ def test_msm_window_sizes(monkeypatch):
 
 @pytest.mark.parametrize("group", [ZK_G1, ZK_G2])
 @pytest.mark.parametrize("masked", [False, True])
-def test_d_msm_matches_oracle(group, masked):  # dmsm_test.rs:13-93
-    curve = "bn254"
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_d_msm_matches_oracle(group, masked, curve):  # dmsm_test.rs:13-93
     c = CURVES[curve]
     m, l = 16, 2
     pp, o = ctx(curve, l), opp(curve, l)
@@ -116,9 +116,8 @@ def test_d_msm_matches_oracle(group, masked):  # dmsm_test.rs:13-93
     assert G.eq(o.unpack2(got, ops)[0], want)        # dmsm_test.rs:50-51
 
 
-@pytest.mark.parametrize("l", [2, 4])
-def test_deg_red_matches_oracle(l):  # deg_red.rs:142-191
-    curve = "bls12_377"
+@pytest.mark.parametrize("curve,l", [("bls12_377", 2), ("bls12_377", 4), ("bls12_381", 2), ("bn254", 2)])
+def test_deg_red_matches_oracle(curve, l):  # deg_red.rs:142-191 (BLS12-377 as the reference's tests; BLS12-381 = config 5)
     pp, o = ctx(curve, l), opp(curve, l)
     nch = 21
     secrets = rand_vec(80, nch * l, o.p)
@@ -137,9 +136,10 @@ def test_deg_red_matches_oracle(l):  # deg_red.rs:142-191
     assert down_parties(pp, dm.out_mask, pp.n, nch) == [m.out_mask for m in masks]
 
 
-@pytest.mark.parametrize("m", [32, 4096 + 64])
-def test_d_pp_matches_oracle(m):  # dpp_test.rs:16-91 and a multi-block scan
-    curve, l = "bls12_377", 2
+@pytest.mark.parametrize("curve,m", [("bls12_377", 32), ("bls12_377", 4096 + 64), ("bls12_381", 32),
+                                     ("bls12_381", 4096 + 64), ("bn254", 32)])
+def test_d_pp_matches_oracle(curve, m):  # dpp_test.rs:16-91 and a multi-block scan; BLS12-381 = BASELINE config 5
+    l = 2
     pp, o = ctx(curve, l), opp(curve, l)
     m -= m % l
     num, den = rand_vec(90, m, o.p), rand_vec(91, m, o.p)

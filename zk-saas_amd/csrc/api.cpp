@@ -71,19 +71,22 @@ int zk_malloc(zk_ctx* ctx, size_t bytes, void** out_d) {
   return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipMalloc");
 }
 int zk_free(zk_ctx* ctx, void* p_d) {
-  CTX_OR_FAIL();
-  // a fixed-base table is found by the ADDRESS of its base vector: drop the tables of vectors inside this allocation,
-  // or a later allocation at the same address would silently be multiplied through a stale table
+  // ctx may be NULL (a buffer outliving its context is still released)
+  IEngine* e = ctx ? ctx->eng : nullptr;
+  if (e) (void)hipSetDevice(e->device);
+  // a fixed-base table is found by the ADDRESS of its base vector: drop the tables (of every context) over vectors
+  // inside this allocation, or a later allocation at the same address would be multiplied through a stale table
   if (p_d) {
     hipDeviceptr_t abase = nullptr;
     size_t asize = 0;
     if (hipMemGetAddressRange(&abase, &asize, (hipDeviceptr_t)p_d) == hipSuccess && asize)
-      e->msm_forget_range(abase, asize);
+      zk::TableRegistry::inst().forget_range(abase, asize);
     else
-      e->msm_forget_range(p_d, 1);
+      zk::TableRegistry::inst().forget_range(p_d, 1);
   }
   hipError_t h = hipFree(p_d);
-  return h == hipSuccess ? ZK_OK : e->hip_fail(h, "hipFree");
+  if (h == hipSuccess) return ZK_OK;
+  return e ? e->hip_fail(h, "hipFree") : ZK_ERR_GENERIC;
 }
 int zk_memcpy_h2d(zk_ctx* ctx, void* dst_d, const void* src, size_t bytes, void* stream) {
   CTX_OR_FAIL();
@@ -278,7 +281,8 @@ int zk_groth16_msms_finish(zk_ctx* ctx, const zk_crs_share* crs, const void* h_s
 // ---- profiling slots (bench.py roofline leg) ----
 static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king_fft2_kernel", "msm_accumulate_kernel<G1>",
                                                          "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",
-                                                         "msm_finalize+reduce", "king_degred_kernel"};
+                                                         "msm_finalize+reduce<G1>", "king_degred_kernel",
+                                                         "msm_finalize+reduce<G2>"};
 int zk_profile_enable(zk_ctx* ctx, int on) {
   CTX_OR_FAIL();
   e->prof.reset();

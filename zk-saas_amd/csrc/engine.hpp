@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -24,7 +25,7 @@ struct Status {
 // Per-kernel timing slots: HIP events recorded on the launching stream around selected kernels, so that a
 // host program can read a kernel's average launch duration over exactly its own timed region (bench.py).
 enum ProfSlot { PROF_NTT_PASS = 0, PROF_KING, PROF_MSM_ACC_G1, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE,
-                PROF_DEGRED, PROF_NSLOTS };
+                PROF_DEGRED, PROF_MSM_REDUCE_G2, PROF_NSLOTS };
 
 struct Profiler {
   bool on = false;
@@ -95,6 +96,76 @@ struct ProfScope {
   }
 };
 
+// Fixed-base tables (zk_msm_precompute) are found by the ADDRESS of the registered base vector, so the registry is
+// process-wide: a zk_free issued through ANY context (or a NULL one) invalidates every table over the freed range,
+// whichever context built it.  Device addresses are unique across the GPUs of a process (unified addressing).
+// Lookups hand out shared ownership, so a table dropped while an MSM is in flight stays alive until that MSM ends.
+// A registered vector must not be modified in place while its table exists (call zk_msm_forget first).
+struct MsmTable {
+  const char* base = nullptr;     // the registered affine vector [len]
+  size_t len = 0, elem = 0;
+  int c = 0, nwin = 0, wide = 0, bits = 0, device = 0;
+  const void* owner = nullptr;    // the engine that built it (dropped with it)
+  void* data = nullptr;           // [nwin][len] affine
+  ~MsmTable() {
+    if (data) (void)hipFree(data);
+  }
+};
+class TableRegistry {
+ public:
+  static TableRegistry& inst() {
+    static TableRegistry r;
+    return r;
+  }
+  std::shared_ptr<const MsmTable> find(const void* p, size_t npts, size_t elem, int bits, size_t* offset) {
+    std::lock_guard<std::mutex> g(mu_);
+    const char* q = (const char*)p;
+    for (auto& t : v_)
+      if (t->elem == elem && t->bits == bits && q >= t->base && q + npts * elem <= t->base + t->len * elem &&
+          (size_t)(q - t->base) % elem == 0) {
+        *offset = (size_t)(q - t->base) / elem;
+        return t;
+      }
+    return nullptr;
+  }
+  void add(std::shared_ptr<MsmTable> t) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& o : v_)                              // the same registration again (another context): keep the first
+      if (o->base == t->base && o->len == t->len && o->elem == t->elem && o->c == t->c && o->bits == t->bits) return;
+    for (auto it = v_.begin(); it != v_.end();)     // otherwise a new table replaces every table it overlaps
+      if ((*it)->base < t->base + t->len * t->elem && t->base < (*it)->base + (*it)->len * (*it)->elem) it = v_.erase(it);
+      else ++it;
+    v_.push_back(std::move(t));
+  }
+  int forget(const void* base) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto it = v_.begin(); it != v_.end(); ++it)
+      if ((*it)->base == (const char*)base) {
+        v_.erase(it);
+        return 1;
+      }
+    return 0;
+  }
+  // drop every table whose base vector overlaps [lo, lo + bytes) (the allocation is being freed)
+  void forget_range(const void* lo_, size_t bytes) {
+    std::lock_guard<std::mutex> g(mu_);
+    const char* lo = (const char*)lo_;
+    for (auto it = v_.begin(); it != v_.end();)
+      if ((*it)->base < lo + bytes && lo < (*it)->base + (*it)->len * (*it)->elem) it = v_.erase(it);
+      else ++it;
+  }
+  void forget_owner(const void* owner) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto it = v_.begin(); it != v_.end();)
+      if ((*it)->owner == owner) it = v_.erase(it);
+      else ++it;
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<std::shared_ptr<MsmTable>> v_;
+};
+
 // Abstract interface the C ABI dispatches to (one implementation per curve).
 class IEngine {
  public:
@@ -149,7 +220,6 @@ class IEngine {
   virtual int set_option(const char* name, long long value) = 0;
   virtual int msm_precompute(int group, const void* bases, size_t len, hipStream_t st) = 0;
   virtual int msm_forget(const void* bases) = 0;
-  virtual void msm_forget_range(const void* base, size_t bytes) = 0;
   virtual int msm_table_info(int group, const void* bases, int* info) = 0;
   virtual int msm_mask_sample(int group, const void* gen_affine, uint64_t seed, void* in_mask, void* out_mask) = 0;
   virtual int r1cs_qap(const void* pa, const void* ca, const void* va, const void* pb, const void* cb, const void* vb,

@@ -45,6 +45,7 @@ class Engine : public IEngine {
     device = device_;
   }
   ~Engine() override {
+    TableRegistry::inst().forget_owner(this);
     for (auto& kv : gentabs_) (void)hipFree(kv.second);
     for (auto& kv : gtabs_) {
       (void)hipFree(kv.second.tab);
@@ -1145,7 +1146,6 @@ class Engine : public IEngine {
   int msm_forget(const void* bases) override {
     return msm_.forget_table(bases) ? ZK_OK : fail(ZK_ERR_BAD_INPUT, "no table registered for this base vector");
   }
-  void msm_forget_range(const void* base, size_t bytes) override { msm_.forget_range(base, bytes); }
   int msm_table_info(int group, const void* bases, int* info) override {
     using Fq = Fp<typename Cfg::FqP>;
     using Fq2 = Fp2<typename Cfg::FqP>;

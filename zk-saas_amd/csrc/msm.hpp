@@ -738,13 +738,13 @@ class MsmRunner {
     constexpr bool G2FLD = sizeof(Fld) != sizeof(Fq);
     // fixed-base table registered for this base vector (and the same window layout / offset for the second one)?
     size_t toff = 0, toff2 = 0;
-    const Table* tab = find_table(bases, npts, sizeof(Affine<Fld>), &toff);
+    std::shared_ptr<const MsmTable> tab = find_table(bases, npts, sizeof(Affine<Fld>), &toff), tab2;
     if (tab && NB == 2) {
-      const Table* tab2 = find_table(bases2, npts, sizeof(Affine<Fld>), &toff2);
+      tab2 = find_table(bases2, npts, sizeof(Affine<Fld>), &toff2);
       if (!tab2 || tab2->len != tab->len || toff2 != toff || tab2->c != tab->c) tab = nullptr;
-      else bases2 = tab2->data.p;
+      else bases2 = tab2->data;
     }
-    if (tab) bases = tab->data.p;
+    if (tab) bases = tab->data;
     const int c_req = tab ? tab->c : pick_c(npts, G2FLD);
     // BITS+1 bits (room for the signed-digit carry) are spread EVENLY over the windows: `wide` windows of c bits and
     // nwin-wide of c-1.  A plain c-bit split leaves a top window of a few bits (254 = 19*13 + 7) whose 64 buckets
@@ -885,7 +885,7 @@ class MsmRunner {
     }
     MSM_STAGE("accumulate");
     {
-    ProfScope ps_(eng->prof, PROF_MSM_REDUCE, st, (double)npts);
+    ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_REDUCE_G2 : PROF_MSM_REDUCE, st, (double)nkeys * NB);   // units: buckets
     MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
     msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + 127) / 128), NB), dim3(128), 0, st>>>(
         partial, max_segs, offsets, nkeys, buckets, heavy);
@@ -1186,25 +1186,10 @@ class MsmRunner {
     if (coef_d_) (void)hipFree(coef_d_);
   }
 
-  // ---- fixed-base tables (zk_msm_precompute): looked up by the address range of the base vector
-  struct Table {
-    const char* base = nullptr;     // the registered affine vector [len]
-    size_t len = 0, elem = 0;
-    int c = 0, nwin = 0, wide = 0;
-    DevBuf data;                    // [nwin][len] affine
-  };
-  std::vector<std::unique_ptr<Table>> tables_;
-  std::mutex tmu_;
+  // ---- fixed-base tables (zk_msm_precompute): process-wide registry keyed by address (engine.hpp TableRegistry)
   int table_c = 16;               // window bits of new tables (zk_ctx_set_option "msm_table_c")
-  const Table* find_table(const void* p, size_t npts, size_t elem, size_t* offset) {
-    std::lock_guard<std::mutex> g(tmu_);
-    const char* q = (const char*)p;
-    for (auto& t : tables_)
-      if (t->elem == elem && q >= t->base && q + npts * elem <= t->base + t->len * elem && (q - t->base) % elem == 0) {
-        *offset = (size_t)(q - t->base) / elem;
-        return t.get();
-      }
-    return nullptr;
+  std::shared_ptr<const MsmTable> find_table(const void* p, size_t npts, size_t elem, size_t* offset) {
+    return TableRegistry::inst().find(p, npts, elem, FrP::BITS, offset);
   }
   template <class Fld>
   int precompute_t(IEngine* eng, const void* bases, size_t len, hipStream_t st) {
@@ -1214,55 +1199,36 @@ class MsmRunner {
     const int nwin = (T + table_c - 1) / table_c;
     const int c = (T + nwin - 1) / nwin;
     if ((size_t)nwin * len >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "base vector too long for a table");
-    auto t = std::make_unique<Table>();
+    auto t = std::make_shared<MsmTable>();
     t->base = (const char*)bases;
     t->len = len;
     t->elem = sizeof(Affine<Fld>);
     t->c = c;
     t->nwin = nwin;
     t->wide = T - nwin * (c - 1);
-    hipError_t he = t->data.ensure((size_t)nwin * len * sizeof(Affine<Fld>));
+    t->bits = FrP::BITS;
+    t->device = eng->device;
+    t->owner = eng;
+    hipError_t he = hipMalloc(&t->data, (size_t)nwin * len * sizeof(Affine<Fld>));
     if (he != hipSuccess) return eng->hip_fail(he, "msm table");
     using KF = typename KernelField<Fld>::type;
     msm_table_kernel<KF><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, len, c, nwin, t->wide, (Affine<KF>*)t->data.p);
+        (const Affine<KF>*)bases, len, c, nwin, t->wide, (Affine<KF>*)t->data);
     he = hipGetLastError();
     if (he == hipSuccess) he = hipStreamSynchronize(st);
     if (he != hipSuccess) return eng->hip_fail(he, "msm_table_kernel");
-    std::lock_guard<std::mutex> g(tmu_);
-    for (auto it = tables_.begin(); it != tables_.end(); ++it)
-      if ((*it)->base == t->base) {
-        tables_.erase(it);
-        break;
-      }
-    tables_.push_back(std::move(t));
+    TableRegistry::inst().add(std::move(t));
     return ZK_OK;
 #else
     (void)eng; (void)bases; (void)len; (void)st;
     return ZK_ERR_GENERIC;
 #endif
   }
-  int forget_table(const void* bases) {
-    std::lock_guard<std::mutex> g(tmu_);
-    for (auto it = tables_.begin(); it != tables_.end(); ++it)
-      if ((*it)->base == (const char*)bases) {
-        tables_.erase(it);
-        return 1;
-      }
-    return 0;
-  }
-  // drop every table whose base vector starts inside [base, base + bytes) (the allocation is being freed)
-  void forget_range(const void* base, size_t bytes) {
-    std::lock_guard<std::mutex> g(tmu_);
-    const char* lo = (const char*)base;
-    for (auto it = tables_.begin(); it != tables_.end();)
-      if ((*it)->base >= lo && (*it)->base < lo + bytes) it = tables_.erase(it);
-      else ++it;
-  }
+  int forget_table(const void* bases) { return TableRegistry::inst().forget(bases); }
   // [window bits, digit windows] of the table registered for `bases`, or zeros
   void table_info(const void* bases, size_t elem, int* out) {
     size_t off;
-    const Table* t = find_table(bases, 1, elem, &off);
+    auto t = find_table(bases, 1, elem, &off);
     out[0] = t ? t->c : 0;
     out[1] = t ? t->nwin : 0;
   }

@@ -254,6 +254,46 @@ class Witness:
         self.ax_share, self.len_w = deal(w[ni:], seed + 4)
 
 
+class ProofMasks:
+    """All preprocessing material of one proof, dealt as groth16/examples/sha256.rs:226-291 does: six FftMask (three
+    for the d_ifft with the coset shift w_2m and rearranged output, three for the d_fft), one DegRedMask and five
+    MsmMask (A, B-in-G1, B-in-G2, C.w, C.u), all sampled by the library's dealers (zk_fft_mask_sample,
+    zk_degred_mask_sample, zk_msm_mask_sample).  `.ct` is the zk_groth16_masks to pass to prove()."""
+
+    def __init__(self, pp, log_m, seed):
+        from . import api
+        m = 1 << log_m
+        w2m = _root_of_unity(pp.curve, log_m + 1)
+        self.fft = [api.FftMask.sample(pp, k < 3, w2m if k < 3 else None, 1 if k < 3 else 0, log_m, seed + k)
+                    for k in range(6)]
+        self.degred = api.DegRedMask.sample(pp, m // pp.l, seed + 6)
+        g1 = _affine_codec(pp, list(G1_GEN[pp.curve]), False)
+        gg = G2_GEN[pp.curve]
+        g2 = _affine_codec(pp, [gg[0][0], gg[0][1], gg[1][0], gg[1][1]], True)
+        self.msm = [api.MsmMask.sample(pp, ZK_G2 if k == 2 else ZK_G1, g2 if k == 2 else g1, seed + 7 + k)
+                    for k in range(5)]
+        ct = Masks()
+        for k in range(6):
+            ct.fft_in[k], ct.fft_out[k] = self.fft[k].in_mask.ptr, self.fft[k].out_mask.ptr
+        ct.degred_in, ct.degred_out = self.degred.in_mask.ptr, self.degred.out_mask.ptr
+        for k in range(5):
+            ct.msm_in[k], ct.msm_out[k] = self.msm[k].in_mask.ctypes.data, self.msm[k].out_mask.ctypes.data
+        self.ct = ct
+
+
+def verifying_key(pp, setup):
+    """ark_groth16::VerifyingKey of a trapdoor setup as affine coordinate ints (verifier side, not the hot path):
+    dict(alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1)."""
+    nl = pp.fq.nl
+    g1 = base_points(pp, ZK_G1, pp.upload_fr([setup.alpha] + list(setup.gamma_abc)), 1 + len(setup.gamma_abc))
+    g2 = base_points(pp, ZK_G2, pp.upload_fr([setup.beta, setup.gamma, setup.delta]), 3)
+    a1 = pp.fq.decode(g1.to_numpy().reshape(-1, nl))
+    a2 = pp.fq.decode(g2.to_numpy().reshape(-1, nl))
+    p1 = [(a1[2 * i], a1[2 * i + 1]) for i in range(len(a1) // 2)]
+    p2 = [((a2[4 * i], a2[4 * i + 1]), (a2[4 * i + 2], a2[4 * i + 3])) for i in range(3)]
+    return {"alpha_g1": p1[0], "gamma_abc_g1": p1[1:], "beta_g2": p2[0], "gamma_g2": p2[1], "delta_g2": p2[2]}
+
+
 def prove(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
     """dsha256 (sha256.rs:32-129) for all parties. Returns (pi_a [n][3nl], pi_b [n][6nl], pi_c [n][3nl]) Jacobian."""
     nl = pp.fq.nl
@@ -262,6 +302,8 @@ def prove(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
     pc = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
     rr, ss = pp.fr.encode_one(r), pp.fr.encode_one(s)
     assert crs.len_a == wit.len_a and crs.len_w == wit.len_w
+    if isinstance(masks, ProofMasks):
+        masks = masks.ct
     pp._check(pp.lib.zk_groth16_prove(pp.h, C.byref(crs.ct), wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr,
                                       wit.a_share.ptr, wit.ax_share.ptr, rr.ctypes.data, ss.ctypes.data, wit.log_m,
                                       None if masks is None else C.byref(masks), seed, pa.ctypes.data,

@@ -142,8 +142,17 @@ class _Builder:
         return bits[:32]
 
 
-def build(a_val, b_val, p):
-    """Returns (R1CS, full_assignment) for inputs a, b < 2^216 over the prime field p."""
+REFERENCE_WIRES = 29823      # witnessSize of the reference's compiled fixture
+
+
+def build(a_val, b_val, p, pad_wires=None):
+    """Returns (R1CS, full_assignment) for inputs a, b < 2^216 over the prime field p.
+
+    pad_wires: total number of variables to pad the system to (REFERENCE_WIRES = 29 823 gives exactly the vector
+    lengths of the reference's run: a_share / ax_share 14 911 per party).  circomlib's
+    Sha256_2 spends ~3.5k more intermediate signals than the gadgets used here; the padding stands in for them with
+    extra bit wires (alternating pattern derived from the digest) under their booleanity constraint
+    w * (w - 1) = 0, so the padded system is still satisfied only by a valid witness."""
     assert 0 <= a_val < (1 << 216) and 0 <= b_val < (1 << 216)
     B = _Builder(p)
     a = B.var(a_val)
@@ -182,6 +191,13 @@ def build(a_val, b_val, p):
     out_lc = B.add(*[B.scale(dbit(255 - i), 1 << i) for i in range(216)])
     B.values[1] = B.val(out_lc)
     B.enforce(out_lc, B.const(1), {1: 1})
+    if pad_wires is not None:
+        if pad_wires < len(B.values):
+            raise ValueError("pad_wires below the size of the circuit (%d variables)" % len(B.values))
+        k = 0
+        while len(B.values) < pad_wires:
+            B.bit((B.values[1] >> (k % 216)) & 1)       # bit() adds the wire and its booleanity constraint
+            k += 1
     r1cs = R1CS(2, len(B.values) - 2, B.A, B.B, B.C)
     return r1cs, B.values
 
