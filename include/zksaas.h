@@ -239,13 +239,23 @@ int zk_fr_from_bytes(zk_ctx* ctx, const void* bytes_d, size_t len, void* x_out_d
 /* The five zk_d_msm_local of the prover for this rank's parties, overlapped: _begin starts S, H, V, W (they only
  * need the witness shares; crs vectors are [nparties][len] here) on internal streams and returns; _finish runs U
  * on `stream` once h_share_d [nparties][m/l] is available, joins, and writes out[0..4] = S, H, V(G2), W, U
- * (Jacobian, host).  skip_h != 0 when r = 0 (prove.rs:96-98).  Stream ordering: _begin's internal streams wait
- * for everything already queued on the legacy default stream (it has no stream argument); zk_groth16_prove's
- * internal streams wait for everything already queued on its `stream`. */
+ * (Jacobian, host).  skip_h != 0 when r = 0 (prove.rs:96-98).  masks (optional): msm_in[k] = this rank's nparties
+ * in-mask points of MSM k (the other members are ignored here).  The internal streams wait for everything already
+ * queued on `stream` (the shares may still be in flight there).  crs must stay valid until _finish returns. */
 int zk_groth16_msms_begin(zk_ctx* ctx, const zk_crs_share* crs, const void* a_share_d, const void* ax_share_d,
-                          int first_party, int nparties, int skip_h);
-int zk_groth16_msms_finish(zk_ctx* ctx, const zk_crs_share* crs, const void* h_share_d, int first_party, int nparties,
-                           void* const* out, void* stream);
+                          int first_party, int nparties, int skip_h, const zk_groth16_masks* masks, void* stream);
+int zk_groth16_msms_finish(zk_ctx* ctx, const void* h_share_d, void* const* out, void* stream);
+/* Asynchronous form of zk_groth16_prove (what `tokio::spawn(dsha256(..))` is to the reference, multi.rs:317-327):
+ * _async enqueues the whole proof -- device pipelines on internal streams, host-side terms on the context's worker
+ * pool -- and returns a handle without waiting; _wait joins and writes the shares.  Up to two proofs may be in
+ * flight per context (each has its own scratch); inputs must stay valid and unmodified until _wait returns.
+ * _abort joins and discards a proof in flight (also safe after a failed call). */
+int zk_groth16_prove_async(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                           const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r,
+                           const void* s, int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* stream,
+                           int* handle);
+int zk_groth16_wait(zk_ctx* ctx, int handle, void* pi_a, void* pi_b, void* pi_c);
+int zk_groth16_abort(zk_ctx* ctx, int handle);
 int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                         const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c);
 

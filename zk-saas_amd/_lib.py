@@ -14,7 +14,7 @@ SYMBOLS = [
     "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
     "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove", "zk_profile_enable",
     "zk_profile_slots", "zk_profile_name", "zk_profile_read", "zk_d_msm_local", "zk_group_add", "zk_groth16_assemble",
-    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
+    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_groth16_prove_async", "zk_groth16_wait", "zk_groth16_abort", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
 ]
 
@@ -108,8 +108,11 @@ def load():
     lib.zk_fr_to_bytes.argtypes = [vp, vp, sz, vp, vp]
     lib.zk_fr_from_bytes.argtypes = [vp, vp, sz, vp, vp]
     lib.zk_groth16_assemble.argtypes = [vp, vp, vp, vp, C.POINTER(vp), vp, vp, vp, vp]
-    lib.zk_groth16_msms_begin.argtypes = [vp, vp, vp, vp, i32, i32, i32]
-    lib.zk_groth16_msms_finish.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp), vp]
+    lib.zk_groth16_msms_begin.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.zk_groth16_msms_finish.argtypes = [vp, vp, C.POINTER(vp), vp]
+    lib.zk_groth16_prove_async.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, C.POINTER(i32)]
+    lib.zk_groth16_wait.argtypes = [vp, i32, vp, vp, vp]
+    lib.zk_groth16_abort.argtypes = [vp, i32]
     lib.zk_vec_scale.argtypes = [vp, vp, vp, sz, vp]
     lib.zk_deg_red_parties.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, vp, vp, sz, u64, vp, vp]
     lib.zk_d_msm_parties.argtypes = [vp, i32, vp, vp, sz, C.POINTER(C.c_uint32), i32, vp, vp, vp, vp]

@@ -268,14 +268,29 @@ int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, con
 }
 
 int zk_groth16_msms_begin(zk_ctx* ctx, const zk_crs_share* crs, const void* a_share_d, const void* ax_share_d,
-                          int first_party, int nparties, int skip_h) {
+                          int first_party, int nparties, int skip_h, const zk_groth16_masks* masks, void* stream) {
   CTX_OR_FAIL();
-  return e->msms_begin(crs, a_share_d, ax_share_d, first_party, nparties, skip_h);
+  return e->msms_begin(crs, a_share_d, ax_share_d, first_party, nparties, skip_h, masks, S(stream));
 }
-int zk_groth16_msms_finish(zk_ctx* ctx, const zk_crs_share* crs, const void* h_share_d, int first_party, int nparties,
-                           void* const* out, void* stream) {
+int zk_groth16_msms_finish(zk_ctx* ctx, const void* h_share_d, void* const* out, void* stream) {
   CTX_OR_FAIL();
-  return e->msms_finish(crs, h_share_d, first_party, nparties, out, S(stream));
+  return e->msms_finish(h_share_d, out, S(stream));
+}
+int zk_groth16_prove_async(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                           const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r,
+                           const void* s, int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* stream,
+                           int* handle) {
+  CTX_OR_FAIL();
+  return e->groth16_prove_async(crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
+                                S(stream), handle);
+}
+int zk_groth16_wait(zk_ctx* ctx, int handle, void* pi_a, void* pi_b, void* pi_c) {
+  CTX_OR_FAIL();
+  return e->groth16_wait(handle, pi_a, pi_b, pi_c);
+}
+int zk_groth16_abort(zk_ctx* ctx, int handle) {
+  CTX_OR_FAIL();
+  return e->groth16_abort(handle);
 }
 
 // ---- profiling slots (bench.py roofline leg) ----

@@ -173,7 +173,9 @@ class IEngine {
   Profiler prof;
   int l = 0, n = 0, t = 0, device = 0;
   Status last;
+  std::mutex last_mu;               // host worker tasks report failures too
   int fail(int code, const std::string& m, int party = -1) {
+    std::lock_guard<std::mutex> lk(last_mu);
     last.code = code;
     last.msg = m;
     last.party = party;
@@ -229,9 +231,13 @@ class IEngine {
   virtual int groth16_assemble(const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                                const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count,
-                         int skip_h) = 0;
-  virtual int msms_finish(const zk_crs_share* crs, const void* h_share, int first, int count, void* const* out,
-                          hipStream_t st) = 0;
+                         int skip_h, const zk_groth16_masks* masks, hipStream_t st) = 0;
+  virtual int msms_finish(const void* h_share, void* const* out, hipStream_t st) = 0;
+  virtual int groth16_prove_async(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                                  const void* a_share, const void* ax_share, const void* r, const void* s, int log_m,
+                                  const zk_groth16_masks* masks, uint64_t seed, hipStream_t st, int* handle) = 0;
+  virtual int groth16_wait(int handle, void* pi_a, void* pi_b, void* pi_c) = 0;
+  virtual int groth16_abort(int handle) = 0;
   virtual int pss_pack_points(int group, const void* points, size_t nchunks, int nv, void* shares, hipStream_t st) = 0;
   virtual int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
                        hipStream_t st) = 0;

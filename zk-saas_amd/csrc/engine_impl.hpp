@@ -7,6 +7,7 @@
 #include "groth16.hpp"
 #include "qap.hpp"
 #include "msm.hpp"
+#include "hostpool.hpp"
 
 namespace zk {
 
@@ -45,6 +46,9 @@ class Engine : public IEngine {
     device = device_;
   }
   ~Engine() override {
+    for (auto& j : jobs_)
+      if (j.active) abort_job(j);
+    pool_.reset();                                   // joins the host workers before anything they use goes away
     TableRegistry::inst().forget_owner(this);
     for (auto& kv : gentabs_) (void)hipFree(kv.second);
     for (auto& kv : gtabs_) {
@@ -786,14 +790,18 @@ class Engine : public IEngine {
   }
   int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
                void* h, hipStream_t st) override {
+    return circom_h_ws(qa, qb, qc, log_m, mk, seed, h, hwork_, st);
+  }
+  int circom_h_ws(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
+                  void* h, DevBuf& hwork, hipStream_t st) {
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     if (log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large for this field");
     if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     size_t Lc = ((size_t)1 << log_m) / l;
     size_t per = (size_t)n * Lc;
-    ZK_HIP(hwork_.ensure(6 * per * sizeof(Fr)));
-    Fr* W0 = (Fr*)hwork_.p;
+    ZK_HIP(hwork.ensure(6 * per * sizeof(Fr)));
+    Fr* W0 = (Fr*)hwork.p;
     Fr* W1 = W0 + 3 * per;
     const void* q[3] = {qa, qb, qc};
     for (int k = 0; k < 3; k++)
@@ -817,185 +825,243 @@ class Engine : public IEngine {
   }
 
   // ---------------------------------------------------------------- prover (prove.rs, sha256.rs:32-129)
-  int groth16_prove(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
-                    const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
-                    uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
-    using Fq = Fp<typename Cfg::FqP>;
-    using Fq2 = Fp2<typename Cfg::FqP>;
-    using P1 = XYZZ<Fq>;
-    using P2 = XYZZ<Fq2>;
-    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
-    if (!crs || !r_ || !s_ || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    size_t Lc = ((size_t)1 << log_m) / l;
-    if (crs->len_u != Lc) return fail(ZK_ERR_BAD_INPUT, "h_query share length must be m/l");   // dmsm/mod.rs:71
-    Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
-    auto aff1 = [](const void* p) {
-      Affine<Fq> a;
-      memcpy(&a, p, sizeof(a));
-      return P1::from_affine(a);
-    };
-    auto aff2 = [](const void* p) {
-      Affine<Fq2> a;
-      memcpy(&a, p, sizeof(a));
-      return P2::from_affine(a);
-    };
-    // scalar multiples of CRS constants do not depend on the device work: overlap them with it
-    P1 rN, sK, rsM;
+  // One proof in flight = one ProveJob: its device scratch, the pending MSMs and the host-side terms.  Everything the
+  // host contributes (scalar multiples of CRS constants, of the out-masks and of the in-mask sums, MSM window folds)
+  // is a task of the context's persistent pool, submitted when the proof starts and running beside the device work
+  // (the overlap the reference gets from tokio::try_join!, prove.rs:209-227); prove_end only adds points.
+  using Fq_ = Fp<typename Cfg::FqP>;
+  using Fq2_ = Fp2<typename Cfg::FqP>;
+  using P1 = XYZZ<Fq_>;
+  using P2 = XYZZ<Fq2_>;
+  static constexpr int NJOBS = 2;                   // proofs in flight per context (zk_groth16_prove_async)
+  struct ProveJob {
+    bool active = false;
+    int slot = 0;
+    zk_crs_share crs{};
+    zk_groth16_masks mk{};
+    bool has_mk = false, r_zero = false, split_v = false, full = true;
+    int first = 0, count = 0;
+    Fr r, s;
+    DevBuf hwork, hshare;
+    MsmPending pS, pV0, pV1, pW, pU;
+    P1 S, H, W, U, sS, rH;
+    P2 V0, V1;
+    P1 rN, sK, rsM, s_cA, r_cB1;
     P2 sK2;
-    CPre<P1> pre;
-    const bool uniform = !mk || (!mk->msm_out[0] && !mk->msm_out[1] && !mk->msm_out[2] && !mk->msm_out[3] &&
-                                 !mk->msm_out[4]);
-    std::thread host([&]() {
-      P1 d1 = aff1(crs->delta_g1);
-      rN = host_scalar_mul<FrP, Fq>(d1, r);
-      sK = host_scalar_mul<FrP, Fq>(d1, s);
-      rsM = host_scalar_mul<FrP, Fq>(d1, r * s);
-      sK2 = host_scalar_mul<FrP, Fq2>(aff2(crs->delta_g2), s);
-      // s*(A - S) and r*(B1 - H): the part of C that does not wait for any MSM (prove.rs:229-235, linearity)
-      pre.s_cA = host_scalar_mul<FrP, Fq>(xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1)), s);
-      pre.r_cB1 = host_scalar_mul<FrP, Fq>(xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1)), r);
-    });
-    struct Joiner {
-      std::thread& t;
-      ~Joiner() {
-        if (t.joinable()) t.join();
-      }
-    } joiner{host};
+    P1 in1[5], s_in0, r_in1;                        // in-mask sums (index 2 unused) and their multiples
+    P2 in2;
+    std::vector<P1> s_om0, r_om1;                   // per party: s * out_mask_A[p], r * out_mask_B1[p]
+    std::vector<std::future<void>> fut;
+    int rc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    Status err;                                     // first failure reported by a task (tasks must not touch `last`)
+    std::mutex emu;
+  };
+  ProveJob jobs_[NJOBS];
 
-    // The four MSMs over the witness shares (S, H, V, W) do not depend on h: they run on their own streams
-    // (one host thread each, because every MSM ends with a small host-side fold) concurrently with circom_h;
-    // the reference gets the same overlap from tokio::try_join! (prove.rs:209-227).  U follows circom_h.
-    ZK_HIP(hshare_.ensure((size_t)n * Lc * sizeof(Fr)));
+  static P1 aff1(const void* p) {
+    Affine<Fq_> a;
+    memcpy(&a, p, sizeof(a));
+    return P1::from_affine(a);
+  }
+  static P2 aff2(const void* p) {
+    Affine<Fq2_> a;
+    memcpy(&a, p, sizeof(a));
+    return P2::from_affine(a);
+  }
+  void drain(ProveJob& j) {
+    for (auto& f : j.fut)
+      if (f.valid()) f.wait();
+    j.fut.clear();
+  }
+  // engine-level failure recorded from a pool task (IEngine::fail is not thread-safe)
+  int task_fail(ProveJob& j, int code, const std::string& msg) {
+    std::lock_guard<std::mutex> lk(j.emu);
+    if (j.err.code == ZK_OK) {
+      j.err.code = code;
+      j.err.msg = msg;
+    }
+    return code;
+  }
+
+  // Starts one proof (full = all n parties and the assembly; otherwise the five partial d_msm sums of parties
+  // [first, first + count) for the multi-GPU flow, where circom_h is driven by the caller and h arrives in finish).
+  int prove_begin(ProveJob& j, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                  const void* a_share, const void* ax_share, const Fr& r, const Fr& s, int log_m,
+                  const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st) {
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    if (j.active) return fail(ZK_ERR_BAD_INPUT, "a proof is already in flight on this slot");
     int rc = ensure_streams();
     if (rc) return rc;
-    P1 S, H, W, U;
-    P2 V;
-    const bool r_zero = r.is_zero();
-    int rcs[4] = {0, 0, 0, 0};
+    j.crs = *crs;
+    j.has_mk = mk != nullptr;
+    j.mk = mk ? *mk : zk_groth16_masks{};
+    j.r = r;
+    j.s = s;
+    j.r_zero = r.is_zero();
+    j.full = full;
+    j.first = first;
+    j.count = count;
+    j.err = Status{};
+    for (int i = 0; i < 8; i++) j.rc[i] = 0;
+    j.S = j.H = j.W = j.U = j.sS = j.rH = j.s_in0 = j.r_in1 = P1::identity();
+    j.V0 = j.V1 = j.in2 = P2::identity();
+    for (int k = 0; k < 5; k++) j.in1[k] = P1::identity();
+    j.s_om0.assign(n, P1::identity());
+    j.r_om1.assign(n, P1::identity());
+    const size_t Lc = ((size_t)1 << log_m) / l;
     const int dev = device;
-    const bool serial = getenv("ZK_SERIAL_MSM") != nullptr;     // diagnostics: clean per-kernel timings
-    // circom_h and the U-MSM that depends on it form a long dependent chain: they run on a high-priority internal
-    // stream (ordered after the caller's stream through an event).  Holding the other MSM streams (or only their
-    // accumulate launches) back until circom_h has finished was measured and rejected: 8.6-8.8 ms per proof against
-    // 6.9 ms when everything is issued at once.
-    hipStream_t hs = streams_[5];
+    const int ws0 = j.slot * 6;
     // every internal stream is ordered after the work already queued on the caller's stream (the shares may still
     // be in flight there: found by tools/c5_bls381.py, where the a_share pack kernel of a 2^22 witness was still
     // running when the S/H/V MSMs started reading it)
-    ZK_HIP(hipEventRecord(ev_in_, st));
-    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_, 0));
-    int rc_h = circom_h(qa, qb, qc, log_m, mk, seed, hshare_.p, hs);
-    if (rc_h) return rc_h;
-    auto spawn = [&](auto fn) {
-      if (serial) {
-        fn();
-        return std::thread();
-      }
-      return std::thread(fn);
+    ZK_HIP(hipEventRecord(ev_in_[j.slot], st));
+    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_[j.slot], 0));
+    j.active = true;
+    ProveJob* J = &j;
+    const size_t cstride = crs->len_a;
+    // ---- device pipelines: the four MSMs over the witness shares do not depend on h.  Each is enqueued by a pool task
+    // (a launch is a dozen kernel launches), which then waits for the slot's event and folds the windows on the host.
+    // V (G2) is the longest chain: issued first, on high-priority streams, as two halves of the party range.
+    j.split_v = count >= 2;
+    const int nh = j.split_v ? count / 2 : count;
+    const Fr* cf = msm_.coef_d_ + first;
+    auto msm_task = [this, J, dev](auto fld_tag, int which, const void* bases, const void* bases2, const void* scal,
+                                   size_t npts, const Fr* coef, size_t plen, hipStream_t stream, int wslot,
+                                   MsmPending* pend, auto* out1, auto* out2) {
+      using Fld = decltype(fld_tag);
+      J->fut.push_back(pool_->submit([=]() {
+        (void)hipSetDevice(dev);
+        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2);
+        if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
+        J->rc[which] = rc2;
+        if constexpr (std::is_same<Fld, Fq_>::value) {
+          if (!rc2 && which == 0 && J->full) {        // s*S and r*H off the tail (prove.rs:229-235, linearity)
+            J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
+            if (!J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
+          }
+        }
+      }));
     };
-    auto join = [](std::thread& t) {
-      if (t.joinable()) t.join();
-    };
-    // V (G2) is the longest chain: it is issued first, on high-priority streams, as two halves of the party range
-    P2 V0, V1;
-    int rcv1 = 0;
-    const int nh = n / 2;
-    const size_t half_bytes_b = (size_t)nh * crs->len_a * sizeof(Affine<Fq2>);
-    const size_t half_bytes_s = (size_t)nh * crs->len_a * sizeof(Fr);
-    const bool split_v = (n >= 2) && !(mk && mk->msm_in[2]);
-    std::thread tV = spawn([&]() {
-      (void)hipSetDevice(dev);
-      if (split_v)
-        rcs[2] = msm_.template d_msm_range_t<Fq2>(this, crs->v_d, a_share, crs->len_a, 0, nh, nullptr, &V0, streams_[2], 3);
-      else
-        rcs[2] = msm_.template d_msm_sum_t<Fq2>(this, crs->v_d, a_share, crs->len_a, mk ? mk->msm_in[2] : nullptr, &V,
-                                                streams_[2], 3);
-    });
-    std::thread tV1 = spawn([&]() {
-      (void)hipSetDevice(dev);
-      if (split_v)
-        rcv1 = msm_.template d_msm_range_t<Fq2>(this, (const char*)crs->v_d + half_bytes_b,
-                                                (const char*)a_share + half_bytes_s, crs->len_a, nh, n - nh, nullptr,
-                                                &V1, streams_[4], 5);
-    });
-    // S and H multiply two base vectors by the same witness shares: one sort, shared launches (msm.hpp run_t)
-    std::thread tS = spawn([&]() {
-      (void)hipSetDevice(dev);
-      if (r_zero) {
-        rcs[0] = msm_.template d_msm_sum_t<Fq>(this, crs->s_d, a_share, crs->len_a, mk ? mk->msm_in[0] : nullptr, &S,
-                                               streams_[0], 1);
-      } else {
-        rcs[0] = msm_.template d_msm_sum2_t<Fq>(this, crs->s_d, crs->h_d, a_share, crs->len_a,
-                                                mk ? mk->msm_in[0] : nullptr, mk ? mk->msm_in[1] : nullptr, &S, &H,
-                                                streams_[0], 1);
+    const char* vb = (const char*)crs->v_d;
+    const char* as = (const char*)a_share;
+    msm_task(Fq2_{}, 2, vb, nullptr, as, (size_t)nh * cstride, cf, cstride, streams_[2], ws0 + 3, &j.pV0, &j.V0,
+             (P2*)nullptr);
+    if (j.split_v)
+      msm_task(Fq2_{}, 3, vb + (size_t)nh * cstride * sizeof(Affine<Fq2_>), nullptr, as + (size_t)nh * cstride * sizeof(Fr),
+               (size_t)(count - nh) * cstride, cf + nh, cstride, streams_[4], ws0 + 5, &j.pV1, &j.V1, (P2*)nullptr);
+    // S and H multiply two base vectors by the same witness shares: one sort, shared launches
+    msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride, streams_[0],
+             ws0 + 1, &j.pS, &j.S, &j.H);
+    msm_task(Fq_{}, 1, crs->w_d, nullptr, ax_share, (size_t)count * crs->len_w, cf, crs->len_w, streams_[3], ws0 + 4,
+             &j.pW, &j.W, (P1*)nullptr);
+    // ---- host terms that depend on nothing but the inputs
+    if (full) {
+      j.fut.push_back(pool_->submit([J]() {
+        P1 d1 = aff1(J->crs.delta_g1);
+        J->rN = host_scalar_mul<FrP, Fq_>(d1, J->r);
+        J->s_cA = host_scalar_mul<FrP, Fq_>(xyzz_add_ni(xyzz_add_ni(aff1(J->crs.a_query0), J->rN), aff1(J->crs.alpha_g1)), J->s);
+      }));
+      j.fut.push_back(pool_->submit([J]() {
+        P1 d1 = aff1(J->crs.delta_g1);
+        J->sK = host_scalar_mul<FrP, Fq_>(d1, J->s);
+        J->r_cB1 = host_scalar_mul<FrP, Fq_>(xyzz_add_ni(xyzz_add_ni(aff1(J->crs.b_g1_query0), J->sK), aff1(J->crs.beta_g1)), J->r);
+      }));
+      j.fut.push_back(pool_->submit([J]() { J->rsM = host_scalar_mul<FrP, Fq_>(aff1(J->crs.delta_g1), J->r * J->s); }));
+      j.fut.push_back(pool_->submit([J]() { J->sK2 = host_scalar_mul<FrP, Fq2_>(aff2(J->crs.delta_g2), J->s); }));
+    }
+    if (mk) {
+      // in-mask terms sum_p coef_p * mask_p (the king's unpack2 + sum over the masked points, dmsm/mod.rs:85-86)
+      for (int k = 0; k < 5; k++) {
+        if (!mk->msm_in[k] || (k == 1 && j.r_zero)) continue;
+        const void* im = mk->msm_in[k];
+        j.fut.push_back(pool_->submit([this, J, k, im, first, count]() {
+          if (k == 2) {
+            J->in2 = msm_.template mask_term<Fq2_>(im, first, count);
+          } else {
+            J->in1[k] = msm_.template mask_term<Fq_>(im, first, count);
+            if (k == 0 && J->full) J->s_in0 = host_scalar_mul<FrP, Fq_>(J->in1[0], J->s);
+            if (k == 1 && J->full) J->r_in1 = host_scalar_mul<FrP, Fq_>(J->in1[1], J->r);
+          }
+        }));
       }
-      if (!rcs[0] && uniform) {                                     // off the tail: these finish early
-        std::thread th([&]() {
-          if (!r_zero) pre.rH = host_scalar_mul<FrP, Fq>(H, r);
-        });
-        pre.sS = host_scalar_mul<FrP, Fq>(S, s);
-        th.join();
-      }
-    });
-    std::thread tH;
-    std::thread tW = spawn([&]() {
-      (void)hipSetDevice(dev);
-      rcs[3] = msm_.template d_msm_sum_t<Fq>(this, crs->w_d, ax_share, crs->len_w, mk ? mk->msm_in[3] : nullptr, &W,
-                                             streams_[3], 4);
-    });
-    // the U-MSM (needs h) follows circom_h on the same high-priority stream
-    rc = msm_.template d_msm_sum_t<Fq>(this, crs->u_d, hshare_.p, crs->len_u, mk ? mk->msm_in[4] : nullptr, &U, hs, 0);
-    join(tS);
-    join(tH);
-    join(tV);
-    join(tV1);
-    join(tW);
-    if (split_v) V = xyzz_add_ni(V0, V1);
-    if (rcv1) return rcv1;
-    host.join();
-    if (rc) return rc;
-    for (int i = 0; i < 4; i++)
-      if (rcs[i]) return rcs[i];
-
-    pre.valid = uniform;
-    return assemble_t(crs, r, s, rN, sK, rsM, sK2, S, H, V, W, U, mk, pi_a, pi_b, pi_c, &pre);
+      // per-party multiples of the out-masks of A and B1 that enter C = s*A + r*B1 + ...
+      if (full)
+        for (int p = 0; p < n; p++) {
+          if (mk->msm_out[0])
+            j.fut.push_back(pool_->submit([J, p]() {
+              J->s_om0[p] = host_scalar_mul<FrP, Fq_>(jacobian_to_xyzz(((const Jacobian<Fq_>*)J->mk.msm_out[0])[p]), J->s);
+            }));
+          if (mk->msm_out[1] && !j.r_zero)
+            j.fut.push_back(pool_->submit([J, p]() {
+              J->r_om1[p] = host_scalar_mul<FrP, Fq_>(jacobian_to_xyzz(((const Jacobian<Fq_>*)J->mk.msm_out[1])[p]), J->r);
+            }));
+        }
+    }
+    // ---- circom_h and the U-MSM that depends on it form a long dependent chain: high-priority internal stream.
+    // Holding the other MSM streams (or only their accumulate launches) back until circom_h has finished was
+    // measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
+    if (full) {
+      hipStream_t hs = streams_[5];
+      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+      if (he != hipSuccess) return hip_fail(he, "h share buffer");
+      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
+      if (rc) return rc;
+      rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
+                                      ws0 + 0, &j.pU);
+      if (rc) return rc;
+    }
+    return ZK_OK;
   }
 
-  // precomputed pieces of C = s*A + r*B1 - rs*delta + W + U for the case without out-masks (all parties equal)
-  template <class P1>
-  struct CPre {
-    bool valid = false;
-    P1 s_cA = P1::identity(), r_cB1 = P1::identity(), sS = P1::identity(), rH = P1::identity();
-  };
+  // the U-MSM of a partial job (h comes from the caller's king rounds)
+  int prove_launch_u(ProveJob& j, const void* h_share, hipStream_t st) {
+    return msm_.template launch_t<Fq_>(this, j.crs.u_d, h_share, (size_t)j.count * j.crs.len_u, msm_.coef_d_ + j.first,
+                                      j.crs.len_u, st, j.slot * 6 + 0, &j.pU);
+  }
 
-  // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party (shares differ only through the out-masks)
-  template <class P1, class P2>
-  int assemble_t(const zk_crs_share* crs, const Fr& r, const Fr& s, const P1& rN, const P1& sK, const P1& rsM,
-                 const P2& sK2, const P1& S, const P1& H, const P2& V, const P1& W, const P1& U,
-                 const zk_groth16_masks* mk, void* pi_a, void* pi_b, void* pi_c, const CPre<P1>* pre = nullptr) {
-    using Fq = Fp<typename Cfg::FqP>;
-    using Fq2 = Fp2<typename Cfg::FqP>;
-    auto aff1 = [](const void* p) {
-      Affine<Fq> a;
-      memcpy(&a, p, sizeof(a));
-      return P1::from_affine(a);
-    };
-    auto aff2 = [](const void* p) {
-      Affine<Fq2> a;
-      memcpy(&a, p, sizeof(a));
-      return P2::from_affine(a);
-    };
-    const bool r_zero = r.is_zero();
-    P1 cA = xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1));
-    P1 cB1 = xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1));
-    P2 cB2 = xyzz_add_ni(xyzz_add_ni(aff2(crs->b_g2_query0), sK2), aff2(crs->beta_g2));
-    auto om1 = [&](int k, int p, const P1& v) {
-      if (!mk || !mk->msm_out[k]) return v;
-      return xyzz_add_ni(v, jacobian_to_xyzz(((const Jacobian<Fq>*)mk->msm_out[k])[p]));
-    };
-    Jacobian<Fq>* oa = (Jacobian<Fq>*)pi_a;
-    Jacobian<Fq2>* ob = (Jacobian<Fq2>*)pi_b;
-    Jacobian<Fq>* oc = (Jacobian<Fq>*)pi_c;
+  // joins everything; sums[0..4] = S, H, V, W, U including the in-mask terms
+  int prove_join(ProveJob& j, P1* S, P1* H, P2* V, P1* W, P1* U) {
+    int rc = msm_.template finish_t<Fq_>(this, &j.pU, &j.U);
+    drain(j);
+    j.active = false;
+    if (rc) return rc;
+    for (int i = 0; i < 8; i++)
+      if (j.rc[i]) {
+        // a pool task failed: its message was recorded on the engine by msm_launch (hip_fail); keep it
+        return j.rc[i];
+      }
+    if (j.err.code) return fail(j.err.code, j.err.msg);
+    *S = xyzz_add_ni(j.S, j.in1[0]);
+    *H = j.r_zero ? P1::identity() : xyzz_add_ni(j.H, j.in1[1]);
+    *V = xyzz_add_ni(xyzz_add_ni(j.V0, j.V1), j.in2);
+    *W = xyzz_add_ni(j.W, j.in1[3]);
+    *U = xyzz_add_ni(j.U, j.in1[4]);
+    return ZK_OK;
+  }
+
+  int prove_end(ProveJob& j, void* pi_a, void* pi_b, void* pi_c) {
+    P1 S, H, W, U;
+    P2 V;
+    int rc = prove_join(j, &S, &H, &V, &W, &U);
+    if (rc) return rc;
+    const zk_groth16_masks* mk = j.has_mk ? &j.mk : nullptr;
+    // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party; C = s*A + r*B1 - rs*delta + W + U by linearity:
+    //   s*A_p = s*(a0 + r*delta + alpha) + s*S + s*in0 + s*om0_p     (every term was computed beside the device work)
+    P1 cA = xyzz_add_ni(xyzz_add_ni(aff1(j.crs.a_query0), j.rN), aff1(j.crs.alpha_g1));
+    P1 cB1 = xyzz_add_ni(xyzz_add_ni(aff1(j.crs.b_g1_query0), j.sK), aff1(j.crs.beta_g1));
+    P2 cB2 = xyzz_add_ni(xyzz_add_ni(aff2(j.crs.b_g2_query0), j.sK2), aff2(j.crs.beta_g2));
+    P1 A0 = xyzz_add_ni(cA, S);
+    P2 B0 = xyzz_add_ni(cB2, V);
+    P1 C0 = xyzz_add_ni(xyzz_add_ni(j.s_cA, j.sS), j.s_in0);
+    if (!j.r_zero) C0 = xyzz_add_ni(C0, xyzz_add_ni(xyzz_add_ni(j.r_cB1, j.rH), j.r_in1));
+    C0 = xyzz_add_ni(C0, j.rsM.neg());
+    C0 = xyzz_add_ni(C0, xyzz_add_ni(W, U));
+    (void)cB1;
+    (void)H;
+    Jacobian<Fq_>* oa = (Jacobian<Fq_>*)pi_a;
+    Jacobian<Fq2_>* ob = (Jacobian<Fq2_>*)pi_b;
+    Jacobian<Fq_>* oc = (Jacobian<Fq_>*)pi_c;
+    auto om1 = [&](int k, int p) { return jacobian_to_xyzz(((const Jacobian<Fq_>*)mk->msm_out[k])[p]); };
     const bool uniform = !mk || (!mk->msm_out[0] && !mk->msm_out[1] && !mk->msm_out[2] && !mk->msm_out[3] &&
                                  !mk->msm_out[4]);
     for (int p = 0; p < n; p++) {
@@ -1005,25 +1071,91 @@ class Engine : public IEngine {
         oc[p] = oc[0];
         continue;
       }
-      P1 A = xyzz_add_ni(cA, om1(0, p, S));
-      P1 B1 = r_zero ? P1::identity() : xyzz_add_ni(cB1, om1(1, p, H));
-      P2 Vp = V;
-      if (mk && mk->msm_out[2]) Vp = xyzz_add_ni(Vp, jacobian_to_xyzz(((const Jacobian<Fq2>*)mk->msm_out[2])[p]));
-      P2 B2 = xyzz_add_ni(cB2, Vp);
-      P1 C;
-      if (pre && pre->valid && uniform) {
-        C = xyzz_add_ni(pre->s_cA, pre->sS);
-        if (!r_zero) C = xyzz_add_ni(C, xyzz_add_ni(pre->r_cB1, pre->rH));
-      } else {
-        C = xyzz_add_ni(host_scalar_mul<FrP, Fq>(A, s), host_scalar_mul<FrP, Fq>(B1, r));
+      P1 A = A0, C = C0;
+      P2 B2 = B0;
+      if (!uniform) {
+        if (mk->msm_out[0]) {
+          A = xyzz_add_ni(A, om1(0, p));
+          C = xyzz_add_ni(C, j.s_om0[p]);
+        }
+        if (mk->msm_out[1] && !j.r_zero) C = xyzz_add_ni(C, j.r_om1[p]);
+        if (mk->msm_out[2]) B2 = xyzz_add_ni(B2, jacobian_to_xyzz(((const Jacobian<Fq2_>*)mk->msm_out[2])[p]));
+        if (mk->msm_out[3]) C = xyzz_add_ni(C, om1(3, p));
+        if (mk->msm_out[4]) C = xyzz_add_ni(C, om1(4, p));
       }
-      C = xyzz_add_ni(C, rsM.neg());
-      C = xyzz_add_ni(C, om1(3, p, W));
-      C = xyzz_add_ni(C, om1(4, p, U));
       oa[p] = xyzz_to_jacobian(A);
       ob[p] = xyzz_to_jacobian(B2);
       oc[p] = xyzz_to_jacobian(C);
     }
+    return ZK_OK;
+  }
+
+  int check_prove_args(const zk_crs_share* crs, const void* r_, const void* s_, int log_m) {
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    if (!crs || !r_ || !s_) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int log_l = ilog2(l);
+    if (log_m < log_l || log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (crs->len_u != ((size_t)1 << log_m) / l)
+      return fail(ZK_ERR_BAD_INPUT, "h_query share length must be m/l");   // dmsm/mod.rs:71
+    return ZK_OK;
+  }
+
+  int groth16_prove(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
+                    const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
+                    uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int h = -1;
+    int rc = groth16_prove_async(crs, qa, qb, qc, a_share, ax_share, r_, s_, log_m, mk, seed, st, &h);
+    if (rc) return rc;
+    return groth16_wait(h, pi_a, pi_b, pi_c);
+  }
+  int groth16_prove_async(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
+                          const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
+                          uint64_t seed, hipStream_t st, int* handle) override {
+    int rc = check_prove_args(crs, r_, s_, log_m);
+    if (rc) return rc;
+    if (!qa || !qb || !qc || !a_share || !ax_share || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int slot = -1;
+    for (int i = 0; i < NJOBS; i++)
+      if (!jobs_[i].active) {
+        slot = i;
+        break;
+      }
+    if (slot < 0) return fail(ZK_ERR_BAD_INPUT, "too many proofs in flight (zk_groth16_wait one first)");
+    ProveJob& j = jobs_[slot];
+    j.slot = slot;
+    Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
+    rc = prove_begin(j, crs, qa, qb, qc, a_share, ax_share, r, s, log_m, mk, seed, true, 0, n, st);
+    if (rc) {
+      Status keep = last;
+      abort_job(j);
+      last = keep;
+      return rc;
+    }
+    *handle = slot;
+    return ZK_OK;
+  }
+  int groth16_wait(int handle, void* pi_a, void* pi_b, void* pi_c) override {
+    if (handle < 0 || handle >= NJOBS || !jobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no proof in flight on this handle");
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    return prove_end(jobs_[handle], pi_a, pi_b, pi_c);
+  }
+  // joins a job's tasks and device work and marks it free (after an error, or zk_groth16_abort)
+  void abort_job(ProveJob& j) {
+    drain(j);
+    MsmPending* ps[5] = {&j.pS, &j.pV0, &j.pV1, &j.pW, &j.pU};
+    for (MsmPending* p : ps)
+      if (p->active) {
+        (void)hipEventSynchronize(p->slot->ev);
+        p->active = false;
+        p->tab.reset();
+        p->tab2.reset();
+      }
+    j.active = false;
+  }
+  int groth16_abort(int handle) override {
+    if (handle < 0 || handle >= NJOBS) return fail(ZK_ERR_BAD_INPUT, "bad handle");
+    abort_job(jobs_[handle]);
     return ZK_OK;
   }
 
@@ -1195,104 +1327,110 @@ class Engine : public IEngine {
     }
     return fail(ZK_ERR_BAD_INPUT, "bad group");
   }
-  // A, B, C shares from the five d_msm king outputs (prove.rs) -- used when the MSMs were computed per rank.
+  // A, B, C shares from the five d_msm king outputs (prove.rs:40-56, 99-110, 148-158, 229-235) -- used when the MSMs
+  // were computed per rank and summed by the caller; sums[0..4] = S, H, V (G2), W, U.
   int groth16_assemble(const zk_crs_share* crs, const void* r_, const void* s_, const void* const* sums,
                        const zk_groth16_masks* mk, void* pi_a, void* pi_b, void* pi_c) override {
-    using Fq = Fp<typename Cfg::FqP>;
-    using Fq2 = Fp2<typename Cfg::FqP>;
-    using P1 = XYZZ<Fq>;
-    using P2 = XYZZ<Fq2>;
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     if (!crs || !r_ || !s_ || !sums || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
     auto j1 = [](const void* p) {
-      Jacobian<Fq> j;
+      Jacobian<Fq_> j;
       memcpy(&j, p, sizeof(j));
       return jacobian_to_xyzz(j);
     };
-    Jacobian<Fq2> jv;
+    Jacobian<Fq2_> jv;
     memcpy(&jv, sums[2], sizeof(jv));
-    Affine<Fq> d1a;
-    memcpy(&d1a, crs->delta_g1, sizeof(d1a));
-    Affine<Fq2> d2a;
-    memcpy(&d2a, crs->delta_g2, sizeof(d2a));
-    P1 d1 = P1::from_affine(d1a);
-    P1 rN = host_scalar_mul<FrP, Fq>(d1, r), sK = host_scalar_mul<FrP, Fq>(d1, s),
-       rsM = host_scalar_mul<FrP, Fq>(d1, r * s);
-    P2 sK2 = host_scalar_mul<FrP, Fq2>(P2::from_affine(d2a), s);
-    return assemble_t<P1, P2>(crs, r, s, rN, sK, rsM, sK2, j1(sums[0]), j1(sums[1]), jacobian_to_xyzz(jv), j1(sums[3]),
-                              j1(sums[4]), mk, pi_a, pi_b, pi_c);
+    const bool r_zero = r.is_zero();
+    P1 d1 = aff1(crs->delta_g1);
+    P1 rN = host_scalar_mul<FrP, Fq_>(d1, r), sK = host_scalar_mul<FrP, Fq_>(d1, s),
+       rsM = host_scalar_mul<FrP, Fq_>(d1, r * s);
+    P2 sK2 = host_scalar_mul<FrP, Fq2_>(aff2(crs->delta_g2), s);
+    P1 A0 = xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1)), j1(sums[0]));
+    P1 B10 = r_zero ? P1::identity()
+                    : xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1)), j1(sums[1]));
+    P2 B20 = xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff2(crs->b_g2_query0), sK2), aff2(crs->beta_g2)), jacobian_to_xyzz(jv));
+    P1 WU = xyzz_add_ni(xyzz_add_ni(j1(sums[3]), j1(sums[4])), rsM.neg());
+    Jacobian<Fq_>* oa = (Jacobian<Fq_>*)pi_a;
+    Jacobian<Fq2_>* ob = (Jacobian<Fq2_>*)pi_b;
+    Jacobian<Fq_>* oc = (Jacobian<Fq_>*)pi_c;
+    auto om1 = [&](int k, int p, const P1& v) {
+      if (!mk || !mk->msm_out[k]) return v;
+      return xyzz_add_ni(v, jacobian_to_xyzz(((const Jacobian<Fq_>*)mk->msm_out[k])[p]));
+    };
+    const bool uniform = !mk || (!mk->msm_out[0] && !mk->msm_out[1] && !mk->msm_out[2] && !mk->msm_out[3] &&
+                                 !mk->msm_out[4]);
+    for (int p = 0; p < n; p++) {
+      if (uniform && p > 0) {
+        oa[p] = oa[0];
+        ob[p] = ob[0];
+        oc[p] = oc[0];
+        continue;
+      }
+      P1 A = om1(0, p, A0);
+      P1 B1 = r_zero ? P1::identity() : om1(1, p, B10);
+      P2 B2 = B20;
+      if (mk && mk->msm_out[2]) B2 = xyzz_add_ni(B2, jacobian_to_xyzz(((const Jacobian<Fq2_>*)mk->msm_out[2])[p]));
+      P1 C = xyzz_add_ni(host_scalar_mul<FrP, Fq_>(A, s), host_scalar_mul<FrP, Fq_>(B1, r));
+      C = xyzz_add_ni(C, om1(4, p, om1(3, p, WU)));
+      oa[p] = xyzz_to_jacobian(A);
+      ob[p] = xyzz_to_jacobian(B2);
+      oc[p] = xyzz_to_jacobian(C);
+    }
+    return ZK_OK;
   }
 
   // ---- the five partial d_msm of one rank, concurrently (multi-GPU flow) ---------------------------------
-  // begin: S, H, V, W over this rank's parties start on internal streams; finish: U (needs h) runs, all join.
-  struct MsmJob {
-    std::thread th[4];
-    XYZZ<Fp<typename Cfg::FqP>> S, H, W, U;
-    XYZZ<Fp2<typename Cfg::FqP>> V;
-    int rc[4] = {0, 0, 0, 0};
-    bool active = false;
-  } job_;
-  int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count,
-                 int skip_h) override {
-    using Fq = Fp<typename Cfg::FqP>;
-    using Fq2 = Fp2<typename Cfg::FqP>;
+  // begin: S, H, V, W over this rank's parties [first, first + count) start on internal streams (crs vectors and
+  // shares are [count][len]; masks, if any: msm_in[k] holds this rank's `count` in-mask points); finish: U (needs h)
+  // runs on `stream`, everything joins; out[0..4] = S, H, V(G2), W, U including the in-mask terms.
+  int msms_begin(const zk_crs_share* crs, const void* a_share, const void* ax_share, int first, int count, int skip_h,
+                 const zk_groth16_masks* mk, hipStream_t st) override {
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
-    if (job_.active) return fail(ZK_ERR_BAD_INPUT, "zk_groth16_msms_begin called twice");
+    if (!crs || !a_share || !ax_share) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     if (first < 0 || count <= 0 || first + count > n) return fail(ZK_ERR_BAD_INPUT, "bad party range");
-    int rc = ensure_streams();
-    if (rc) return rc;
-    const int dev = device;
-    // no stream argument: the inputs are ordered after everything queued on the legacy default stream
-    ZK_HIP(hipEventRecord(ev_in_, nullptr));
-    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_, 0));
-    job_.active = true;
-    for (int i = 0; i < 4; i++) job_.rc[i] = 0;
-    job_.H = XYZZ<Fq>::identity();
-    job_.th[0] = std::thread([=]() {
-      (void)hipSetDevice(dev);
-      job_.rc[2] = msm_.template d_msm_range_t<Fq2>(this, crs->v_d, a_share, crs->len_a, first, count, nullptr, &job_.V,
-                                                    streams_[2], 3);
-    });
-    job_.th[1] = std::thread([=]() {
-      (void)hipSetDevice(dev);
-      if (skip_h)
-        job_.rc[0] = msm_.template d_msm_range_t<Fq>(this, crs->s_d, a_share, crs->len_a, first, count, nullptr, &job_.S,
-                                                     streams_[0], 1);
-      else        // S and H share the scalars: one sort (msm.hpp run_t with two base vectors)
-        job_.rc[0] = msm_.template d_msm_range2_t<Fq>(this, crs->s_d, crs->h_d, a_share, crs->len_a, first, count,
-                                                      &job_.S, &job_.H, streams_[0], 1);
-    });
-    job_.th[3] = std::thread([=]() {
-      (void)hipSetDevice(dev);
-      job_.rc[3] = msm_.template d_msm_range_t<Fq>(this, crs->w_d, ax_share, crs->len_w, first, count, nullptr, &job_.W,
-                                                   streams_[3], 4);
-    });
-    return ZK_OK;
+    ProveJob& j = jobs_[0];
+    if (j.active) return fail(ZK_ERR_BAD_INPUT, "zk_groth16_msms_begin called twice");
+    j.slot = 0;
+    Fr r = skip_h ? Fr::zero() : Fr::one();          // only r == 0 matters here (H skipped, prove.rs:96-98)
+    int rc = prove_begin(j, crs, nullptr, nullptr, nullptr, a_share, ax_share, r, Fr::one(), 0, mk, 0, false, first,
+                         count, st);
+    if (rc) {
+      Status keep = last;
+      abort_job(j);
+      last = keep;
+    }
+    return rc;
   }
-  int msms_finish(const zk_crs_share* crs, const void* h_share, int first, int count, void* const* out,
-                  hipStream_t st) override {
-    using Fq = Fp<typename Cfg::FqP>;
-    using Fq2 = Fp2<typename Cfg::FqP>;
-    if (!job_.active) return fail(ZK_ERR_BAD_INPUT, "zk_groth16_msms_finish without begin");
-    int rc = msm_.template d_msm_range_t<Fq>(this, crs->u_d, h_share, crs->len_u, first, count, nullptr, &job_.U, st, 0);
-    for (int i = 0; i < 4; i++)
-      if (job_.th[i].joinable()) job_.th[i].join();
-    job_.active = false;
+  int msms_finish(const void* h_share, void* const* out, hipStream_t st) override {
+    ProveJob& j = jobs_[0];
+    if (!j.active || j.full) return fail(ZK_ERR_BAD_INPUT, "zk_groth16_msms_finish without begin");
+    if (!h_share || !out) {
+      abort_job(j);
+      return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    }
+    int rc = prove_launch_u(j, h_share, st);
+    if (rc) {
+      Status keep = last;
+      abort_job(j);
+      last = keep;
+      return rc;
+    }
+    P1 S, H, W, U;
+    P2 V;
+    rc = prove_join(j, &S, &H, &V, &W, &U);
     if (rc) return rc;
-    for (int i = 0; i < 4; i++)
-      if (job_.rc[i]) return job_.rc[i];
-    Jacobian<Fq> j;
-    j = xyzz_to_jacobian(job_.S);
-    memcpy(out[0], &j, sizeof(j));
-    j = xyzz_to_jacobian(job_.H);
-    memcpy(out[1], &j, sizeof(j));
-    Jacobian<Fq2> j2 = xyzz_to_jacobian(job_.V);
+    Jacobian<Fq_> jj;
+    jj = xyzz_to_jacobian(S);
+    memcpy(out[0], &jj, sizeof(jj));
+    jj = xyzz_to_jacobian(H);
+    memcpy(out[1], &jj, sizeof(jj));
+    Jacobian<Fq2_> j2 = xyzz_to_jacobian(V);
     memcpy(out[2], &j2, sizeof(j2));
-    j = xyzz_to_jacobian(job_.W);
-    memcpy(out[3], &j, sizeof(j));
-    j = xyzz_to_jacobian(job_.U);
-    memcpy(out[4], &j, sizeof(j));
+    jj = xyzz_to_jacobian(W);
+    memcpy(out[3], &jj, sizeof(jj));
+    jj = xyzz_to_jacobian(U);
+    memcpy(out[4], &jj, sizeof(jj));
     return ZK_OK;
   }
 
@@ -1305,16 +1443,25 @@ class Engine : public IEngine {
       bool prio = (i == 2 || i == 4 || i == 5);      // the two G2 halves and the circom_h -> U chain
       ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio ? hi : lo));
     }
-    ZK_HIP(hipEventCreateWithFlags(&ev_in_, hipEventDisableTiming));
+    for (int i = 0; i < NJOBS; i++) ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
+    // host workers: the MSM tasks block on their events while the scalar-multiple tasks run
+    int nthreads = getenv("ZK_HOST_THREADS") ? atoi(getenv("ZK_HOST_THREADS")) : 0;
+    if (nthreads <= 0) {
+      unsigned hc = std::thread::hardware_concurrency();
+      nthreads = hc >= 32 ? 16 : (hc >= 8 ? 8 : 4);
+    }
+    const int dev = device;
+    pool_.reset(new HostPool(nthreads, [dev]() { (void)hipSetDevice(dev); }));
     streams_ready_ = true;
     return ZK_OK;
   }
+  std::unique_ptr<HostPool> pool_;
+  hipEvent_t ev_in_[NJOBS] = {nullptr, nullptr};
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_in_ = nullptr;
   bool streams_ready_ = false;
   bool force_simple_ntt = false;
   std::map<std::string, void*> base_tables_;
-  DevBuf hwork_, hshare_;
+  DevBuf hwork_;
   Fr* pmat_ = nullptr;
   std::vector<Fr> pmat_host_;
   DevBuf flag_;   // 4-byte device flag for the validating kernels

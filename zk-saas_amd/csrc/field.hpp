@@ -408,4 +408,14 @@ struct Fp2T {
   static ZK_HD Fp2 mul_ni(const Fp2& a, const Fp2& b) { return a * b; }
 };
 
+// true for the quadratic extension (G2 coordinates)
+template <class F>
+struct IsExtField {
+  static constexpr bool value = false;
+};
+template <class P, bool INL>
+struct IsExtField<Fp2T<P, INL>> {
+  static constexpr bool value = true;
+};
+
 }  // namespace zk

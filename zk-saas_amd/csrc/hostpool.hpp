@@ -1,0 +1,65 @@
+// A small persistent pool of host worker threads owned by a context.
+//
+// What runs here is the host-side part of the reference's per-party work that is a few hundred group operations on
+// single points: the king's unpack2 + sum over n masked points (dist-primitives/src/dmsm/mod.rs:85-86), the scalar
+// multiples of CRS constants and of the out-masks in prove.rs:40-56, 99-110, 229-235, and the final window fold of an
+// MSM.  All of it is submitted when a proof starts and runs beside the device work; nothing spawns threads per call.
+#pragma once
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <future>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace zk {
+
+class HostPool {
+ public:
+  explicit HostPool(int nthreads, std::function<void()> on_start = nullptr) {
+    for (int i = 0; i < nthreads; i++)
+      workers_.emplace_back([this, on_start]() {
+        if (on_start) on_start();
+        for (;;) {
+          std::packaged_task<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;       // stop_ and drained
+            job = std::move(q_.front());
+            q_.pop_front();
+          }
+          job();
+        }
+      });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  std::future<void> submit(std::function<void()> fn) {
+    std::packaged_task<void()> job(std::move(fn));
+    std::future<void> f = job.get_future();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      q_.push_back(std::move(job));
+    }
+    cv_.notify_one();
+    return f;
+  }
+  int size() const { return (int)workers_.size(); }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::packaged_task<void()>> q_;
+  std::vector<std::thread> workers_;
+  bool stop_ = false;
+};
+
+}  // namespace zk

@@ -42,7 +42,7 @@ constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
 // the steps is more total work: d_msm 8 x 2^17 went from 5.0 to 5.65 ms).
 template <class Fld>
 constexpr int red_g() { return sizeof(XYZZ<Fld>) == 256 ? 2 : 4; }
-constexpr int MSM_WS = 6;             // independent workspaces (concurrent MSMs on separate streams)
+constexpr int MSM_WS = 12;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate streams)
 
 struct SegDesc {
   uint32_t bucket, start, end;
@@ -657,299 +657,147 @@ struct KernelField<Fp2T<P, false>> {
 };
 
 // ---------------------------------------------------------------------------------------------------- host
-template <class Cfg>
-class MsmRunner {
- public:
-  using FrP = typename Cfg::FrP;
-  using Fr = Fp<FrP>;
-  using Fq = Fp<typename Cfg::FqP>;
-  using Fq2 = Fp2<typename Cfg::FqP>;
+// One workspace slot = device scratch + a pinned host buffer for the (S, A) pairs + the event that marks the end of
+// the slot's last launch.  Independent MSMs run on different slots / streams.
+struct MsmSlot {
+  DevBuf ws;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  hipEvent_t ev = nullptr;
+  ~MsmSlot() {
+    if (pinned) (void)hipHostFree(pinned);
+    if (ev) (void)hipEventDestroy(ev);
+  }
+  hipError_t ensure_pinned(size_t b) {
+    if (b <= pinned_bytes) return hipSuccess;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_bytes = 0;
+    hipError_t e = hipHostMalloc(&pinned, b, hipHostMallocDefault);
+    if (e == hipSuccess) pinned_bytes = b;
+    return e;
+  }
+};
 
-  // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
-  // with nwin = ceil((BITS+1)/c) windows of evenly spread width (see run_t); ties go to the wider window
-  // (more buckets = more lanes with shorter chains).
-  static int pick_c(size_t npts, bool g2 = false) {
-    if (g2)
-      if (const char* e = getenv("ZK_MSM_C_G2")) {
-        int c = atoi(e);
-        if (c >= 2 && c <= 20) return c;
-      }
-    if (const char* e = getenv("ZK_MSM_C")) {
+// A launched MSM (or two sharing one sort) whose (S, A) pairs are on their way to the slot's pinned buffer.
+// msm_fold() waits for the event and folds on the host.
+struct MsmPending {
+  bool active = false;
+  int kwin = 0, c = 0, wide = 0, nb = 1, red_k = 0;
+  uint32_t bpw = 0;
+  MsmSlot* slot = nullptr;
+  std::shared_ptr<const MsmTable> tab, tab2;     // keep the tables alive while the kernels run
+};
+
+struct MsmTuning {
+  size_t bigsort_min;
+};
+
+// Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
+// with nwin = ceil((BITS+1)/c) windows of evenly spread width (see msm_launch); ties go to the wider window
+// (more buckets = more lanes with shorter chains).
+template <class FrP>
+inline int msm_pick_c(size_t npts, bool g2 = false) {
+  if (g2)
+    if (const char* e = getenv("ZK_MSM_C_G2")) {
       int c = atoi(e);
       if (c >= 2 && c <= 20) return c;
     }
-    int best = 4;
-    double best_cost = 1e300;
-    for (int c = 4; c <= 20; c++) {                     // > 17 only pays from ~2^25 points on (cost model below)
-      int nwin = (FrP::BITS + c) / c;
-      int ceff = (FrP::BITS + nwin) / nwin;          // widest window after spreading BITS+1 bits over nwin windows
-      // per-bucket work is priced at 4 additions up to 17 bits (tuned on 10^5..10^7 points) and at 10 above: measured
-      // on BLS12-381, 20-bit windows lose 13% at 2^24 points and win 8% at 2^26
-      double cost = (double)nwin * ((double)npts + (ceff > 17 ? 10.0 : 4.0) * (double)((size_t)1 << (ceff - 1)));
-      if (cost <= best_cost) {
-        best_cost = cost;
-        best = c;
-      }
-    }
-    return best;
+  if (const char* e = getenv("ZK_MSM_C")) {
+    int c = atoi(e);
+    if (c >= 2 && c <= 20) return c;
   }
+  int best = 4;
+  double best_cost = 1e300;
+  for (int c = 4; c <= 20; c++) {                     // > 17 only pays from ~2^25 points on (cost model below)
+    int nwin = (FrP::BITS + c) / c;
+    int ceff = (FrP::BITS + nwin) / nwin;          // widest window after spreading BITS+1 bits over nwin windows
+    // per-bucket work is priced at 4 additions up to 17 bits (tuned on 10^5..10^7 points) and at 10 above: measured
+    // on BLS12-381, 20-bit windows lose 13% at 2^24 points and win 8% at 2^26
+    double cost = (double)nwin * ((double)npts + (ceff > 17 ? 10.0 : 4.0) * (double)((size_t)1 << (ceff - 1)));
+    if (cost <= best_cost) {
+      best_cost = cost;
+      best = c;
+    }
+  }
+  return best;
+}
 
-  // points per accumulate lane (a bucket longer than this is cut into segments)
-  static uint32_t pick_seg(size_t npts, int nwin, bool g2 = false) {
-    if (g2)
-      if (const char* e = getenv("ZK_MSM_SEG_G2")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= 1024) return (uint32_t)v;
-      }
-    if (const char* e = getenv("ZK_MSM_SEG")) {
+// points per accumulate lane (a bucket longer than this is cut into segments)
+inline uint32_t msm_pick_seg(size_t npts, bool g2 = false) {
+  if (g2)
+    if (const char* e = getenv("ZK_MSM_SEG_G2")) {
       int v = atoi(e);
       if (v >= 1 && v <= 1024) return (uint32_t)v;
     }
-    // Measured on MI355X (SHA-256 circuit, 111k-point MSMs): the accumulate kernel's duration is set by its
-    // longest lane chain, so short segments win (8.9 ms/proof at 16 vs 10.9 at 64); for multi-million-point MSMs
-    // the buckets are long anyway and 64 keeps the number of partial sums down.
-    (void)nwin;
-    return npts >= ((size_t)1 << 21) ? 64u : (uint32_t)MSM_SEG_MAX;
+  if (const char* e = getenv("ZK_MSM_SEG")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 1024) return (uint32_t)v;
   }
+  // Measured on MI355X (SHA-256 circuit, 111k-point MSMs): the accumulate kernel's duration is set by its
+  // longest lane chain, so short segments win (8.9 ms/proof at 16 vs 10.9 at 64); for multi-million-point MSMs
+  // the buckets are long anyway and 64 keeps the number of partial sums down.
+  return npts >= ((size_t)1 << 21) ? 64u : (uint32_t)MSM_SEG_MAX;
+}
 
-  // the window split run_t uses (see there)
-  static void plan(size_t npts, bool g2, int* out) {
-    const int c_req = pick_c(npts ? npts : 1, g2);
-    const int T = FrP::BITS + 1;
-    const int nwin = (T + c_req - 1) / c_req;
-    out[0] = (T + nwin - 1) / nwin;
-    out[1] = nwin;
-    out[2] = (int)pick_seg(npts, nwin, g2);
-    out[3] = g2 ? 28 : 10;
-  }
+template <class FrP>
+inline void msm_plan_of(size_t npts, bool g2, int* out) {
+  const int c_req = msm_pick_c<FrP>(npts ? npts : 1, g2);
+  const int T = FrP::BITS + 1;
+  const int nwin = (T + c_req - 1) / c_req;
+  out[0] = (T + nwin - 1) / nwin;
+  out[1] = nwin;
+  out[2] = (int)msm_pick_seg(npts, g2);
+  out[3] = g2 ? 28 : 10;
+}
 
-  template <class Fld>
-  // bases2 / result2 (optional): a second base vector multiplied by the SAME scalars (Groth16's a_query and
-  // b_g1_query over the witness shares): one sort, and every later launch covers both through blockIdx.y.
-  int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-            XYZZ<Fld>* result, hipStream_t st, int wslot = 0, const void* bases2 = nullptr,
-            XYZZ<Fld>* result2 = nullptr) {
-#if defined(__HIPCC__)
-    *result = XYZZ<Fld>::identity();
-    if (result2) *result2 = XYZZ<Fld>::identity();
-    const unsigned NB = (bases2 && result2) ? 2u : 1u;
-    if (npts == 0) return ZK_OK;
-    if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
-    constexpr bool G2FLD = sizeof(Fld) != sizeof(Fq);
-    // fixed-base table registered for this base vector (and the same window layout / offset for the second one)?
-    size_t toff = 0, toff2 = 0;
-    std::shared_ptr<const MsmTable> tab = find_table(bases, npts, sizeof(Affine<Fld>), &toff), tab2;
-    if (tab && NB == 2) {
-      tab2 = find_table(bases2, npts, sizeof(Affine<Fld>), &toff2);
-      if (!tab2 || tab2->len != tab->len || toff2 != toff || tab2->c != tab->c) tab = nullptr;
-      else bases2 = tab2->data;
-    }
-    if (tab) bases = tab->data;
-    const int c_req = tab ? tab->c : pick_c(npts, G2FLD);
-    // BITS+1 bits (room for the signed-digit carry) are spread EVENLY over the windows: `wide` windows of c bits and
-    // nwin-wide of c-1.  A plain c-bit split leaves a top window of a few bits (254 = 19*13 + 7) whose 64 buckets
-    // each receive npts/64 points: hot atomics in the sort, long chains, and a heavy-bucket pass in every MSM.
-    const int T = FrP::BITS + 1;
-    const int nwin = (T + c_req - 1) / c_req;
-    const int c = (T + nwin - 1) / nwin;            // widest window
-    const int wide = T - nwin * (c - 1);            // 1 <= wide <= nwin
-    const uint32_t B = 1u << (c - 1);
-    const int kwin = tab ? 1 : nwin;                // bucket sets: with a table all windows share one
-    const size_t nkeys = (size_t)kwin * B;
-    const size_t max_sorted = npts * nwin;
-    const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
-    uint32_t seg = pick_seg(npts, nwin, G2FLD);
-    {
-      // keep the average bucket at no more than ~4 segments: with 2^26 points and 2^16 buckets per window a 64-point
-      // segment would leave 16 partial sums per bucket, i.e. every bucket on the slow heavy-bucket path
-      const size_t avg = (tab ? npts * nwin : npts) >> (c - 1);
-      uint32_t want = 1;
-      while ((size_t)want * 4 < avg && want < 1024) want <<= 1;
-      const bool overridden = getenv("ZK_MSM_SEG") || (G2FLD && getenv("ZK_MSM_SEG_G2"));
-      if (!overridden && want > seg) seg = want;
-    }
-    const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
-    constexpr int RED_THREADS = red_threads<Fld>();
-    constexpr int RED_G = red_g<Fld>();
-    const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
-    const size_t iscan_blocks = (nkeys + ISCAN_BLOCK - 1) / ISCAN_BLOCK;
+// Enqueue the whole device pipeline of one MSM on `st` (digits .. reduce), the asynchronous copy of the (S, A) pairs
+// into the slot's pinned buffer and the slot's event; no host synchronisation.  bases2 (optional): a second base
+// vector multiplied by the SAME scalars (Groth16's a_query and b_g1_query over the witness shares): one sort, and
+// every later launch covers both through blockIdx.y.  Defined in msm_impl.hpp, instantiated once per (curve, group) in
+// its own translation unit (msm_<curve>_g<k>.hip) so that the heavy kernels compile in parallel.
+template <class FrP, class Fld>
+int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* bases, const void* bases2,
+               const void* scalars, size_t npts, const Fp<FrP>* coef_d, size_t part_len, hipStream_t st,
+               MsmPending* out);
+// zk_msm_precompute's table kernel (same translation units)
+template <class FrP, class Fld>
+int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,
+                     hipStream_t st);
 
-    // workspace layout
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-      size_t o = off;
-      off += (bytes + 255) & ~(size_t)255;
-      return o;
-    };
-    size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
-           o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
-           o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
-           o_out = take(NB * (size_t)kwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
-    // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
-    const size_t big_min = bigsort_min;
-    const int lo_bits = c - 1 - BIG_HI;
-    const bool big = !tab && npts >= big_min && lo_bits >= 1 && lo_bits <= 12;
-    size_t o_bins = 0, o_tmp = 0;
-    if (big) {
-      o_bins = take((3 * ((size_t)nwin << BIG_HI) + 1) * 4);
-      o_tmp = take(max_sorted * sizeof(uint2));
-    }
-    if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
-    hipError_t he = ws_[wslot].ensure(off);
-    if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
-    char* ws = (char*)ws_[wslot].p;
-    uint32_t* counts = (uint32_t*)(ws + o_counts);
-    uint32_t* lenhist = (uint32_t*)(ws + o_lenhist);   // [SEG_BINS] histogram, [SEG_BINS] cursors
-    uint32_t* order = (uint32_t*)(ws + o_order);
-    uint32_t* cursor = (uint32_t*)(ws + o_cursor);
-    uint2* offsets = (uint2*)(ws + o_offsets);
-    uint2* bt = (uint2*)(ws + o_bt);
-    uint32_t* sorted = (uint32_t*)(ws + o_sorted);
-    SegDesc* segs = (SegDesc*)(ws + o_segs);
-    using KF = typename KernelField<Fld>::type;     // same layout as Fld
-    static_assert(sizeof(KF) == sizeof(Fld), "kernel field layout");
-    XYZZ<KF>* partial = (XYZZ<KF>*)(ws + o_partial);
-    XYZZ<KF>* buckets = (XYZZ<KF>*)(ws + o_buckets);
-    XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
-    uint32_t* heavy = (uint32_t*)(ws + o_heavy);
-
-#define MSM_HIP(x)                                           \
-  do {                                                       \
-    hipError_t _e = (x);                                     \
-    if (_e != hipSuccess) return eng->hip_fail(_e, #x);      \
-  } while (0)
-    const bool dbg = getenv("ZK_DEBUG_SYNC") != nullptr;
-#define MSM_STAGE(name)                                                          \
-  do {                                                                           \
-    if (dbg) {                                                                   \
-      hipError_t _e = hipStreamSynchronize(st);                                  \
-      fprintf(stderr, "[zk msm] %s done (%s) npts=%zu c=%d nwin=%d\n", name,     \
-              hipGetErrorString(_e), npts, c, nwin);                             \
-      if (_e != hipSuccess) return eng->hip_fail(_e, name);                      \
-    }                                                                            \
-  } while (0)
-    MSM_HIP(hipMemsetAsync(counts, 0, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
-    dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
-    constexpr bool IS_G2 = sizeof(Fld) != sizeof(Fq);
-    const size_t plen = part_len ? part_len : npts;
-    {
-    ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts);
-    if (big) {
-      const uint32_t nbins = (uint32_t)nwin << BIG_HI;
-      uint32_t* bin_counts = (uint32_t*)(ws + o_bins);
-      uint32_t* bin_base = bin_counts + nbins;
-      uint32_t* bin_cursor = bin_base + nbins + 1;
-      uint2* tmp = (uint2*)(ws + o_tmp);
-      MSM_HIP(hipMemsetAsync(bin_counts, 0, nbins * 4, st));
-      const unsigned tiles = (unsigned)((npts + BIG_TILE - 1) / BIG_TILE);
-      msm_part_hist_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d, plen,
-                                                                                  c, nwin, wide, lo_bits, bin_counts);
-      msm_bin_scan_kernel<<<dim3(1), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor);
-      msm_part_scatter_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-          (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, lo_bits, bin_cursor, tmp);
-      msm_bin_sort_kernel<<<dim3(nbins), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, lo_bits, (uint32_t)(c - 1), counts,
-                                                                     sorted);
-      MSM_STAGE("big sort");
-    } else {
-      msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                  pre_off, counts, nullptr, nullptr);
-      MSM_STAGE("digits/count");
-    }
-    iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
-                                                                                     nullptr, 0, seg);
-    iscan_carry_kernel<<<dim3(1), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks);
-    iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
-                                                                                     offsets, 1, seg);
-    MSM_STAGE("scan");
-    msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg,
-                                                                                   lenhist);
-    msm_order_kernel<<<dim3((unsigned)((max_segs + 255) / 256)), dim3(256), 0, st>>>(segs, offsets, nkeys, seg, lenhist,
-                                                                                     lenhist + SEG_BINS, order);
-    MSM_STAGE("expand");
-    if (!big)
-      msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                  pre_off, nullptr, cursor, sorted);
-    }
-    MSM_STAGE("scatter");
-    {
-    ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB);
-    size_t acc_wgs = (max_segs + 127) / 128;
-    {
-      static const int cap_g1 = getenv("ZK_ACC_WGS_G1") ? atoi(getenv("ZK_ACC_WGS_G1")) : 0;
-      static const int cap_g2 = getenv("ZK_ACC_WGS_G2") ? atoi(getenv("ZK_ACC_WGS_G2")) : 0;
-      const int cap = IS_G2 ? cap_g2 : cap_g1;
-      if (cap > 0 && acc_wgs > (size_t)cap) acc_wgs = (size_t)cap;
-    }
-    msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
-    }
-    MSM_STAGE("accumulate");
-    {
-    ProfScope ps_(eng->prof, IS_G2 ? PROF_MSM_REDUCE_G2 : PROF_MSM_REDUCE, st, (double)nkeys * NB);   // units: buckets
-    MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
-    msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + 127) / 128), NB), dim3(128), 0, st>>>(
-        partial, max_segs, offsets, nkeys, buckets, heavy);
-    {
-      size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
-      // small fixed grid (it strides over the heavy list, which is empty for well-spread scalars): a launch of many
-      // workgroups of this register-hungry kernel would wait for whole SIMDs to drain just to find nothing to do
-      static const unsigned heavy_wgs = getenv("ZK_FIN_HEAVY_WGS") ? (unsigned)atoi(getenv("ZK_FIN_HEAVY_WGS")) : 48u;
-      msm_finalize_heavy_kernel<KF><<<dim3(heavy_wgs ? heavy_wgs : 48u, NB), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, max_segs, offsets,
-                                                                                              nkeys, heavy, buckets);
-    }
-    MSM_STAGE("finalize");
-    size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
-    static bool attr_set = false;
-    if (!attr_set && red_lds > 48 * 1024) {
-      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<KF, RED_THREADS, RED_G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)red_lds));
-      attr_set = true;
-    }
-    msm_reduce_kernel<KF, RED_THREADS, RED_G><<<dim3((unsigned)(kwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
-        buckets, nkeys, B, bpw, out);
-    }
-    MSM_HIP(hipGetLastError());
-    MSM_STAGE("reduce");
-    std::vector<XYZZ<Fld>> hall(NB * (size_t)kwin * bpw * 2);
-    MSM_HIP(hipMemcpyAsync(hall.data(), out, hall.size() * sizeof(XYZZ<Fld>), hipMemcpyDeviceToHost, st));
-    MSM_HIP(hipStreamSynchronize(st));
-#undef MSM_HIP
-#undef MSM_STAGE
-    // host: window value X_w = sum_blk A_blk + K * sum_blk blk * S_blk with K = RED_THREADS * RED_G = 2^kbits, then
-    // Horner over the windows from the top.  The factor K costs nothing: the weighted sum enters the Horner chain
-    // kbits doublings before X_w's own addition.  The per-window block sums are independent; for extension-field
-    // points (1.1 us per host addition) they are spread over a few host threads.
-    auto fold = [&](const XYZZ<Fld>* h) -> XYZZ<Fld> {
+// Wait for a launched MSM and fold on the host: window value X_w = sum_blk A_blk + K * sum_blk blk * S_blk with
+// K = RED_THREADS * RED_G = 2^kbits, then Horner over the windows from the top.  The factor K costs nothing: the
+// weighted sum enters the Horner chain kbits doublings before X_w's own addition.
+template <class Fld>
+int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2) {
+  *result = XYZZ<Fld>::identity();
+  if (result2) *result2 = XYZZ<Fld>::identity();
+  if (!p.active) return ZK_OK;
+  p.active = false;
+  hipError_t he = hipEventSynchronize(p.slot->ev);
+  p.tab.reset();
+  p.tab2.reset();
+  if (he != hipSuccess) return eng->hip_fail(he, "msm event");
+  const int kwin = p.kwin, c = p.c, wide = p.wide;
+  const uint32_t bpw = p.bpw;
+  const XYZZ<Fld>* hall = (const XYZZ<Fld>*)p.slot->pinned;
+  auto fold = [&](const XYZZ<Fld>* h) -> XYZZ<Fld> {
     std::vector<XYZZ<Fld>> wsum((size_t)kwin, XYZZ<Fld>::identity()), wts((size_t)kwin, XYZZ<Fld>::identity());
-    auto block_sums = [&](int w0, int w1) {
-      for (int w = w0; w < w1; w++) {
-        XYZZ<Fld> acc = XYZZ<Fld>::identity(), run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
-        for (int blk = (int)bpw - 1; blk >= 0; blk--) {
-          acc = xyzz_add_ni(acc, h[((size_t)w * bpw + blk) * 2 + 1]);
-          if (blk >= 1) {
-            run = xyzz_add_ni(run, h[((size_t)w * bpw + blk) * 2]);   // sum_{blk' >= blk} S
-            wt = xyzz_add_ni(wt, run);                                 // accumulates sum blk * S_blk
-          }
+    for (int w = 0; w < kwin; w++) {
+      XYZZ<Fld> acc = XYZZ<Fld>::identity(), run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
+      for (int blk = (int)bpw - 1; blk >= 0; blk--) {
+        acc = xyzz_add_ni(acc, h[((size_t)w * bpw + blk) * 2 + 1]);
+        if (blk >= 1) {
+          run = xyzz_add_ni(run, h[((size_t)w * bpw + blk) * 2]);   // sum_{blk' >= blk} S
+          wt = xyzz_add_ni(wt, run);                                 // accumulates sum blk * S_blk
         }
-        wsum[(size_t)w] = acc;
-        wts[(size_t)w] = wt;
       }
-    };
-    const int fold_threads = (G2FLD && bpw > 1 && kwin >= 8) ? 4 : 1;
-    if (fold_threads > 1) {
-      std::thread th[3];
-      const int per_t = (kwin + fold_threads - 1) / fold_threads;
-      for (int i = 1; i < fold_threads; i++)
-        th[i - 1] = std::thread(block_sums, std::min(kwin, i * per_t), std::min(kwin, (i + 1) * per_t));
-      block_sums(0, std::min(kwin, per_t));
-      for (int i = 1; i < fold_threads; i++) th[i - 1].join();
-    } else {
-      block_sums(0, kwin);
+      wsum[(size_t)w] = acc;
+      wts[(size_t)w] = wt;
     }
-    constexpr uint64_t KBLK = (uint64_t)RED_THREADS * RED_G;
+    const uint64_t KBLK = (uint64_t)p.red_k;
     int kbits = 0;
     while (((uint64_t)1 << kbits) < KBLK) kbits++;
-    static_assert((KBLK & (KBLK - 1)) == 0, "RED_THREADS * RED_G must be a power of two");
     XYZZ<Fld> total = XYZZ<Fld>::identity();
     for (int w = kwin - 1; w >= 0; w--) {
       const int cw = w < wide ? c : c - 1;
@@ -964,21 +812,69 @@ class MsmRunner {
       total = xyzz_add_ni(total, wsum[(size_t)w]);
     }
     return total;
-    };
-    if (NB == 2) {
-      // the second fold runs beside the first (both are short dependent chains on the host)
-      std::thread t2([&]() { *result2 = fold(hall.data() + (size_t)kwin * bpw * 2); });
-      *result = fold(hall.data());
-      t2.join();
-    } else {
-      *result = fold(hall.data());
+  };
+  *result = fold(hall);
+  if (p.nb == 2 && result2) *result2 = fold(hall + (size_t)kwin * bpw * 2);
+  return ZK_OK;
+}
+
+// sum_p k_p * P_p for a handful of points by Straus' interleaving (4-bit windows, one shared doubling chain):
+// 14 np + 252 + 64 np group operations instead of 381 np.  Host side: the in-mask term of d_msm, the king's
+// unpack2 + sum over n points.
+template <class FrP, class Fld>
+inline XYZZ<Fld> host_straus(const XYZZ<Fld>* pts, const Fp<FrP>* k_mont, int np) {
+  std::vector<XYZZ<Fld>> tab((size_t)np * 15);
+  std::vector<Fp<FrP>> k((size_t)np);
+  for (int p = 0; p < np; p++) {
+    k[p] = k_mont[p].from_mont();
+    tab[(size_t)p * 15] = pts[p];
+    for (int d = 1; d < 15; d++)
+      tab[(size_t)p * 15 + d] = (d & 1) ? xyzz_dbl_ni(tab[(size_t)p * 15 + d / 2])
+                                        : xyzz_add_ni(tab[(size_t)p * 15 + d - 1], pts[p]);
+  }
+  XYZZ<Fld> acc = XYZZ<Fld>::identity();
+  for (int nib = FrP::N * 8 - 1; nib >= 0; nib--) {
+    for (int i = 0; i < 4; i++) acc = xyzz_dbl_ni(acc);
+    for (int p = 0; p < np; p++) {
+      uint32_t d = (k[p].v[nib / 8] >> (4 * (nib % 8))) & 15u;
+      if (d) acc = xyzz_add_ni(acc, tab[(size_t)p * 15 + d - 1]);
     }
-    return ZK_OK;
-#else
-    (void)eng; (void)bases; (void)scalars; (void)npts; (void)coef_d; (void)part_len; (void)result; (void)st;
-    (void)bases2; (void)result2;
-    return ZK_ERR_GENERIC;
-#endif
+  }
+  return acc;
+}
+
+template <class Cfg>
+class MsmRunner {
+ public:
+  using FrP = typename Cfg::FrP;
+  using Fr = Fp<FrP>;
+  using Fq = Fp<typename Cfg::FqP>;
+  using Fq2 = Fp2<typename Cfg::FqP>;
+
+  static void plan(size_t npts, bool g2, int* out) { msm_plan_of<FrP>(npts, g2, out); }
+
+  // launch on workspace slot `wslot`; the result is collected with finish_t
+  template <class Fld>
+  int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
+               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr) {
+    if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
+    if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
+    MsmTuning tune{bigsort_min};
+    return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend);
+  }
+  template <class Fld>
+  int finish_t(IEngine* eng, MsmPending* pend, XYZZ<Fld>* result, XYZZ<Fld>* result2 = nullptr) {
+    return msm_fold<Fld>(eng, *pend, result, result2);
+  }
+  // blocking form
+  template <class Fld>
+  int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
+            XYZZ<Fld>* result, hipStream_t st, int wslot = 0, const void* bases2 = nullptr,
+            XYZZ<Fld>* result2 = nullptr) {
+    MsmPending pend;
+    int rc = launch_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &pend, bases2);
+    if (rc) return rc;
+    return finish_t<Fld>(eng, &pend, result, result2);
   }
 
   template <class Fld>
@@ -1000,88 +896,51 @@ class MsmRunner {
       return ZK_OK;
     }
     if (group == ZK_G2) {
-      if (!Cfg::HAS_G2) return eng->fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
-      XYZZ<Fq2> r;
-      int rc = run_t<Fq2>(eng, bases, scalars, npts, coef_d, part_len, &r, st);
-      if (rc) return rc;
-      write_jacobian(out, r);
-      return ZK_OK;
+      if constexpr (Cfg::HAS_G2) {
+        XYZZ<Fq2> r;
+        int rc = run_t<Fq2>(eng, bases, scalars, npts, coef_d, part_len, &r, st);
+        if (rc) return rc;
+        write_jacobian(out, r);
+        return ZK_OK;
+      } else {
+        return eng->fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+      }
     }
     return eng->fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
   }
 
+  // sum_p coef[first + p] * mask_p over `count` Jacobian points (the in-mask term of d_msm's king step)
+  template <class Fld>
+  XYZZ<Fld> mask_term(const void* in_mask, int first, int count, const Fr* coef = nullptr) const {
+    const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
+    std::vector<XYZZ<Fld>> pts((size_t)count);
+    for (int p = 0; p < count; p++) pts[p] = jacobian_to_xyzz(jm[p]);
+    return host_straus<FrP, Fld>(pts.data(), coef ? coef : coef_h_.data() + first, count);
+  }
+
   // d_msm for all n parties on this device (dmsm/mod.rs:59-102), fused (DESIGN.md "d_msm"):
   //   king output = sum_k unpack2(c_shares)[k] = sum_p coef_p * (msm_p + in_mask_p),  coef_p = sum_k U2[k][p]
-  // and sum_p coef_p * msm_p is ONE msm over the n*len points with scalars pre-multiplied by coef_p; the
-  // n in-mask points ride along as extra bases with scalars coef_p.
-  // sum_p coef_p * (msm_p + in_mask_p): what the king reconstructs and sums (dmsm/mod.rs:85-86)
-  template <class Fld>
-  int d_msm_sum_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const void* in_mask,
-                  XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
-    const int n = eng->n;
-    XYZZ<Fld> r;
-    int rc = run_t<Fld>(eng, bases, scalars, (size_t)n * len, coef_d_, len, &r, st, wslot);
-    if (rc) return rc;
-    if (in_mask) {
-      // the n in-mask points contribute sum_p coef_p * mask_p (n host scalar multiplications)
-      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
-      std::vector<Affine<Fld>> aff(n);
-      for (int p = 0; p < n; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
-      std::vector<char> mt = host_lincomb<Fld>(aff);
-      r = xyzz_add_ni(r, *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
-    }
-    *result = r;
-    return ZK_OK;
-  }
-
-  // two base vectors over the same scalar shares (S and H of the prover): one sort, shared launches
-  template <class Fld>
-  int d_msm_sum2_t(IEngine* eng, const void* bases_a, const void* bases_b, const void* scalars, size_t len,
-                   const void* in_mask_a, const void* in_mask_b, XYZZ<Fld>* result_a, XYZZ<Fld>* result_b,
-                   hipStream_t st, int wslot = 0) {
-    const int n = eng->n;
-    XYZZ<Fld> ra, rb;
-    int rc = run_t<Fld>(eng, bases_a, scalars, (size_t)n * len, coef_d_, len, &ra, st, wslot, bases_b, &rb);
-    if (rc) return rc;
-    const void* masks[2] = {in_mask_a, in_mask_b};
-    XYZZ<Fld>* rs[2] = {&ra, &rb};
-    for (int k = 0; k < 2; k++)
-      if (masks[k]) {
-        const Jacobian<Fld>* jm = (const Jacobian<Fld>*)masks[k];
-        std::vector<Affine<Fld>> aff(n);
-        for (int p = 0; p < n; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
-        std::vector<char> mt = host_lincomb<Fld>(aff);
-        *rs[k] = xyzz_add_ni(*rs[k], *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
-      }
-    *result_a = ra;
-    *result_b = rb;
-    return ZK_OK;
-  }
-
-  // the same for a contiguous range of parties held by this rank (bases/scalars [nparties][len])
+  // and sum_p coef_p * msm_p is ONE msm over the n*len points with scalars pre-multiplied by coef_p; the in-mask
+  // term is evaluated on the host while the device pipeline runs.
+  // parties [first, first + count): bases/scalars [count][len]
   template <class Fld>
   int d_msm_range_t(IEngine* eng, const void* bases, const void* scalars, size_t len, int first, int count,
                     const void* in_mask, XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
-    XYZZ<Fld> r;
-    int rc = run_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, &r, st, wslot);
+    MsmPending pend;
+    int rc = launch_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, st, wslot, &pend);
     if (rc) return rc;
-    if (in_mask) {
-      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
-      std::vector<Affine<Fld>> aff(count);
-      for (int p = 0; p < count; p++) aff[p] = xyzz_to_affine(jacobian_to_xyzz(jm[p]));
-      std::vector<char> mt = host_lincomb<Fld>(aff, first);
-      r = xyzz_add_ni(r, *reinterpret_cast<XYZZ<Fld>*>(mt.data()));
-    }
-    *result = r;
+    XYZZ<Fld> mt = XYZZ<Fld>::identity();
+    if (in_mask) mt = mask_term<Fld>(in_mask, first, count);
+    XYZZ<Fld> r;
+    rc = finish_t<Fld>(eng, &pend, &r);
+    if (rc) return rc;
+    *result = in_mask ? xyzz_add_ni(r, mt) : r;
     return ZK_OK;
   }
-
-  // S and H of one rank's party range: two base vectors, one sort
   template <class Fld>
-  int d_msm_range2_t(IEngine* eng, const void* bases_a, const void* bases_b, const void* scalars, size_t len, int first,
-                     int count, XYZZ<Fld>* result_a, XYZZ<Fld>* result_b, hipStream_t st, int wslot = 0) {
-    return run_t<Fld>(eng, bases_a, scalars, (size_t)count * len, coef_d_ + first, len, result_a, st, wslot, bases_b,
-                      result_b);
+  int d_msm_sum_t(IEngine* eng, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                  XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
+    return d_msm_range_t<Fld>(eng, bases, scalars, len, 0, eng->n, in_mask, result, st, wslot);
   }
 
   template <class Fld>
@@ -1101,25 +960,6 @@ class MsmRunner {
     return ZK_OK;
   }
 
-  template <class Fld>
-  std::vector<char> host_lincomb(const std::vector<Affine<Fld>>& pts, int first = 0) {
-    XYZZ<Fld> acc = XYZZ<Fld>::identity();
-    for (size_t p = 0; p < pts.size(); p++) {
-      Fr k = coef_h_[first + p].from_mont();
-      XYZZ<Fld> base = XYZZ<Fld>::from_affine(pts[p]);
-      XYZZ<Fld> r = XYZZ<Fld>::identity();
-      for (int i = FrP::N - 1; i >= 0; i--)
-        for (int b = 31; b >= 0; b--) {
-          r = xyzz_dbl_ni(r);
-          if ((k.v[i] >> b) & 1) r = xyzz_add_ni(r, base);
-        }
-      acc = xyzz_add_ni(acc, r);
-    }
-    std::vector<char> out(sizeof(XYZZ<Fld>));
-    memcpy(out.data(), &acc, sizeof(acc));
-    return out;
-  }
-
   int d_msm(IEngine* eng, int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
             const void* out_mask, void* out, hipStream_t st) {
     if (!out) return eng->fail(ZK_ERR_BAD_INPUT, "null output");
@@ -1127,8 +967,8 @@ class MsmRunner {
     if (!coef_d_) return eng->fail(ZK_ERR_GENERIC, "d_msm coefficients not initialised");
     if (group == ZK_G1) return d_msm_t<Fq>(eng, bases, scalars, len, in_mask, out_mask, out, st);
     if (group == ZK_G2) {
-      if (!Cfg::HAS_G2) return eng->fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
-      return d_msm_t<Fq2>(eng, bases, scalars, len, in_mask, out_mask, out, st);
+      if constexpr (Cfg::HAS_G2) return d_msm_t<Fq2>(eng, bases, scalars, len, in_mask, out_mask, out, st);
+      else return eng->fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     }
     return eng->fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
   }
@@ -1148,20 +988,7 @@ class MsmRunner {
     int rc = he == hipSuccess ? run_t<Fld>(eng, bases, scalars, (size_t)np * len, cd, len, &r, st) : eng->hip_fail(he, "memcpy");
     (void)hipFree(cd);
     if (rc) return rc;
-    if (in_mask) {
-      const Jacobian<Fld>* jm = (const Jacobian<Fld>*)in_mask;
-      for (int p = 0; p < np; p++) {
-        XYZZ<Fld> mp = jacobian_to_xyzz(jm[p]);
-        Fr k = coef[p].from_mont();
-        XYZZ<Fld> acc = XYZZ<Fld>::identity();
-        for (int i = FrP::N - 1; i >= 0; i--)
-          for (int b = 31; b >= 0; b--) {
-            acc = xyzz_dbl_ni(acc);
-            if ((k.v[i] >> b) & 1) acc = xyzz_add_ni(acc, mp);
-          }
-        r = xyzz_add_ni(r, acc);
-      }
-    }
+    if (in_mask) r = xyzz_add_ni(r, mask_term<Fld>(in_mask, 0, np, coef.data()));
     const Jacobian<Fld>* om = (const Jacobian<Fld>*)out_mask;
     Jacobian<Fld>* o = (Jacobian<Fld>*)out;
     for (int p = 0; p < eng->n; p++) {
@@ -1188,12 +1015,8 @@ class MsmRunner {
 
   // ---- fixed-base tables (zk_msm_precompute): process-wide registry keyed by address (engine.hpp TableRegistry)
   int table_c = 16;               // window bits of new tables (zk_ctx_set_option "msm_table_c")
-  std::shared_ptr<const MsmTable> find_table(const void* p, size_t npts, size_t elem, size_t* offset) {
-    return TableRegistry::inst().find(p, npts, elem, FrP::BITS, offset);
-  }
   template <class Fld>
   int precompute_t(IEngine* eng, const void* bases, size_t len, hipStream_t st) {
-#if defined(__HIPCC__)
     if (!bases || !len) return eng->fail(ZK_ERR_BAD_INPUT, "null base vector");
     const int T = FrP::BITS + 1;
     const int nwin = (T + table_c - 1) / table_c;
@@ -1211,31 +1034,25 @@ class MsmRunner {
     t->owner = eng;
     hipError_t he = hipMalloc(&t->data, (size_t)nwin * len * sizeof(Affine<Fld>));
     if (he != hipSuccess) return eng->hip_fail(he, "msm table");
-    using KF = typename KernelField<Fld>::type;
-    msm_table_kernel<KF><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, len, c, nwin, t->wide, (Affine<KF>*)t->data);
-    he = hipGetLastError();
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    int rc = msm_table_launch<FrP, Fld>(eng, bases, len, c, nwin, t->wide, t->data, st);
+    if (rc) return rc;
+    he = hipStreamSynchronize(st);
     if (he != hipSuccess) return eng->hip_fail(he, "msm_table_kernel");
     TableRegistry::inst().add(std::move(t));
     return ZK_OK;
-#else
-    (void)eng; (void)bases; (void)len; (void)st;
-    return ZK_ERR_GENERIC;
-#endif
   }
   int forget_table(const void* bases) { return TableRegistry::inst().forget(bases); }
   // [window bits, digit windows] of the table registered for `bases`, or zeros
   void table_info(const void* bases, size_t elem, int* out) {
     size_t off;
-    auto t = find_table(bases, 1, elem, &off);
+    auto t = TableRegistry::inst().find(bases, 1, elem, FrP::BITS, &off);
     out[0] = t ? t->c : 0;
     out[1] = t ? t->nwin : 0;
   }
 
   // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min"; env ZK_MSM_BIGSORT_MIN at start)
   size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)3 << 16);
-  DevBuf ws_[MSM_WS];
+  MsmSlot slots_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;
 };

@@ -1,0 +1,6 @@
+// Pippenger kernels for G1 of one curve (own translation unit: see msm_impl.hpp).
+#include "curves.hpp"
+#include "msm_impl.hpp"
+namespace zk {
+ZK_INSTANTIATE_MSM(Bn254Fr, Fp<Bn254Fq>)
+}  // namespace zk

@@ -311,6 +311,36 @@ def prove(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
     return pa, pb, pc
 
 
+class ProofInFlight:
+    """A proof started with prove_async (zk_groth16_prove_async); wait() joins it and returns the shares."""
+
+    def __init__(self, pp, handle, keep):
+        self.pp, self.handle, self._keep = pp, handle, keep
+
+    def wait(self):
+        pp = self.pp
+        nl = pp.fq.nl
+        pa = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
+        pb = np.zeros((pp.n, 6 * nl), dtype=np.uint64)
+        pc = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
+        pp._check(pp.lib.zk_groth16_wait(pp.h, self.handle, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data))
+        self._keep = None
+        return pa, pb, pc
+
+
+def prove_async(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
+    """zk_groth16_prove_async: enqueue one proof and return at once; up to two may be in flight per context."""
+    rr, ss = pp.fr.encode_one(r), pp.fr.encode_one(s)
+    assert crs.len_a == wit.len_a and crs.len_w == wit.len_w
+    keep = (crs, wit, masks, rr, ss)
+    mk = masks.ct if isinstance(masks, ProofMasks) else masks
+    h = C.c_int(-1)
+    pp._check(pp.lib.zk_groth16_prove_async(pp.h, C.byref(crs.ct), wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr,
+                                            wit.a_share.ptr, wit.ax_share.ptr, rr.ctypes.data, ss.ctypes.data,
+                                            wit.log_m, None if mk is None else C.byref(mk), seed, stream, C.byref(h)))
+    return ProofInFlight(pp, h.value, keep)
+
+
 def libsnark_h(pp, qap, fft_masks, log_m, seed=0):
     """groth16/src/ext_wit.rs:14-102 for all parties: 3 d_ifft (coset shift g = F::GENERATOR, rearranged) ->
     3 d_fft (rearranged) -> (a*b - c) / Z(g) -> d_ifft with g^-1.  qap: three device buffers [n][m/l] (consumed);

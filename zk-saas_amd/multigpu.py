@@ -81,15 +81,15 @@ class GpuBackend:
                                           "a_query0", "b_g1_query0", "delta_g1", "alpha_g1", "beta_g1", "b_g2_query0",
                                           "delta_g2", "beta_g2")])
         pp._check(pp.lib.zk_groth16_msms_begin(pp.h, C.byref(self._local_crs), inp["a_share"].data_ptr(),
-                                               inp["ax_share"].data_ptr(), first, count, int(skip_h)))
+                                               inp["ax_share"].data_ptr(), first, count, int(skip_h), None,
+                                               self.stream()))
 
     def msms_finish(self, h, first, count):
         pp = self.pp
         nl = pp.fq.nl
         outs = [np.zeros(3 * nl * (2 if i == 2 else 1), dtype=np.uint64) for i in range(5)]
         arr = (C.c_void_p * 5)(*[x.ctypes.data for x in outs])
-        pp._check(pp.lib.zk_groth16_msms_finish(pp.h, C.byref(self._local_crs), h.data_ptr(), first, count, arr,
-                                                self.stream()))
+        pp._check(pp.lib.zk_groth16_msms_finish(pp.h, h.data_ptr(), arr, self.stream()))
         return outs
 
     def group_add(self, group, a, b):
@@ -349,7 +349,7 @@ def bench(args, rank, local_rank, world):
                    "fixed_base_tables": table_windows is not None},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
         "proof_matches_single_gpu": ok,
-        "roofline": roofline_of(prof, ntt_passes=2, pp=pp, table_windows=table_windows),   # rank 0's dominant kernel
+        "roofline": roofline_of(prof, ntt_passes=2, masks_on=False, pp=pp, table_windows=table_windows),   # rank 0's dominant kernel
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
 
