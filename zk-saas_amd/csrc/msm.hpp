@@ -28,20 +28,12 @@
 #include "ec.hpp"
 #include "engine.hpp"
 #include "ntt.hpp"
+#include "quad.hpp"
 
 namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
-// bucket-reduce workgroup: 256 lanes, 128 for the largest point type (two LDS planes must fit in 160 KiB)
-template <class Fld>
-constexpr int red_threads() { return sizeof(XYZZ<Fld>) > 256 ? 128 : 256; }
-// buckets per lane in the bucket reduction: the reduction is a chain of 2G + 2 log RT + log G + 1 dependent group
-// additions.  G = 2 (22 steps instead of 27) pays only where the launch is latency-bound, i.e. has few waves: the
-// extension-field MSMs of a proof.  For base-field points it was measured and rejected (twice the lanes for 24/27 of
-// the steps is more total work: d_msm 8 x 2^17 went from 5.0 to 5.65 ms).
-template <class Fld>
-constexpr int red_g() { return sizeof(XYZZ<Fld>) == 256 ? 2 : 4; }
 constexpr int MSM_WS = 12;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate streams)
 
 struct SegDesc {
@@ -468,153 +460,132 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
   }
 }
 
-// One lane per bucket sums its segments when there are few; buckets with many segments (skewed digit
-// distributions: the sparsely used top window, degenerate scalars such as all ones) are queued on `heavy` and
-// summed by a whole workgroup each in msm_finalize_heavy_kernel, so no lane ever walks a long chain.
+// ------------------------------------------------------------------------------------------------ finalize / reduce
+// Everything after the accumulate kernel is a short chain of dependent group additions over few points, so it runs on
+// the lane-cooperative addition of quad.hpp (one point per quad of lanes, 4 multiplication rounds per addition).
 //
-// Every kernel below has exactly ONE (inlined) group-addition call site inside a loop and keeps the lanes' running
-// values in LDS between iterations: an out-of-line addition would pass its 128..384-byte operands through scratch
-// memory (measured: 0.25 GB of scratch writes per G2 reduce launch), several inlined copies would blow up code size.
+//   finalize        bucket = sum of its segment partials: one quad per bucket; buckets with more than FIN_SEQ segments
+//                   (skewed digit distributions: degenerate scalars such as all ones) are queued on `heavy` and summed
+//                   by a whole workgroup each, so no quad ever walks a long chain
+//   reduce stage A  the buckets of one window, indexed by k = digit magnitude in [1, B], form a (HI+1) x LO matrix
+//                   k = hi*LO + lo.  Row sums R_hi and column sums C_lo are PLAIN sums (trees of depth log2 LO / HI):
+//                        sum_k k*bucket_k = LO * sum_hi hi*R_hi + sum_lo lo*C_lo
+//   reduce stage B  bit slices of those two short weighted sums: TR_j = sum of R_hi over hi with bit j set, TC_j
+//                   likewise -- again plain sums
+//   host            X_w = sum_j 2^(j + log2 LO) TR_j + sum_j 2^j TC_j is a Horner walk over c bit positions that joins
+//                   the walk over the windows (msm_fold): 2 c group operations per window on single points
+// The dependent depth is (LO/64 - 1 + 6) + ~8 quad additions instead of the 27 full additions of a running-sum
+// reduction, and the work stays at ~2 additions per bucket.
 constexpr uint32_t FIN_SEQ = 16;
-constexpr int FIN_HEAVY_THREADS = 128;
+constexpr int QUAD_THREADS = 256;                 // 64 points per workgroup: one wave per SIMD of a CU
+constexpr int QUAD_VL = QUAD_THREADS / 4;
 
 template <class Fld>
-__global__ __launch_bounds__(128) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
-                                                          const uint2* __restrict__ offsets, size_t nkeys,
-                                                          XYZZ<Fld>* __restrict__ buckets0,
-                                                          uint32_t* __restrict__ heavy /* [0] = count */) {
+__global__ __launch_bounds__(QUAD_THREADS) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
+                                                                   const uint2* __restrict__ offsets, size_t nkeys,
+                                                                   XYZZ<Fld>* __restrict__ buckets0,
+                                                                   uint32_t* __restrict__ heavy /* [0] = count */) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
-  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = threadIdx.x & 3;
+  size_t k = (size_t)blockIdx.x * QUAD_VL + (threadIdx.x >> 2);
   if (k >= nkeys) return;
   uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
   if (s1 - s0 > FIN_SEQ) {
-    if (blockIdx.y == 0) {             // the heavy list depends on the sort only: built once, used for every y
+    if (blockIdx.y == 0 && q == 0) {   // the heavy list depends on the sort only: built once, used for every y
       uint32_t slot = atomicAdd(heavy, 1u);
       heavy[1 + slot] = (uint32_t)k;
     }
     return;
   }
-  XYZZ<Fld> acc = XYZZ<Fld>::identity();
-  if (s1 > s0) acc = load_elem(partial + s0);
-  for (uint32_t s = s0 + 1; s < s1; s++) acc = xyzz_add(acc, load_elem(partial + s));
-  store_elem(buckets + k, acc);
+  Fld acc = qidentity<Fld>(q);
+  if (s1 > s0) acc = qload(partial + s0, q);
+  for (uint32_t s = s0 + 1; s < s1; s++) acc = qadd(acc, qload(partial + s, q), q);
+  qstore(buckets + k, q, acc);
 }
 
 template <class Fld>
-__global__ __launch_bounds__(FIN_HEAVY_THREADS) void msm_finalize_heavy_kernel(
+__global__ __launch_bounds__(QUAD_THREADS) void msm_finalize_heavy_kernel(
     const XYZZ<Fld>* __restrict__ partial0, size_t pstride, const uint2* __restrict__ offsets, size_t nkeys,
     const uint32_t* __restrict__ heavy, XYZZ<Fld>* __restrict__ buckets0) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  __builtin_amdgcn_s_setprio(3);
   const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
   const uint32_t nheavy = heavy[0];
-  const int tid = threadIdx.x;
-  constexpr int LOGT = 7;
-  static_assert((1 << LOGT) == FIN_HEAVY_THREADS, "FIN_HEAVY_THREADS");
+  const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
   for (uint32_t hbk = blockIdx.x; hbk < nheavy; hbk += gridDim.x) {
     uint32_t k = heavy[1 + hbk];
     uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
-    uint32_t rounds = (s1 - s0 + FIN_HEAVY_THREADS - 1) / FIN_HEAVY_THREADS;   // uniform across the workgroup
-    sh[tid] = XYZZ<Fld>::identity();
-    for (uint32_t it = 0; it < rounds + LOGT; it++) {
-      XYZZ<Fld> a = sh[tid];
-      XYZZ<Fld> b = XYZZ<Fld>::identity();
-      bool wr = true;
-      if (it < rounds) {                       // strided accumulation of the segments
-        uint32_t s = s0 + it * FIN_HEAVY_THREADS + tid;
-        if (s < s1) b = load_elem(partial + s);
-      } else {                                 // tree over the workgroup
-        int off = FIN_HEAVY_THREADS >> (it - rounds + 1);
-        wr = tid < off;
-        if (wr) b = sh[tid + off];
-      }
-      XYZZ<Fld> r = xyzz_add(a, b);
-      __syncthreads();
-      if (wr) sh[tid] = r;
-      __syncthreads();
-    }
-    if (tid == 0) store_elem(buckets + k, sh[0]);
+    Fld acc = qidentity<Fld>(q);
+    for (uint32_t s = s0 + vl; s < s1; s += QUAD_VL) acc = qadd(acc, qload(partial + s, q), q);
+    acc = wg_quad_sum(acc, sh, vl, q, QUAD_VL);
+    if (vl == 0) qstore(buckets + k, q, acc);
     __syncthreads();
   }
 }
 
-// -------------------------------------------------------------------------------------------------- reduce
-// Workgroup (w, blk) covers buckets [blk*RT*RED_G, ...) of window w and emits
-//   S = sum bucket_b,   A = sum (b - base + 1) * bucket_b      (base = first bucket of the workgroup)
-// as a fixed program of 2*RED_G + log RT + log RED_G + 1 + log RT addition steps over two LDS planes:
-//   [0, 2G)        per-lane suffix sums of its RED_G buckets: RUN += bucket_g ; ACC += RUN
-//   [.., +log RT)  suffix scan of RUN across the lanes (suf[t] = sum_{t' >= t} RUN[t'])  -> S = suf[0]
-//   [.., +log G)   sum_t t*RUN[t] = sum_{j>=1} suf[j]; lane weight is t*RED_G: RUN[t] <- RED_G * suf[t] (t >= 1)
-//   [.., +1)       ACC += RUN
-//   [.., +log RT)  tree sum of ACC -> A
-template <class Fld, int RT, int RED_G>
-__global__ __launch_bounds__(RT) void msm_reduce_kernel(const XYZZ<Fld>* __restrict__ buckets0, size_t nkeys,
-                                                       uint32_t B, uint32_t blocks_per_window,
-                                                       XYZZ<Fld>* __restrict__ out0 /* [y][nwin][bpw][2] */) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
-  const XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
-  XYZZ<Fld>* __restrict__ out = out0 + (size_t)blockIdx.y * gridDim.x * 2;
+// stage A: group = row 0..HI or column 0..LO-1 of one bucket set; a workgroup of 64 quads handles 64 / nvl groups,
+// nvl quads each (nvl = 64: one group per workgroup, shortest chain -- few groups, latency matters; nvl = 4: many
+// groups, the serial part dominates and the waves stay full).  blockIdx.y = bucket set (base vector y, window w).
+template <class Fld>
+__global__ __launch_bounds__(QUAD_THREADS) void msm_reduce_a_kernel(const XYZZ<Fld>* __restrict__ buckets0, uint32_t B,
+                                                                   int lo_bits, int nvl, XYZZ<Fld>* __restrict__ out0) {
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ uint4 smem_red[];
-  XYZZ<Fld>* RUN = reinterpret_cast<XYZZ<Fld>*>(smem_red);
-  XYZZ<Fld>* ACC = RUN + RT;
-  constexpr int LOGT = RT == 512 ? 9 : RT == 256 ? 8 : 7;
-  static_assert((1 << LOGT) == RT, "RT must be 128, 256 or 512");
-  constexpr int LOGG = RED_G == 1 ? 0 : RED_G == 2 ? 1 : RED_G == 4 ? 2 : 3;
-  static_assert((1 << LOGG) == RED_G, "RED_G must be 1, 2, 4 or 8");
-  const uint32_t w = blockIdx.x / blocks_per_window, blk = blockIdx.x % blocks_per_window;
-  const uint32_t base = blk * RT * RED_G;
-  const int tid = threadIdx.x;
-  const XYZZ<Fld>* wb = buckets + (size_t)w * B;
-  RUN[tid] = XYZZ<Fld>::identity();
-  ACC[tid] = XYZZ<Fld>::identity();
-  constexpr int P0 = 2 * RED_G, P1 = P0 + LOGT, P2 = P1 + LOGG, P3 = P2 + 1, P4 = P3 + LOGT;
-  for (int st = 0; st < P4; st++) {
-    XYZZ<Fld> a, b = XYZZ<Fld>::identity();
-    XYZZ<Fld>* dst = RUN + tid;
-    bool wr = true;
-    if (st < P0) {
-      if ((st & 1) == 0) {
-        uint32_t bi = base + tid * RED_G + (RED_G - 1 - st / 2);
-        a = RUN[tid];
-        if (bi < B) b = load_elem(wb + bi);
-      } else {
-        a = ACC[tid];
-        b = RUN[tid];
-        dst = ACC + tid;
-      }
-    } else if (st < P1) {
-      int off = 1 << (st - P0);
-      a = RUN[tid];
-      if (tid + off < RT) b = RUN[tid + off];
-    } else if (st < P2) {
-      if (st == P1) {                       // S is complete: emit it, then lane 0 drops out of the weighted sum
-        if (tid == 0) store_elem(out + ((size_t)blockIdx.x) * 2, RUN[0]);
-        a = tid == 0 ? XYZZ<Fld>::identity() : RUN[tid];
-      } else {
-        a = RUN[tid];
-      }
-      b = a;                                // doubling through the addition's equal-operands path
-    } else if (st < P3) {
-      a = ACC[tid];
-      b = (LOGG == 0 && tid == 0) ? XYZZ<Fld>::identity() : RUN[tid];
-      dst = ACC + tid;
-    } else {
-      int off = RT >> (st - P3 + 1);
-      a = ACC[tid];
-      wr = tid < off;
-      if (wr) b = ACC[tid + off];
-      dst = ACC + tid;
+  XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);
+  const uint32_t LO = 1u << lo_bits, HI = B >> lo_bits;          // k = hi * LO + lo, 1 <= k <= B
+  const uint32_t ngroups = HI + 1 + LO;
+  const XYZZ<Fld>* __restrict__ wb = buckets0 + (size_t)blockIdx.y * B;     // bucket of digit magnitude k is wb[k - 1]
+  const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
+  const uint32_t g = blockIdx.x * (uint32_t)(QUAD_VL / nvl) + (uint32_t)(vl / nvl);
+  const uint32_t sub = (uint32_t)(vl & (nvl - 1));
+  Fld acc = qidentity<Fld>(q);
+  if (g <= HI) {                                    // row hi = g: lo runs over the row
+    for (uint32_t lo = sub; lo < LO; lo += (uint32_t)nvl) {
+      uint32_t k = g * LO + lo;
+      if (k >= 1 && k <= B) acc = qadd(acc, qload(wb + (k - 1), q), q);
     }
-    XYZZ<Fld> r = xyzz_add(a, b);
-    __syncthreads();
-    if (wr) *dst = r;
-    __syncthreads();
+  } else if (g < ngroups) {                         // column lo = g - HI - 1: hi runs over the column
+    const uint32_t lo = g - HI - 1;
+    for (uint32_t hi = sub; hi <= HI; hi += (uint32_t)nvl) {
+      uint32_t k = hi * LO + lo;
+      if (k >= 1 && k <= B) acc = qadd(acc, qload(wb + (k - 1), q), q);
+    }
   }
-  if (tid == 0) store_elem(out + ((size_t)blockIdx.x) * 2 + 1, ACC[0]);
+  acc = wg_quad_sum(acc, sh, vl, q, nvl);
+  if (sub == 0 && g < ngroups) qstore(out0 + (size_t)blockIdx.y * ngroups + g, q, acc);
+}
+
+// stage B: slice j <= hb: TR_j over the rows, otherwise TC_(j - hb - 1) over the columns; same workgroup layout
+template <class Fld>
+__global__ __launch_bounds__(QUAD_THREADS) void msm_reduce_b_kernel(const XYZZ<Fld>* __restrict__ rc0, uint32_t B, int lo_bits,
+                                                                   int nvl, XYZZ<Fld>* __restrict__ out0) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ uint4 smem_red[];
+  XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);
+  const uint32_t LO = 1u << lo_bits, HI = B >> lo_bits;
+  const uint32_t ngroups = HI + 1 + LO;
+  int hb = 0;
+  while ((1u << hb) < HI) hb++;                      // HI = 2^hb: row weights 0..HI have bits 0..hb
+  const int nslices = hb + 1 + lo_bits;
+  const XYZZ<Fld>* __restrict__ rc = rc0 + (size_t)blockIdx.y * ngroups;
+  const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
+  const int j = (int)blockIdx.x * (QUAD_VL / nvl) + vl / nvl;
+  const uint32_t sub = (uint32_t)(vl & (nvl - 1));
+  Fld acc = qidentity<Fld>(q);
+  if (j <= hb) {
+    for (uint32_t hi = sub; hi <= HI; hi += (uint32_t)nvl)
+      if ((hi >> j) & 1u) acc = qadd(acc, qload(rc + hi, q), q);
+  } else if (j < nslices) {
+    const int jj = j - hb - 1;
+    for (uint32_t lo = sub; lo < LO; lo += (uint32_t)nvl)
+      if ((lo >> jj) & 1u) acc = qadd(acc, qload(rc + HI + 1 + lo, q), q);
+  }
+  acc = wg_quad_sum(acc, sh, vl, q, nvl);
+  if (sub == 0 && j < nslices) qstore(out0 + (size_t)blockIdx.y * nslices + j, q, acc);
 }
 
 // Fixed-base table (zk_msm_precompute): row w holds 2^(start of window w) * P_i in affine form, so that every window's
@@ -683,8 +654,7 @@ struct MsmSlot {
 // msm_fold() waits for the event and folds on the host.
 struct MsmPending {
   bool active = false;
-  int kwin = 0, c = 0, wide = 0, nb = 1, red_k = 0;
-  uint32_t bpw = 0;
+  int kwin = 0, c = 0, wide = 0, nb = 1, lo_bits = 0;
   MsmSlot* slot = nullptr;
   std::shared_ptr<const MsmTable> tab, tab2;     // keep the tables alive while the kernels run
 };
@@ -765,9 +735,9 @@ template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,
                      hipStream_t st);
 
-// Wait for a launched MSM and fold on the host: window value X_w = sum_blk A_blk + K * sum_blk blk * S_blk with
-// K = RED_THREADS * RED_G = 2^kbits, then Horner over the windows from the top.  The factor K costs nothing: the
-// weighted sum enters the Horner chain kbits doublings before X_w's own addition.
+// Wait for a launched MSM and fold on the host.  The device left, per window, the c bit slices of the weighted bucket
+// sum (msm_reduce_b_kernel): X_w = sum_j 2^(j + lo_bits) TR_j + sum_j 2^j TC_j, and the result is sum_w 2^(start of w)
+// X_w -- one Horner walk over all bit positions from the top: a doubling per bit and an addition per slice.
 template <class Fld>
 int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2) {
   *result = XYZZ<Fld>::identity();
@@ -778,43 +748,24 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
   p.tab.reset();
   p.tab2.reset();
   if (he != hipSuccess) return eng->hip_fail(he, "msm event");
-  const int kwin = p.kwin, c = p.c, wide = p.wide;
-  const uint32_t bpw = p.bpw;
+  const int kwin = p.kwin, c = p.c, wide = p.wide, lo_bits = p.lo_bits, nslices = p.c;
+  const int hb = c - 1 - lo_bits;                  // row slices 0..hb come first, then lo_bits column slices
   const XYZZ<Fld>* hall = (const XYZZ<Fld>*)p.slot->pinned;
   auto fold = [&](const XYZZ<Fld>* h) -> XYZZ<Fld> {
-    std::vector<XYZZ<Fld>> wsum((size_t)kwin, XYZZ<Fld>::identity()), wts((size_t)kwin, XYZZ<Fld>::identity());
-    for (int w = 0; w < kwin; w++) {
-      XYZZ<Fld> acc = XYZZ<Fld>::identity(), run = XYZZ<Fld>::identity(), wt = XYZZ<Fld>::identity();
-      for (int blk = (int)bpw - 1; blk >= 0; blk--) {
-        acc = xyzz_add_ni(acc, h[((size_t)w * bpw + blk) * 2 + 1]);
-        if (blk >= 1) {
-          run = xyzz_add_ni(run, h[((size_t)w * bpw + blk) * 2]);   // sum_{blk' >= blk} S
-          wt = xyzz_add_ni(wt, run);                                 // accumulates sum blk * S_blk
-        }
-      }
-      wsum[(size_t)w] = acc;
-      wts[(size_t)w] = wt;
-    }
-    const uint64_t KBLK = (uint64_t)p.red_k;
-    int kbits = 0;
-    while (((uint64_t)1 << kbits) < KBLK) kbits++;
     XYZZ<Fld> total = XYZZ<Fld>::identity();
     for (int w = kwin - 1; w >= 0; w--) {
-      const int cw = w < wide ? c : c - 1;
-      if (bpw > 1 && kbits <= cw) {
-        for (int i = 0; i < cw - kbits; i++) total = xyzz_dbl_ni(total);
-        total = xyzz_add_ni(total, wts[(size_t)w]);
-        for (int i = 0; i < kbits; i++) total = xyzz_dbl_ni(total);
-      } else {
-        for (int i = 0; i < cw; i++) total = xyzz_dbl_ni(total);
-        if (bpw > 1) total = xyzz_add_ni(total, xyzz_mul_small(wts[(size_t)w], KBLK));
+      const XYZZ<Fld>* sl = h + (size_t)w * nslices;
+      const int cw = (kwin == 1 || w < wide) ? c : c - 1;
+      for (int t = cw - 1; t >= 0; t--) {
+        total = xyzz_dbl_ni(total);
+        const XYZZ<Fld>& s = t >= lo_bits ? sl[t - lo_bits] : sl[hb + 1 + t];
+        if (!s.is_identity()) total = xyzz_add_ni(total, s);
       }
-      total = xyzz_add_ni(total, wsum[(size_t)w]);
     }
     return total;
   };
   *result = fold(hall);
-  if (p.nb == 2 && result2) *result2 = fold(hall + (size_t)kwin * bpw * 2);
+  if (p.nb == 2 && result2) *result2 = fold(hall + (size_t)kwin * nslices);
   return ZK_OK;
 }
 

@@ -50,9 +50,10 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     if (!overridden && want > seg) seg = want;
   }
   const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
-  constexpr int RED_THREADS = red_threads<Fld>();
-  constexpr int RED_G = red_g<Fld>();
-  const uint32_t bpw = (B + RED_THREADS * RED_G - 1) / (RED_THREADS * RED_G);
+  // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
+  const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
+  const uint32_t red_groups = (B >> lo_bits) + 1 + (1u << lo_bits);
+  const int nslices = c;                           // (log2 HI + 1) row slices + lo_bits column slices
   const size_t iscan_blocks = (nkeys + ISCAN_BLOCK - 1) / ISCAN_BLOCK;
 
   // workspace layout
@@ -65,10 +66,11 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
          o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
          o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
-         o_out = take(NB * (size_t)kwin * bpw * 2 * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
+         o_rc = take(NB * (size_t)kwin * red_groups * sizeof(XYZZ<Fld>)),
+         o_out = take(NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
   // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
-    const int lo_bits = c - 1 - BIG_HI;
-  const bool big = !tab && npts >= tune.bigsort_min && lo_bits >= 1 && lo_bits <= 12;
+    const int sort_lo = c - 1 - BIG_HI;
+  const bool big = !tab && npts >= tune.bigsort_min && sort_lo >= 1 && sort_lo <= 12;
   size_t o_bins = 0, o_tmp = 0;
   if (big) {
     o_bins = take((3 * ((size_t)nwin << BIG_HI) + 1) * 4);
@@ -76,7 +78,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   }
   hipError_t he = slot.ws.ensure(off);
   if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
-  const size_t out_bytes = NB * (size_t)kwin * bpw * 2 * sizeof(XYZZ<Fld>);
+  const size_t out_bytes = NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>);
   he = slot.ensure_pinned(out_bytes);
   if (he != hipSuccess) return eng->hip_fail(he, "msm pinned buffer");
   if (!slot.ev) {
@@ -96,6 +98,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   static_assert(sizeof(KF) == sizeof(Fld), "kernel field layout");
   XYZZ<KF>* partial = (XYZZ<KF>*)(ws + o_partial);
   XYZZ<KF>* buckets = (XYZZ<KF>*)(ws + o_buckets);
+  XYZZ<KF>* rc = (XYZZ<KF>*)(ws + o_rc);
   XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
   uint32_t* heavy = (uint32_t*)(ws + o_heavy);
 
@@ -128,11 +131,11 @@ do {                                                                           \
     MSM_HIP(hipMemsetAsync(bin_counts, 0, nbins * 4, st));
     const unsigned tiles = (unsigned)((npts + BIG_TILE - 1) / BIG_TILE);
     msm_part_hist_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d, plen,
-                                                                                c, nwin, wide, lo_bits, bin_counts);
+                                                                                c, nwin, wide, sort_lo, bin_counts);
     msm_bin_scan_kernel<<<dim3(1), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor);
     msm_part_scatter_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, lo_bits, bin_cursor, tmp);
-    msm_bin_sort_kernel<<<dim3(nbins), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, lo_bits, (uint32_t)(c - 1), counts,
+        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, bin_cursor, tmp);
+    msm_bin_sort_kernel<<<dim3(nbins), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_lo, (uint32_t)(c - 1), counts,
                                                                    sorted);
     MSM_STAGE("big sort");
   } else {
@@ -172,30 +175,27 @@ do {                                                                           \
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_REDUCE_G2 : PROF_MSM_REDUCE, st, (double)nkeys * NB);   // units: buckets
   MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
-  msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + 127) / 128), NB), dim3(128), 0, st>>>(
+  msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + QUAD_VL - 1) / QUAD_VL), NB), dim3(QUAD_THREADS), 0, st>>>(
       partial, max_segs, offsets, nkeys, buckets, heavy);
+  const size_t quad_lds = QUAD_VL * sizeof(XYZZ<Fld>);
   {
-    size_t fin_lds = FIN_HEAVY_THREADS * sizeof(XYZZ<Fld>);
-    // small fixed grid (it strides over the heavy list, which is empty for well-spread scalars): a launch of many
-    // workgroups of this register-hungry kernel would wait for whole SIMDs to drain just to find nothing to do
+    // small fixed grid (it strides over the heavy list, which is empty for well-spread scalars)
     static const unsigned heavy_wgs = getenv("ZK_FIN_HEAVY_WGS") ? (unsigned)atoi(getenv("ZK_FIN_HEAVY_WGS")) : 48u;
-    msm_finalize_heavy_kernel<KF><<<dim3(heavy_wgs ? heavy_wgs : 48u, NB), dim3(FIN_HEAVY_THREADS), fin_lds, st>>>(partial, max_segs, offsets,
-                                                                                            nkeys, heavy, buckets);
+    msm_finalize_heavy_kernel<KF><<<dim3(heavy_wgs ? heavy_wgs : 48u, NB), dim3(QUAD_THREADS), quad_lds, st>>>(
+        partial, max_segs, offsets, nkeys, heavy, buckets);
   }
   MSM_STAGE("finalize");
-  size_t red_lds = 2 * RED_THREADS * sizeof(XYZZ<Fld>);
-  if (red_lds > 48 * 1024) {
-    static std::mutex attr_mu;
-    static std::vector<int> attr_done;          // per device (the attribute belongs to the device's code object)
-    std::lock_guard<std::mutex> lk(attr_mu);
-    if (std::find(attr_done.begin(), attr_done.end(), eng->device) == attr_done.end()) {
-      MSM_HIP(hipFuncSetAttribute((const void*)msm_reduce_kernel<KF, RED_THREADS, RED_G>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)red_lds));
-      attr_done.push_back(eng->device);
-    }
-  }
-  msm_reduce_kernel<KF, RED_THREADS, RED_G><<<dim3((unsigned)(kwin * bpw), NB), dim3(RED_THREADS), red_lds, st>>>(
-      buckets, nkeys, B, bpw, out);
+  // quads per group: few groups (one bucket set) -> whole workgroups per group, shortest dependent chain; many groups
+  // (one bucket set per window) -> 4 quads per group, waves stay full
+  const size_t tot_groups = (size_t)red_groups * NB * kwin;
+  const int nvl_a = tot_groups <= 1024 ? QUAD_VL : (tot_groups <= 4096 ? 16 : 4);
+  const size_t tot_slices = (size_t)nslices * NB * kwin;
+  const int nvl_b = tot_slices <= 256 ? QUAD_VL : 16;
+  const unsigned gpw_a = QUAD_VL / nvl_a, gpw_b = QUAD_VL / nvl_b;
+  msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)kwin), dim3(QUAD_THREADS), quad_lds, st>>>(
+      buckets, B, lo_bits, nvl_a, rc);
+  msm_reduce_b_kernel<KF><<<dim3(((unsigned)nslices + gpw_b - 1) / gpw_b, NB * (unsigned)kwin), dim3(QUAD_THREADS), quad_lds,
+                            st>>>(rc, B, lo_bits, nvl_b, out);
   }
   MSM_HIP(hipGetLastError());
   MSM_STAGE("reduce");
@@ -208,8 +208,7 @@ do {                                                                           \
   pend->c = c;
   pend->wide = wide;
   pend->nb = (int)NB;
-  pend->red_k = RED_THREADS * RED_G;
-  pend->bpw = bpw;
+  pend->lo_bits = lo_bits;
   pend->slot = &slot;
   pend->tab = std::move(tab);
   pend->tab2 = std::move(tab2);
