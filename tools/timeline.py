@@ -1,25 +1,35 @@
-"""Per-stream kernel timeline of one proof from a rocprofv3 --kernel-trace csv (diagnostics).
+"""Per-stream kernel timeline of one proof from a rocprofv3 --kernel-trace result (rocpd sqlite database or csv).
 
-usage: python tools/timeline.py gpurun_out/prof/p_kernel_trace.csv [proof_index_from_end]
-A proof starts at each launch of the first kernel of circom_h's stream-independent prefix (msm_digits on any stream
-after a gap); here simply: split the trace at every `king_degred_kernel` end (one per proof).
+usage: python tools/timeline.py gpurun_out/prof/p_results.db [proof_index_from_end]
+Proof boundaries: gaps of more than 150 us with no kernel running.
 """
 import csv
 import re
+import sqlite3
 import sys
 from collections import defaultdict
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+path = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+if path.endswith(".db"):
+    cur = sqlite3.connect(path).cursor()
+    rows = [{"Kernel_Name": r[0], "Start_Timestamp": r[1], "End_Timestamp": r[2], "Stream_Id": r[3], "Grid_Size_X": r[4]}
+            for r in cur.execute("select name, start, end, stream_id, grid_x from kernels")]
+else:
+    rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+
+
 def short(n):
     n = re.sub(r"^void zk::", "", n)
+    n = re.sub(r"^zk::", "", n)
     m = re.match(r"(\w+)", n)
     s = m.group(1) if m else n
     if "Fp2" in n:
         s += "<G2>"
     return s
-# proof boundaries: gaps > 150 us with no kernel running
+
+
 bounds, end = [0], 0
 for i, r in enumerate(rows):
     st = int(r["Start_Timestamp"])
@@ -39,5 +49,5 @@ for q, rs in sorted(by.items(), key=lambda kv: int(kv[1][0]["Start_Timestamp"]))
     print(f"-- stream/queue {q}")
     for r in rs:
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
-        if e - s >= 0.03:
+        if e - s >= 0.02:
             print(f"   {s:7.3f} -> {e:7.3f}  ({e - s:6.3f})  {short(r['Kernel_Name'])}  grid={r.get('Grid_Size_X', r.get('Grid_Size'))}")

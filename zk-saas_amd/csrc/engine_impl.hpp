@@ -925,13 +925,26 @@ class Engine : public IEngine {
     j.split_v = count >= 2;
     const int nh = j.split_v ? count / 2 : count;
     const Fr* cf = msm_.coef_d_ + first;
-    auto msm_task = [this, J, dev](auto fld_tag, int which, const void* bases, const void* bases2, const void* scal,
-                                   size_t npts, const Fr* coef, size_t plen, hipStream_t stream, int wslot,
-                                   MsmPending* pend, auto* out1, auto* out2) {
+    // ZK_GATE_ACC=1 (experiment): the accumulate launches of the witness MSMs wait until circom_h has left the chip
+    static const bool gate_acc = getenv("ZK_GATE_ACC") != nullptr;
+    hipEvent_t gate = nullptr;
+    bool h_done = false;
+    if (full && gate_acc) {
+      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+      if (he != hipSuccess) return hip_fail(he, "h share buffer");
+      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
+      if (rc) return rc;
+      ZK_HIP(hipEventRecord(ev_gate_[j.slot], streams_[5]));
+      gate = ev_gate_[j.slot];
+      h_done = true;
+    }
+    auto msm_task = [this, J, dev, gate](auto fld_tag, int which, const void* bases, const void* bases2, const void* scal,
+                                         size_t npts, const Fr* coef, size_t plen, hipStream_t stream, int wslot,
+                                         MsmPending* pend, auto* out1, auto* out2) {
       using Fld = decltype(fld_tag);
       J->fut.push_back(pool_->submit([=]() {
         (void)hipSetDevice(dev);
-        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2);
+        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2, gate);
         if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
         J->rc[which] = rc2;
         if constexpr (std::is_same<Fld, Fq_>::value) {
@@ -1002,10 +1015,12 @@ class Engine : public IEngine {
     // measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
     if (full) {
       hipStream_t hs = streams_[5];
-      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
-      if (he != hipSuccess) return hip_fail(he, "h share buffer");
-      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
-      if (rc) return rc;
+      if (!h_done) {
+        hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+        if (he != hipSuccess) return hip_fail(he, "h share buffer");
+        rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
+        if (rc) return rc;
+      }
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
                                       ws0 + 0, &j.pU);
       if (rc) return rc;
@@ -1443,7 +1458,10 @@ class Engine : public IEngine {
       bool prio = (i == 2 || i == 4 || i == 5);      // the two G2 halves and the circom_h -> U chain
       ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio ? hi : lo));
     }
-    for (int i = 0; i < NJOBS; i++) ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
+    for (int i = 0; i < NJOBS; i++) {
+      ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
+      ZK_HIP(hipEventCreateWithFlags(&ev_gate_[i], hipEventDisableTiming));
+    }
     // host workers: the MSM tasks block on their events while the scalar-multiple tasks run
     int nthreads = getenv("ZK_HOST_THREADS") ? atoi(getenv("ZK_HOST_THREADS")) : 0;
     if (nthreads <= 0) {
@@ -1457,6 +1475,7 @@ class Engine : public IEngine {
   }
   std::unique_ptr<HostPool> pool_;
   hipEvent_t ev_in_[NJOBS] = {nullptr, nullptr};
+  hipEvent_t ev_gate_[NJOBS] = {nullptr, nullptr};
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool streams_ready_ = false;
   bool force_simple_ntt = false;

@@ -99,8 +99,8 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
 // The order inside a bucket is arbitrary, as before; bucket sums do not depend on it.
 constexpr int BIG_HI = 8;
 constexpr int BIG_THREADS = 256;
-constexpr int BIG_PTS_PER_THREAD = 16;
-constexpr int BIG_TILE = BIG_THREADS * BIG_PTS_PER_THREAD;
+constexpr int BIG_PTS_PER_THREAD = 16;   // points per thread for multi-million-point MSMs; fewer for small ones so that
+                                         // the tiles (BIG_THREADS * points-per-thread points each) still fill the chip
 
 // signed-digit walk over one scalar (shared by all sort kernels): fn(window, bucket index, negative)
 template <class FrP, class Fn>
@@ -138,17 +138,20 @@ template <class FrP>
 __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP>* __restrict__ scalars, size_t npts,
                                                                     const Fp<FrP>* __restrict__ coef, size_t part_len,
                                                                     int c, int nwin, int wide, int lo_bits,
+                                                                    int ppt /* points per thread */,
+                                                                    uint32_t wmask /* 0: fixed-base table, all windows
+                                                                    share one bucket set; ~0: one set per window */,
                                                                     uint32_t* __restrict__ bin_counts) {
   extern __shared__ uint32_t big_lds[];
-  const uint32_t nbins = (uint32_t)nwin << BIG_HI;
+  const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) big_lds[b] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * BIG_TILE;
-  for (int k = 0; k < BIG_PTS_PER_THREAD; k++) {
+  const size_t base = (size_t)blockIdx.x * BIG_THREADS * ppt;
+  for (int k = 0; k < ppt; k++) {
     size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (i >= npts) break;
     msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i), c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[((uint32_t)w << BIG_HI) | (b >> lo_bits)], 1u); });
+                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[(((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits)], 1u); });
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS)
@@ -189,20 +192,22 @@ template <class FrP>
 __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<FrP>* __restrict__ scalars,
                                                                        size_t npts, const Fp<FrP>* __restrict__ coef,
                                                                        size_t part_len, int c, int nwin, int wide,
-                                                                       int lo_bits, uint32_t* __restrict__ bin_cursor,
+                                                                       int lo_bits, int ppt, uint32_t wmask,
+                                                                       uint32_t pre_stride, uint32_t pre_off,
+                                                                       uint32_t* __restrict__ bin_cursor,
                                                                        uint2* __restrict__ tmp) {
   extern __shared__ uint32_t big_lds[];
-  const uint32_t nbins = (uint32_t)nwin << BIG_HI;
+  const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
   uint32_t* cnt = big_lds;            // per-bin count of this tile, then the running local rank
   uint32_t* gbase = big_lds + nbins;  // start of this tile's range inside the bin
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) cnt[b] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * BIG_TILE;
-  for (int k = 0; k < BIG_PTS_PER_THREAD; k++) {
+  const size_t base = (size_t)blockIdx.x * BIG_THREADS * ppt;
+  for (int k = 0; k < ppt; k++) {
     size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (i >= npts) break;
     msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i), c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[((uint32_t)w << BIG_HI) | (b >> lo_bits)], 1u); });
+                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[(((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits)], 1u); });
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) {
@@ -212,14 +217,15 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
   }
   __syncthreads();
   const uint32_t lo_mask = (1u << lo_bits) - 1;
-  for (int k = 0; k < BIG_PTS_PER_THREAD; k++) {
+  for (int k = 0; k < ppt; k++) {
     size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (i >= npts) break;
     msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i), c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t neg) {
-                              uint32_t bin = ((uint32_t)w << BIG_HI) | (b >> lo_bits);
+                              uint32_t bin = (((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits);
                               uint32_t r = atomicAdd(&cnt[bin], 1u);
-                              tmp[gbase[bin] + r] = make_uint2((uint32_t)i | (neg << 31), b & lo_mask);
+                              uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + (uint32_t)i : (uint32_t)i;
+                              tmp[gbase[bin] + r] = make_uint2(idx | (neg << 31), b & lo_mask);
                             });
   }
 }
@@ -465,8 +471,8 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
 // the lane-cooperative addition of quad.hpp (one point per quad of lanes, 4 multiplication rounds per addition).
 //
 //   finalize        bucket = sum of its segment partials: one quad per bucket; buckets with more than FIN_SEQ segments
-//                   (skewed digit distributions: degenerate scalars such as all ones) are queued on `heavy` and summed
-//                   by a whole workgroup each, so no quad ever walks a long chain
+//                   (skewed digit distributions: degenerate scalars such as all ones) are summed by their whole
+//                   workgroup afterwards, so no quad ever walks a long chain
 //   reduce stage A  the buckets of one window, indexed by k = digit magnitude in [1, B], form a (HI+1) x LO matrix
 //                   k = hi*LO + lo.  Row sums R_hi and column sums C_lo are PLAIN sums (trees of depth log2 LO / HI):
 //                        sum_k k*bucket_k = LO * sum_hi hi*R_hi + sum_lo lo*C_lo
@@ -483,46 +489,39 @@ constexpr int QUAD_VL = QUAD_THREADS / 4;
 template <class Fld>
 __global__ __launch_bounds__(QUAD_THREADS) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
                                                                    const uint2* __restrict__ offsets, size_t nkeys,
-                                                                   XYZZ<Fld>* __restrict__ buckets0,
-                                                                   uint32_t* __restrict__ heavy /* [0] = count */) {
+                                                                   XYZZ<Fld>* __restrict__ buckets0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
-  const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
-  XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
-  const int q = threadIdx.x & 3;
-  size_t k = (size_t)blockIdx.x * QUAD_VL + (threadIdx.x >> 2);
-  if (k >= nkeys) return;
-  uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
-  if (s1 - s0 > FIN_SEQ) {
-    if (blockIdx.y == 0 && q == 0) {   // the heavy list depends on the sort only: built once, used for every y
-      uint32_t slot = atomicAdd(heavy, 1u);
-      heavy[1 + slot] = (uint32_t)k;
-    }
-    return;
-  }
-  Fld acc = qidentity<Fld>(q);
-  if (s1 > s0) acc = qload(partial + s0, q);
-  for (uint32_t s = s0 + 1; s < s1; s++) acc = qadd(acc, qload(partial + s, q), q);
-  qstore(buckets + k, q, acc);
-}
-
-template <class Fld>
-__global__ __launch_bounds__(QUAD_THREADS) void msm_finalize_heavy_kernel(
-    const XYZZ<Fld>* __restrict__ partial0, size_t pstride, const uint2* __restrict__ offsets, size_t nkeys,
-    const uint32_t* __restrict__ heavy, XYZZ<Fld>* __restrict__ buckets0) {
-  __builtin_amdgcn_s_setprio(3);
   const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
-  const uint32_t nheavy = heavy[0];
+  __shared__ uint32_t nheavy, heavy[QUAD_VL];
+  if (threadIdx.x == 0) nheavy = 0;
+  __syncthreads();
   const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
-  for (uint32_t hbk = blockIdx.x; hbk < nheavy; hbk += gridDim.x) {
-    uint32_t k = heavy[1 + hbk];
-    uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
+  const size_t k = (size_t)blockIdx.x * QUAD_VL + vl;
+  if (k < nkeys) {
+    const uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
+    if (s1 - s0 > FIN_SEQ) {
+      if (q == 0) heavy[atomicAdd(&nheavy, 1u)] = (uint32_t)vl;
+    } else {
+      Fld acc = qidentity<Fld>(q);
+      if (s1 > s0) acc = qload(partial + s0, q);
+      for (uint32_t s = s0 + 1; s < s1; s++) acc = qadd(acc, qload(partial + s, q), q);
+      qstore(buckets + k, q, acc);
+    }
+  }
+  __syncthreads();
+  // buckets with many segments (degenerate scalars): the whole workgroup sums one at a time -- strided accumulation
+  // over its 64 quads, then a tree -- so that no quad walks a long chain.  Empty for well-spread scalars.
+  const uint32_t nh = nheavy;
+  for (uint32_t h = 0; h < nh; h++) {
+    const size_t kh = (size_t)blockIdx.x * QUAD_VL + heavy[h];
+    const uint32_t s0 = offsets[kh].y, s1 = offsets[kh + 1].y;
     Fld acc = qidentity<Fld>(q);
     for (uint32_t s = s0 + vl; s < s1; s += QUAD_VL) acc = qadd(acc, qload(partial + s, q), q);
     acc = wg_quad_sum(acc, sh, vl, q, QUAD_VL);
-    if (vl == 0) qstore(buckets + k, q, acc);
+    if (vl == 0) qstore(buckets + kh, q, acc);
     __syncthreads();
   }
 }
@@ -661,6 +660,7 @@ struct MsmPending {
 
 struct MsmTuning {
   size_t bigsort_min;
+  hipEvent_t gate = nullptr;      // if set: the accumulate launch waits for this event (sort work still runs ahead)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -807,10 +807,10 @@ class MsmRunner {
   // launch on workspace slot `wslot`; the result is collected with finish_t
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr) {
+               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, hipEvent_t gate = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min};
+    MsmTuning tune{bigsort_min, gate};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend);
   }
   template <class Fld>
@@ -1002,7 +1002,7 @@ class MsmRunner {
   }
 
   // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min"; env ZK_MSM_BIGSORT_MIN at start)
-  size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)3 << 16);
+  size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)1 << 14);
   MsmSlot slots_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;

@@ -67,13 +67,14 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
          o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
          o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
          o_rc = take(NB * (size_t)kwin * red_groups * sizeof(XYZZ<Fld>)),
-         o_out = take(NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>)), o_heavy = take((nkeys + 1) * 4);
+         o_out = take(NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>));
   // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
     const int sort_lo = c - 1 - BIG_HI;
-  const bool big = !tab && npts >= tune.bigsort_min && sort_lo >= 1 && sort_lo <= 12;
+  const bool big = npts >= tune.bigsort_min && sort_lo >= 1 && sort_lo <= 12;
+  const int kbin = tab ? 1 : nwin;                 // window components of the sort bins
   size_t o_bins = 0, o_tmp = 0;
   if (big) {
-    o_bins = take((3 * ((size_t)nwin << BIG_HI) + 1) * 4);
+    o_bins = take((3 * ((size_t)kbin << BIG_HI) + 1) * 4);
     o_tmp = take(max_sorted * sizeof(uint2));
   }
   hipError_t he = slot.ws.ensure(off);
@@ -100,7 +101,6 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   XYZZ<KF>* buckets = (XYZZ<KF>*)(ws + o_buckets);
   XYZZ<KF>* rc = (XYZZ<KF>*)(ws + o_rc);
   XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
-  uint32_t* heavy = (uint32_t*)(ws + o_heavy);
 
 #define MSM_HIP(x)                                           \
 do {                                                       \
@@ -123,18 +123,23 @@ do {                                                                           \
   {
   ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts);
   if (big) {
-    const uint32_t nbins = (uint32_t)nwin << BIG_HI;
+    const uint32_t nbins = (uint32_t)kbin << BIG_HI;
     uint32_t* bin_counts = (uint32_t*)(ws + o_bins);
     uint32_t* bin_base = bin_counts + nbins;
     uint32_t* bin_cursor = bin_base + nbins + 1;
     uint2* tmp = (uint2*)(ws + o_tmp);
     MSM_HIP(hipMemsetAsync(bin_counts, 0, nbins * 4, st));
-    const unsigned tiles = (unsigned)((npts + BIG_TILE - 1) / BIG_TILE);
+    // tile = BIG_THREADS * ppt points: ~1024 tiles for small MSMs, 16 points per thread for the multi-million ones
+    int ppt = BIG_PTS_PER_THREAD;
+    while (ppt > 1 && (npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt) < 1024) ppt >>= 1;
+    const unsigned tiles = (unsigned)((npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
+    const uint32_t wmask = tab ? 0u : ~0u;
     msm_part_hist_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d, plen,
-                                                                                c, nwin, wide, sort_lo, bin_counts);
+                                                                                c, nwin, wide, sort_lo, ppt, wmask,
+                                                                                bin_counts);
     msm_bin_scan_kernel<<<dim3(1), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor);
     msm_part_scatter_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, bin_cursor, tmp);
+        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp);
     msm_bin_sort_kernel<<<dim3(nbins), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_lo, (uint32_t)(c - 1), counts,
                                                                    sorted);
     MSM_STAGE("big sort");
@@ -174,16 +179,9 @@ do {                                                                           \
   MSM_STAGE("accumulate");
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_REDUCE_G2 : PROF_MSM_REDUCE, st, (double)nkeys * NB);   // units: buckets
-  MSM_HIP(hipMemsetAsync(heavy, 0, 4, st));
-  msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + QUAD_VL - 1) / QUAD_VL), NB), dim3(QUAD_THREADS), 0, st>>>(
-      partial, max_segs, offsets, nkeys, buckets, heavy);
   const size_t quad_lds = QUAD_VL * sizeof(XYZZ<Fld>);
-  {
-    // small fixed grid (it strides over the heavy list, which is empty for well-spread scalars)
-    static const unsigned heavy_wgs = getenv("ZK_FIN_HEAVY_WGS") ? (unsigned)atoi(getenv("ZK_FIN_HEAVY_WGS")) : 48u;
-    msm_finalize_heavy_kernel<KF><<<dim3(heavy_wgs ? heavy_wgs : 48u, NB), dim3(QUAD_THREADS), quad_lds, st>>>(
-        partial, max_segs, offsets, nkeys, heavy, buckets);
-  }
+  msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + QUAD_VL - 1) / QUAD_VL), NB), dim3(QUAD_THREADS), quad_lds, st>>>(
+      partial, max_segs, offsets, nkeys, buckets);
   MSM_STAGE("finalize");
   // quads per group: few groups (one bucket set) -> whole workgroups per group, shortest dependent chain; many groups
   // (one bucket set per window) -> 4 quads per group, waves stay full
