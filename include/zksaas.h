@@ -259,6 +259,69 @@ int zk_groth16_abort(zk_ctx* ctx, int handle);
 int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                         const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c);
 
+/* ---- the star network on one multi-GPU node (mpc-net/src/lib.rs:43-53, 89-176 `MpcNet`; ser_net.rs:16-120) -------
+ * One process per GPU; rank rho drives the k = n / world parties [rho*k, (rho+1)*k) (party p -> rank p / k is the only
+ * party -> device map supported; pass it as party_to_rank or NULL); the king (party 0) lives on rank 0.
+ * `sid` = MultiplexedStreamID: channels 0..2 may be in flight at once (ext_wit.rs:158-170), calls on one channel are
+ * ordered (multi.rs:418-445); channel 3 is used internally by zk_dist_groth16_prove.
+ * Transports: ZK_NET_RCCL (ncclSend / ncclRecv over xGMI on device buffers), ZK_NET_SHM (staged through POSIX shared
+ * memory: tests, several ranks on one GPU; with ctx == NULL the buffers of the raw verbs are HOST memory),
+ * ZK_NET_LOCAL (world = 1).
+ * Timeouts (lib.rs:98-135, ser_net.rs:57-94,122-125): a rank that does not enter a round within the timeout (default
+ * 30 s, zk_net_set_timeout_ms) is left out of it; the king continues with the remaining parties through
+ * lagrange_unpack when enough remain (else ZK_ERR_PROTOCOL "Not enough shares"), the late rank's call returns
+ * ZK_ERR_PROTOCOL with its first party id.  zk_dist_groth16_prove needs every party.
+ * id: ZK_NET_ID_BYTES made by zk_net_unique_id on rank 0 and handed to every rank by the launcher. */
+typedef struct zk_net zk_net;
+enum zk_transport { ZK_NET_LOCAL = 0, ZK_NET_RCCL = 1, ZK_NET_SHM = 2 };
+#define ZK_NET_ID_BYTES 512
+int zk_net_unique_id(void* id_out);
+int zk_net_create(zk_ctx* ctx, int transport, int rank, int world, int n_parties /* used when ctx == NULL */,
+                  const int* party_to_rank, const void* id, size_t shm_bytes_per_channel, zk_net** out);
+void zk_net_destroy(zk_net* net);
+const char* zk_net_last_error(zk_net* net, int* party);
+int zk_net_set_timeout_ms(zk_net* net, uint64_t ms);
+int zk_net_info(const zk_net* net, int info[4]);          /* rank, world, first party, parties per rank */
+/* raw verbs (what the primitives below are made of; exposed for hosts that compose their own rounds).
+ * zk_net_enter: join the next round on `sid`; *mask = ranks taking part.  gather = client_send_or_king_receive
+ * (lib.rs:89-135): bytes_per_rank from every rank, the king's `full` receives the present ranks' blocks compacted in
+ * rank order.  scatter = client_receive_or_king_send (:137-176): rank r receives block r of the king's `full`.
+ * *_host move small host values (<= 4096 bytes) through the control block.  Transfers on a channel are enqueued on
+ * the channel's stream; zk_net_sync waits for it with the timeout as deadline. */
+int zk_net_enter(zk_net* net, int sid, uint32_t* mask);
+int zk_net_gather(zk_net* net, int sid, uint32_t mask, const void* local, size_t bytes_per_rank, void* full);
+int zk_net_scatter(zk_net* net, int sid, uint32_t mask, const void* full, size_t bytes_per_rank, void* local);
+int zk_net_gather_host(zk_net* net, int sid, uint32_t mask, const void* mine, size_t bytes, void* all);
+int zk_net_bcast_host(zk_net* net, int sid, uint32_t mask, void* buf, size_t bytes);
+int zk_net_sync(zk_net* net, int sid);
+
+/* ---- the reference's entry points as they are CALLED there: per party (here: per rank = its k parties), with a net
+ * and a stream id, collectively by all ranks.  Buffers hold THIS RANK's rows: shares [k][m/l], masks [k][m/l] (NULL =
+ * the *::zero() mask), MSM masks / outputs k Jacobian points (host).
+ *   d_fft(pd_shares, rearrange, &FftMask, pp, &net, sid)            dfft/mod.rs:99-134   -> zk_dist_d_fft
+ *   d_ifft(pd_shares, rearrange, &FftMask, dom, g, pp, &net, sid)   dfft/mod.rs:137-175  -> zk_dist_d_ifft
+ *   deg_red(px, pp, &DegRedMask, &net, sid)                         deg_red.rs:80-126    -> zk_dist_deg_red
+ *   d_pp(num, den, &DegRedMask, pp, &net, sid)                      dpp/mod.rs:15-87     -> zk_dist_d_pp
+ *   d_msm(bases, scalars, &MsmMask, pp, &net, sid)                  dmsm/mod.rs:59-102   -> zk_dist_d_msm
+ *   circom_h(qap_share, pp, masks.., &net)  (channels 0..2)         ext_wit.rs:104-181   -> zk_dist_circom_h
+ *   dsha256(pp, crs_share, qap_share, a_share, ax_share, .., &net)  sha256.rs:32-129     -> zk_dist_groth16_prove */
+int zk_dist_d_fft(zk_ctx* ctx, zk_net* net, int sid, void* shares_d, const void* in_mask_d, const void* out_mask_d,
+                  int rearrange, int log2_m, uint64_t seed, void* stream);
+int zk_dist_d_ifft(zk_ctx* ctx, zk_net* net, int sid, void* shares_d, const void* in_mask_d, const void* out_mask_d,
+                   int rearrange, int log2_m, const void* g, uint64_t seed, void* stream);
+int zk_dist_deg_red(zk_ctx* ctx, zk_net* net, int sid, void* x_d, const void* in_mask_d, const void* out_mask_d,
+                    size_t len, uint64_t seed, void* stream);
+int zk_dist_d_pp(zk_ctx* ctx, zk_net* net, int sid, const void* num_d, const void* den_d, const void* in_mask_d,
+                 const void* out_mask_d, size_t len, uint64_t seed, void* out_d, void* stream);
+int zk_dist_d_msm(zk_ctx* ctx, zk_net* net, int sid, int group, const void* bases_d, const void* scalars_d, size_t len,
+                  const void* in_mask, const void* out_mask, void* out, void* stream);
+int zk_dist_circom_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                     const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream);
+int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                          const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r, const void* s,
+                          int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
+                          void* stream);
+
 /* ---- per-kernel timing (measurement only) -----------------------------------------------------------------
  * When enabled, HIP events are recorded on the launching stream around the kernels of each slot; zk_profile_read
  * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the

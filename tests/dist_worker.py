@@ -1,0 +1,186 @@
+"""Worker of tests/test_gpu_dist.py: one rank of the library's star network (zk_dist_* over zk_net_*), several ranks
+sharing the one GPU of the test box through the shared-memory transport.  Every rank deals the SAME inputs (seeded),
+runs the all-parties-in-one-call form on its own context as the reference result, and compares its rows of the
+collective result with it -- bit for bit for share vectors, as group elements for points."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows(a, first, k):
+    return a[first:first + k]
+
+
+def run(rank, world, net_id, scenario, q, transport="shm"):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import zksaas_amd as zk
+        from zksaas_amd import groth16 as zg
+        from zksaas_amd import multigpu as mg
+        from zksaas_amd import net as znet
+        from zksaas_amd.api import ZK_G1, ZK_G2, DeviceBuffer, FftMask, DegRedMask, MsmMask
+        from oracle.curve import g1, g2
+        from oracle.params import BN254
+        from oracle.prng import rand_fp
+        from gpu_util import dec_jacobian
+        from test_oracle_groth16 import small_r1cs
+
+        pp = zk.PackedSharingParams("bn254", 2)
+        pp.set_option("msm_bigsort_min", 0 if rank % 2 else 1 << 30)      # both sort paths across the ranks
+        net = znet.StarNet(pp, rank, world, net_id, transport, timeout_ms=1500 if scenario == "late" else 60000)
+        first, k, n = net.first, net.k, pp.n
+        eb = pp.fr.nbytes
+        P = BN254.r
+        G1, G2 = g1(BN254), g2(BN254)
+        rng = np.random.default_rng(7)
+
+        def rand_fr(count):
+            a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+            a[:, 3] &= np.uint64((1 << 60) - 1)
+            return a
+
+        def loc(arr, ln):            # this rank's rows of a full [n][ln] limb array, as a device buffer
+            return DeviceBuffer.from_numpy(pp, arr.reshape(n, ln, 4)[first:first + k])
+
+        def lmask(m, ln, cls):
+            return cls(mg.rows(m.in_mask, first, k, ln * eb), mg.rows(m.out_mask, first, k, ln * eb))
+
+        def same_rows(dev_local, dev_full, ln):
+            return np.array_equal(dev_local.to_numpy().reshape(k, ln, 4), dev_full.to_numpy().reshape(n, ln, 4)[first:first + k])
+
+        checks = {}
+        if scenario == "late":
+            # one party per rank (world = 8); the last rank enters after the timeout and is left out
+            log_m = 10
+            Lc = (1 << log_m) // 2
+            sh = rand_fr(n * Lc)
+            if rank == world - 1:
+                time.sleep(4.0)
+                try:
+                    znet.dist_d_fft(pp, net, 0, loc(sh, Lc), FftMask.zero(), False, log_m, seed=3)
+                    q.put((rank, False, "late rank was admitted"))
+                except zk.ZkError as e:
+                    q.put((rank, e.code == 2 and e.party == first, "code %d party %d" % (e.code, e.party)))
+                net.close()
+                return
+            present = list(range(n - 1))
+            got = znet.dist_d_fft(pp, net, 0, loc(sh, Lc), FftMask.zero(), False, log_m, seed=3)
+            # reference: fft1 on the present parties' rows, then the king with the party list (lagrange_unpack)
+            full = DeviceBuffer.from_numpy(pp, sh.reshape(n, Lc, 4)[: n - 1])
+            pp._check(pp.lib.zk_fft1(pp.h, full.ptr, log_m, 0, n - 1, None, None))
+            out = pp.alloc_fr(n * Lc)
+            import ctypes as C
+            arr = (C.c_uint32 * (n - 1))(*present)
+            pp._check(pp.lib.zk_fft2_king(pp.h, full.ptr, arr, n - 1, log_m, 0, None, 0, 0, 3, out.ptr, None, None))
+            pp.sync()
+            net.sync(0)
+            checks["d_fft_dropout"] = same_rows(got, out, Lc)
+            # d_msm with the same party missing
+            ln = 300
+            gen = pp.fq.encode([1, 2]).reshape(-1)
+            bases = np.tile(gen, (n * ln, 1)).reshape(n, ln, 8)
+            scal = rand_fr(n * ln).reshape(n, ln, 4)
+            got = znet.dist_d_msm(pp, net, 1, ZK_G1, DeviceBuffer.from_numpy(pp, bases[first:first + k]),
+                                  DeviceBuffer.from_numpy(pp, scal[first:first + k]), ln)
+            ref = zk.api.d_msm_parties(pp, ZK_G1, DeviceBuffer.from_numpy(pp, bases[: n - 1]),
+                                       DeviceBuffer.from_numpy(pp, scal[: n - 1]), ln, present)
+            checks["d_msm_dropout"] = G1.eq(dec_jacobian(pp, got[0]), dec_jacobian(pp, ref[first]))
+            q.put((rank, all(checks.values()), repr(checks)))
+            net.close()
+            return
+
+        # ---- d_fft / d_ifft with masks, both output arrangements
+        log_m = 12
+        m = 1 << log_m
+        Lc = m // 2
+        sh = rand_fr(n * Lc)
+        for inverse, rearr in ((False, False), (True, True), (False, True)):
+            g = zg._root_of_unity("bn254", log_m + 1) if inverse else None
+            mk = FftMask.sample(pp, rearr, g, int(inverse), log_m, 40 + int(inverse))
+            full = DeviceBuffer.from_numpy(pp, sh)
+            mine = loc(sh, Lc)
+            if inverse:
+                zk.d_ifft(pp, full, mk, rearr, log_m, g=g, seed=5)
+                znet.dist_d_ifft(pp, net, 1, mine, lmask(mk, Lc, FftMask), rearr, log_m, g=g, seed=5)
+            else:
+                zk.d_fft(pp, full, mk, rearr, log_m, seed=5)
+                znet.dist_d_fft(pp, net, 1, mine, lmask(mk, Lc, FftMask), rearr, log_m, seed=5)
+            pp.sync()
+            checks["d_%sfft_%d" % ("i" if inverse else "", rearr)] = same_rows(mine, full, Lc)
+        # zero masks (the king folds 1/m into its table)
+        full, mine = DeviceBuffer.from_numpy(pp, sh), loc(sh, Lc)
+        zk.d_ifft(pp, full, FftMask.zero(), True, log_m, seed=6)
+        znet.dist_d_ifft(pp, net, 2, mine, FftMask.zero(), True, log_m, seed=6)
+        pp.sync()
+        checks["d_ifft_zero_masks"] = same_rows(mine, full, Lc)
+        # ---- deg_red, d_pp
+        ln = 777
+        x = rand_fr(n * ln)
+        dm = DegRedMask.sample(pp, ln, 50)
+        full, mine = DeviceBuffer.from_numpy(pp, x), loc(x, ln)
+        zk.deg_red(pp, full, dm, ln, seed=8)
+        znet.dist_deg_red(pp, net, 0, mine, lmask(dm, ln, DegRedMask), ln, seed=8)
+        pp.sync()
+        checks["deg_red"] = same_rows(mine, full, ln)
+        num, den = rand_fr(2 * ln), rand_fr(2 * ln)
+        ns, ds = pp.pack(DeviceBuffer.from_numpy(pp, num), ln, 60), pp.pack(DeviceBuffer.from_numpy(pp, den), ln, 61)
+        ref = zk.d_pp(pp, ns, ds, dm, ln, seed=9)
+        got = znet.dist_d_pp(pp, net, 2, mg.rows(ns, first, k, ln * eb), mg.rows(ds, first, k, ln * eb),
+                             lmask(dm, ln, DegRedMask), ln, seed=9)
+        pp.sync()
+        checks["d_pp"] = same_rows(got, ref, ln)
+        # ---- d_msm G1 / G2 with masks
+        for grp, Gp, is2 in ((ZK_G1, G1, False), (ZK_G2, G2, True)):
+            ln = 500
+            gen_i = BN254.g2 if is2 else BN254.g1
+            flat = [gen_i[0][0], gen_i[0][1], gen_i[1][0], gen_i[1][1]] if is2 else list(gen_i)
+            gen = pp.fq.encode(flat).reshape(-1)
+            sc_pts = DeviceBuffer.from_numpy(pp, rand_fr(n * ln))
+            bases = zg.base_points(pp, grp, sc_pts, n * ln)
+            scal = DeviceBuffer.from_numpy(pp, rand_fr(n * ln))
+            mm = MsmMask.sample(pp, grp, gen, 70 + int(is2))
+            ref = zk.d_msm(pp, grp, bases, scal, ln, mm)
+            w = gen.size * 8
+            got = znet.dist_d_msm(pp, net, 0, grp, mg.rows(bases, first, k, ln * w), mg.rows(scal, first, k, ln * eb), ln,
+                                  MsmMask(mm.in_mask[first:first + k], mm.out_mask[first:first + k]))
+            checks["d_msm_g%d" % (2 if is2 else 1)] = all(
+                Gp.eq(dec_jacobian(pp, got[p], is2), dec_jacobian(pp, ref[first + p], is2)) for p in range(k))
+        # ---- the prover, all twelve masks, small circuit
+        r1, wv = small_r1cs()
+        td = [rand_fp(42, i, P) for i in range(5)]
+        setup = zg.SetupScalars("bn254", r1, *td)
+        crs = zg.Crs(pp, setup)
+        wit = zg.Witness(pp, "bn254", r1, wv, seed=5)
+        masks = zg.ProofMasks(pp, setup.log_m, seed=500)
+        r, s = rand_fp(43, 0, P), rand_fp(43, 1, P)
+        for rr, mk in ((r, masks), (0, None)):
+            ref = zg.prove(pp, crs, wit, rr, s, masks=mk, seed=9)
+            lcrs = mg.LocalCrs(pp, crs, first, k)
+            qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k)
+            mct, keep = mg.local_masks(pp, mk, wit.log_m, first, k)
+            got = znet.dist_prove(pp, net, lcrs.ct, qap, a_sh, ax_sh, rr, s, wit.log_m, masks=mct, seed=9)
+            ok = all(G1.eq(dec_jacobian(pp, got[0][p]), dec_jacobian(pp, ref[0][first + p])) and
+                     G2.eq(dec_jacobian(pp, got[1][p], True), dec_jacobian(pp, ref[1][first + p], True)) and
+                     G1.eq(dec_jacobian(pp, got[2][p]), dec_jacobian(pp, ref[2][first + p])) for p in range(k))
+            checks["prove_%s" % ("masks" if mk else "r0")] = ok
+        # circom_h alone: shares identical to the all-in-one call
+        h_ref = pp.alloc_fr(n * ((1 << wit.log_m) // 2))
+        import ctypes as C
+        pp._check(pp.lib.zk_circom_h(pp.h, wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr, wit.log_m, C.byref(masks.ct), 4,
+                                     h_ref.ptr, None))
+        qap, _, _ = mg.local_witness(pp, wit, first, k)
+        mct, keep = mg.local_masks(pp, masks, wit.log_m, first, k)
+        h = znet.dist_circom_h(pp, net, qap, wit.log_m, masks=mct, seed=4)
+        pp.sync()
+        checks["circom_h"] = same_rows(h, h_ref, (1 << wit.log_m) // 2)
+        q.put((rank, all(checks.values()), repr(checks)))
+        net.close()
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-2500:] + repr(e)))

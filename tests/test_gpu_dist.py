@@ -1,0 +1,71 @@
+"""The per-rank collective entry points (zk_dist_* over zk_net_*, csrc/net.hpp): the reference's call shape -- every
+party calls d_fft / d_ifft / deg_red / d_pp / d_msm / circom_h / dsha256 with a net and a stream id -- on the GPU.
+  * world = 1 (local and RCCL transports): results identical to the all-parties-in-one-call entry points;
+  * 2 and 4 ranks sharing this box's one GPU through the shared-memory transport (RCCL needs a GPU per rank): every
+    rank's rows identical to the single-context results, masks on;
+  * 8 ranks, one enters late: it is left out (ZK_ERR_PROTOCOL for it) and the others finish through lagrange_unpack
+    (ser_net.rs:57-94);
+  * bench.py --gpus 2 for the c2 / c3 / c4 workloads as the driver launches it."""
+import json
+import multiprocessing as mp
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _spawn(world, scenario, transport="shm"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    from zksaas_amd.net import StarNet
+    net_id = StarNet.unique_id()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=dist_worker.run, args=(r, world, net_id, scenario, q, transport)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    bad = [r for r in results if not r[1]]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("transport", ["local", "rccl"])
+def test_world_of_one_equals_the_all_parties_calls(transport):
+    _spawn(1, "flow", transport)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharing_the_gpu_over_shared_memory(world):
+    _spawn(world, "flow")
+
+
+def test_late_rank_is_left_out_on_the_gpu():
+    _spawn(8, "late")
+
+
+@pytest.mark.parametrize("workload", ["c4", "c2", "c3"])
+def test_bench_two_ranks_as_the_driver_launches_it(workload):
+    """bench.py --gpus 2 through torch.distributed.run, both ranks on the one GPU of this box (ZK_NET=shm); for c4
+    bench.py itself compares the sharded proof with the single-context proof."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, ZK_NET="shm", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", workload]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["parties_per_gpu"] == 4 and res["value"] > 0
+    if workload == "c4":
+        assert res["proof_matches_single_gpu"] is True and res["config"]["masks"] is True

@@ -158,30 +158,6 @@ def test_sha256_fixture_proof():
     assert G1.eq(Cc, G1.mul(G1.from_affine(BN254.g1), sc_))
 
 
-def test_sharded_code_path_on_one_rank():
-    """multigpu.DistProver + GpuBackend (zk_d_msm_local, zk_group_add, zk_groth16_assemble) with world = 1
-    must give the same shares as zk_groth16_prove."""
-    import torch
-    from zksaas_amd import multigpu as mg
-    r1, w = small_r1cs()
-    pp = ctx("bn254", 2)
-    setup = zg.SetupScalars("bn254", r1, *_trapdoor(46))
-    crs = zg.Crs(pp, setup)
-    wit = zg.Witness(pp, "bn254", r1, w, seed=8)
-    r, s = rand_fp(47, 0, P), rand_fp(47, 1, P)
-    want = zg.prove(pp, crs, wit, r, s, seed=21)
-    be = mg.GpuBackend(pp)
-    net = mg.StarNet(None, 0, 1)
-    prover = mg.DistProver(be, net, pp.n, pp.l, wit.log_m, zg._root_of_unity("bn254", wit.log_m + 1))
-    inp = mg._local_inputs(be, pp, crs, wit, 0, 1)
-    got = prover.prove(inp, r, s, 21)
-    G1, G2 = g1(BN254), g2(BN254)
-    for i in range(pp.n):
-        assert G1.eq(dec_jacobian(pp, got[0][i]), dec_jacobian(pp, want[0][i]))
-        assert G2.eq(dec_jacobian(pp, got[1][i], True), dec_jacobian(pp, want[1][i], True))
-        assert G1.eq(dec_jacobian(pp, got[2][i]), dec_jacobian(pp, want[2][i]))
-
-
 def test_libsnark_h_matches_oracle():  # ext_wit.rs:287-417 (m = 32, masked)
     m, l = 32, 2
     pp, o = ctx("bn254", l), opp("bn254", l)
@@ -241,32 +217,6 @@ def test_pack_points_with_random_points_reconstructs():
         for p_ in range(o.n):
             v = pp.fq.decode(rows[p_, j].reshape(2, 4))
             assert (v[0], v[1]) == G1.to_affine(want[p_])
-
-
-def test_two_ranks_sharing_the_gpu_give_the_single_rank_proof():
-    """The multi-rank flow of bench.py --gpus 2 (party sharding, partial MSM sums, king rounds through
-    gather/scatter/all-gather) launched exactly as the driver launches it, with both ranks on the one GPU of this box
-    and the collectives staged through host memory over gloo (ZK_DIST_VIA_CPU=1; RCCL needs one GPU per rank).
-    bench.py itself compares the sharded proof with the single-context proof."""
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, ZK_DIST_VIA_CPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1"]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["proof_matches_single_gpu"] is True
-    assert res["config"]["parties_per_gpu"] == 4
 
 
 def test_proof_with_fixed_base_tables_equals_proof_without():

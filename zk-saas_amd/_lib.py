@@ -14,7 +14,11 @@ SYMBOLS = [
     "zk_fft2_king", "zk_d_fft", "zk_d_ifft", "zk_fft_mask_sample", "zk_deg_red", "zk_degred_mask_sample", "zk_d_pp",
     "zk_msm", "zk_d_msm", "zk_base_mul", "zk_circom_h", "zk_groth16_prove", "zk_profile_enable",
     "zk_profile_slots", "zk_profile_name", "zk_profile_read", "zk_d_msm_local", "zk_group_add", "zk_groth16_assemble",
-    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_groth16_prove_async", "zk_groth16_wait", "zk_groth16_abort", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
+    "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_groth16_prove_async", "zk_groth16_wait", "zk_groth16_abort",
+    "zk_net_unique_id", "zk_net_create", "zk_net_destroy", "zk_net_last_error", "zk_net_set_timeout_ms", "zk_net_info",
+    "zk_net_enter", "zk_net_gather", "zk_net_scatter", "zk_net_gather_host", "zk_net_bcast_host", "zk_net_sync",
+    "zk_dist_d_fft", "zk_dist_d_ifft", "zk_dist_deg_red", "zk_dist_d_pp", "zk_dist_d_msm", "zk_dist_circom_h",
+    "zk_dist_groth16_prove", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
 ]
 
@@ -41,12 +45,13 @@ def _share_hip_runtime_with_torch():
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    for name in ("libamdhip64.so", "librccl.so"):      # one HIP runtime and one RCCL per process
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def load():
@@ -113,6 +118,28 @@ def load():
     lib.zk_groth16_prove_async.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, C.POINTER(i32)]
     lib.zk_groth16_wait.argtypes = [vp, i32, vp, vp, vp]
     lib.zk_groth16_abort.argtypes = [vp, i32]
+    u32p = C.POINTER(C.c_uint32)
+    lib.zk_net_unique_id.argtypes = [vp]
+    lib.zk_net_create.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32), vp, sz, C.POINTER(vp)]
+    lib.zk_net_destroy.argtypes = [vp]
+    lib.zk_net_destroy.restype = None
+    lib.zk_net_last_error.argtypes = [vp, C.POINTER(i32)]
+    lib.zk_net_last_error.restype = C.c_char_p
+    lib.zk_net_set_timeout_ms.argtypes = [vp, u64]
+    lib.zk_net_info.argtypes = [vp, C.POINTER(i32)]
+    lib.zk_net_enter.argtypes = [vp, i32, u32p]
+    lib.zk_net_gather.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
+    lib.zk_net_scatter.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
+    lib.zk_net_gather_host.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
+    lib.zk_net_bcast_host.argtypes = [vp, i32, C.c_uint32, vp, sz]
+    lib.zk_net_sync.argtypes = [vp, i32]
+    lib.zk_dist_d_fft.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, u64, vp]
+    lib.zk_dist_d_ifft.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, vp, u64, vp]
+    lib.zk_dist_deg_red.argtypes = [vp, vp, i32, vp, vp, vp, sz, u64, vp]
+    lib.zk_dist_d_pp.argtypes = [vp, vp, i32, vp, vp, vp, vp, sz, u64, vp, vp]
+    lib.zk_dist_d_msm.argtypes = [vp, vp, i32, i32, vp, vp, sz, vp, vp, vp, vp]
+    lib.zk_dist_circom_h.argtypes = [vp, vp, vp, vp, vp, i32, vp, u64, vp, vp]
+    lib.zk_dist_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, vp, vp, vp]
     lib.zk_vec_scale.argtypes = [vp, vp, vp, sz, vp]
     lib.zk_deg_red_parties.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, vp, vp, sz, u64, vp, vp]
     lib.zk_d_msm_parties.argtypes = [vp, i32, vp, vp, sz, C.POINTER(C.c_uint32), i32, vp, vp, vp, vp]

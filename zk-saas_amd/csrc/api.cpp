@@ -11,6 +11,10 @@
 struct zk_ctx {
   zk::IEngine* eng;
 };
+struct zk_net {
+  zk::Net net;
+  std::string last;      // message of the last failure of a raw verb
+};
 
 using zk::IEngine;
 
@@ -291,6 +295,135 @@ int zk_groth16_wait(zk_ctx* ctx, int handle, void* pi_a, void* pi_b, void* pi_c)
 int zk_groth16_abort(zk_ctx* ctx, int handle) {
   CTX_OR_FAIL();
   return e->groth16_abort(handle);
+}
+
+// ---- the star network and the per-rank collective forms (net.hpp) ----
+int zk_net_unique_id(void* id_out) {
+  if (!id_out) return ZK_ERR_BAD_INPUT;
+  unsigned char* p = (unsigned char*)id_out;
+  memset(p, 0, ZK_NET_ID_BYTES);
+  std::string err;
+  zk::Rccl& R = zk::Rccl::inst();
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && R.load(&err)) {
+    for (int s = 0; s < zk::NET_NSID; s++) {
+      zk::Rccl::UniqueId uid;
+      if (R.GetUniqueId(&uid) != 0) return ZK_ERR_GENERIC;
+      memcpy(p + (size_t)s * 128, &uid, 128);
+    }
+    return ZK_OK;
+  }
+  // no GPU / no RCCL (host-memory tests of the protocol): a random tag names the shared-memory block
+  FILE* f = fopen("/dev/urandom", "rb");
+  if (!f) return ZK_ERR_GENERIC;
+  size_t got = fread(p, 1, ZK_NET_ID_BYTES, f);
+  fclose(f);
+  return got == ZK_NET_ID_BYTES ? ZK_OK : ZK_ERR_GENERIC;
+}
+int zk_net_create(zk_ctx* ctx, int transport, int rank, int world, int n_parties, const int* party_to_rank,
+                  const void* id, size_t shm_bytes, zk_net** out) {
+  if (!out) return ZK_ERR_BAD_INPUT;
+  *out = nullptr;
+  const int n = ctx ? ctx->eng->n : n_parties;
+  if (n <= 0 || world <= 0 || n % world) return ZK_ERR_BAD_INPUT;
+  if (party_to_rank)       // only the contiguous map is supported: party p lives on rank p / (n / world)
+    for (int p = 0; p < n; p++)
+      if (party_to_rank[p] != p / (n / world)) return ZK_ERR_BAD_INPUT;
+  if (ctx) (void)hipSetDevice(ctx->eng->device);
+  zk_net* z = new (std::nothrow) zk_net();
+  if (!z) return ZK_ERR_GENERIC;
+  int rc = z->net.open(transport, rank, world, n, ctx ? ctx->eng->device : -1, ctx == nullptr, (const unsigned char*)id,
+                       shm_bytes);
+  *out = z;               // kept on failure so that zk_net_last_error can be read; the caller destroys it
+  return rc;
+}
+void zk_net_destroy(zk_net* net) { delete net; }
+const char* zk_net_last_error(zk_net* net, int* party) {
+  if (!net) return "null net";
+  if (party) *party = net->net.err_party;
+  return net->net.err.c_str();
+}
+int zk_net_set_timeout_ms(zk_net* net, uint64_t ms) {
+  if (!net) return ZK_ERR_BAD_INPUT;
+  net->net.timeout_ms = ms;
+  return ZK_OK;
+}
+int zk_net_info(const zk_net* net, int info[4]) {
+  if (!net || !info) return ZK_ERR_BAD_INPUT;
+  info[0] = net->net.rank;
+  info[1] = net->net.world;
+  info[2] = net->net.first_party(net->net.rank);
+  info[3] = net->net.parties_per_rank();
+  return ZK_OK;
+}
+int zk_net_enter(zk_net* net, int sid, uint32_t* mask) {
+  if (!net || !mask) return ZK_ERR_BAD_INPUT;
+  return net->net.enter(sid, mask);
+}
+int zk_net_gather(zk_net* net, int sid, uint32_t mask, const void* local, size_t bytes_per_rank, void* full) {
+  if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
+  return net->net.gather(sid, mask, local, bytes_per_rank, full);
+}
+int zk_net_scatter(zk_net* net, int sid, uint32_t mask, const void* full, size_t bytes_per_rank, void* local) {
+  if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
+  return net->net.scatter(sid, mask, full, bytes_per_rank, local);
+}
+int zk_net_gather_host(zk_net* net, int sid, uint32_t mask, const void* mine, size_t bytes, void* all) {
+  if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
+  return net->net.gather_host(sid, mask, mine, bytes, all);
+}
+int zk_net_bcast_host(zk_net* net, int sid, uint32_t mask, void* buf, size_t bytes) {
+  if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
+  return net->net.bcast_host(sid, mask, buf, bytes);
+}
+int zk_net_sync(zk_net* net, int sid) {
+  if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
+  return net->net.sync_deadline(sid);
+}
+#define NET_OR_FAIL()                                                         \
+  CTX_OR_FAIL();                                                              \
+  if (!net) return e->fail(ZK_ERR_NOT_CONNECTED, "null net");                 \
+  if (net->net.host_mode) return e->fail(ZK_ERR_BAD_INPUT, "host-mode net");  \
+  if (sid < 0 || sid >= zk::NET_NSID) return e->fail(ZK_ERR_BAD_INPUT, "bad channel id")
+int zk_dist_d_fft(zk_ctx* ctx, zk_net* net, int sid, void* shares_d, const void* in_mask_d, const void* out_mask_d,
+                  int rearrange, int log2_m, uint64_t seed, void* stream) {
+  NET_OR_FAIL();
+  return e->dist_d_fft(&net->net, sid, shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 0, nullptr, seed, S(stream));
+}
+int zk_dist_d_ifft(zk_ctx* ctx, zk_net* net, int sid, void* shares_d, const void* in_mask_d, const void* out_mask_d,
+                   int rearrange, int log2_m, const void* g, uint64_t seed, void* stream) {
+  NET_OR_FAIL();
+  return e->dist_d_fft(&net->net, sid, shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 1, g, seed, S(stream));
+}
+int zk_dist_deg_red(zk_ctx* ctx, zk_net* net, int sid, void* x_d, const void* in_mask_d, const void* out_mask_d,
+                    size_t len, uint64_t seed, void* stream) {
+  NET_OR_FAIL();
+  return e->dist_deg_red(&net->net, sid, x_d, in_mask_d, out_mask_d, len, seed, S(stream));
+}
+int zk_dist_d_pp(zk_ctx* ctx, zk_net* net, int sid, const void* num_d, const void* den_d, const void* in_mask_d,
+                 const void* out_mask_d, size_t len, uint64_t seed, void* out_d, void* stream) {
+  NET_OR_FAIL();
+  return e->dist_d_pp(&net->net, sid, num_d, den_d, in_mask_d, out_mask_d, len, seed, out_d, S(stream));
+}
+int zk_dist_d_msm(zk_ctx* ctx, zk_net* net, int sid, int group, const void* bases_d, const void* scalars_d, size_t len,
+                  const void* in_mask, const void* out_mask, void* out, void* stream) {
+  NET_OR_FAIL();
+  return e->dist_d_msm(&net->net, sid, group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
+}
+int zk_dist_circom_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                     const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream) {
+  const int sid = 0;
+  NET_OR_FAIL();
+  return e->dist_circom_h(&net->net, qap_a_d, qap_b_d, qap_c_d, log2_m, masks, seed, h_d, S(stream));
+}
+int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                          const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r, const void* s,
+                          int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
+                          void* stream) {
+  const int sid = 0;
+  NET_OR_FAIL();
+  return e->dist_prove(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed, pi_a,
+                       pi_b, pi_c, S(stream));
 }
 
 // ---- profiling slots (bench.py roofline leg) ----

@@ -13,6 +13,7 @@
 #include "field.hpp"
 #include "ntt.hpp"
 #include "pss.hpp"
+#include "net.hpp"
 
 namespace zk {
 
@@ -238,6 +239,21 @@ class IEngine {
                                   const zk_groth16_masks* masks, uint64_t seed, hipStream_t st, int* handle) = 0;
   virtual int groth16_wait(int handle, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int groth16_abort(int handle) = 0;
+  // per-rank collective forms (net.hpp): this rank's k = n / world parties, king = rank 0
+  virtual int dist_d_fft(Net* net, int sid, void* shares, const void* in_mask, const void* out_mask, int rearrange,
+                         int log_m, int inverse, const void* g, uint64_t seed, hipStream_t st) = 0;
+  virtual int dist_deg_red(Net* net, int sid, void* x, const void* in_mask, const void* out_mask, size_t len,
+                           uint64_t seed, hipStream_t st) = 0;
+  virtual int dist_d_pp(Net* net, int sid, const void* num, const void* den, const void* in_mask, const void* out_mask,
+                        size_t len, uint64_t seed, void* out, hipStream_t st) = 0;
+  virtual int dist_d_msm(Net* net, int sid, int group, const void* bases, const void* scalars, size_t len,
+                         const void* in_mask, const void* out_mask, void* out, hipStream_t st) = 0;
+  virtual int dist_circom_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m,
+                            const zk_groth16_masks* masks, uint64_t seed, void* h, hipStream_t st) = 0;
+  virtual int dist_prove(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                         const void* a_share, const void* ax_share, const void* r, const void* s, int log_m,
+                         const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
+                         hipStream_t st) = 0;
   virtual int pss_pack_points(int group, const void* points, size_t nchunks, int nv, void* shares, hipStream_t st) = 0;
   virtual int base_mul(int group, const void* base_affine, const void* scalars, size_t len, void* out_affine,
                        hipStream_t st) = 0;

@@ -622,18 +622,18 @@ class Engine : public IEngine {
   }
 
   // ---------------------------------------------------------------- d_pp (dpp/mod.rs:15-87)
-  int d_pp(const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
-           void* out, hipStream_t st) override {
-    if (!len) return ZK_OK;
-    if (!num || !den || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+  // the king's part up to the fresh shares of the prefix products (dpp/mod.rs:40-73): unpack num and den of the listed
+  // parties, divide (one shared inversion per block instead of :54-57's inverse() per element), scan, pack
+  int d_pp_king(const Fr* num, const Fr* den, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
+                hipStream_t st) {
     size_t m = len * l;
     ZK_HIP(scratch_.ensure(3 * m * sizeof(Fr)));
     Fr* nu = (Fr*)scratch_.p;
     Fr* de = nu + m;
     Fr* x = de + m;
-    int rc = pss_unpack(num, nullptr, n, len, true, nu, st);
+    int rc = pss_unpack(num, parties, np, len, true, nu, st);
     if (rc) return rc;
-    rc = pss_unpack(den, nullptr, n, len, true, de, st);
+    rc = pss_unpack(den, parties, np, len, true, de, st);
     if (rc) return rc;
     ZK_HIP(hipMemsetAsync(err_flag_, 0, sizeof(int), st));
     size_t nthreads = (m + DPP_CHUNK - 1) / DPP_CHUNK;
@@ -654,7 +654,13 @@ class Engine : public IEngine {
       scan_block_kernel<Fr><<<dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st>>>(x, m, nullptr, bp);
     }
     ZK_HIP(hipGetLastError());
-    rc = pss_pack(x, len, 0, seed, false, out, st);
+    return pss_pack(x, len, 0, seed, false, out, st);
+  }
+  int d_pp(const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
+           void* out, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!num || !den || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int rc = d_pp_king((const Fr*)num, (const Fr*)den, nullptr, n, len, seed, (Fr*)out, st);
     if (rc) return rc;
     return deg_red_np((const Fr*)out, (const Fr*)in_mask, nullptr, n, len, seed ^ 0x3333, (Fr*)out,
                       (const Fr*)out_mask, st);
@@ -1356,16 +1362,22 @@ class Engine : public IEngine {
     };
     Jacobian<Fq2_> jv;
     memcpy(&jv, sums[2], sizeof(jv));
+    return assemble_points(crs, r, s, j1(sums[0]), j1(sums[1]), jacobian_to_xyzz(jv), j1(sums[3]), j1(sums[4]), mk, n, pi_a,
+                           pi_b, pi_c);
+  }
+  // the same for `np` parties whose out-masks are rows 0..np-1 of mk->msm_out[*]
+  int assemble_points(const zk_crs_share* crs, const Fr& r, const Fr& s, const P1& S, const P1& H, const P2& V, const P1& W,
+                      const P1& U, const zk_groth16_masks* mk, int np, void* pi_a, void* pi_b, void* pi_c) {
     const bool r_zero = r.is_zero();
     P1 d1 = aff1(crs->delta_g1);
     P1 rN = host_scalar_mul<FrP, Fq_>(d1, r), sK = host_scalar_mul<FrP, Fq_>(d1, s),
        rsM = host_scalar_mul<FrP, Fq_>(d1, r * s);
     P2 sK2 = host_scalar_mul<FrP, Fq2_>(aff2(crs->delta_g2), s);
-    P1 A0 = xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1)), j1(sums[0]));
+    P1 A0 = xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff1(crs->a_query0), rN), aff1(crs->alpha_g1)), S);
     P1 B10 = r_zero ? P1::identity()
-                    : xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1)), j1(sums[1]));
-    P2 B20 = xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff2(crs->b_g2_query0), sK2), aff2(crs->beta_g2)), jacobian_to_xyzz(jv));
-    P1 WU = xyzz_add_ni(xyzz_add_ni(j1(sums[3]), j1(sums[4])), rsM.neg());
+                    : xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff1(crs->b_g1_query0), sK), aff1(crs->beta_g1)), H);
+    P2 B20 = xyzz_add_ni(xyzz_add_ni(xyzz_add_ni(aff2(crs->b_g2_query0), sK2), aff2(crs->beta_g2)), V);
+    P1 WU = xyzz_add_ni(xyzz_add_ni(W, U), rsM.neg());
     Jacobian<Fq_>* oa = (Jacobian<Fq_>*)pi_a;
     Jacobian<Fq2_>* ob = (Jacobian<Fq2_>*)pi_b;
     Jacobian<Fq_>* oc = (Jacobian<Fq_>*)pi_c;
@@ -1375,7 +1387,7 @@ class Engine : public IEngine {
     };
     const bool uniform = !mk || (!mk->msm_out[0] && !mk->msm_out[1] && !mk->msm_out[2] && !mk->msm_out[3] &&
                                  !mk->msm_out[4]);
-    for (int p = 0; p < n; p++) {
+    for (int p = 0; p < np; p++) {
       if (uniform && p > 0) {
         oa[p] = oa[0];
         ob[p] = ob[0];
@@ -1447,6 +1459,355 @@ class Engine : public IEngine {
     jj = xyzz_to_jacobian(U);
     memcpy(out[4], &jj, sizeof(jj));
     return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- per-rank collective forms (net.hpp)
+  // Every rank calls these collectively with the rows of ITS k = n / world parties ([k][len] buffers, masks
+  // likewise); rank 0 hosts the king.  A call first enters the round on the control plane (net.enter): ranks that do
+  // not show up within the timeout are left out and the king goes through lagrange_unpack (pss.rs:170-221) like
+  // ser_net.rs:57-94 does with `Partial` results.
+  DevBuf dist_in_[NET_NSID], dist_out_[NET_NSID], dist_coef_[NET_NSID];
+  DevBuf dist_w0_, dist_w1_, dist_h_;
+
+  int net_err(Net* net, int rc) {
+    if (rc == ZK_OK) return rc;
+    return fail(rc, "net: " + net->err, net->err_party);
+  }
+  // parties of the ranks in `mask`, ascending
+  std::vector<uint32_t> parties_of(const Net* net, uint32_t mask) const {
+    std::vector<uint32_t> ps;
+    const int k = net->parties_per_rank();
+    for (int r = 0; r < net->world; r++)
+      if (mask & (1u << r))
+        for (int p = 0; p < k; p++) ps.push_back((uint32_t)(r * k + p));
+    return ps;
+  }
+  hipStream_t net_stream(Net* net, int sid, hipStream_t st) { return net->stream(sid) ? net->stream(sid) : st; }
+
+  // one king round on channel sid: gather the local rows -> king step on rank 0 -> scatter.  `king` is called on rank 0
+  // with (in [np][len], parties, np, out [n][len], stream).
+  template <class KingFn>
+  int king_round(Net* net, int sid, uint32_t mask, Fr* local, size_t len, KingFn king) {
+    const int k = net->parties_per_rank();
+    const size_t bytes = (size_t)k * len * sizeof(Fr);
+    Fr *fin = nullptr, *fout = nullptr;
+    if (net->rank == 0) {
+      ZK_HIP(dist_in_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      fin = (Fr*)dist_in_[sid].p;
+      fout = (Fr*)dist_out_[sid].p;
+    }
+    int rc = net_err(net, net->gather(sid, mask, local, bytes, fin));
+    if (rc) return rc;
+    if (net->rank == 0) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      rc = king(fin, ps.data(), (int)ps.size(), fout, net_stream(net, sid, nullptr));
+      if (rc) return rc;
+    }
+    return net_err(net, net->scatter(sid, mask, fout, bytes, local));
+  }
+
+  int dist_d_fft_on(Net* net, int sid, uint32_t mask, Fr* shares, const Fr* in_mask, const Fr* out_mask, int rearrange,
+                    int log_m, int inverse, const void* g, uint64_t seed, bool do_fft1) {
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l;
+    hipStream_t s = net_stream(net, sid, nullptr);
+    int rc;
+    if (do_fft1) {
+      // d_ifft scales by 1/m before anything else (dfft/mod.rs:159); without an in-mask the king folds the factor
+      // into its g^i table (same field values), with one it has to come before the mask is added (:254-258)
+      if (inverse && in_mask) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(shares, &c, (size_t)k * Lc, s);
+        if (rc) return rc;
+      }
+      rc = fft1(shares, log_m, inverse, (size_t)k, in_mask, s);
+      if (rc) return rc;
+    } else if (in_mask) {
+      rc = vec_add(shares, in_mask, (size_t)k * Lc, s);
+      if (rc) return rc;
+    }
+    const int scale = (inverse && !in_mask) ? 1 : 0;
+    rc = king_round(net, sid, mask, shares, Lc, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
+      const Fr* U = nullptr;
+      int r2 = umat_for(ps, np, &U);
+      if (r2) return r2;
+      return king_dispatch(in, nullptr, np, log_m, inverse, U, g, scale, rearrange, seed, out, nullptr, false, ks);
+    });
+    if (rc) return rc;
+    if (out_mask) return vec_add(shares, out_mask, (size_t)k * Lc, s);
+    return ZK_OK;
+  }
+  int dist_d_fft(Net* net, int sid, void* shares, const void* in_mask, const void* out_mask, int rearrange, int log_m,
+                 int inverse, const void* g, uint64_t seed, hipStream_t st) override {
+    if (!shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (log_m < ilog2(l) || log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    rc = dist_d_fft_on(net, sid, mask, (Fr*)shares, (const Fr*)in_mask, (const Fr*)out_mask, rearrange, log_m, inverse, g,
+                       seed, true);
+    if (rc) return rc;
+    return net_err(net, net->end(sid, st));
+  }
+
+  int dist_deg_red_on(Net* net, int sid, uint32_t mask, Fr* x, const Fr* in_mask, const Fr* out_mask, size_t len,
+                      uint64_t seed) {
+    const int k = net->parties_per_rank();
+    hipStream_t s = net_stream(net, sid, nullptr);
+    int rc;
+    if (in_mask) {
+      rc = vec_add(x, in_mask, (size_t)k * len, s);
+      if (rc) return rc;
+    }
+    rc = king_round(net, sid, mask, x, len, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
+      return deg_red_np(in, nullptr, ps, np, len, seed, out, nullptr, ks);
+    });
+    if (rc) return rc;
+    if (out_mask) return vec_add(x, out_mask, (size_t)k * len, s);
+    return ZK_OK;
+  }
+  int dist_deg_red(Net* net, int sid, void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
+                   hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!x) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    rc = dist_deg_red_on(net, sid, mask, (Fr*)x, (const Fr*)in_mask, (const Fr*)out_mask, len, seed);
+    if (rc) return rc;
+    return net_err(net, net->end(sid, st));
+  }
+
+  // d_pp (dpp/mod.rs:15-87): round 1 gathers num || den, the king divides, scans and packs fresh shares of the prefix
+  // products, round 2 is deg_red (:84-86)
+  int dist_d_pp(Net* net, int sid, const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len,
+                uint64_t seed, void* out, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!num || !den || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const int k = net->parties_per_rank();
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    hipStream_t s = net_stream(net, sid, nullptr);
+    const size_t bytes = (size_t)k * len * sizeof(Fr);
+    Fr *fin = nullptr, *fout = nullptr;
+    const std::vector<uint32_t> ps = parties_of(net, mask);
+    const int np = (int)ps.size();
+    if (net->rank == 0) {
+      ZK_HIP(dist_in_[sid].ensure((size_t)2 * n * len * sizeof(Fr)));
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      fin = (Fr*)dist_in_[sid].p;
+      fout = (Fr*)dist_out_[sid].p;
+    }
+    rc = net_err(net, net->gather(sid, mask, num, bytes, fin));
+    if (rc) return rc;
+    rc = net_err(net, net->gather(sid, mask, den, bytes, fin ? fin + (size_t)np * len : nullptr));
+    if (rc) return rc;
+    if (net->rank == 0) {
+      rc = d_pp_king(fin, fin + (size_t)np * len, ps.data(), np, len, seed, fout, s);
+      if (rc) return rc;
+    }
+    rc = net_err(net, net->scatter(sid, mask, fout, bytes, out));
+    if (rc) return rc;
+    rc = dist_deg_red_on(net, sid, mask, (Fr*)out, (const Fr*)in_mask, (const Fr*)out_mask, len, seed ^ 0x3333);
+    if (rc) return rc;
+    return net_err(net, net->end(sid, st));
+  }
+
+  // d_msm (dmsm/mod.rs:59-102): this rank's fused contribution sum_p coef_p (msm_p + in_mask_p) goes to the king as ONE
+  // point; the king sums the ranks' points (= unpack2 + sum over all parties) and sends the result to everyone.
+  template <class Fld>
+  int dist_d_msm_t(Net* net, int sid, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                   const void* out_mask, void* out, hipStream_t st) {
+    const int k = net->parties_per_rank(), first = net->first_party(net->rank);
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    // coefficients of my parties in the king's linear form; they depend on who takes part (pss.rs:170-221)
+    const Fr* cd = msm_.coef_d_ + first;
+    std::vector<Fr> csub;
+    if (mask != net->full_mask()) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      std::vector<Fr> coef;
+      rc = coefs_for(ps.data(), (int)ps.size(), coef);
+      if (rc) return rc;
+      size_t pos = 0;
+      while (pos < ps.size() && ps[pos] != (uint32_t)first) pos++;
+      csub.assign(coef.begin() + pos, coef.begin() + pos + k);
+      ZK_HIP(dist_coef_[sid].ensure(k * sizeof(Fr)));
+      ZK_HIP(hipMemcpy(dist_coef_[sid].p, csub.data(), k * sizeof(Fr), hipMemcpyHostToDevice));
+      cd = (const Fr*)dist_coef_[sid].p;
+    }
+    MsmPending pend;
+    rc = msm_.template launch_t<Fld>(this, bases, scalars, (size_t)k * len, cd, len, st, MSM_WS - 1 - sid, &pend);
+    if (rc) return rc;
+    XYZZ<Fld> mine = XYZZ<Fld>::identity();
+    if (in_mask) mine = msm_.template mask_term<Fld>(in_mask, first, k, csub.empty() ? nullptr : csub.data());
+    XYZZ<Fld> r;
+    rc = msm_.template finish_t<Fld>(this, &pend, &r);
+    if (rc) return rc;
+    mine = xyzz_add_ni(mine, r);
+    std::vector<XYZZ<Fld>> all((size_t)net->world);
+    rc = net_err(net, net->gather_host(sid, mask, &mine, sizeof(mine), all.data()));
+    if (rc) return rc;
+    XYZZ<Fld> total = XYZZ<Fld>::identity();
+    if (net->rank == 0) {
+      int cnt = 0;
+      for (int rr = 0; rr < net->world; rr++)
+        if (mask & (1u << rr)) total = xyzz_add_ni(total, all[cnt++]);
+    }
+    rc = net_err(net, net->bcast_host(sid, mask, &total, sizeof(total)));
+    if (rc) return rc;
+    const Jacobian<Fld>* om = (const Jacobian<Fld>*)out_mask;
+    Jacobian<Fld>* o = (Jacobian<Fld>*)out;
+    for (int p = 0; p < k; p++) {
+      XYZZ<Fld> v = total;
+      if (om) v = xyzz_add_ni(v, jacobian_to_xyzz(om[p]));
+      o[p] = xyzz_to_jacobian(v);
+    }
+    return ZK_OK;
+  }
+  int dist_d_msm(Net* net, int sid, int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                 const void* out_mask, void* out, hipStream_t st) override {
+    if (!out) return fail(ZK_ERR_BAD_INPUT, "null output");
+    if (len && (!bases || !scalars)) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (group == ZK_G1) return dist_d_msm_t<Fq_>(net, sid, bases, scalars, len, in_mask, out_mask, out, st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2) return dist_d_msm_t<Fq2_>(net, sid, bases, scalars, len, in_mask, out_mask, out, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
+  // circom_h (ext_wit.rs:104-181): the three d_ifft, then the three d_fft, each triple in flight together on channels
+  // 0..2 (ext_wit.rs:158-170 joins them); then a*b - c and deg_red on channel 0.  masks: LOCAL rows.
+  int dist_circom_h_on(Net* net, const uint32_t* cmask, const void* qa, const void* qb, const void* qc, int log_m,
+                       const zk_groth16_masks* mk, uint64_t seed, void* h, hipStream_t st) {
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
+    ZK_HIP(dist_w0_.ensure(3 * per * sizeof(Fr)));
+    Fr* W = (Fr*)dist_w0_.p;
+    const void* q[3] = {qa, qb, qc};
+    for (int j = 0; j < 3; j++) ZK_HIP(hipMemcpyAsync(W + j * per, q[j], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    Fr w2m = root_of_unity(log_m + 1);
+    const bool has_in = mk && mk->fft_in[0];
+    int rc;
+    for (int phase = 0; phase < 2; phase++) {
+      const int inverse = phase == 0 ? 1 : 0;
+      // the local stages of the three vectors as one batched launch on the caller's stream
+      if (inverse && has_in) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(W, &c, 3 * per, st);
+        if (rc) return rc;
+      }
+      rc = fft1(W, log_m, inverse, 3 * (size_t)k, nullptr, st);
+      if (rc) return rc;
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->begin(j, st));
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        const int mi = phase * 3 + j;
+        const bool masked = mk && mk->fft_in[mi];
+        if ((mk && mk->fft_in[mi] != nullptr) != has_in) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in circom_h");
+        (void)masked;
+        rc = dist_d_fft_on(net, j, cmask[j], W + j * per, mk ? (const Fr*)mk->fft_in[mi] : nullptr,
+                           mk ? (const Fr*)mk->fft_out[mi] : nullptr, phase == 0 ? 1 : 0, log_m, inverse,
+                           phase == 0 ? (const void*)&w2m : nullptr, seed + mi, false);
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->end(j, st));
+        if (rc) return rc;
+      }
+    }
+    rc = vec_mul_sub(h, W, W + per, W + 2 * per, per, st);
+    if (rc) return rc;
+    rc = net_err(net, net->begin(0, st));
+    if (rc) return rc;
+    rc = dist_deg_red_on(net, 0, cmask[0], (Fr*)h, mk ? (const Fr*)mk->degred_in : nullptr,
+                         mk ? (const Fr*)mk->degred_out : nullptr, Lc, seed + 6);
+    if (rc) return rc;
+    return net_err(net, net->end(0, st));
+  }
+  int dist_circom_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk,
+                    uint64_t seed, void* h, hipStream_t st) override {
+    if (log_m < ilog2(l) || log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    uint32_t cmask[3];
+    for (int j = 0; j < 3; j++) {
+      int rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    if (cmask[1] != cmask[0] || cmask[2] != cmask[0])
+      return fail(ZK_ERR_PROTOCOL, "the three channels of circom_h saw different parties", -1);
+    return dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, h, st);
+  }
+
+  // dsha256 per rank (sha256.rs:32-129): all shares and masks are this rank's k parties' rows; pi_*: k Jacobian points
+  int dist_prove(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
+                 const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
+                 uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
+    int rc = check_prove_args(crs, r_, s_, log_m);
+    if (rc) return rc;
+    if (!qa || !qb || !qc || !a_share || !ax_share || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const int k = net->parties_per_rank(), first = net->first_party(net->rank);
+    const size_t Lc = ((size_t)1 << log_m) / l;
+    uint32_t cmask[NET_NSID];
+    for (int j = 0; j < NET_NSID; j++) {
+      rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    for (int j = 0; j < NET_NSID; j++)
+      if (cmask[j] != net->full_mask())
+        return fail(ZK_ERR_PROTOCOL, "a party did not show up for the proof (timed out)", -1);
+    Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
+    ProveJob& j = jobs_[0];
+    if (j.active) return fail(ZK_ERR_BAD_INPUT, "a proof is already in flight");
+    j.slot = 0;
+    // the four MSMs over the witness shares start now and overlap the king rounds of circom_h (prove.rs try_join!)
+    rc = prove_begin(j, crs, nullptr, nullptr, nullptr, a_share, ax_share, r, s, log_m, mk, seed, false, first, k, st);
+    auto bail = [&](int code) {
+      Status keep = last;
+      abort_job(j);
+      last = keep;
+      return code;
+    };
+    if (rc) return bail(rc);
+    ZK_HIP(dist_h_.ensure((size_t)k * Lc * sizeof(Fr)));
+    rc = dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, dist_h_.p, st);
+    if (rc) return bail(rc);
+    rc = prove_launch_u(j, dist_h_.p, st);
+    if (rc) return bail(rc);
+    struct Sums {
+      P1 S, H, W, U;
+      P2 V;
+    } mine, total;
+    rc = prove_join(j, &mine.S, &mine.H, &mine.V, &mine.W, &mine.U);
+    if (rc) return rc;
+    // d_msm's king step for the five products at once: one small message per rank (dmsm/mod.rs:76-92)
+    static_assert(sizeof(Sums) <= NET_PAYLOAD, "payload");
+    std::vector<Sums> all((size_t)net->world);
+    rc = net_err(net, net->gather_host(3, cmask[3], &mine, sizeof(mine), all.data()));
+    if (rc) return rc;
+    total = mine;
+    if (net->rank == 0)
+      for (int rr = 1; rr < net->world; rr++) {
+        total.S = xyzz_add_ni(total.S, all[rr].S);
+        total.H = xyzz_add_ni(total.H, all[rr].H);
+        total.V = xyzz_add_ni(total.V, all[rr].V);
+        total.W = xyzz_add_ni(total.W, all[rr].W);
+        total.U = xyzz_add_ni(total.U, all[rr].U);
+      }
+    rc = net_err(net, net->bcast_host(3, cmask[3], &total, sizeof(total)));
+    if (rc) return rc;
+    return assemble_points(crs, r, s, total.S, total.H, total.V, total.W, total.U, mk, k, pi_a, pi_b, pi_c);
   }
 
   int ensure_streams() {

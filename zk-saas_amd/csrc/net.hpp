@@ -1,0 +1,579 @@
+// The MPC star network of the reference on one multi-GPU node, inside the library.
+//
+// Reference: mpc-net/src/lib.rs:43-53 (`MpcNet`: n_parties, party_id, is_king, per-channel `MultiplexedStreamID`),
+// :89-135 `client_send_or_king_receive` (every party sends to the king; the king waits up to 30 s per peer and
+// otherwise reports the peer as timed out), :137-176 `client_receive_or_king_send` (the king sends each party ITS
+// OWN answer, equal lengths enforced), and mpc-net/src/ser_net.rs:16-120 (the serialising wrappers; `Partial`
+// results when some parties are missing, ser_net.rs:57-94).  One process drives one GPU and the k = n / world
+// parties mapped to it (contiguous blocks; the king = party 0 lives on rank 0).
+//
+// Two planes:
+//   control  a small POSIX shared-memory block (all ranks are on one node): per channel an arrival word per rank, the
+//            king's verdict (which ranks take part in this round -- the emulation of mpc-net's timeout / `Partial`
+//            semantics: a rank that does not enter a collective within the timeout is left out, the king continues
+//            through lagrange_unpack if enough parties remain, the late rank gets ZK_ERR_PROTOCOL), and a small
+//            payload area for host-side values (the partial points of d_msm);
+//   data     transport RCCL: ncclSend / ncclRecv in one group per round on the channel's own communicator and HIP
+//            stream (xGMI, GPU-resident payload, raw Montgomery limbs -- nothing is serialised), only among the ranks
+//            of the verdict, so a missing rank cannot hang the others;
+//            transport SHM: the same verbs staged through a shared-memory segment (D2H, H2D); used by the tests (two
+//            ranks on one GPU, or no GPU at all: with a NULL context the buffers are host memory) and as a
+//            fallback where RCCL cannot run.
+//            transport LOCAL: world = 1, plain device copies.
+// Three channels can be in flight at once (ext_wit.rs:158-170 joins three d_ifft / d_fft on CHANNEL0-2): each has its
+// own communicator, stream, sequence counter and staging segment.
+#pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/zksaas.h"
+
+namespace zk {
+
+constexpr int NET_MAXR = 16;          // ranks (<= n parties)
+constexpr int NET_NSID = 4;           // channels: 0..2 = MultiplexedStreamID::{Zero,One,Two}, 3 = internal
+constexpr int NET_PAYLOAD = 4096;     // host payload bytes per rank and channel
+constexpr uint32_t NET_MAGIC = 0x7a6b6e31;
+
+struct NetChan {
+  std::atomic<uint64_t> arrive[NET_MAXR];
+  std::atomic<uint64_t> verdict_seq;
+  std::atomic<uint32_t> verdict_mask;
+  std::atomic<uint64_t> rank_tick[NET_MAXR];     // data plane SHM: rank's slot written (gather) / consumed (scatter)
+  std::atomic<uint64_t> king_tick;               // king consumed the gather slots / filled the scatter slots
+  std::atomic<uint64_t> pay_tick[NET_MAXR];
+  std::atomic<uint64_t> pay_king;
+  unsigned char payload[NET_MAXR][NET_PAYLOAD];
+  unsigned char pay_out[NET_PAYLOAD];
+};
+struct NetCtl {
+  std::atomic<uint32_t> magic;
+  std::atomic<uint32_t> attached;
+  NetChan chan[NET_NSID];
+};
+
+// librccl entry points, resolved at run time (the PyTorch wheel ships its own copy: whichever copy is already
+// loaded in the process is used, so there is one RCCL per process)
+struct Rccl {
+  typedef int (*get_uid_t)(void*);
+  typedef int (*init_rank_t)(void**, int, struct UniqueId, int);
+  struct UniqueId {
+    char internal[128];
+  };
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* handle = nullptr;
+  bool load(std::string* err) {
+    if (handle) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+      handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+      if (handle) break;
+    }
+    if (!handle)
+      for (const char* nm : names) {
+        handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (handle) break;
+      }
+    if (!handle) {
+      *err = std::string("librccl not found: ") + dlerror();
+      return false;
+    }
+    auto sym = [&](const char* s) { return dlsym(handle, s); };
+    GetUniqueId = (int (*)(UniqueId*))sym("ncclGetUniqueId");
+    CommInitRank = (int (*)(void**, int, UniqueId, int))sym("ncclCommInitRank");
+    CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    CommAbort = (int (*)(void*))sym("ncclCommAbort");
+    GroupStart = (int (*)())sym("ncclGroupStart");
+    GroupEnd = (int (*)())sym("ncclGroupEnd");
+    Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+    Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+    GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv) {
+      *err = "librccl lacks a required symbol";
+      return false;
+    }
+    return true;
+  }
+  static Rccl& inst() {
+    static Rccl r;
+    return r;
+  }
+};
+
+inline uint64_t net_now_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000 + (uint64_t)ts.tv_nsec / 1000000;
+}
+
+class Net {
+ public:
+  int transport = ZK_NET_LOCAL, rank = 0, world = 1, n = 0, device = -1;
+  bool host_mode = false;                 // no GPU context: buffers are host memory (tests of the protocol flow)
+  uint64_t timeout_ms = 30000;            // mpc-net/src/lib.rs:98 `timeout(Duration::from_secs(30), ..)`
+  std::string err;
+  int err_party = -1;
+
+  ~Net() { close(); }
+
+  int parties_per_rank() const { return n / world; }
+  int first_party(int r) const { return r * parties_per_rank(); }
+
+  // id: NET_NSID RCCL unique ids (RCCL transport) or any 128-byte tag shared by the ranks (first 16 bytes name the
+  // shared-memory block)
+  int open(int transport_, int rank_, int world_, int n_, int device_, bool host_mode_, const unsigned char* id,
+           size_t shm_bytes_per_chan) {
+    transport = transport_;
+    rank = rank_;
+    world = world_;
+    n = n_;
+    device = device_;
+    host_mode = host_mode_;
+    if (world < 1 || world > NET_MAXR || rank < 0 || rank >= world || n % world) return fail("bad rank / world size (world must divide n)");
+    if (world == 1 && transport != ZK_NET_RCCL) transport = ZK_NET_LOCAL;
+    if (transport == ZK_NET_LOCAL) {
+      if (world != 1) return fail("the local transport needs world = 1");
+      return make_streams();
+    }
+    if (!id) return fail("net id missing");
+    if (transport != ZK_NET_RCCL && transport != ZK_NET_SHM) return fail("unknown transport");
+    if (host_mode && transport == ZK_NET_RCCL) return fail("RCCL needs a GPU context");
+    uint64_t hsh = 1469598103934665603ull;          // FNV-1a over the id: the name of the shared control block
+    for (int i = 0; i < 128 * NET_NSID; i++) hsh = (hsh ^ id[i]) * 1099511628211ull;
+    char tag[40];
+    snprintf(tag, sizeof tag, "/zksaas_%016llx", (unsigned long long)hsh);
+    name_ = tag;
+    if (!map_ctl()) return ZK_ERR_NOT_CONNECTED;
+    if (transport == ZK_NET_SHM) {
+      cap_ = shm_bytes_per_chan ? shm_bytes_per_chan : ((size_t)64 << 20);
+      cap_ = (cap_ / world) & ~(size_t)255;       // per rank slot
+      for (int s = 0; s < NET_NSID; s++)
+        if (!map_data(s)) return ZK_ERR_NOT_CONNECTED;
+    } else {
+      Rccl& R = Rccl::inst();
+      if (!R.load(&err)) return ZK_ERR_NOT_CONNECTED;
+      for (int s = 0; s < NET_NSID; s++) {
+        Rccl::UniqueId uid;
+        memcpy(&uid, id + (size_t)s * 128, 128);
+        int rc = R.CommInitRank(&comm_[s], world, uid, rank);
+        if (rc) return fail(std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(rc) : "?"));
+      }
+    }
+    if (int rc = make_streams()) return rc;
+    // attach barrier: nobody proceeds before every rank mapped the block
+    ctl_->attached.fetch_add(1);
+    uint64_t dl = net_now_ms() + timeout_ms;
+    while (ctl_->attached.load() < (uint32_t)world) {
+      if (net_now_ms() > dl) return fail("timed out waiting for the other ranks to attach", ZK_ERR_NOT_CONNECTED);
+      relax();
+    }
+    return ZK_OK;
+  }
+
+  int make_streams() {
+    if (host_mode) return ZK_OK;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // king rounds are latency chains: highest priority
+    for (int s = 0; s < NET_NSID; s++) {
+      if (hipStreamCreateWithPriority(&stream_[s], hipStreamNonBlocking, hi) != hipSuccess) return fail("hipStreamCreate");
+      if (hipEventCreateWithFlags(&ev_in_[s], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
+      if (hipEventCreateWithFlags(&ev_out_[s], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
+    }
+    return ZK_OK;
+  }
+
+  void close() {
+    if (transport == ZK_NET_RCCL)
+      for (int s = 0; s < NET_NSID; s++)
+        if (comm_[s]) {
+          Rccl& R = Rccl::inst();
+          if (aborted_ && R.CommAbort) (void)R.CommAbort(comm_[s]);
+          else (void)R.CommDestroy(comm_[s]);
+          comm_[s] = nullptr;
+        }
+    for (int s = 0; s < NET_NSID; s++) {
+      if (stream_[s]) (void)hipStreamDestroy(stream_[s]);
+      if (ev_in_[s]) (void)hipEventDestroy(ev_in_[s]);
+      if (ev_out_[s]) (void)hipEventDestroy(ev_out_[s]);
+      stream_[s] = nullptr;
+      ev_in_[s] = ev_out_[s] = nullptr;
+      if (data_[s]) munmap(data_[s], cap_ * world);
+      data_[s] = nullptr;
+    }
+    if (ctl_) munmap(ctl_, sizeof(NetCtl));
+    ctl_ = nullptr;
+    if (rank == 0 && !name_.empty()) {
+      shm_unlink(name_.c_str());
+      for (int s = 0; s < NET_NSID; s++) shm_unlink((name_ + "_d" + std::to_string(s)).c_str());
+    }
+    name_.clear();
+  }
+
+  hipStream_t stream(int sid) const { return stream_[sid]; }
+  // channel stream ordered after the caller's stream / caller's stream ordered after the channel stream
+  int begin(int sid, hipStream_t caller) {
+    if (host_mode) return ZK_OK;
+    if (hipEventRecord(ev_in_[sid], caller) != hipSuccess || hipStreamWaitEvent(stream_[sid], ev_in_[sid], 0) != hipSuccess)
+      return fail("stream ordering");
+    return ZK_OK;
+  }
+  int end(int sid, hipStream_t caller) {
+    if (host_mode) return ZK_OK;
+    if (hipEventRecord(ev_out_[sid], stream_[sid]) != hipSuccess || hipStreamWaitEvent(caller, ev_out_[sid], 0) != hipSuccess)
+      return fail("stream ordering");
+    return ZK_OK;
+  }
+
+  // ---- control plane: enter a collective round on channel `sid`; returns the mask of participating ranks.
+  // A rank that is not in the verdict gets ZK_ERR_PROTOCOL (it arrived after the king's timeout).
+  int enter(int sid, uint32_t* mask) {
+    if (sid < 0 || sid >= NET_NSID) return fail("bad channel id", ZK_ERR_BAD_INPUT);
+    seq_[sid]++;
+    op_[sid] = 0;
+    if (transport == ZK_NET_LOCAL) {
+      *mask = 1;
+      return ZK_OK;
+    }
+    NetChan& c = ctl_->chan[sid];
+    const uint64_t s = seq_[sid];
+    c.arrive[rank].store(s, std::memory_order_release);
+    relax_reset();
+    if (rank == 0) {
+      uint64_t dl = net_now_ms() + timeout_ms;
+      uint32_t m = 1;
+      for (;;) {
+        m = 0;
+        for (int r = 0; r < world; r++)
+          if (c.arrive[r].load(std::memory_order_acquire) >= s) m |= 1u << r;
+        if (m == full_mask() || net_now_ms() > dl) break;
+        relax();
+      }
+      c.verdict_mask.store(m, std::memory_order_relaxed);
+      c.verdict_seq.store(s, std::memory_order_release);
+      *mask = m;
+      return ZK_OK;
+    }
+    uint64_t dl = net_now_ms() + 2 * timeout_ms + 1000;
+    while (c.verdict_seq.load(std::memory_order_acquire) < s) {
+      if (net_now_ms() > dl) return fail("the king did not answer (timed out)", ZK_ERR_NOT_CONNECTED);
+      relax();
+    }
+    if (c.verdict_seq.load(std::memory_order_acquire) != s)
+      return fail_party("this rank entered the round after the king's timeout", first_party(rank));
+    uint32_t m = c.verdict_mask.load(std::memory_order_relaxed);
+    *mask = m;
+    if (!(m & (1u << rank))) return fail_party("this rank entered the round after the king's timeout", first_party(rank));
+    return ZK_OK;
+  }
+  uint32_t full_mask() const { return world >= 32 ? 0xffffffffu : ((1u << world) - 1); }
+
+  // ---- data plane.  bytes = bytes PER RANK (k parties' rows); the king's `full` holds the present ranks' blocks
+  // compacted in rank order (so that a dropout leaves the [np][len] layout the king kernels take).
+  int gather(int sid, uint32_t mask, const void* local, size_t bytes, void* full) {
+    const int op = op_[sid]++;
+    if (transport == ZK_NET_LOCAL) return copy_dd(full, local, bytes, sid);
+    if (transport == ZK_NET_RCCL) {
+      Rccl& R = Rccl::inst();
+      int rc = R.GroupStart();
+      if (rank == 0) {
+        int slot = 0;
+        for (int r = 0; r < world && !rc; r++) {
+          if (!(mask & (1u << r))) continue;
+          char* dst = (char*)full + (size_t)slot * bytes;
+          if (r == 0) rc = hipMemcpyAsync(dst, local, bytes, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          else rc = R.Recv(dst, bytes, /*ncclUint8*/ 1, r, comm_[sid], stream_[sid]);
+          slot++;
+        }
+      } else {
+        rc = R.Send(local, bytes, 1, 0, comm_[sid], stream_[sid]);
+      }
+      int rc2 = R.GroupEnd();
+      if (rc || rc2) return rccl_fail(rc ? rc : rc2, "gather");
+      return ZK_OK;
+    }
+    // SHM
+    NetChan& c = ctl_->chan[sid];
+    for (size_t off = 0, ch = 0; off < bytes || (bytes == 0 && ch == 0); off += cap_, ch++) {
+      const size_t len = bytes - off < cap_ ? bytes - off : cap_;
+      const uint64_t t = tick(sid, op, ch);
+      // my slot is free once the king consumed what I posted last (king_tick is monotonic)
+      if (rank != 0 && !wait_ge(c.king_tick, last_g_[sid], "king (gather slot)")) return ZK_ERR_NOT_CONNECTED;
+      if (int rc = copy_out(data_[sid] + (size_t)rank * cap_, (const char*)local + off, len, sid)) return rc;
+      c.rank_tick[rank].store(t, std::memory_order_release);
+      last_g_[sid] = t;
+      if (rank == 0) {
+        int slot = 0;
+        for (int r = 0; r < world; r++) {
+          if (!(mask & (1u << r))) continue;
+          if (!wait_ge(c.rank_tick[r], t, "peer (gather)")) return ZK_ERR_NOT_CONNECTED;
+          if (int rc = copy_in((char*)full + (size_t)slot * bytes + off, data_[sid] + (size_t)r * cap_, len, sid)) return rc;
+          slot++;
+        }
+        if (int rc = sync(sid)) return rc;
+        c.king_tick.store(t, std::memory_order_release);
+      }
+      if (bytes == 0) break;
+    }
+    return ZK_OK;
+  }
+
+  int scatter(int sid, uint32_t mask, const void* full, size_t bytes, void* local) {
+    const int op = op_[sid]++;
+    if (transport == ZK_NET_LOCAL) return copy_dd(local, full, bytes, sid);
+    if (transport == ZK_NET_RCCL) {
+      Rccl& R = Rccl::inst();
+      int rc = R.GroupStart();
+      if (rank == 0) {
+        for (int r = 0; r < world && !rc; r++) {
+          if (!(mask & (1u << r))) continue;
+          const char* src = (const char*)full + (size_t)r * bytes;        // the king's output is [n][len]: all parties
+          if (r == 0) rc = hipMemcpyAsync(local, src, bytes, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          else rc = R.Send(src, bytes, 1, r, comm_[sid], stream_[sid]);
+        }
+      } else {
+        rc = R.Recv(local, bytes, 1, 0, comm_[sid], stream_[sid]);
+      }
+      int rc2 = R.GroupEnd();
+      if (rc || rc2) return rccl_fail(rc ? rc : rc2, "scatter");
+      return ZK_OK;
+    }
+    NetChan& c = ctl_->chan[sid];
+    for (size_t off = 0, ch = 0; off < bytes || (bytes == 0 && ch == 0); off += cap_, ch++) {
+      const size_t len = bytes - off < cap_ ? bytes - off : cap_;
+      const uint64_t t = tick(sid, op, ch);
+      if (rank == 0) {
+        for (int r = 1; r < world; r++) {      // every present rank consumed what the king sent it last
+          if (!(mask & (1u << r))) continue;
+          if (!wait_ge(c.rank_tick[r], last_s_[sid][r], "peer (scatter slot)")) return ZK_ERR_NOT_CONNECTED;
+        }
+        for (int r = 0; r < world; r++) {
+          if (!(mask & (1u << r))) continue;
+          if (int rc = copy_out(data_[sid] + (size_t)r * cap_, (const char*)full + (size_t)r * bytes + off, len, sid)) return rc;
+          last_s_[sid][r] = t;
+        }
+        if (int rc = sync(sid)) return rc;
+        c.king_tick.store(t, std::memory_order_release);
+      }
+      if (!wait_ge(c.king_tick, t, "king (scatter)")) return ZK_ERR_NOT_CONNECTED;
+      if (int rc = copy_in((char*)local + off, data_[sid] + (size_t)rank * cap_, len, sid)) return rc;
+      if (int rc = sync(sid)) return rc;
+      c.rank_tick[rank].store(t, std::memory_order_release);
+      if (bytes == 0) break;
+    }
+    return ZK_OK;
+  }
+
+  // small host values: every present rank contributes `bytes` (<= NET_PAYLOAD); the king receives them compacted in
+  // rank order in `all` (king only) -- d_msm's "send the masked MSM result to the king" (dmsm/mod.rs:76-84)
+  int gather_host(int sid, uint32_t mask, const void* mine, size_t bytes, void* all) {
+    const int op = op_[sid]++;
+    if (bytes > (size_t)NET_PAYLOAD) return fail("host payload too large", ZK_ERR_BAD_INPUT);
+    if (transport == ZK_NET_LOCAL) {
+      memcpy(all, mine, bytes);
+      return ZK_OK;
+    }
+    NetChan& c = ctl_->chan[sid];
+    const uint64_t t = tick(sid, op, 0);
+    memcpy(c.payload[rank], mine, bytes);
+    c.pay_tick[rank].store(t, std::memory_order_release);
+    if (rank == 0) {
+      int slot = 0;
+      for (int r = 0; r < world; r++) {
+        if (!(mask & (1u << r))) continue;
+        if (!wait_ge(c.pay_tick[r], t, "peer (host gather)")) return ZK_ERR_NOT_CONNECTED;
+        memcpy((char*)all + (size_t)slot * bytes, c.payload[r], bytes);
+        slot++;
+      }
+    }
+    return ZK_OK;
+  }
+  // the king's answer, the same bytes for everyone (dmsm/mod.rs:87 `king sends the result to all`)
+  int bcast_host(int sid, uint32_t mask, void* buf, size_t bytes) {
+    const int op = op_[sid]++;
+    (void)mask;
+    if (bytes > (size_t)NET_PAYLOAD) return fail("host payload too large", ZK_ERR_BAD_INPUT);
+    if (transport == ZK_NET_LOCAL) return ZK_OK;
+    NetChan& c = ctl_->chan[sid];
+    const uint64_t t = tick(sid, op, 0);
+    if (rank == 0) {
+      memcpy(c.pay_out, buf, bytes);
+      c.pay_king.store(t, std::memory_order_release);
+    } else {
+      if (!wait_ge(c.pay_king, t, "king (host broadcast)")) return ZK_ERR_NOT_CONNECTED;
+      memcpy(buf, c.pay_out, bytes);
+    }
+    return ZK_OK;
+  }
+
+  int sync(int sid) {
+    if (host_mode || !stream_[sid]) return ZK_OK;
+    if (hipStreamSynchronize(stream_[sid]) != hipSuccess) return fail("hipStreamSynchronize");
+    return ZK_OK;
+  }
+  // Watchdog for the RCCL data plane: wait for the channel's stream with a deadline instead of forever; on expiry the
+  // communicators are aborted (ncclCommAbort) and the caller gets ZK_ERR_PROTOCOL -- a hung collective must not hang
+  // the prover (ser_net.rs:122-125).
+  int sync_deadline(int sid) {
+    if (host_mode || !stream_[sid]) return ZK_OK;
+    uint64_t dl = net_now_ms() + timeout_ms;
+    for (;;) {
+      hipError_t e = hipStreamQuery(stream_[sid]);
+      if (e == hipSuccess) return ZK_OK;
+      if (e != hipErrorNotReady) return fail("stream error while waiting for a collective");
+      if (net_now_ms() > dl) {
+        aborted_ = true;
+        return fail_party("collective did not complete within the timeout", 0);
+      }
+      relax();
+    }
+  }
+
+  int fail(const std::string& m, int code = ZK_ERR_GENERIC) {
+    err = m;
+    err_party = -1;
+    last_code = code;
+    return code;
+  }
+  int fail_party(const std::string& m, int party) {
+    err = m;
+    err_party = party;
+    last_code = ZK_ERR_PROTOCOL;
+    return ZK_ERR_PROTOCOL;
+  }
+  int last_code = ZK_OK;
+
+ private:
+  // waits are short when every rank is alive (a few microseconds between neighbours on one node): spin first, then
+  // back off to 20 us sleeps so that a long wait (a dead peer, up to the timeout) does not burn a core
+  void relax() {
+    if (++spins_ < 4000) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      return;
+    }
+    timespec ts{0, 20000};
+    nanosleep(&ts, nullptr);
+  }
+  void relax_reset() { spins_ = 0; }
+  uint32_t spins_ = 0;
+  uint64_t tick(int sid, int op, size_t chunk) const { return (seq_[sid] << 24) | ((uint64_t)(op & 0xff) << 16) | (chunk & 0xffff); }
+  bool wait_ge(std::atomic<uint64_t>& a, uint64_t v, const char* what) {
+    // ticks are ordered by (round, operation, chunk)
+    uint64_t dl = net_now_ms() + timeout_ms;
+    relax_reset();
+    while (a.load(std::memory_order_acquire) < v) {
+      if (net_now_ms() > dl) {
+        fail(std::string("timed out waiting for ") + what, ZK_ERR_NOT_CONNECTED);
+        return false;
+      }
+      relax();
+    }
+    return true;
+  }
+  bool map_ctl() {
+    int fd = shm_open(name_.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0) {
+      fail("shm_open failed", ZK_ERR_NOT_CONNECTED);
+      return false;
+    }
+    if (ftruncate(fd, sizeof(NetCtl)) != 0) {
+      ::close(fd);
+      fail("ftruncate failed", ZK_ERR_NOT_CONNECTED);
+      return false;
+    }
+    void* p = mmap(nullptr, sizeof(NetCtl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    ::close(fd);
+    if (p == MAP_FAILED) {
+      fail("mmap failed", ZK_ERR_NOT_CONNECTED);
+      return false;
+    }
+    ctl_ = (NetCtl*)p;      // a fresh segment is zero-filled: all sequence words start at 0
+    return true;
+  }
+  bool map_data(int s) {
+    std::string nm = name_ + "_d" + std::to_string(s);
+    int fd = shm_open(nm.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)(cap_ * world)) != 0) {
+      if (fd >= 0) ::close(fd);
+      fail("shm data segment", ZK_ERR_NOT_CONNECTED);
+      return false;
+    }
+    void* p = mmap(nullptr, cap_ * world, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    ::close(fd);
+    if (p == MAP_FAILED) {
+      fail("mmap data segment", ZK_ERR_NOT_CONNECTED);
+      return false;
+    }
+    data_[s] = (char*)p;
+    return true;
+  }
+  int copy_dd(void* dst, const void* src, size_t bytes, int sid) {
+    if (dst == src || !bytes) return ZK_OK;
+    if (host_mode) {
+      memmove(dst, src, bytes);
+      return ZK_OK;
+    }
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_[sid] ? stream_[sid] : nullptr) != hipSuccess)
+      return fail("hipMemcpy d2d");
+    return ZK_OK;
+  }
+  // device (or host) -> shared segment, blocking
+  int copy_out(char* shm, const char* src, size_t len, int sid) {
+    if (!len) return ZK_OK;
+    if (host_mode) {
+      memcpy(shm, src, len);
+      return ZK_OK;
+    }
+    if (hipMemcpyAsync(shm, src, len, hipMemcpyDeviceToHost, stream_[sid]) != hipSuccess) return fail("hipMemcpy d2h");
+    return sync(sid);
+  }
+  int copy_in(char* dst, const char* shm, size_t len, int sid) {
+    if (!len) return ZK_OK;
+    if (host_mode) {
+      memcpy(dst, shm, len);
+      return ZK_OK;
+    }
+    if (hipMemcpyAsync(dst, shm, len, hipMemcpyHostToDevice, stream_[sid]) != hipSuccess) return fail("hipMemcpy h2d");
+    return ZK_OK;
+  }
+  int rccl_fail(int rc, const char* what) {
+    Rccl& R = Rccl::inst();
+    return fail(std::string("RCCL ") + what + ": " + (R.GetErrorString ? R.GetErrorString(rc) : "error"));
+  }
+
+  std::string name_;
+  NetCtl* ctl_ = nullptr;
+  char* data_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap_ = 0;
+  void* comm_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_in_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_out_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t seq_[NET_NSID] = {0, 0, 0, 0};
+  uint64_t last_g_[NET_NSID] = {0, 0, 0, 0};
+  uint64_t last_s_[NET_NSID][NET_MAXR] = {};
+  int op_[NET_NSID] = {0, 0, 0, 0};
+  bool aborted_ = false;
+};
+
+}  // namespace zk

@@ -1,23 +1,23 @@
-"""The MPC star topology on one multi-GPU node: one process per GPU (torch.distributed, backend "nccl" = RCCL
-over xGMI), the n = 4l parties split over the ranks, king = party 0 on rank 0.
+"""One process per GPU: the launcher side of the star network (the network itself is in the library: csrc/net.hpp
+behind zk_net_* / zk_dist_*, mirrored by zksaas_amd/net.py).
 
-mpc-net/src/lib.rs:89-176 defines two collectives -- every party sends to the king
-(`client_send_or_king_receive`) and the king sends each party its own answer
-(`client_receive_or_king_send`) -- i.e. gather and scatter.  Here they are
-`torch.distributed.gather` / `scatter` on device tensors holding raw Montgomery limbs (no serialization);
-d_msm's "king sums and broadcasts one point" is an all-gather of one partial point per rank.
-
-Data-path compute goes through a small backend object so that the protocol flow can be exercised on CPU
-(gloo, world_size 2) with a stand-in backend in the tests; the product backend is `GpuBackend` (C ABI).
+What is here: slicing a full dealing into the rows of this rank's parties, and the `bench.py --gpus N --workload ...`
+drivers for the BASELINE configs:
+    c2  d_fft, m = 2^20, BN254          (dist-primitives/examples/dfft_test.rs via scripts/dfft_test.zsh)
+    c3  d_msm, 2^20 G1 points per party (dist-primitives/examples/dmsm_bench.rs via scripts/dmsm_bench.zsh)
+    c4  Groth16 on the SHA-256 circuit  (groth16/examples/sha256.rs)  -- the headline metric
+    c5  BLS12-381, 2^24 - 2 constraints, d_fft + d_msm + deg_red composed
+torch.distributed (gloo, CPU) is used for the bootstrap only -- handing rank 0's net id to the other ranks, the
+barriers that bracket the timed region and the max over ranks; nothing on the data path goes through it.
 """
-import ctypes as C
 import os
 import time
 
 import numpy as np
 
 from . import groth16 as zg
-from .api import ZK_G1, ZK_G2
+from . import net as znet
+from .api import ZK_G1, ZK_G2, DeviceBuffer, FftMask
 
 
 def party_range(rank, world, n):
@@ -25,352 +25,235 @@ def party_range(rank, world, n):
     return rank * k, k
 
 
-class GpuBackend:
-    """All compute through libzksaas_hip.so on torch int64 tensors [..., limbs] resident on this rank's GPU."""
-
-    def __init__(self, pp):
-        import torch
-        self.torch = torch
-        self.pp = pp
-        self.device = torch.device("cuda", torch.cuda.current_device())
-
-    def stream(self):
-        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
-
-    def empty(self, *shape):
-        return self.torch.empty(*shape, dtype=self.torch.int64, device=self.device)
-
-    def from_numpy(self, arr):
-        return self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(self.device)
-
-    def fft1(self, t, log_m, inverse):
-        pp = self.pp
-        batch = t.numel() // (4 * ((1 << log_m) // pp.l))
-        pp._check(pp.lib.zk_fft1(pp.h, t.data_ptr(), log_m, int(inverse), batch, None, self.stream()))
-
-    def king_fft2(self, tin, tout, log_m, inverse, g, scale, rearrange, seed):
-        pp = self.pp
-        garr = None if g is None else pp.fr.encode_one(g)
-        pp._check(pp.lib.zk_fft2_king(pp.h, tin.data_ptr(), None, pp.n, log_m, int(inverse),
-                                      None if garr is None else garr.ctypes.data, int(scale), int(rearrange), seed,
-                                      tout.data_ptr(), None, self.stream()))
-
-    def mul_sub(self, out, a, b, c):
-        pp = self.pp
-        pp._check(pp.lib.zk_vec_mul_sub(pp.h, out.data_ptr(), a.data_ptr(), b.data_ptr(), c.data_ptr(),
-                                        out.numel() // 4, self.stream()))
-
-    def deg_red(self, x, length, seed):
-        pp = self.pp
-        pp._check(pp.lib.zk_deg_red(pp.h, x.data_ptr(), None, None, length, seed, self.stream()))
-
-    def msm_local(self, group, bases, scalars, length, first, count):
-        pp = self.pp
-        nl = pp.fq.nl * (2 if group == ZK_G2 else 1)
-        out = np.zeros(3 * nl, dtype=np.uint64)
-        pp._check(pp.lib.zk_d_msm_local(pp.h, group, bases.data_ptr(), scalars.data_ptr(), length, first, count, None,
-                                        out.ctypes.data, self.stream()))
-        return out
-
-    def msms_begin(self, inp, first, count, skip_h):
-        """start S, H, V, W for this rank's parties (overlaps the circom_h rounds)"""
-        pp = self.pp
-        self._local_crs = zg.CrsShare(inp["s"].data_ptr(), inp["h"].data_ptr(), inp["v"].data_ptr(),
-                                      inp["w"].data_ptr(), inp["u"].data_ptr(), inp["len_a"], inp["len_w"],
-                                      inp["u"].shape[1], *[getattr(inp["crs_ct"], f) for f in (
-                                          "a_query0", "b_g1_query0", "delta_g1", "alpha_g1", "beta_g1", "b_g2_query0",
-                                          "delta_g2", "beta_g2")])
-        pp._check(pp.lib.zk_groth16_msms_begin(pp.h, C.byref(self._local_crs), inp["a_share"].data_ptr(),
-                                               inp["ax_share"].data_ptr(), first, count, int(skip_h), None,
-                                               self.stream()))
-
-    def msms_finish(self, h, first, count):
-        pp = self.pp
-        nl = pp.fq.nl
-        outs = [np.zeros(3 * nl * (2 if i == 2 else 1), dtype=np.uint64) for i in range(5)]
-        arr = (C.c_void_p * 5)(*[x.ctypes.data for x in outs])
-        pp._check(pp.lib.zk_groth16_msms_finish(pp.h, h.data_ptr(), arr, self.stream()))
-        return outs
-
-    def group_add(self, group, a, b):
-        pp = self.pp
-        out = np.zeros_like(a)
-        pp._check(pp.lib.zk_group_add(pp.h, group, a.ctypes.data, b.ctypes.data, out.ctypes.data))
-        return out
-
-    def assemble(self, crs_ct, r, s, sums):
-        pp = self.pp
-        nl = pp.fq.nl
-        pa = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
-        pb = np.zeros((pp.n, 6 * nl), dtype=np.uint64)
-        pc = np.zeros((pp.n, 3 * nl), dtype=np.uint64)
-        rr, ss = pp.fr.encode_one(r), pp.fr.encode_one(s)
-        arr = (C.c_void_p * 5)(*[x.ctypes.data for x in sums])
-        pp._check(pp.lib.zk_groth16_assemble(pp.h, C.byref(crs_ct), rr.ctypes.data, ss.ctypes.data, arr, None,
-                                             pa.ctypes.data, pb.ctypes.data, pc.ctypes.data))
-        return pa, pb, pc
-
-    def point_to_tensor(self, arr):
-        return self.from_numpy(arr)
-
-    def tensor_to_points(self, t):
-        return t.cpu().numpy().view(np.uint64)
-
-    def sync(self):
-        self.torch.cuda.synchronize()
+def rows(buf, first, k, row_bytes):
+    """the contiguous rows [first, first + k) of a party-major device buffer [n][row]"""
+    return buf.view(first * row_bytes, k * row_bytes)
 
 
-class StarNet:
-    """gather-to-king / scatter-from-king over torch.distributed (rank 0 hosts the king).
+class LocalCrs:
+    """zk_crs_share over this rank's rows of a full PackedProvingKeyShare dealing (views, no copies)."""
 
-    `via_cpu` stages every collective through host tensors (gloo): a debugging mode that lets two ranks share ONE
-    GPU (RCCL refuses duplicate devices), used to exercise the complete multi-rank GPU code path on a 1-GPU box."""
+    def __init__(self, pp, crs, first, k):
+        e1, e2 = 2 * pp.fq.nbytes, 4 * pp.fq.nbytes
+        self.s = rows(crs.s, first, k, crs.len_a * e1)
+        self.h = rows(crs.h, first, k, crs.len_a * e1)
+        self.v = rows(crs.v, first, k, crs.len_a * e2)
+        self.w = rows(crs.w, first, k, crs.len_w * e1)
+        self.u = rows(crs.u, first, k, crs.len_u * e1)
+        self.len_a, self.len_w, self.len_u, self.k = crs.len_a, crs.len_w, crs.len_u, k
+        s1, s2 = crs.s1, crs.s2
+        self._keep = (crs, s1, s2)
+        self.ct = zg.CrsShare(self.s.ptr, self.h.ptr, self.v.ptr, self.w.ptr, self.u.ptr, crs.len_a, crs.len_w, crs.len_u,
+                              s1[0].ctypes.data, s1[1].ctypes.data, s1[2].ctypes.data, s1[3].ctypes.data,
+                              s1[4].ctypes.data, s2[0].ctypes.data, s2[1].ctypes.data, s2[2].ctypes.data)
 
-    def __init__(self, dist, rank, world, via_cpu=False):
-        self.dist, self.rank, self.world, self.via_cpu = dist, rank, world, via_cpu
-
-    def gather(self, local, full):
-        """local [k, ...] from every rank -> full [n, ...] on rank 0 (party-major = rank-major)."""
-        if self.world == 1:
-            full.copy_(local)
-            return
-        if self.via_cpu:
-            loc = local.cpu()
-            if self.rank == 0:
-                parts = [loc.new_empty(loc.shape) for _ in range(self.world)]
-                self.dist.gather(loc, gather_list=parts, dst=0)
-                for dst, src in zip(full.chunk(self.world, dim=0), parts):
-                    dst.copy_(src)
-            else:
-                self.dist.gather(loc, dst=0)
-            return
-        if self.rank == 0:
-            parts = list(full.chunk(self.world, dim=0))
-            self.dist.gather(local, gather_list=parts, dst=0)
-        else:
-            self.dist.gather(local, dst=0)
-
-    def scatter(self, full, local):
-        """full [n, ...] on rank 0 -> local [k, ...] on every rank."""
-        if self.world == 1:
-            local.copy_(full)
-            return
-        if self.via_cpu:
-            loc = local.cpu()
-            if self.rank == 0:
-                self.dist.scatter(loc, scatter_list=[p.cpu().contiguous() for p in full.chunk(self.world, dim=0)], src=0)
-            else:
-                self.dist.scatter(loc, src=0)
-            local.copy_(loc)
-            return
-        if self.rank == 0:
-            parts = [p.contiguous() for p in full.chunk(self.world, dim=0)]
-            self.dist.scatter(local, scatter_list=parts, src=0)
-        else:
-            self.dist.scatter(local, src=0)
-
-    def all_gather(self, local):
-        if self.world == 1:
-            return [local]
-        if self.via_cpu:
-            loc = local.cpu()
-            outs = [loc.new_empty(loc.shape) for _ in range(self.world)]
-            self.dist.all_gather(outs, loc)
-            return outs
-        outs = [local.new_empty(local.shape) for _ in range(self.world)]
-        self.dist.all_gather(outs, local)
-        return outs
+    def precompute(self, pp):
+        from . import api
+        for buf, grp, ln in ((self.s, ZK_G1, self.len_a), (self.h, ZK_G1, self.len_a), (self.v, ZK_G2, self.len_a),
+                             (self.w, ZK_G1, self.len_w), (self.u, ZK_G1, self.len_u)):
+            api.msm_precompute(pp, grp, buf, self.k * ln)
 
 
-class DistProver:
-    """dsha256 (groth16/examples/sha256.rs:32-129) with the parties sharded over ranks.
-
-    Per rank: qap [3][k][Lc], a_share [k][len_a], ax_share [k][len_w], CRS share vectors [k][len] (all tensors of
-    Montgomery limbs), k = n / world."""
-
-    def __init__(self, backend, net, n, l, log_m, w2m):
-        self.be, self.net, self.n, self.l, self.log_m, self.w2m = backend, net, n, l, log_m, w2m
-        self.first, self.k = party_range(net.rank, net.world, n)
-        self.Lc = (1 << log_m) // l
-        be = backend
-        self.W = be.empty(3, self.k, self.Lc, 4)
-        self.h = be.empty(self.k, self.Lc, 4)
-        if net.rank == 0:
-            self.full_in = be.empty(n, self.Lc, 4)
-            self.full_out = be.empty(n, self.Lc, 4)
-        else:
-            self.full_in = self.full_out = None
-
-    def _round(self, x, inverse, g, scale, rearrange, seed):
-        """fft1 on the local parties was done by the caller; king step for one vector: gather -> king -> scatter."""
-        self.net.gather(x, self.full_in)
-        if self.net.rank == 0:
-            self.be.king_fft2(self.full_in, self.full_out, self.log_m, inverse, g, scale, rearrange, seed)
-        self.net.scatter(self.full_out, x)
-
-    def circom_h(self, qap, seed):
-        """ext_wit.rs:104-181 (zero masks)."""
-        be = self.be
-        self.W.copy_(qap)
-        be.fft1(self.W, self.log_m, True)                       # 3 x d_ifft: local stages for a, b, c at once
-        for j in range(3):
-            self._round(self.W[j], True, self.w2m, True, True, seed + j)
-        be.fft1(self.W, self.log_m, False)                      # 3 x d_fft
-        for j in range(3):
-            self._round(self.W[j], False, None, False, False, seed + 3 + j)
-        be.mul_sub(self.h, self.W[0], self.W[1], self.W[2])     # ext_wit.rs:173-177
-        self.net.gather(self.h, self.full_in)                   # deg_red (ext_wit.rs:179)
-        if self.net.rank == 0:
-            be.deg_red(self.full_in, self.Lc, seed + 6)
-        self.net.scatter(self.full_in, self.h)
-        return self.h
-
-    def prove(self, inp, r, s, seed):
-        be = self.be
-        first, k = self.first, self.k
-        if hasattr(be, "msms_begin"):
-            # the four MSMs over the witness shares overlap the king rounds of circom_h (prove.rs try_join!)
-            be.msms_begin(inp, first, k, skip_h=(r == 0))
-            h = self.circom_h(inp["qap"], seed)
-            parts = be.msms_finish(h, first, k)
-        else:
-            h = self.circom_h(inp["qap"], seed)
-            parts = [
-                be.msm_local(ZK_G1, inp["s"], inp["a_share"], inp["len_a"], first, k),
-                be.msm_local(ZK_G1, inp["h"], inp["a_share"], inp["len_a"], first, k) if r else None,
-                be.msm_local(ZK_G2, inp["v"], inp["a_share"], inp["len_a"], first, k),
-                be.msm_local(ZK_G1, inp["w"], inp["ax_share"], inp["len_w"], first, k),
-                be.msm_local(ZK_G1, inp["u"], h, self.Lc, first, k),
-            ]
-            if parts[1] is None:
-                parts[1] = np.zeros_like(parts[0])
-        # d_msm's king: sum of the ranks' partial points, known to every rank afterwards (dmsm/mod.rs:85-92)
-        flat = np.concatenate(parts)
-        gathered = [be.tensor_to_points(t).reshape(-1) for t in self.net.all_gather(be.point_to_tensor(flat))]
-        sizes = [len(p) for p in parts]
-        sums = []
-        off = 0
-        for idx, sz in enumerate(sizes):
-            grp = ZK_G2 if idx == 2 else ZK_G1
-            acc = np.ascontiguousarray(gathered[0][off:off + sz])
-            for g in gathered[1:]:
-                acc = be.group_add(grp, acc, np.ascontiguousarray(g[off:off + sz]))
-            sums.append(acc)
-            off += sz
-        return be.assemble(inp["crs_ct"], r, s, sums)
-
-
-def _local_inputs(be, pp, crs, wit, rank, world):
-    """Slice this rank's parties out of the full dealing (setup time, not timed)."""
-    n, nl = pp.n, pp.fr.nl
-    first, k = party_range(rank, world, n)
+def local_witness(pp, wit, first, k):
+    eb = pp.fr.nbytes
     Lc = (1 << wit.log_m) // pp.l
-    sl = lambda buf, length, width: buf.to_numpy().reshape(n, length, width)[first:first + k]
-    qap = np.stack([sl(q, Lc, nl) for q in wit.qap])
-    return {
-        "qap": be.from_numpy(qap), "a_share": be.from_numpy(sl(wit.a_share, wit.len_a, nl)),
-        "ax_share": be.from_numpy(sl(wit.ax_share, wit.len_w, nl)), "s": be.from_numpy(sl(crs.s, crs.len_a, 2 * nl)),
-        "h": be.from_numpy(sl(crs.h, crs.len_a, 2 * nl)), "v": be.from_numpy(sl(crs.v, crs.len_a, 4 * nl)),
-        "w": be.from_numpy(sl(crs.w, crs.len_w, 2 * nl)), "u": be.from_numpy(sl(crs.u, crs.len_u, 2 * nl)),
-        "len_a": crs.len_a, "len_w": crs.len_w, "crs_ct": crs.ct,
-    }
+    qap = [rows(q, first, k, Lc * eb) for q in wit.qap]
+    return qap, rows(wit.a_share, first, k, wit.len_a * eb), rows(wit.ax_share, first, k, wit.len_w * eb)
+
+
+def local_masks(pp, masks, log_m, first, k):
+    """zk_groth16_masks over this rank's rows of a ProofMasks dealing; returns (struct, keep-alive list)"""
+    if masks is None:
+        return None, None
+    eb = pp.fr.nbytes
+    Lc = (1 << log_m) // pp.l
+    keep = []
+    ct = zg.Masks()
+    for i in range(6):
+        a, b = rows(masks.fft[i].in_mask, first, k, Lc * eb), rows(masks.fft[i].out_mask, first, k, Lc * eb)
+        keep += [a, b]
+        ct.fft_in[i], ct.fft_out[i] = a.ptr, b.ptr
+    a, b = rows(masks.degred.in_mask, first, k, Lc * eb), rows(masks.degred.out_mask, first, k, Lc * eb)
+    keep += [a, b]
+    ct.degred_in, ct.degred_out = a.ptr, b.ptr
+    for i in range(5):
+        a = np.ascontiguousarray(masks.msm[i].in_mask[first:first + k])
+        b = np.ascontiguousarray(masks.msm[i].out_mask[first:first + k])
+        keep += [a, b]
+        ct.msm_in[i], ct.msm_out[i] = a.ctypes.data, b.ctypes.data
+    return ct, keep
+
+
+def _bootstrap(rank, world):
+    """rank 0's net id to everyone (setup, untimed); returns (dist module or None, id)"""
+    if world == 1:
+        return None, znet.StarNet.unique_id()
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    box = [znet.StarNet.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return dist, box[0]
+
+
+def _timed(dist, torch, step, steps, warmup):
+    """W untimed steps, barrier + device sync, K timed steps, device sync + barrier, max over ranks"""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def _rand_fr(pp, count, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    return DeviceBuffer.from_numpy(pp, a)
 
 
 def bench(args, rank, local_rank, world):
-    """bench.py's N > 1 leg (also runnable with world == 1 for testing the sharded code path)."""
+    """bench.py's sharded leg (N > 1, or any workload other than the single-GPU c4 line)."""
     import torch
-    import torch.distributed as dist
     import zksaas_amd as zk
-    from bench import build_inputs, read_profile, roofline_of
+    from bench import HBM_PEAK_GBS, MAD_ISSUE_BOUND_G, build_inputs, read_profile, roofline_of, reconstruct
 
-    via_cpu = bool(os.environ.get("ZK_DIST_VIA_CPU"))      # debugging: several ranks on one GPU, gloo collectives
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if via_cpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    pp = zk.PackedSharingParams("bn254", 2, device=local_rank)
+    transport = os.environ.get("ZK_NET", "rccl" if world > 1 else "local")
+    dist, net_id = _bootstrap(rank, world)
+    wl = args.workload
+    curve = "bls12_381" if wl == "c5" else "bn254"
+    pp = zk.PackedSharingParams(curve, 2, device=local_rank)
     if pp.n % world:
         raise SystemExit("the number of GPUs must divide n = %d parties" % pp.n)
-    r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
-    be = GpuBackend(pp)
-    net = StarNet(dist, rank, world, via_cpu=via_cpu)
-    w2m = zg._root_of_unity("bn254", wit.log_m + 1)
-    prover = DistProver(be, net, pp.n, pp.l, wit.log_m, w2m)
-    inp = _local_inputs(be, pp, crs, wit, rank, world)
-    table_windows = None
-    if not getattr(args, "no_tables", False):
-        # fixed-base tables for THIS rank's slices of the five query vectors (setup time, as a prover service would)
-        from . import api
-        k = pp.n // world
-        for key, grp, ln in (("s", api.ZK_G1, crs.len_a), ("h", api.ZK_G1, crs.len_a), ("v", api.ZK_G2, crs.len_a),
-                             ("w", api.ZK_G1, crs.len_w), ("u", api.ZK_G1, crs.len_u)):
-            api.msm_precompute(pp, grp, inp[key], k * ln)
-        table_windows = api.msm_table_info(pp, api.ZK_G1, inp["s"])["windows"]
-    seed = 1000
-    for _ in range(args.warmup):
-        proof = prover.prove(inp, r, s, seed)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    pp._check(pp.lib.zk_profile_enable(pp.h, 1))        # HIP-event kernel slots of THIS rank (rank 0 reports its own)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = prover.prove(inp, r, s, seed)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else be.device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    prof = read_profile(pp)
-    pp._check(pp.lib.zk_profile_enable(pp.h, 0))
-    # untimed cross-check on rank 0 against the single-GPU prover on the full dealing
-    ok = None
-    if rank == 0:
-        ref = zg.prove(pp, crs, wit, r, s, seed=seed)
-        ok = bool(all(np.array_equal(_norm(pp, a[0], g2), _norm(pp, b[0], g2))
-                      for a, b, g2 in ((proof[0], ref[0], False), (proof[1], ref[1], True), (proof[2], ref[2], False))))
-    if world > 1:
-        dist.barrier()
-    proofs_per_s = args.steps / dt
-    return {
-        "metric": "Groth16 proofs/sec (SHA-256 circuit)", "value": round(proofs_per_s, 3), "unit": "proofs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (256-bit Montgomery)",
-        "data": "synthetic: SHA-256(a=1,b=2) circuit rebuilt from its semantics, seeded trapdoor CRS, seeded shares",
-        "config": {"workload": "BASELINE configs[3]: full distributed Groth16 on the SHA-256 circuit, BN254, l=2, "
-                               "n=8 parties sharded over %d GPUs (king on GPU 0), zero masks" % world,
-                   "constraints": r1.num_constraints, "wires": r1.num_variables, "domain": 1 << wit.log_m,
-                   "parties": pp.n, "parties_per_gpu": pp.n // world, "packing_factor": pp.l,
-                   "fixed_base_tables": table_windows is not None},
-        "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
-        "proof_matches_single_gpu": ok,
-        "roofline": roofline_of(prof, ntt_passes=2, masks_on=False, pp=pp, table_windows=table_windows),   # rank 0's dominant kernel
-        "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
-    }
+    net = znet.StarNet(pp, rank, world, net_id, transport)
+    first, k = net.first, net.k
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "dtype": "u32 limbs (256-bit Montgomery)", "transport": transport, "parties_per_gpu": k}
+    eb = pp.fr.nbytes
+    per = lambda dt: dt / args.steps
+    if wl == "c2":
+        log_m = 20
+        m = 1 << log_m
+        Lc = m // pp.l
+        sh = _rand_fr(pp, k * Lc, 100 + rank)
+        full_mask = None if args.no_masks else FftMask.sample(pp, False, None, 0, log_m, 11)
+        mk = FftMask.zero() if full_mask is None else FftMask(rows(full_mask.in_mask, first, k, Lc * eb),
+                                                             rows(full_mask.out_mask, first, k, Lc * eb))
+        dt = _timed(dist, torch, lambda i: znet.dist_d_fft(pp, net, 0, sh, mk, False, log_m, seed=i), args.steps,
+                    args.warmup)
+        alg = (32 if full_mask is not None else 16) * m * 32          # SURVEY.md 8d: all parties, with / without masks
+        gbs = alg / per(dt) / 1e9
+        res = dict(base, metric="d_fft per second (m = 2^20, BN254 Fr, l = 2, n = 8)", value=round(args.steps / dt, 3),
+                   unit="d_fft/s", ms_per_step=round(per(dt) * 1e3, 4), scaling="strong",
+                   data="synthetic: seeded random share vectors",
+                   config={"workload": "BASELINE configs[1]: d_fft 2^20-point BN254 Fr NTT, king on GPU 0", "m": m,
+                           "masks": full_mask is not None},
+                   roofline={"bound": "hbm", "kernel": "d_fft end to end (all ranks)", "achieved": round(gbs, 1),
+                             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
+                             "traffic": None, "algorithmic_bytes_per_launch": alg})
+    elif wl == "c3":
+        ln = 1 << 20
+        g1 = pp.fq.encode([1, 2]).reshape(-1)
+        bases = DeviceBuffer.from_numpy(pp, np.tile(g1, (k * ln, 1)))
+        sc = _rand_fr(pp, k * ln, 200 + rank)
+        dt = _timed(dist, torch, lambda i: znet.dist_d_msm(pp, net, 0, ZK_G1, bases, sc, ln), args.steps, args.warmup)
+        alg = pp.n * ln * 96
+        from .api import msm_plan
+        plan = msm_plan(pp, ZK_G1, k * ln)
+        muls = pp.n * ln * plan["windows"] * plan["muls_per_add"]
+        gbs, gm = alg / per(dt) / 1e9, muls / per(dt) / 1e9
+        res = dict(base, metric="d_msm per second (2^20 G1 points per party, BN254)", value=round(args.steps / dt, 3),
+                   unit="d_msm/s", ms_per_step=round(per(dt) * 1e3, 4), scaling="strong",
+                   points_per_sec=round(pp.n * ln * args.steps / dt, 1),
+                   data="synthetic: tiled generator bases, seeded scalars",
+                   config={"workload": "BASELINE configs[2]: d_msm 2^20 G1 Pippenger per party (BN254), 8 parties",
+                           "plan": plan},
+                   roofline={"bound": "hbm", "kernel": "d_msm end to end (all ranks)", "achieved": round(gbs, 1),
+                             "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
+                             "traffic": None, "algorithmic_bytes_per_launch": alg,
+                             "alu": {"achieved": round(gm, 1), "peak": round(MAD_ISSUE_BOUND_G * world, 1),
+                                     "unit": "G modmul/s", "frac": round(gm / (MAD_ISSUE_BOUND_G * world), 3)}})
+    elif wl == "c4":
+        r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
+        masks = None if args.no_masks else zg.ProofMasks(pp, wit.log_m, seed=77)
+        lcrs = LocalCrs(pp, crs, first, k)
+        qap, a_sh, ax_sh = local_witness(pp, wit, first, k)
+        mct, keep = local_masks(pp, masks, wit.log_m, first, k)
+        if not args.no_tables:
+            lcrs.precompute(pp)
+        out = {}
 
+        def step(i):
+            out["proof"] = znet.dist_prove(pp, net, lcrs.ct, qap, a_sh, ax_sh, r, s, wit.log_m, masks=mct, seed=2000 + i)
+        step(0)
+        pp._check(pp.lib.zk_profile_enable(pp.h, 1))
+        dt = _timed(dist, torch, step, args.steps, args.warmup)
+        prof = read_profile(pp)
+        pp._check(pp.lib.zk_profile_enable(pp.h, 0))
+        # untimed cross-check: the ranks' shares put together reconstruct the single-context proof
+        ok = None
+        mine = np.concatenate([x.reshape(-1) for x in out["proof"]])
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+        else:
+            parts = [mine]
+        if rank == 0:
+            nl = pp.fq.nl
+            sizes = [k * 3 * nl, k * 6 * nl, k * 3 * nl]
+            cols = [[], [], []]
+            for p in parts:
+                o = 0
+                for j, sz in enumerate(sizes):
+                    cols[j].append(p[o:o + sz].reshape(k, -1))
+                    o += sz
+            full = tuple(np.concatenate(c) for c in cols)
+            ref = zg.prove(pp, crs, wit, r, s, masks=masks, seed=1)
+            ok = bool(reconstruct(pp, full) == reconstruct(pp, ref))
+        proofs_per_s = args.steps / dt
+        res = dict(base, metric="Groth16 proofs/sec (SHA-256 circuit)", value=round(proofs_per_s, 3), unit="proofs/s",
+                   ms_per_step=round(per(dt) * 1e3, 4), scaling="strong",
+                   data="synthetic: SHA-256(a=1,b=2) circuit rebuilt from its semantics and padded to the reference "
+                        "fixture's 29 823 wires, seeded trapdoor CRS, seeded shares and masks",
+                   config={"workload": "BASELINE configs[3]: full distributed Groth16 on the SHA-256 circuit, BN254, l=2, "
+                                       "n=8 parties sharded over %d GPUs (king on GPU 0), %s" % (
+                                           world, "zero masks" if masks is None else "all 12 masks sampled and applied"),
+                           "masks": masks is not None, "constraints": r1.num_constraints, "wires": r1.num_variables,
+                           "domain": 1 << wit.log_m, "len_a": crs.len_a, "len_w": crs.len_w, "len_u": crs.len_u,
+                           "parties": pp.n, "packing_factor": pp.l, "fixed_base_tables": not args.no_tables},
+                   constraints_per_sec=round(proofs_per_s * r1.num_constraints, 1), proof_matches_single_gpu=ok,
+                   roofline=roofline_of(prof, ntt_passes=2, masks_on=masks is not None, pp=pp),
+                   kernels=[{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]])
+    else:   # c5
+        from . import synthetic
+        log_m = int(os.environ.get("ZK_C5_LOG_M", "24"))
+        inst = synthetic.SyntheticInstance(pp, log_m, seed=1, parties=(first, k))
+        wit = inst.witness(seed=100)
+        r, s = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321
+        out = {}
 
-def _norm(pp, jac, g2):
-    """canonical affine ints of a Jacobian point (host-side, for the untimed cross-check only)."""
-    q = pp.fq.p
-    v = pp.fq.decode(np.asarray(jac).reshape(-1, pp.fq.nl))
-    if g2:
-        z = (v[4], v[5])
-        if z == (0, 0):
-            return np.zeros(1)
-        def mul(a, b):
-            return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
-        nrm = pow((z[0] * z[0] + z[1] * z[1]) % q, q - 2, q)
-        zi = (z[0] * nrm % q, (-z[1]) * nrm % q)
-        zi2 = mul(zi, zi)
-        zi3 = mul(zi2, zi)
-        x, y = mul((v[0], v[1]), zi2), mul((v[2], v[3]), zi3)
-        return np.array([x[0], x[1], y[0], y[1]], dtype=object)
-    if v[2] == 0:
-        return np.zeros(1)
-    zi = pow(v[2], q - 2, q)
-    return np.array([v[0] * zi * zi % q, v[1] * zi * zi * zi % q], dtype=object)
+        def step(i):
+            out["proof"] = znet.dist_prove(pp, net, inst.crs.ct, wit.qap, wit.a_share, wit.ax_share, r, s, log_m, seed=7 + i)
+        dt = _timed(dist, torch, step, args.steps, args.warmup)
+        res = dict(base, metric="Groth16 proofs/sec (BLS12-381, 2^%d - 2 constraints)" % log_m,
+                   value=round(args.steps / dt, 4), unit="proofs/s", ms_per_step=round(per(dt) * 1e3, 2), scaling="strong",
+                   constraints_per_sec=round(inst.nc * args.steps / dt, 1),
+                   data="synthetic R1CS and pseudo-random CRS built on the device (zksaas_amd/synthetic.py)",
+                   config={"workload": "BASELINE configs[4]: BLS12-381 2^%d-constraint synthetic R1CS, d_fft + d_msm + "
+                                       "deg_red composed, zero masks" % log_m, "constraints": inst.nc, "parties": pp.n},
+                   roofline=None)
+    net.close()
+    return res

@@ -40,8 +40,11 @@ class SyntheticInstance:
     """num_variables = m, one public input besides the constant (ni = 2), nc = m - 2 constraints
     A_i = w[i] + 3 w[7i+1],  B_i = w[i+1]  (indices mod m)."""
 
-    def __init__(self, pp, log_m, seed=1):
+    def __init__(self, pp, log_m, seed=1, parties=None):
+        """parties = (first, k): build only the CRS rows and witness shares of parties [first, first + k) (one rank of a
+        multi-GPU run; the instance itself -- R1CS, assignment, discrete logs -- is the same on every rank)."""
         self.pp, self.log_m = pp, log_m
+        self.first, self.k = parties if parties is not None else (0, pp.n)
         m = 1 << log_m
         self.m, self.ni, self.nc, self.nv = m, 2, m - 2, m
         l, n = pp.l, pp.n
@@ -73,8 +76,10 @@ class SyntheticInstance:
         self.single_logs = dict(zip(("a0", "b0", "delta", "alpha", "beta"), singles))
 
         def packed(logs, nch, group):
-            sh = pp.det_pack(logs, nch)
-            pts = zg.base_points(pp, group, sh, n * nch)
+            sh = pp.det_pack(logs, nch)                                  # [n][nch] discrete logs of the share points
+            mine = sh.view(self.first * nch * eb, self.k * nch * eb)
+            pts = zg.base_points(pp, group, mine, self.k * nch)
+            del mine
             sh.free()
             return pts
         self.s = packed(self.logs["a"], self.len_a, ZK_G1)
@@ -99,12 +104,13 @@ class SyntheticInstance:
         """QAP::pss (qap.rs:91-135) + pack_from_witness (sha256.rs:131-156) with share randomness `seed`."""
         pp, l, eb = self.pp, self.pp.l, self.pp.fr.nbytes
         qap = []
+        sl = lambda buf, ln: buf if self.k == pp.n else buf.view(self.first * ln * eb, self.k * ln * eb)
         for k, d in enumerate(self.r1cs.qap(self.w)):
             pp._check(pp.lib.zk_bitrev(pp.h, d.ptr, self.log_m, None))
-            qap.append(pp.pack(d, self.m // l, seed + k, order=1))
+            qap.append(sl(pp.pack(d, self.m // l, seed + k, order=1), self.m // l))
             d.free()
-        a_share = pp.pack(self.w.view(1 * eb), self.len_a, seed + 3)
-        ax_share = pp.pack(self.w.view(self.ni * eb), self.len_w, seed + 4)
+        a_share = sl(pp.pack(self.w.view(1 * eb), self.len_a, seed + 3), self.len_a)
+        ax_share = sl(pp.pack(self.w.view(self.ni * eb), self.len_w, seed + 4), self.len_w)
         return types.SimpleNamespace(qap=qap, a_share=a_share, ax_share=ax_share, log_m=self.log_m, len_a=self.len_a,
                                      len_w=self.len_w)
 
