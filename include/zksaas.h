@@ -53,6 +53,17 @@ int zk_memcpy_h2d(zk_ctx* ctx, void* dst_d, const void* src, size_t bytes, void*
 int zk_memcpy_d2h(zk_ctx* ctx, void* dst, const void* src_d, size_t bytes, void* stream);
 int zk_stream_sync(zk_ctx* ctx, void* stream);
 
+/* ---- share randomness ----------------------------------------------------------------------------------------
+ * The t random points of every `pack` (pss.rs:90-122; the reference draws them from thread_rng / test_rng:
+ * dfft/mod.rs:251, pack.rs:14, deg_red.rs:108) come from a ChaCha20 stream keyed per context from the operating
+ * system's generator; every launch that packs gets fresh nonces, so NO `seed` argument below influences them and two
+ * calls never share randomness.  zk_ctx_set_option("rng_replay", 1) (or ZK_RNG_REPLAY=1 in the environment when the
+ * context is created) switches to the documented replayable generator (DESIGN.md "Randomness": SplitMix64 over
+ * (seed, index)) that the parity tests use to compare shares bit for bit with the oracle -- only then do the `seed`
+ * arguments matter.  zk_chacha20_block: the block function (RFC 7539 2.3, words 12..15 = counter, nonce), exported
+ * for known-answer tests. */
+void zk_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]);
+
 /* ---- packed secret sharing over Fr (secret-sharing/src/pss.rs) ------------------------------------
  * `order`: 0 = chunk j packs secrets[j*l .. j*l+l-1]  (pack_vec, dist-primitives/src/utils/pack.rs:8-20)
  *          1 = chunk j packs secrets[j], secrets[j+nchunks], ...  (stride packing, dfft/mod.rs:286-299,
@@ -210,7 +221,7 @@ int zk_msm_plan(zk_ctx* ctx, int group, size_t len, int plan[4]);
 int zk_msm_precompute(zk_ctx* ctx, int group, const void* bases_d, size_t len, void* stream);
 int zk_msm_forget(zk_ctx* ctx, const void* bases_d);
 int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
-/* Tunables of this context (no reference counterpart).  "msm_bigsort_min": point count from which zk_msm sorts with
+/* Tunables of this context (no reference counterpart).  "rng_replay": see "share randomness".  "msm_bigsort_min": point count from which zk_msm sorts with
  * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
  * "msm_table_c": window bits (8..20, default 16) of tables built by later zk_msm_precompute calls.
  * Unknown name -> ZK_ERR_BAD_INPUT. */

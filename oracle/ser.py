@@ -6,8 +6,13 @@ and not vendored; format per SURVEY.md 8c: Fp -> canonical
 little-endian bytes (non-Montgomery); Vec<T> -> u64 LE length + items;
 short-Weierstrass affine -> x (Fq2: c0 || c1) with flag bits in the top bits of
 the last byte: bit 7 = y is the lexicographically larger of (y, -y), bit 6 =
-point at infinity (x = 0).
+point at infinity (x = 0).  ark-bls12-381 ^0.4 overrides the point encoding with
+the zcash / IETF one (big-endian x, Fq2 as c1 || c0, flags compressed / infinity
+/ sort in the three top bits of the FIRST byte): ``*_zcash`` below, pinned on the
+published compressed generators in tests/test_circom.py.
 """
+
+BLS12_381_Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 
 
 def fp_bytes(v, nbytes):
@@ -22,7 +27,34 @@ def _fq_size(q):
     return (q.bit_length() + 7) // 8
 
 
+def _fq2_gt(a, b):
+    # ark-ff QuadExtField Ord: compare c1 first, then c0
+    return (a[1], a[0]) > (b[1], b[0])
+
+
+def g1_zcash(p, q):
+    n = _fq_size(q)
+    if p is None:
+        return bytes([0xC0]) + bytes(n - 1)
+    b = bytearray(int(p[0]).to_bytes(n, "big"))
+    b[0] |= 0x80 | (0x20 if p[1] > (q - p[1]) % q else 0)
+    return bytes(b)
+
+
+def g2_zcash(p, q):
+    n = _fq_size(q)
+    if p is None:
+        return bytes([0xC0]) + bytes(2 * n - 1)
+    x, y = p
+    b = bytearray(int(x[1]).to_bytes(n, "big") + int(x[0]).to_bytes(n, "big"))
+    neg = ((q - y[0]) % q, (q - y[1]) % q)
+    b[0] |= 0x80 | (0x20 if _fq2_gt(y, neg) else 0)
+    return bytes(b)
+
+
 def g1_compressed(p, q):
+    if q == BLS12_381_Q:
+        return g1_zcash(p, q)
     n = _fq_size(q)
     if p is None:
         b = bytearray(n)
@@ -35,12 +67,9 @@ def g1_compressed(p, q):
     return bytes(b)
 
 
-def _fq2_gt(a, b):
-    # ark-ff QuadExtField Ord: compare c1 first, then c0
-    return (a[1], a[0]) > (b[1], b[0])
-
-
 def g2_compressed(p, q):
+    if q == BLS12_381_Q:
+        return g2_zcash(p, q)
     n = _fq_size(q)
     if p is None:
         b = bytearray(2 * n)

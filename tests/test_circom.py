@@ -93,7 +93,7 @@ def test_read_r1cs_rejects_malformed():
 
 def _stub_pp(curve):
     from zksaas_amd.fields import FQ, MontCodec
-    return types.SimpleNamespace(fq=MontCodec(FQ[curve]))
+    return types.SimpleNamespace(fq=MontCodec(FQ[curve]), curve=curve)
 
 
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
@@ -118,6 +118,48 @@ def test_point_wire_format_matches_oracle_and_round_trips(curve):
     assert blob == oser.proof_compressed(a, b, c, cv.q)
     assert len(blob) == (128 if curve == "bn254" else 192)
     assert wire.proof_from_bytes(pp, blob, curve) == (a, b, c)
+
+
+def test_bls12_381_uses_the_zcash_encoding_pinned_on_the_published_generators():
+    """ark-bls12-381 0.4 serialises points in the zcash / IETF format (big-endian, flags in the first byte); the
+    compressed generators are published constants (draft-irtf-cfrg-pairing-friendly-curves, zcash protocol spec)."""
+    from zksaas_amd import wire
+    cv = CURVES["bls12_381"]
+    pp = _stub_pp("bls12_381")
+    g1c = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+                        "6c55e83ff97a1aeffb3af00adb22c6bb")
+    g2c = bytes.fromhex("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049"
+                        "334cf11213945d57e5ac7d055d042b7e024aa2b2f08f0a91260805272dc51051"
+                        "c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
+    assert wire.point_to_bytes(pp, cv.g1, False) == g1c == oser.g1_compressed(cv.g1, cv.q)
+    assert wire.point_to_bytes(pp, cv.g2, True) == g2c == oser.g2_compressed(cv.g2, cv.q)
+    assert wire.point_from_bytes(pp, g1c, False, "bls12_381") == cv.g1
+    assert wire.point_from_bytes(pp, g2c, True, "bls12_381") == cv.g2
+    # the negated generators carry the sort flag (bit 5), infinity is c0 00 .. 00
+    G1 = ocurve.g1(cv)
+    neg = G1.to_affine(G1.neg(G1.from_affine(cv.g1)))
+    assert wire.point_to_bytes(pp, neg, False)[0] == g1c[0] | 0x20 and wire.point_to_bytes(pp, neg, False)[1:] == g1c[1:]
+    assert wire.point_to_bytes(pp, None, False) == bytes([0xC0]) + bytes(47)
+    assert wire.point_from_bytes(pp, bytes([0xC0]) + bytes(95), True, "bls12_381") is None
+    with pytest.raises(ValueError):
+        wire.point_from_bytes(pp, bytes([0x17]) + g1c[1:], False, "bls12_381")     # compression flag missing
+    with pytest.raises(ValueError):
+        wire.point_from_bytes(pp, bytes([0xE0]) + bytes(47), False, "bls12_381")    # infinity with the sort flag
+
+
+def test_bls12_377_g1_round_trips_with_tonelli_shanks():
+    """the curve the reference's own tests use: q = 1 mod 4, so the square root is Tonelli-Shanks"""
+    from zksaas_amd import wire
+    cv = CURVES["bls12_377"]
+    pp = _stub_pp("bls12_377")
+    G1 = ocurve.g1(cv)
+    rng = random.Random(12)
+    for pt in [None, cv.g1] + [G1.to_affine(G1.mul(G1.from_affine(cv.g1), rng.randrange(1, cv.r))) for _ in range(4)]:
+        blob = wire.point_to_bytes(pp, pt, False)
+        assert blob == oser.g1_compressed(pt, cv.q) and len(blob) == 48
+        assert wire.point_from_bytes(pp, blob, False, "bls12_377") == pt
+    with pytest.raises(ValueError):
+        wire.point_to_bytes(pp, None, True) and wire.point_from_bytes(pp, bytes(96), True, "bls12_377")
 
 
 def test_point_from_bytes_rejects_invalid():

@@ -1,4 +1,5 @@
 """GPU parity (through the C ABI) for the PSS layer: secret-sharing/src/pss.rs, utils/pack.rs, dfft bitrev."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -76,3 +77,44 @@ def test_bitrev(logn):
     want = list(x)
     bitrev_permute(want)
     assert pp.download_fr(buf) == want
+
+
+def test_production_share_randomness_is_fresh_per_call_and_ignores_the_seed():
+    """Outside of replay mode the t random points come from the context's ChaCha20 stream: the same secrets packed
+    twice with the SAME seed give different shares (fresh nonces), different contexts differ too (fresh keys), and
+    everything still reconstructs; d_fft and deg_red king steps likewise."""
+    import zksaas_amd as zk
+    from oracle.prng import rand_vec
+    from oracle.params import BN254
+    pp = zk.PackedSharingParams("bn254", 2)
+    pp2 = zk.PackedSharingParams("bn254", 2)
+    try:
+        for c in (pp, pp2):
+            c.set_option("rng_replay", 0)
+        nch = 200
+        sec = rand_vec(11, 2 * nch, BN254.r)
+        a = pp.pack(up(pp, sec), nch, seed=5)
+        b = pp.pack(up(pp, sec), nch, seed=5)
+        c = pp2.pack(up(pp2, sec), nch, seed=5)
+        sa, sb, sc_ = (x.to_numpy() for x in (a, b, c))
+        assert not np.array_equal(sa, sb) and not np.array_equal(sa, sc_) and not np.array_equal(sb, sc_)
+        # no share row repeats between the two packs (the randomness is fresh everywhere, not just somewhere)
+        assert (sa.reshape(-1, 4) == sb.reshape(-1, 4)).all(axis=1).sum() == 0
+        for ctx_, x in ((pp, a), (pp, b), (pp2, c)):
+            assert ctx_.download_fr(ctx_.unpack(x, nch)) == sec
+        # king steps: two d_fft of the same input differ share-wise, agree after reconstruction
+        m = 256
+        x = rand_vec(12, pp.n * m // 2, BN254.r)
+        u, v = up(pp, x), up(pp, x)
+        zk.d_fft(pp, u, zk.FftMask.zero(), False, 8, seed=3)
+        zk.d_fft(pp, v, zk.FftMask.zero(), False, 8, seed=3)
+        assert not np.array_equal(u.to_numpy(), v.to_numpy())
+        assert pp.download_fr(pp.unpack(u, m // 2)) == pp.download_fr(pp.unpack(v, m // 2))
+        pp.set_option("rng_replay", 1)          # and replay mode is deterministic again
+        u, v = up(pp, x), up(pp, x)
+        zk.d_fft(pp, u, zk.FftMask.zero(), False, 8, seed=3)
+        zk.d_fft(pp, v, zk.FftMask.zero(), False, 8, seed=3)
+        assert np.array_equal(u.to_numpy(), v.to_numpy())
+    finally:
+        pp.close()
+        pp2.close()

@@ -57,3 +57,22 @@ def test_mont_codec_roundtrip():
         assert codec.decode(codec.encode(vals)) == vals
         # Montgomery one = R mod p
         assert int(codec.encode([1])[0][0]) == ((1 << (64 * codec.nl)) % c.r) & ((1 << 64) - 1)
+
+
+def test_chacha20_block_known_answer():
+    """RFC 7539 section 2.3.2 test vector through the library's block function (the share-randomness stream)."""
+    import ctypes as C
+    import struct
+    import zksaas_amd as zk
+    lib = zk.load()
+    key = (C.c_uint32 * 8)(*struct.unpack("<8I", bytes(range(32))))
+    out = (C.c_uint32 * 16)()
+    # words 12..15 = (counter 1, nonce 00:00:00:09 00:00:00:4a 00:00:00:00)
+    lib.zk_chacha20_block(key, 1 | (0x09000000 << 32), 0x4A000000, out)
+    assert struct.pack("<16I", *out).hex() == (
+        "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+        "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    # and it is a function of every input word
+    ref = list(out)
+    lib.zk_chacha20_block(key, 2 | (0x09000000 << 32), 0x4A000000, out)
+    assert list(out) != ref

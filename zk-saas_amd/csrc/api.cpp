@@ -7,6 +7,7 @@
 
 #include "../../include/zksaas.h"
 #include "engine.hpp"
+#include "prng.hpp"
 
 struct zk_ctx {
   zk::IEngine* eng;
@@ -22,7 +23,12 @@ static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 extern "C" {
 
-const char* zk_version(void) { return "zksaas-hip 0.1 (gfx950)"; }
+const char* zk_version(void) { return "zksaas-hip 0.2 (gfx950)"; }
+
+// the block function behind the share-randomness stream (prng.hpp), for known-answer tests of the host build
+void zk_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]) {
+  zk::chacha20_block(key, counter, nonce, out);
+}
 
 int zk_ctx_create(int curve, int l, int device, zk_ctx** out) {
   if (!out) return ZK_ERR_BAD_INPUT;

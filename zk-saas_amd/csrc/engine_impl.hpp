@@ -1,5 +1,6 @@
 // Engine<Cfg>: per-curve implementation of IEngine (included by exactly one .hip file per curve).
 #pragma once
+#include <atomic>
 #include <cstring>
 #include <memory>
 
@@ -12,7 +13,7 @@
 namespace zk {
 
 template <class F>
-__global__ void rand_fill_kernel(F* __restrict__ out, uint64_t seed, size_t count, uint32_t L, uint32_t transpose_lc_log) {
+__global__ void rand_fill_kernel(F* __restrict__ out, RngSeed seed, size_t count, uint32_t L, uint32_t transpose_lc_log) {
   // out[i] = rand(seed, i); with transpose: value index v = k*L + s is stored at [s][k] (k < 2^log)
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -63,6 +64,7 @@ class Engine : public IEngine {
     if (pack2_) (void)hipFree(pack2_);
     if (ident_) (void)hipFree(ident_);
     if (err_flag_) (void)hipFree(err_flag_);
+    if (rng_key_d_) (void)hipFree(rng_key_d_);
   }
 
   size_t fr_bytes() const override { return sizeof(Fr); }
@@ -74,8 +76,33 @@ class Engine : public IEngine {
     if (ilog2(n) > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large");
     build_matrices();
     ZK_HIP(hipMalloc(&err_flag_, sizeof(int)));
+    // share randomness: ChaCha20 keyed from the operating system's generator (prng.hpp); ZK_RNG_REPLAY=1 or the option
+    // "rng_replay" selects the documented replayable stream the parity tests compare shares with
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f || fread(rng_key_h_, 1, sizeof(rng_key_h_), f) != sizeof(rng_key_h_)) {
+      if (f) fclose(f);
+      return fail(ZK_ERR_GENERIC, "cannot read /dev/urandom for the share-randomness key");
+    }
+    fclose(f);
+    ZK_HIP(hipMalloc((void**)&rng_key_d_, sizeof(rng_key_h_)));
+    ZK_HIP(hipMemcpy(rng_key_d_, rng_key_h_, sizeof(rng_key_h_), hipMemcpyHostToDevice));
+    rng_replay_ = getenv("ZK_RNG_REPLAY") && atoi(getenv("ZK_RNG_REPLAY")) != 0;
     return ZK_OK;
   }
+  // the randomness of one launch: `span` consecutive stream ids (batch items).  Replay mode: the caller's seed;
+  // otherwise the seed is IGNORED and the launch gets fresh nonces of this context's ChaCha20 stream.
+  RngSeed rs(uint64_t seed, uint64_t span = 1) {
+    if (rng_replay_) return RngSeed{seed, nullptr};
+    return RngSeed{rng_nonce_.fetch_add(span), rng_key_d_};
+  }
+  RngSeed rs_host(uint64_t seed) {
+    if (rng_replay_) return RngSeed{seed, nullptr};
+    return RngSeed{rng_nonce_.fetch_add(1), rng_key_h_};
+  }
+  uint32_t rng_key_h_[8] = {0};
+  uint32_t* rng_key_d_ = nullptr;
+  std::atomic<uint64_t> rng_nonce_{1};
+  bool rng_replay_ = false;
 
   // ---------------------------------------------------------------- field helpers (host)
   static Fr root_of_unity(int log_size) {
@@ -322,9 +349,9 @@ class Engine : public IEngine {
   int pack_l(const Fr* sec, size_t nch, int order, uint64_t seed, bool det, Fr* shares, hipStream_t st) {
     dim3 grid((unsigned)((nch + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
     if (det)
-      pss_pack_kernel<FrP, L, true><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, pack2_, shares);
+      pss_pack_kernel<FrP, L, true><<<grid, block, 0, st>>>(sec, nch, order, rs(0), pmat_, pack2_, shares);
     else
-      pss_pack_kernel<FrP, L, false><<<grid, block, 0, st>>>(sec, nch, order, seed, pmat_, pack2_, shares);
+      pss_pack_kernel<FrP, L, false><<<grid, block, 0, st>>>(sec, nch, order, rs(seed), pmat_, pack2_, shares);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -445,12 +472,13 @@ class Engine : public IEngine {
   // ---------------------------------------------------------------- king of d_fft (dfft/mod.rs:264-304)
   template <int L>
   int king_l(const Fr* in, const KingBatch<Fr>& kb, int batch, int np, int log_lc, const Fr* U, const Fr* gen,
-             const GTab* gt, const Fr* in_scale, int rearrange, uint64_t seed, Fr* out, bool negate, hipStream_t st) {
+             const GTab* gt, const Fr* in_scale, int rearrange, uint64_t seed_, Fr* out, bool negate, hipStream_t st) {
     size_t Lc = (size_t)1 << log_lc;
     size_t Wc = Lc < (size_t)KING_THREADS ? Lc : (size_t)KING_THREADS;
     size_t lds = (size_t)L * Wc * sizeof(Fr);
     dim3 grid((unsigned)(Lc / Wc), (unsigned)batch), block(KING_THREADS);
     ProfScope ps_(prof, PROF_KING, st, (double)Lc * batch);
+    const RngSeed seed = rs(seed_, (uint64_t)batch);
     if (negate)
       king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, kb, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
@@ -550,7 +578,7 @@ class Engine : public IEngine {
     size_t m = (size_t)1 << log_m, Lc = m / l;
     ZK_HIP(scratch_.ensure(m * sizeof(Fr)));
     Fr* vals = (Fr*)scratch_.p;   // layout [l][Lc]: value k*l+s at [s][k]
-    rand_fill_kernel<Fr><<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st>>>(vals, seed, m, (uint32_t)l,
+    rand_fill_kernel<Fr><<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st>>>(vals, rs(seed), m, (uint32_t)l,
                                                                                  (uint32_t)(log_m - log_l));
     ZK_HIP(hipGetLastError());
     int rc = pss_pack(vals, Lc, 1, seed ^ 0x1111, false, in_mask, st);
@@ -565,7 +593,7 @@ class Engine : public IEngine {
                const Fr* out_mask, hipStream_t st) {
     dim3 grid((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
     ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
-    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, seed, out, out_mask);
+    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, rs(seed), out, out_mask);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -611,7 +639,7 @@ class Engine : public IEngine {
     size_t cnt = len * l;
     ZK_HIP(scratch_.ensure(cnt * sizeof(Fr)));
     Fr* vals = (Fr*)scratch_.p;
-    rand_fill_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(vals, seed, cnt, (uint32_t)l,
+    rand_fill_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(vals, rs(seed), cnt, (uint32_t)l,
                                                                                    0xffffffffu);
     ZK_HIP(hipGetLastError());
     int rc = pss_pack(vals, len, 0, seed ^ 0x1111, false, in_mask, st);
@@ -1215,14 +1243,15 @@ class Engine : public IEngine {
     const int k = l + t;
     std::vector<Fr> sec_in(k), sec_out(k);
     Fr sum = Fr::zero();
+    const RngSeed r0 = rs_host(seed), r1 = rs_host(seed ^ 0x1111ull), r2 = rs_host(seed ^ 0x2222ull);
     for (int i = 0; i < l; i++) {
-      sec_in[i] = rand_fp<FrP>(seed, (uint64_t)i);
+      sec_in[i] = rand_fp<FrP>(r0, (uint64_t)i);
       sum = sum + sec_in[i];
     }
     for (int i = 0; i < l; i++) sec_out[i] = sum.neg();
     for (int i = 0; i < t; i++) {
-      sec_in[l + i] = rand_fp<FrP>(seed ^ 0x1111ull, (uint64_t)i);
-      sec_out[l + i] = rand_fp<FrP>(seed ^ 0x2222ull, (uint64_t)i);
+      sec_in[l + i] = rand_fp<FrP>(r1, (uint64_t)i);
+      sec_out[l + i] = rand_fp<FrP>(r2, (uint64_t)i);
     }
     Jacobian<Fld>* oi = (Jacobian<Fld>*)in_mask;
     Jacobian<Fld>* oo = (Jacobian<Fld>*)out_mask;
@@ -1311,6 +1340,10 @@ class Engine : public IEngine {
     if (!strcmp(name, "msm_bigsort_min")) {
       if (value < 0) return fail(ZK_ERR_BAD_INPUT, "msm_bigsort_min must be >= 0");
       msm_.bigsort_min = (size_t)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "rng_replay")) {
+      rng_replay_ = value != 0;
       return ZK_OK;
     }
     if (!strcmp(name, "msm_table_c")) {

@@ -81,7 +81,7 @@ ZK_D void pack_chunk(const Fp<P>* v, const Fp<P>* __restrict__ Pm, const PackL2<
 //   order 0: secrets[j*l + i];  order 1: secrets[j + i*nchunks].
 template <class P, int L, bool DET>
 __global__ __launch_bounds__(KING_THREADS) void pss_pack_kernel(const Fp<P>* __restrict__ secrets, size_t nchunks,
-                                                               int order, uint64_t seed,
+                                                               int order, RngSeed seed,
                                                                const Fp<P>* __restrict__ Pm /* [n][l+t] */,
                                                                const PackL2<Fp<P>>* __restrict__ k2,
                                                                Fp<P>* __restrict__ shares /* [n][nchunks] */) {
@@ -153,14 +153,14 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     const Fp<P>* __restrict__ in0, KingBatch<Fp<P>> kb, int np, uint32_t log_lc,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
     const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
-    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, uint64_t seed0, Fp<P>* __restrict__ out0) {
+    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, RngSeed seed0, Fp<P>* __restrict__ out0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
   const F* __restrict__ in = in0 + blockIdx.y * kb.stride;
   F* __restrict__ out = out0 + blockIdx.y * kb.stride;
   const F* __restrict__ in_mask = kb.in_mask[blockIdx.y];
   const F* __restrict__ out_mask = kb.out_mask[blockIdx.y];
-  const uint64_t seed = seed0 + blockIdx.y;
+  const RngSeed seed = seed0.plus(blockIdx.y);
   constexpr int T = L, N = 4 * L;
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
   extern __shared__ uint4 smem[];
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
 template <class P, int L>
 __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
-    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, uint64_t seed,
+    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
     Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;

@@ -4,9 +4,14 @@ library can exchange frames with a real mpc-net peer.
 
 * Fr vectors (the bulk: m/l elements per d_fft message) are converted on the device (`zk_fr_to_bytes` /
   `zk_fr_from_bytes`); `Vec<T>` adds a u64 little-endian length prefix.
-* Group elements (one per d_msm message, three per proof) are converted on the host with Python integers: affine
-  short-Weierstrass points -> x (Fq2: c0 || c1) little-endian, flags in the two top bits of the last byte: bit 7 = y
-  is the lexicographically larger of (y, -y) (Fq2 compares c1 first), bit 6 = point at infinity.
+* Group elements (one per d_msm message, three per proof) are converted on the host with Python integers; vectors
+  of them (CRS shares) on the device (zk_points_decompress).  Two encodings, as in arkworks 0.4:
+    - BN254, BLS12-377 (ark-ec's default short-Weierstrass flags): x (Fq2: c0 || c1) little-endian, flags in the two
+      top bits of the LAST byte: bit 7 = y is the lexicographically larger of (y, -y) (Fq2 compares c1 first), bit 6
+      = point at infinity;
+    - BLS12-381 (ark-bls12-381 overrides it with the zcash / IETF encoding): x BIG-endian (Fq2: c1 || c0), flags in
+      the three top bits of the FIRST byte: bit 7 = compressed (always set), bit 6 = infinity, bit 5 = y is the
+      lexicographically larger.  Pinned on the published compressed generators (tests/test_circom.py).
 
 Marshalling only; nothing here is on the hot path.
 """
@@ -18,7 +23,9 @@ from . import api, fields
 _CURVE_B = {
     "bn254": (3, None),          # b2 = 3 / (9 + u), filled in below
     "bls12_381": (4, (4, 4)),
+    "bls12_377": (1, "none"),    # G2 of BLS12-377 (Fq2 non-residue -5) is not on the reference's hot path
 }
+ZCASH_CURVES = ("bls12_381",)
 
 
 def _bn254_b2():
@@ -29,6 +36,8 @@ def _bn254_b2():
 
 def _curve_b(curve, g2):
     b1, b2 = _CURVE_B[curve]
+    if g2 and b2 == "none":
+        raise ValueError("G2 is not available for " + curve)
     if g2 and b2 is None:
         b2 = _bn254_b2()
     return b2 if g2 else b1
@@ -45,11 +54,32 @@ def _f2_inv(a, q):
 
 
 def _fq_sqrt(a, q):
-    """q = 3 mod 4 for BN254 and BLS12-381."""
+    """q = 3 mod 4 for BN254 and BLS12-381 (one exponentiation); Tonelli-Shanks otherwise (BLS12-377: q = 1 mod 4)."""
+    a %= q
     if a == 0:
         return 0
-    r = pow(a, (q + 1) // 4, q)
-    return r if r * r % q == a else None
+    if q % 4 == 3:
+        r = pow(a, (q + 1) // 4, q)
+        return r if r * r % q == a else None
+    if pow(a, (q - 1) // 2, q) != 1:
+        return None
+    s, t = 0, q - 1
+    while t % 2 == 0:
+        t //= 2
+        s += 1
+    z = 2
+    while pow(z, (q - 1) // 2, q) != q - 1:
+        z += 1
+    c, x, b, m = pow(z, t, q), pow(a, (t + 1) // 2, q), pow(a, t, q), s
+    while b != 1:
+        i, b2 = 0, b
+        while b2 != 1:
+            b2 = b2 * b2 % q
+            i += 1
+        e = pow(c, 1 << (m - i - 1), q)
+        x, c = x * e % q, e * e % q
+        b, m = b * c % q, i
+    return x
 
 
 def _f2_sqrt(a, q):
@@ -108,9 +138,24 @@ def affine_to_jacobian(pp, pt, g2):
     return pp.fq.encode(vals).reshape(-1)
 
 
-def point_to_bytes(pp, pt, g2):
+def point_to_bytes(pp, pt, g2, curve=None):
+    curve = curve or pp.curve
     q = pp.fq.p
     n = (q.bit_length() + 7) // 8
+    if curve in ZCASH_CURVES:
+        if pt is None:
+            b = bytearray(n * (2 if g2 else 1))
+            b[0] = 0xC0
+            return bytes(b)
+        x, y = pt
+        if g2:
+            b = bytearray(x[1].to_bytes(n, "big") + x[0].to_bytes(n, "big"))
+            larger = _f2_gt(y, ((-y[0]) % q, (-y[1]) % q))
+        else:
+            b = bytearray(x.to_bytes(n, "big"))
+            larger = y > (-y) % q
+        b[0] |= 0x80 | (0x20 if larger else 0)
+        return bytes(b)
     if pt is None:
         b = bytearray(n * (2 if g2 else 1))
         b[-1] |= 1 << 6
@@ -128,6 +173,29 @@ def point_to_bytes(pp, pt, g2):
     return bytes(b)
 
 
+def _lift_x(q, bb, x, g2, want_larger):
+    """(x, y) on y^2 = x^3 + b with the requested root, or ValueError"""
+    if g2:
+        if x[0] >= q or x[1] >= q:
+            raise ValueError("coordinate not below the modulus")
+        x3 = _f2_mul(_f2_mul(x, x, q), x, q)
+        y = _f2_sqrt(((x3[0] + bb[0]) % q, (x3[1] + bb[1]) % q), q)
+        if y is None:
+            raise ValueError("x is not on the curve")
+        neg = ((-y[0]) % q, (-y[1]) % q)
+        if _f2_gt(y, neg) != want_larger:
+            y = neg
+        return x, y
+    if x >= q:
+        raise ValueError("coordinate not below the modulus")
+    y = _fq_sqrt((x * x * x + bb) % q, q)
+    if y is None:
+        raise ValueError("x is not on the curve")
+    if (y > (-y) % q) != want_larger:
+        y = (-y) % q
+    return x, y
+
+
 def point_from_bytes(pp, data, g2, curve):
     """deserialize_compressed with validation: x below the modulus and on the curve (arkworks: InvalidData)."""
     q = pp.fq.p
@@ -136,6 +204,21 @@ def point_from_bytes(pp, data, g2, curve):
     if len(data) != size:
         raise ValueError("expected %d bytes" % size)
     b = bytearray(data)
+    bb = _curve_b(curve, g2)
+    if curve in ZCASH_CURVES:
+        flags = b[0] & 0xE0
+        b[0] &= 0x1F
+        if not flags & 0x80:
+            raise ValueError("uncompressed encoding where a compressed one is expected")
+        if flags & 0x40:
+            if flags & 0x20 or any(b):
+                raise ValueError("infinity flag with a non-zero x or a sort flag")
+            return None
+        if g2:
+            x = (int.from_bytes(b[n:], "big"), int.from_bytes(b[:n], "big"))
+        else:
+            x = int.from_bytes(b, "big")
+        return _lift_x(q, bb, x, g2, bool(flags & 0x20))
     flags = b[-1] & 0xC0
     b[-1] &= 0x3F
     if flags == 0xC0:
@@ -144,28 +227,11 @@ def point_from_bytes(pp, data, g2, curve):
         if any(b):
             raise ValueError("infinity flag with a non-zero x")
         return None
-    bb = _curve_b(curve, g2)
     if g2:
         x = (int.from_bytes(b[:n], "little"), int.from_bytes(b[n:], "little"))
-        if x[0] >= q or x[1] >= q:
-            raise ValueError("coordinate not below the modulus")
-        x3 = _f2_mul(_f2_mul(x, x, q), x, q)
-        y = _f2_sqrt(((x3[0] + bb[0]) % q, (x3[1] + bb[1]) % q), q)
-        if y is None:
-            raise ValueError("x is not on the curve")
-        neg = ((-y[0]) % q, (-y[1]) % q)
-        if _f2_gt(y, neg) != bool(flags & 0x80):
-            y = neg
-        return x, y
-    x = int.from_bytes(b, "little")
-    if x >= q:
-        raise ValueError("coordinate not below the modulus")
-    y = _fq_sqrt((x * x * x + bb) % q, q)
-    if y is None:
-        raise ValueError("x is not on the curve")
-    if (y > (-y) % q) != bool(flags & 0x80):
-        y = (-y) % q
-    return x, y
+    else:
+        x = int.from_bytes(b, "little")
+    return _lift_x(q, bb, x, g2, bool(flags & 0x80))
 
 
 def proof_to_bytes(pp, pi_a, pi_b, pi_c):
