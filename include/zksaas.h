@@ -130,6 +130,14 @@ int zk_degred_mask_sample(zk_ctx* ctx, size_t len, uint64_t seed, void* in_mask_
 int zk_d_pp(zk_ctx* ctx, const void* num_d, const void* den_d, const void* in_mask_d, const void* out_mask_d,
             size_t len, uint64_t seed, void* out_d, void* stream);
 
+/* deg_red over GROUP elements (deg_red.rs:80-126 with T = G; DegRedMask::sample with a group generator, :40-66):
+ * x_d, masks, out_d are [n][len] affine points (out_d must not alias x_d); gen_affine (host) = the generator whose
+ * random multiples serve as the t fresh random points of the king's re-pack and as mask values. */
+int zk_deg_red_points(zk_ctx* ctx, int group, const void* x_d, const void* in_mask_d, const void* out_mask_d, size_t len,
+                      const void* gen_affine, uint64_t seed, void* out_d, void* stream);
+int zk_degred_mask_sample_points(zk_ctx* ctx, int group, const void* gen_affine, size_t len, uint64_t seed,
+                                 void* in_mask_d, void* out_mask_d, void* stream);
+
 /* ---- MSM / d_msm (dist-primitives/src/dmsm/mod.rs) ---------------------------------------------------
  * zk_msm: G::msm(bases, scalars) (:73, ark-ec VariableBaseMSM): bases affine, scalars Montgomery Fr;
  *         out (HOST pointer) receives one Jacobian point.  `len_bases != len_scalars` -> ZK_ERR_GENERIC
@@ -247,6 +255,18 @@ int zk_r1cs_qap(zk_ctx* ctx, const void* a_row_ptr_d, const void* a_col_d, const
                 void* b_out_d, void* c_out_d, void* stream);
 int zk_fr_to_bytes(zk_ctx* ctx, const void* x_d, size_t len, void* bytes_out_d, void* stream);
 int zk_fr_from_bytes(zk_ctx* ctx, const void* bytes_d, size_t len, void* x_out_d, void* stream);
+/* Vectors of group elements in ark-serialize's COMPRESSED form (what CRS shares / MSM results look like on an mpc-net
+ * wire, ser_net.rs:111-120) <-> affine Montgomery points on the device: len x (|Fq| bytes for G1, 2 |Fq| for G2).
+ * BN254 / BLS12-377: ark-ec's default flags (little-endian x, bit 7 / 6 of the last byte = y is the larger root /
+ * infinity); BLS12-381: the zcash encoding ark-bls12-381 uses (big-endian, c1 || c0, flags in the first byte).
+ * Decompression validates like arkworks (x below the modulus, on the curve, consistent flags) and returns
+ * ZK_ERR_GENERIC naming the first bad index; it needs q = 3 mod 4 (BN254, BLS12-381). */
+int zk_points_decompress(zk_ctx* ctx, int group, const void* bytes_d, size_t len, void* out_affine_d, void* stream);
+int zk_points_compress(zk_ctx* ctx, int group, const void* affine_d, size_t len, void* bytes_out_d, void* stream);
+/* libsnark_h (ext_wit.rs:14-102) for all parties on this device: fft_in / fft_out: 7 mask pointers each ([n][m/l]
+ * device buffers, NULL entries or NULL arrays = FftMask::zero) in the order 3 x d_ifft, 3 x d_fft, final d_ifft. */
+int zk_libsnark_h(zk_ctx* ctx, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                  const void* const* fft_in, const void* const* fft_out, uint64_t seed, void* h_d, void* stream);
 /* The five zk_d_msm_local of the prover for this rank's parties, overlapped: _begin starts S, H, V, W (they only
  * need the witness shares; crs vectors are [nparties][len] here) on internal streams and returns; _finish runs U
  * on `stream` once h_share_d [nparties][m/l] is available, joins, and writes out[0..4] = S, H, V(G2), W, U

@@ -122,3 +122,85 @@ def test_msm_mask_sample_matches_oracle(curve, group):
     out = zk.d_msm(pp, group, bases, scal, m // l, mask)
     got = [dec_jacobian(pp, out[i], is2) for i in range(pp.n)]
     assert G.eq(o.unpack2(got, ops)[0], G.msm(G.batch_to_affine(x_pub), y_pub))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+@pytest.mark.parametrize("is2", [False, True])
+def test_point_vectors_compressed_on_the_device_match_the_host_codec(curve, is2):
+    """zk_points_compress / zk_points_decompress (ser_net.rs:111-120 payloads) against wire.py / the oracle's
+    ark-serialize restatement, including the identity, both roots, and rejection of invalid encodings."""
+    import random
+    from zksaas_amd import wire
+    from zksaas_amd.api import ZK_G1, ZK_G2
+    from oracle import curve as ocurve, ser as oser
+    from oracle.params import CURVES
+    from gpu_util import enc_affine
+    cv = CURVES[curve]
+    pp = ctx(curve, 2)
+    G = ocurve.g2(cv) if is2 else ocurve.g1(cv)
+    grp = ZK_G2 if is2 else ZK_G1
+    rng = random.Random(5)
+    pts = [None] + [G.to_affine(G.mul(G.from_affine(G.gen), rng.randrange(1, cv.r))) for _ in range(40)]
+    pts += [G.to_affine(G.neg(G.from_affine(p))) for p in pts[1:6]]
+    ofn = oser.g2_compressed if is2 else oser.g1_compressed
+    want = b"".join(ofn(p, cv.q) for p in pts)
+    dev = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts, is2))
+    assert wire.points_to_bytes(pp, grp, dev, len(pts)) == want
+    back, count = wire.points_from_bytes(pp, grp, want)
+    assert count == len(pts)
+    assert np.array_equal(back.to_numpy()[: dev.nbytes // 8], dev.to_numpy())
+    # an x that is not on the curve, and a non-canonical x, are rejected with the index
+    size = len(want) // len(pts)
+    for k in range(1, 200):
+        bad = bytearray(want)
+        bad[3 * size + size // 2] ^= k
+        try:
+            wire.point_from_bytes(pp, bytes(bad[3 * size:4 * size]), is2, curve)
+        except ValueError:
+            with pytest.raises(zk.ZkError) as e:
+                wire.points_from_bytes(pp, grp, bytes(bad))
+            assert e.value.code == 1 and "index 3" in e.value.msg
+            break
+    else:
+        pytest.fail("no invalid mutation found")
+
+
+def test_deg_red_over_group_elements_matches_oracle():
+    """deg_red.rs:80-126 with T = G1 (and DegRedMask::sample with the group generator, :40-66) vs oracle/dist.py with
+    group ops: every output share point equal, masks equal, and the result reconstructs to the secrets."""
+    from zksaas_amd import groth16 as zg
+    from zksaas_amd.api import ZK_G1
+    from oracle import dist as od
+    from oracle.curve import g1, GroupOps
+    from oracle.params import BN254
+    from oracle.prng import rand_fp
+    from gpu_util import enc_affine, opp
+    import ctypes as C
+    pp, o = ctx("bn254", 2), opp("bn254", 2)
+    G = g1(BN254)
+    ops = GroupOps(G)
+    gen = G.from_affine(BN254.g1)
+    nch = 3
+    # shares of degree 2(l+t-1): products of a degree-(l+t-1) scalar sharing with ... simply: random points per party
+    # that ARE a valid higher-degree sharing: pack scalars twice and multiply share-wise, then lift to the group
+    a = [rand_fp(90, i, o.p) for i in range(nch * o.l)]
+    b = [rand_fp(91, i, o.p) for i in range(nch * o.l)]
+    sa, sb = od.transpose(od.pack_vec(a, o, 92)), od.transpose(od.pack_vec(b, o, 93))
+    prod = [[x * y % o.p for x, y in zip(sa[p], sb[p])] for p in range(o.n)]
+    xs = [[G.mul(gen, v) for v in row] for row in prod]
+    masks = od.DegRedMask.sample(o, gen, nch, 94, ops)
+    want = od.deg_red(xs, masks, o, seed=95, ops=ops, gen=gen)
+    aff = lambda rows: zk.DeviceBuffer.from_numpy(pp, np.concatenate([enc_affine(pp, G.batch_to_affine(r)) for r in rows]))
+    g_aff = pp.fq.encode([1, 2]).reshape(-1)
+    im, om = zk.DeviceBuffer(pp, o.n * nch * 64), zk.DeviceBuffer(pp, o.n * nch * 64)
+    pp._check(pp.lib.zk_degred_mask_sample_points(pp.h, ZK_G1, g_aff.ctypes.data, nch, 94, im.ptr, om.ptr, None))
+    assert np.array_equal(im.to_numpy(), aff([m.in_mask for m in masks]).to_numpy())
+    assert np.array_equal(om.to_numpy(), aff([m.out_mask for m in masks]).to_numpy())
+    out = zk.DeviceBuffer(pp, o.n * nch * 64)
+    pp._check(pp.lib.zk_deg_red_points(pp.h, ZK_G1, aff(xs).ptr, im.ptr, om.ptr, nch, g_aff.ctypes.data, 95, out.ptr, None))
+    assert np.array_equal(out.to_numpy(), aff(want).to_numpy())
+    # the re-shared points reconstruct (degree l+t-1 now) to a_i * b_i * G
+    for j in range(nch):
+        rec = o.unpack([want[p][j] for p in range(o.n)], ops)
+        for i in range(o.l):
+            assert G.eq(rec[i], G.mul(gen, a[j * o.l + i] * b[j * o.l + i] % o.p))

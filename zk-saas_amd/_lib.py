@@ -18,7 +18,8 @@ SYMBOLS = [
     "zk_net_unique_id", "zk_net_create", "zk_net_destroy", "zk_net_last_error", "zk_net_set_timeout_ms", "zk_net_info",
     "zk_net_enter", "zk_net_gather", "zk_net_scatter", "zk_net_gather_host", "zk_net_bcast_host", "zk_net_sync",
     "zk_dist_d_fft", "zk_dist_d_ifft", "zk_dist_deg_red", "zk_dist_d_pp", "zk_dist_d_msm", "zk_dist_circom_h",
-    "zk_dist_groth16_prove", "zk_chacha20_block", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
+    "zk_dist_groth16_prove", "zk_chacha20_block", "zk_deg_red_points", "zk_degred_mask_sample_points",
+    "zk_points_decompress", "zk_points_compress", "zk_libsnark_h", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
 ]
 
@@ -121,6 +122,11 @@ def load():
     u32p = C.POINTER(C.c_uint32)
     lib.zk_chacha20_block.argtypes = [u32p, u64, u64, u32p]
     lib.zk_chacha20_block.restype = None
+    lib.zk_deg_red_points.argtypes = [vp, i32, vp, vp, vp, sz, vp, u64, vp, vp]
+    lib.zk_degred_mask_sample_points.argtypes = [vp, i32, vp, sz, u64, vp, vp, vp]
+    lib.zk_points_decompress.argtypes = [vp, i32, vp, sz, vp, vp]
+    lib.zk_points_compress.argtypes = [vp, i32, vp, sz, vp, vp]
+    lib.zk_libsnark_h.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), u64, vp, vp]
     lib.zk_net_unique_id.argtypes = [vp]
     lib.zk_net_create.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32), vp, sz, C.POINTER(vp)]
     lib.zk_net_destroy.argtypes = [vp]

@@ -303,6 +303,30 @@ int zk_groth16_abort(zk_ctx* ctx, int handle) {
   return e->groth16_abort(handle);
 }
 
+int zk_deg_red_points(zk_ctx* ctx, int group, const void* x_d, const void* in_mask_d, const void* out_mask_d, size_t len,
+                      const void* gen_affine, uint64_t seed, void* out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->deg_red_points(group, x_d, in_mask_d, out_mask_d, len, gen_affine, seed, out_d, S(stream));
+}
+int zk_degred_mask_sample_points(zk_ctx* ctx, int group, const void* gen_affine, size_t len, uint64_t seed,
+                                 void* in_mask_d, void* out_mask_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->degred_mask_sample_points(group, gen_affine, len, seed, in_mask_d, out_mask_d, S(stream));
+}
+int zk_points_decompress(zk_ctx* ctx, int group, const void* bytes_d, size_t len, void* out_affine_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->points_codec(group, bytes_d, len, out_affine_d, 1, S(stream));
+}
+int zk_points_compress(zk_ctx* ctx, int group, const void* affine_d, size_t len, void* bytes_out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->points_codec(group, affine_d, len, bytes_out_d, 0, S(stream));
+}
+int zk_libsnark_h(zk_ctx* ctx, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                  const void* const* fft_in, const void* const* fft_out, uint64_t seed, void* h_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->libsnark_h(qap_a_d, qap_b_d, qap_c_d, log2_m, fft_in, fft_out, seed, h_d, S(stream));
+}
+
 // ---- the star network and the per-rank collective forms (net.hpp) ----
 int zk_net_unique_id(void* id_out) {
   if (!id_out) return ZK_ERR_BAD_INPUT;

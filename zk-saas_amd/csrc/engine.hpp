@@ -239,6 +239,13 @@ class IEngine {
                                   const zk_groth16_masks* masks, uint64_t seed, hipStream_t st, int* handle) = 0;
   virtual int groth16_wait(int handle, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int groth16_abort(int handle) = 0;
+  virtual int deg_red_points(int group, const void* x, const void* in_mask, const void* out_mask, size_t len,
+                             const void* gen_affine, uint64_t seed, void* out, hipStream_t st) = 0;
+  virtual int degred_mask_sample_points(int group, const void* gen_affine, size_t len, uint64_t seed, void* in_mask,
+                                        void* out_mask, hipStream_t st) = 0;
+  virtual int points_codec(int group, const void* in, size_t len, void* out, int decompress, hipStream_t st) = 0;
+  virtual int libsnark_h(const void* qa, const void* qb, const void* qc, int log_m, const void* const* fft_in,
+                         const void* const* fft_out, uint64_t seed, void* h, hipStream_t st) = 0;
   // per-rank collective forms (net.hpp): this rank's k = n / world parties, king = rank 0
   virtual int dist_d_fft(Net* net, int sid, void* shares, const void* in_mask, const void* out_mask, int rearrange,
                          int log_m, int inverse, const void* g, uint64_t seed, hipStream_t st) = 0;

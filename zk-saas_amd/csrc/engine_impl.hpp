@@ -9,6 +9,7 @@
 #include "qap.hpp"
 #include "msm.hpp"
 #include "hostpool.hpp"
+#include "points.hpp"
 
 namespace zk {
 
@@ -65,6 +66,8 @@ class Engine : public IEngine {
     if (ident_) (void)hipFree(ident_);
     if (err_flag_) (void)hipFree(err_flag_);
     if (rng_key_d_) (void)hipFree(rng_key_d_);
+    if (u2c_) (void)hipFree(u2c_);
+    if (pmc_) (void)hipFree(pmc_);
   }
 
   size_t fr_bytes() const override { return sizeof(Fr); }
@@ -1492,6 +1495,165 @@ class Engine : public IEngine {
     jj = xyzz_to_jacobian(U);
     memcpy(out[4], &jj, sizeof(jj));
     return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- deg_red over group elements (deg_red.rs:80-126, T = G)
+  // x, masks, out: [n][len] affine.  King: unpack2 over the n (masked) points of a chunk, then pack with t fresh
+  // random group elements (random multiples of `gen`, the `T::rand` of a group; stream `seed`, element j*t + i) --
+  // both are small fixed linear maps, evaluated by points_lincomb_kernel.
+  DevBuf ptw_[3];
+  Fr* u2c_ = nullptr;      // canonical copies of U2 [l][n] and P [n][l+t]
+  Fr* pmc_ = nullptr;
+  int ensure_canon_mats() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (u2c_) return ZK_OK;
+    std::vector<Fr> x, y, z;
+    points(x, y, z);
+    Fr ninv = Fr::from_u64((uint64_t)n).inverse();
+    std::vector<Fr> U2((size_t)l * n), Pc((size_t)n * (l + t));
+    for (int kk = 0; kk < l; kk++)
+      for (int p = 0; p < n; p++) {
+        Fr r2 = z[2 * kk] * x[p].inverse(), a2 = Fr::zero(), c2 = Fr::one();
+        for (int d = 0; d < n; d++) {
+          a2 = a2 + c2;
+          c2 = c2 * r2;
+        }
+        U2[(size_t)kk * n + p] = (a2 * ninv).from_mont();
+      }
+    for (size_t i = 0; i < Pc.size(); i++) Pc[i] = pmat_host_[i].from_mont();
+    int rc = upload(U2, &u2c_);
+    if (rc) return rc;
+    return upload(Pc, &pmc_);
+  }
+  template <class Fld>
+  int deg_red_points_t(const void* x, const void* in_mask, const void* out_mask, size_t len, const void* gen_affine,
+                       uint64_t seed, void* out, hipStream_t st) {
+    if (!len) return ZK_OK;
+    if (!x || !out || !gen_affine) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int rc = ensure_canon_mats();
+    if (rc) return rc;
+    using A = Affine<Fld>;
+    ZK_HIP(ptw_[0].ensure(len * t * sizeof(Fr)));
+    ZK_HIP(ptw_[1].ensure(len * t * sizeof(A)));
+    ZK_HIP(ptw_[2].ensure(len * l * sizeof(A)));
+    Fr* rs_ = (Fr*)ptw_[0].p;
+    A* rnd = (A*)ptw_[1].p;
+    A* sec = (A*)ptw_[2].p;
+    const size_t cnt = len * t;
+    rand_fill_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(rs_, rs(seed), cnt, (uint32_t)t,
+                                                                                   0xffffffffu);
+    ZK_HIP(hipGetLastError());
+    rc = base_mul_t<Fld>(gen_affine, rs_, cnt, rnd, st);
+    if (rc) return rc;
+    // unpack2 of (x + in_mask): rows = l secrets of the chunk, inputs = the n parties' points
+    PtGroup<Fld> gx{(const A*)x, 1, len, n, 0}, gm{(const A*)in_mask, 1, len, n, 0};
+    size_t total = len * (size_t)l;
+    points_lincomb_kernel<FrP, Fld><<<dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st>>>(
+        gx, gm, in_mask ? 2 : 1, u2c_, n, l, len, nullptr, 0, sec, 1, (size_t)l);
+    ZK_HIP(hipGetLastError());
+    // pack: rows = n parties, inputs = l secrets + t random points, + the party's out-mask
+    PtGroup<Fld> gs{sec, (size_t)l, 1, l, 0}, gr{rnd, (size_t)t, 1, t, l};
+    total = len * (size_t)n;
+    points_lincomb_kernel<FrP, Fld><<<dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st>>>(
+        gs, gr, 2, pmc_, l + t, n, len, (const A*)out_mask, len, (A*)out, len, 1);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int deg_red_points(int group, const void* x, const void* in_mask, const void* out_mask, size_t len,
+                     const void* gen_affine, uint64_t seed, void* out, hipStream_t st) override {
+    if (x == out) return fail(ZK_ERR_BAD_INPUT, "deg_red over points cannot run in place");
+    if (group == ZK_G1) return deg_red_points_t<Fq_>(x, in_mask, out_mask, len, gen_affine, seed, out, st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2) return deg_red_points_t<Fq2_>(x, in_mask, out_mask, len, gen_affine, seed, out, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+  // DegRedMask::sample with a group generator (deg_red.rs:40-66): mask values r_i * gen, in_mask = pack(mask),
+  // out_mask = pack(-mask); by linearity: pack the scalars, then multiply the generator
+  int degred_mask_sample_points(int group, const void* gen_affine, size_t len, uint64_t seed, void* in_mask,
+                                void* out_mask, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!gen_affine || !in_mask || !out_mask) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const size_t cnt = (size_t)n * len;
+    ZK_HIP(ptw_[0].ensure(2 * cnt * sizeof(Fr)));
+    Fr* si = (Fr*)ptw_[0].p;
+    Fr* so = si + cnt;
+    int rc = degred_mask_sample(len, seed, si, so, st);
+    if (rc) return rc;
+    rc = base_mul(group, gen_affine, si, cnt, in_mask, st);
+    if (rc) return rc;
+    return base_mul(group, gen_affine, so, cnt, out_mask, st);
+  }
+
+  // ---------------------------------------------------------------- compressed point vectors (ser_net.rs:111-120)
+  template <class Fld>
+  int points_codec_t(const void* in, size_t len, void* out, int decompress, const Fld& b, hipStream_t st) {
+    dim3 g((unsigned)((len + 127) / 128)), blk(128);
+    if (!decompress) {
+      points_compress_kernel<Fld><<<g, blk, 0, st>>>((const Affine<Fld>*)in, len, Cfg::ZCASH ? 1 : 0, (uint8_t*)out);
+      ZK_HIP(hipGetLastError());
+      return ZK_OK;
+    }
+    ZK_HIP(flag_.ensure(4));
+    ZK_HIP(hipMemsetAsync(flag_.p, 0, 4, st));
+    points_decompress_kernel<Fld><<<g, blk, 0, st>>>((const uint8_t*)in, len, b, Cfg::ZCASH ? 1 : 0, (Affine<Fld>*)out,
+                                                    (uint32_t*)flag_.p);
+    ZK_HIP(hipGetLastError());
+    uint32_t bad = 0;
+    ZK_HIP(hipMemcpyAsync(&bad, flag_.p, 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (bad) return fail(ZK_ERR_GENERIC, "invalid compressed point at index " + std::to_string(bad - 1) + " (InvalidData)");
+    return ZK_OK;
+  }
+  int points_codec(int group, const void* in, size_t len, void* out, int decompress, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!in || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if constexpr (!Cfg::SQRT_3MOD4) {
+      if (decompress) return fail(ZK_ERR_BAD_INPUT, "device-side decompression needs q = 3 mod 4 (use the host path)");
+    }
+    if (group == ZK_G1) return points_codec_t<Fq_>(in, len, out, decompress, Fq_::from_u64((uint64_t)Cfg::B1), st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2) {
+        Fq2_ xi{Fq_::from_u64((uint64_t)Cfg::XI0), Fq_::from_u64((uint64_t)Cfg::XI1)};
+        Fq2_ b1{Fq_::from_u64((uint64_t)Cfg::B1), Fq_::zero()};
+        Fq2_ b2 = Cfg::TWIST_MUL ? b1 * xi : b1 * xi.inverse();
+        return points_codec_t<Fq2_>(in, len, out, decompress, b2, st);
+      }
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
+  // ---------------------------------------------------------------- libsnark_h (ext_wit.rs:14-102)
+  // 3 x d_ifft with the coset shift g = F::GENERATOR (rearranged) -> 3 x d_fft (rearranged) -> (a*b - c) / Z(g) ->
+  // d_ifft with g^-1.  Seven masks (or NULL arrays for FftMask::zero).
+  int libsnark_h(const void* qa, const void* qb, const void* qc, int log_m, const void* const* fft_in,
+                 const void* const* fft_out, uint64_t seed, void* h, hipStream_t st) override {
+    if (log_m < ilog2(l) || log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
+    ZK_HIP(hwork_.ensure(6 * per * sizeof(Fr)));
+    Fr* W0 = (Fr*)hwork_.p;
+    Fr* W1 = W0 + 3 * per;
+    const void* q[3] = {qa, qb, qc};
+    for (int k = 0; k < 3; k++) ZK_HIP(hipMemcpyAsync(W0 + k * per, q[k], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    Fr g = generator();
+    auto mi = [&](int k) { return fft_in ? fft_in[k] : nullptr; };
+    auto mo = [&](int k) { return fft_out ? fft_out[k] : nullptr; };
+    int rc;
+    for (int k = 0; k < 3; k++) {
+      rc = d_fft(W0 + k * per, mi(k), mo(k), 1, log_m, 1, &g, seed + k, W1 + k * per, st);
+      if (rc) return rc;
+      rc = d_fft(W1 + k * per, mi(3 + k), mo(3 + k), 1, log_m, 0, nullptr, seed + 3 + k, W0 + k * per, st);
+      if (rc) return rc;
+    }
+    rc = vec_mul_sub(W1, W0, W0 + per, W0 + 2 * per, per, st);
+    if (rc) return rc;
+    // 1 / Z(g), Z(x) = x^m - 1  (ext_wit.rs:78-81)
+    Fr zinv = (g.pow_u64((uint64_t)1 << log_m) - Fr::one()).inverse();
+    rc = vec_scale(W1, &zinv, per, st);
+    if (rc) return rc;
+    Fr ginv = g.inverse();
+    return d_fft(W1, mi(6), mo(6), 0, log_m, 1, &ginv, seed + 6, h, st);
   }
 
   // ---------------------------------------------------------------- per-rank collective forms (net.hpp)

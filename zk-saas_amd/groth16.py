@@ -342,23 +342,15 @@ def prove_async(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
 
 
 def libsnark_h(pp, qap, fft_masks, log_m, seed=0):
-    """groth16/src/ext_wit.rs:14-102 for all parties: 3 d_ifft (coset shift g = F::GENERATOR, rearranged) ->
-    3 d_fft (rearranged) -> (a*b - c) / Z(g) -> d_ifft with g^-1.  qap: three device buffers [n][m/l] (consumed);
+    """groth16/src/ext_wit.rs:14-102 for all parties (zk_libsnark_h): 3 d_ifft (coset shift g = F::GENERATOR,
+    rearranged) -> 3 d_fft (rearranged) -> (a*b - c) / Z(g) -> d_ifft with g^-1.  qap: three device buffers [n][m/l];
     fft_masks: seven api.FftMask (or FftMask.zero()).  Returns the h coefficient shares [n][m/l]."""
-    from . import api
-    curve = pp.curve
-    p = fields.FR[curve]
-    g = fields.FR_GENERATOR[curve]
-    m = 1 << log_m
-    cnt = pp.n * (m // pp.l)
-    ev = []
-    for k in range(3):
-        co = api.d_ifft(pp, qap[k], fft_masks[k], True, log_m, g=g, seed=seed + k, out=pp.alloc_fr(cnt))
-        ev.append(api.d_fft(pp, co, fft_masks[3 + k], True, log_m, seed=seed + 3 + k, out=pp.alloc_fr(cnt)))
-    h = api.vec_mul_sub(pp, pp.alloc_fr(cnt), ev[0], ev[1], ev[2], cnt)
-    zinv = pow((pow(g, m, p) - 1) % p, p - 2, p)            # 1 / Z(g), Z(x) = x^m - 1  (ext_wit.rs:78-81)
-    api.vec_scale(pp, h, zinv, cnt)
-    return api.d_ifft(pp, h, fft_masks[6], False, log_m, g=pow(g, p - 2, p), seed=seed + 6, out=pp.alloc_fr(cnt))
+    cnt = pp.n * ((1 << log_m) // pp.l)
+    h = pp.alloc_fr(cnt)
+    mi = (C.c_void_p * 7)(*[_ptr(m.in_mask) for m in fft_masks])
+    mo = (C.c_void_p * 7)(*[_ptr(m.out_mask) for m in fft_masks])
+    pp._check(pp.lib.zk_libsnark_h(pp.h, _ptr(qap[0]), _ptr(qap[1]), _ptr(qap[2]), log_m, mi, mo, seed, h.ptr, None))
+    return h
 
 
 def crs_from_proving_key(pp, pk, singles_from):

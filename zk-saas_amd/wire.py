@@ -264,3 +264,28 @@ def fr_vec_from_bytes(pp, data, stream=None):
     if len(data) != 8 + count * pp.fr.nbytes:
         raise ValueError("length prefix does not match the payload")
     return api.fr_from_bytes(pp, data[8:], stream), count
+
+
+# ------------------------------------------------------------------------------------------------ point vectors
+def points_from_bytes(pp, group, data, stream=None):
+    """Vec<G::Affine> payload (without the length prefix) in compressed form -> device vector of affine Montgomery
+    points (zk_points_decompress: batched square roots on the GPU).  Raises ZkError (InvalidData) on a bad element."""
+    g2 = group == api.ZK_G2
+    size = pp.fq.nbytes * (2 if g2 else 1)
+    host = np.frombuffer(bytes(data), dtype=np.uint8)
+    if host.size % size:
+        raise ValueError("byte length is not a multiple of the compressed point size")
+    count = host.size // size
+    raw = api.DeviceBuffer.from_numpy(pp, host)
+    out = api.DeviceBuffer(pp, max(count, 1) * 2 * size)
+    pp._check(pp.lib.zk_points_decompress(pp.h, group, raw.ptr, count, out.ptr, stream))
+    return out, count
+
+
+def points_to_bytes(pp, group, pts_d, count, stream=None):
+    g2 = group == api.ZK_G2
+    size = pp.fq.nbytes * (2 if g2 else 1)
+    out = api.DeviceBuffer(pp, max(count, 1) * size)
+    pp._check(pp.lib.zk_points_compress(pp.h, group, api._ptr(pts_d), count, out.ptr, stream))
+    pp.sync(stream)
+    return out.to_numpy(dtype=np.uint8)[: count * size].tobytes()
