@@ -197,8 +197,15 @@ def test_deg_red_over_group_elements_matches_oracle():
     assert np.array_equal(im.to_numpy(), aff([m.in_mask for m in masks]).to_numpy())
     assert np.array_equal(om.to_numpy(), aff([m.out_mask for m in masks]).to_numpy())
     out = zk.DeviceBuffer(pp, o.n * nch * 64)
-    pp._check(pp.lib.zk_deg_red_points(pp.h, ZK_G1, aff(xs).ptr, im.ptr, om.ptr, nch, g_aff.ctypes.data, 95, out.ptr, None))
+    xs_d = aff(xs)                      # keep the buffer alive across the call
+    pp._check(pp.lib.zk_deg_red_points(pp.h, ZK_G1, xs_d.ptr, im.ptr, om.ptr, nch, g_aff.ctypes.data, 95, out.ptr, None))
     assert np.array_equal(out.to_numpy(), aff(want).to_numpy())
+    # zero masks, and the in-place call is refused
+    out0 = zk.DeviceBuffer(pp, o.n * nch * 64)
+    pp._check(pp.lib.zk_deg_red_points(pp.h, ZK_G1, xs_d.ptr, None, None, nch, g_aff.ctypes.data, 95, out0.ptr, None))
+    zero = [od.DegRedMask.zero(nch, G.identity)] * o.n
+    assert np.array_equal(out0.to_numpy(), aff(od.deg_red(xs, zero, o, seed=95, ops=ops, gen=gen)).to_numpy())
+    assert pp.lib.zk_deg_red_points(pp.h, ZK_G1, xs_d.ptr, None, None, nch, g_aff.ctypes.data, 95, xs_d.ptr, None) == 4
     # the re-shared points reconstruct (degree l+t-1 now) to a_i * b_i * G
     for j in range(nch):
         rec = o.unpack([want[p][j] for p in range(o.n)], ops)
