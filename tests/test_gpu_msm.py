@@ -338,3 +338,39 @@ def test_fixed_base_table_is_dropped_with_its_vector_and_errors():
     api.msm_precompute(pp, ZK_G1, b, n)
     assert api.msm_table_info(pp, ZK_G1, b) == {"window_bits": 12, "windows": 22}
     assert G.eq(dec_jacobian(pp, msm(pp, ZK_G1, b, sc_d, n)), G.msm(pts_b, sc))
+
+
+def test_table_registry_is_process_wide_across_contexts():
+    """a table built through context B for a buffer owned by context A must die with the buffer when A frees it
+    (a reallocation at the same address must not be multiplied through the stale table), must be visible to A's MSMs
+    while it lives, must survive B's sibling contexts, and must die with the context that built it."""
+    from zksaas_amd import api
+    c = CURVES["bn254"]
+    A = zk.PackedSharingParams("bn254", 2)
+    B = zk.PackedSharingParams("bn254", 2)
+    G = g1(c)
+    n = 300
+    pts_a, pts_b = _points(G, c, n, 80), _points(G, c, n, 81)
+    sc = rand_vec(82, n, c.r)
+    sc_d = up(A, sc)
+    buf = zk.DeviceBuffer.from_numpy(A, enc_affine(A, pts_a))             # owned by A
+    api.msm_precompute(B, ZK_G1, buf, n)                                   # table built through B
+    assert api.msm_table_info(A, ZK_G1, buf)["windows"] == 16             # ... is found by A's MSMs
+    assert G.eq(dec_jacobian(A, msm(A, ZK_G1, buf, sc_d, n)), G.msm(pts_a, sc))
+    addr = buf.ptr
+    buf.free()                                                             # freed through A
+    again = zk.DeviceBuffer.from_numpy(A, enc_affine(A, pts_b))
+    if again.ptr == addr:
+        assert api.msm_table_info(B, ZK_G1, again)["windows"] == 0
+    assert G.eq(dec_jacobian(B, msm(B, ZK_G1, again, up(B, sc), n)), G.msm(pts_b, sc))
+    # a table dies with the context that built it
+    api.msm_precompute(B, ZK_G1, again, n)
+    assert api.msm_table_info(A, ZK_G1, again)["windows"] == 16
+    B.close()
+    assert api.msm_table_info(A, ZK_G1, again)["windows"] == 0
+    assert G.eq(dec_jacobian(A, msm(A, ZK_G1, again, sc_d, n)), G.msm(pts_b, sc))
+    # and freeing with no context at all (the owner is gone) still releases the memory and any table over it
+    api.msm_precompute(A, ZK_G1, again, n)
+    again.ctx = B                                                          # B.h is None now: zk_free(NULL, p)
+    again.free()
+    A.close()
