@@ -958,8 +958,11 @@ class Engine : public IEngine {
     const size_t cstride = crs->len_a;
     // ---- device pipelines: the four MSMs over the witness shares do not depend on h.  Each is enqueued by a pool task
     // (a launch is a dozen kernel launches), which then waits for the slot's event and folds the windows on the host.
-    // V (G2) is the longest chain: issued first, on high-priority streams, as two halves of the party range.
-    j.split_v = count >= 2;
+    // V (G2) is the longest chain: issued first, on a high-priority stream.  Round 1 ran it as two halves of the party
+    // range on two streams; with the bucket reduction now a visible share of a G2 MSM (0.8 ms of 2.1 ms alone) the
+    // second reduction costs more than the parallelism gains: 257 -> 279 proofs/s unsplit (ZK_SPLIT_V=1 restores it).
+    static const bool split_v_env = getenv("ZK_SPLIT_V") && atoi(getenv("ZK_SPLIT_V")) != 0;
+    j.split_v = count >= 2 && split_v_env;
     const int nh = j.split_v ? count / 2 : count;
     const Fr* cf = msm_.coef_d_ + first;
     // ZK_GATE_ACC=1 (experiment): the accumulate launches of the witness MSMs wait until circom_h has left the chip
@@ -1351,7 +1354,12 @@ class Engine : public IEngine {
     }
     if (!strcmp(name, "msm_table_c")) {
       if (value < 8 || value > 20) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be in 8..20");
-      msm_.table_c = (int)value;
+      msm_.table_c = msm_.table_c_g2 = (int)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "msm_table_c_g2")) {
+      if (value < 8 || value > 20) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be in 8..20");
+      msm_.table_c_g2 = (int)value;
       return ZK_OK;
     }
     return fail(ZK_ERR_BAD_INPUT, "unknown option");

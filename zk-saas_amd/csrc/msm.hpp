@@ -966,11 +966,13 @@ class MsmRunner {
 
   // ---- fixed-base tables (zk_msm_precompute): process-wide registry keyed by address (engine.hpp TableRegistry)
   int table_c = 16;               // window bits of new tables (zk_ctx_set_option "msm_table_c")
+  int table_c_g2 = getenv("ZK_TABLE_C_G2") ? atoi(getenv("ZK_TABLE_C_G2")) : 16;   // ... of G2 tables ("msm_table_c_g2")
   template <class Fld>
   int precompute_t(IEngine* eng, const void* bases, size_t len, hipStream_t st) {
     if (!bases || !len) return eng->fail(ZK_ERR_BAD_INPUT, "null base vector");
     const int T = FrP::BITS + 1;
-    const int nwin = (T + table_c - 1) / table_c;
+    const int tc = IsExtField<Fld>::value ? table_c_g2 : table_c;
+    const int nwin = (T + tc - 1) / tc;
     const int c = (T + nwin - 1) / nwin;
     if ((size_t)nwin * len >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "base vector too long for a table");
     auto t = std::make_shared<MsmTable>();
