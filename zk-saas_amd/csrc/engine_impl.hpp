@@ -997,14 +997,40 @@ class Engine : public IEngine {
     };
     const char* vb = (const char*)crs->v_d;
     const char* as = (const char*)a_share;
-    msm_task(Fq2_{}, 2, vb, nullptr, as, (size_t)nh * cstride, cf, cstride, streams_[2], ws0 + 3, &j.pV0, &j.V0,
-             (P2*)nullptr);
-    if (j.split_v)
-      msm_task(Fq2_{}, 3, vb + (size_t)nh * cstride * sizeof(Affine<Fq2_>), nullptr, as + (size_t)nh * cstride * sizeof(Fr),
-               (size_t)(count - nh) * cstride, cf + nh, cstride, streams_[4], ws0 + 5, &j.pV1, &j.V1, (P2*)nullptr);
-    // S and H multiply two base vectors by the same witness shares: one sort, shared launches
-    msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride, streams_[0],
-             ws0 + 1, &j.pS, &j.S, &j.H);
+    // Measured and rejected as a default (kept behind ZK_SHARE_SORT=1): S, H (G1) and V (G2) multiply three base vectors
+    // by the SAME witness shares with the same window layout, so V can sort (on its high-priority stream) and S/H run
+    // their accumulate on V's sort (msm_impl.hpp "share").  One sort less per proof (0.11 ms of chip time), but S/H then
+    // wait for another stream: 291 vs 289 proofs/s with tables, 215 vs 222 without -- within noise / slightly worse.
+    static const bool share_sort = getenv("ZK_SHARE_SORT") && atoi(getenv("ZK_SHARE_SORT")) != 0;
+    if (!j.split_v && share_sort) {
+      const void* sd = crs->s_d;
+      const void* hd = j.r_zero ? nullptr : crs->h_d;
+      const size_t npts = (size_t)count * cstride;
+      hipStream_t sv = streams_[2], ss = streams_[0];
+      J->fut.push_back(pool_->submit([=]() {
+        (void)hipSetDevice(dev);
+        int rc2 = msm_.template launch_t<Fq2_>(this, vb, as, npts, cf, cstride, sv, ws0 + 3, &J->pV0, nullptr, gate);
+        int rc3 = rc2 ? rc2
+                      : msm_.template launch_t<Fq_>(this, sd, as, npts, cf, cstride, ss, ws0 + 1, &J->pS, hd, gate, &J->pV0);
+        if (!rc3) rc3 = msm_.template finish_t<Fq_>(this, &J->pS, &J->S, &J->H);
+        J->rc[0] = rc3;
+        if (!rc3 && J->full) {                        // s*S and r*H off the tail (prove.rs:229-235, linearity)
+          J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
+          if (!J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
+        }
+        if (!rc2) rc2 = msm_.template finish_t<Fq2_>(this, &J->pV0, &J->V0, (P2*)nullptr);
+        J->rc[2] = rc2;
+      }));
+    } else {
+      msm_task(Fq2_{}, 2, vb, nullptr, as, (size_t)nh * cstride, cf, cstride, streams_[2], ws0 + 3, &j.pV0, &j.V0,
+               (P2*)nullptr);
+      if (j.split_v)
+        msm_task(Fq2_{}, 3, vb + (size_t)nh * cstride * sizeof(Affine<Fq2_>), nullptr, as + (size_t)nh * cstride * sizeof(Fr),
+                 (size_t)(count - nh) * cstride, cf + nh, cstride, streams_[4], ws0 + 5, &j.pV1, &j.V1, (P2*)nullptr);
+      // S and H multiply two base vectors by the same witness shares: one sort, shared launches
+      msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride, streams_[0],
+               ws0 + 1, &j.pS, &j.S, &j.H);
+    }
     msm_task(Fq_{}, 1, crs->w_d, nullptr, ax_share, (size_t)count * crs->len_w, cf, crs->len_w, streams_[3], ws0 + 4,
              &j.pW, &j.W, (P1*)nullptr);
     // ---- host terms that depend on nothing but the inputs

@@ -466,6 +466,49 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
   }
 }
 
+// Extension-field variant: one PAIR of lanes per segment (quad.hpp pair_madd): 128 threads = 64 segments per workgroup.
+template <class Fld>
+__global__ __launch_bounds__(128, 2) void msm_accumulate_pair_kernel(const Affine<Fld>* __restrict__ bases0,
+                                                                    const Affine<Fld>* __restrict__ bases1, size_t pstride,
+                                                                    const uint32_t* __restrict__ sorted,
+                                                                    const SegDesc* __restrict__ segs,
+                                                                    const uint2* __restrict__ offsets, size_t nkeys,
+                                                                    const uint32_t* __restrict__ order,
+                                                                    XYZZ<Fld>* __restrict__ partial0) {
+  const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
+  XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
+  const uint32_t nseg = offsets[nkeys].y;
+  const bool lb = (threadIdx.x & 1) != 0;
+  const size_t npairs = (size_t)gridDim.x * (blockDim.x / 2);
+  for (size_t t = (size_t)blockIdx.x * (blockDim.x / 2) + (threadIdx.x >> 1); t < nseg; t += npairs) {
+    const uint32_t s = order[t];
+    SegDesc d = segs[s];
+    PairAcc<Fld> acc{Fld::one(), Fld::zero()};               // the identity: X = Y = 1, ZZ = ZZZ = 0
+    uint32_t e = sorted[d.start];
+    // my coordinate of the affine point: x for the even lane, y for the odd one (a pair reads one whole point)
+    Fld pt = load_elem(reinterpret_cast<const Fld*>(bases + (e & 0x7fffffffu)) + (lb ? 1 : 0));
+    for (uint32_t p = d.start; p < d.end; p++) {
+      uint32_t e_next = e;
+      Fld pt_next = pt;
+      if (p + 1 < d.end) {
+        e_next = sorted[p + 1];
+        pt_next = load_elem(reinterpret_cast<const Fld*>(bases + (e_next & 0x7fffffffu)) + (lb ? 1 : 0));
+      }
+      // the identity sentinel is (0, 0): both coordinates zero (pair-uniform after the exchange)
+      const bool ident = pt.is_zero() && pswap(pt).is_zero();
+      if (!ident) {
+        Fld c = (lb && (e >> 31)) ? pt.neg() : pt;
+        acc = pair_madd(acc, c, lb);
+      }
+      e = e_next;
+      pt = pt_next;
+    }
+    Fld* o = reinterpret_cast<Fld*>(partial + s);            // X, Y, ZZ, ZZZ
+    store_elem(o + (lb ? 1 : 0), acc.c0);
+    store_elem(o + (lb ? 3 : 2), acc.c1);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ finalize / reduce
 // Everything after the accumulate kernel is a short chain of dependent group additions over few points, so it runs on
 // the lane-cooperative addition of quad.hpp (one point per quad of lanes, 4 multiplication rounds per addition).
@@ -487,7 +530,7 @@ constexpr int QUAD_THREADS = 256;                 // 64 points per workgroup: on
 constexpr int QUAD_VL = QUAD_THREADS / 4;
 
 template <class Fld>
-__global__ __launch_bounds__(QUAD_THREADS) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
+__global__ __launch_bounds__(QUAD_THREADS, 2) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
                                                                    const uint2* __restrict__ offsets, size_t nkeys,
                                                                    XYZZ<Fld>* __restrict__ buckets0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
@@ -530,7 +573,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void msm_finalize_kernel(const XYZZ<F
 // nvl quads each (nvl = 64: one group per workgroup, shortest chain -- few groups, latency matters; nvl = 4: many
 // groups, the serial part dominates and the waves stay full).  blockIdx.y = bucket set (base vector y, window w).
 template <class Fld>
-__global__ __launch_bounds__(QUAD_THREADS) void msm_reduce_a_kernel(const XYZZ<Fld>* __restrict__ buckets0, uint32_t B,
+__global__ __launch_bounds__(QUAD_THREADS, 2) void msm_reduce_a_kernel(const XYZZ<Fld>* __restrict__ buckets0, uint32_t B,
                                                                    int lo_bits, int nvl, XYZZ<Fld>* __restrict__ out0) {
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ uint4 smem_red[];
@@ -560,7 +603,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void msm_reduce_a_kernel(const XYZZ<F
 
 // stage B: slice j <= hb: TR_j over the rows, otherwise TC_(j - hb - 1) over the columns; same workgroup layout
 template <class Fld>
-__global__ __launch_bounds__(QUAD_THREADS) void msm_reduce_b_kernel(const XYZZ<Fld>* __restrict__ rc0, uint32_t B, int lo_bits,
+__global__ __launch_bounds__(QUAD_THREADS, 2) void msm_reduce_b_kernel(const XYZZ<Fld>* __restrict__ rc0, uint32_t B, int lo_bits,
                                                                    int nvl, XYZZ<Fld>* __restrict__ out0) {
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ uint4 smem_red[];
@@ -634,9 +677,11 @@ struct MsmSlot {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   hipEvent_t ev = nullptr;
+  hipEvent_t ev_sort = nullptr;     // the sort of the slot's last launch is complete (consumed by MSMs that share it)
   ~MsmSlot() {
     if (pinned) (void)hipHostFree(pinned);
     if (ev) (void)hipEventDestroy(ev);
+    if (ev_sort) (void)hipEventDestroy(ev_sort);
   }
   hipError_t ensure_pinned(size_t b) {
     if (b <= pinned_bytes) return hipSuccess;
@@ -656,11 +701,25 @@ struct MsmPending {
   int kwin = 0, c = 0, wide = 0, nb = 1, lo_bits = 0;
   MsmSlot* slot = nullptr;
   std::shared_ptr<const MsmTable> tab, tab2;     // keep the tables alive while the kernels run
+  // the sort this launch produced (device pointers into the slot's workspace): another MSM over the SAME scalars with
+  // the same window layout -- Groth16's a_query / b_g1_query / b_g2_query over the witness shares -- may run its
+  // accumulate on it instead of sorting again (MsmTuning::share)
+  struct Sort {
+    const void* scalars = nullptr;
+    const void* coef = nullptr;
+    size_t npts = 0, part_len = 0, nkeys = 0, max_segs = 0;
+    int c = 0, nwin = 0, wide = 0;
+    uint32_t seg = 0, pre_stride = 0, pre_off = 0;
+    const uint32_t *sorted = nullptr, *order = nullptr;
+    const SegDesc* segs = nullptr;
+    const uint2* offsets = nullptr;
+  } sort;
 };
 
 struct MsmTuning {
   size_t bigsort_min;
   hipEvent_t gate = nullptr;      // if set: the accumulate launch waits for this event (sort work still runs ahead)
+  const MsmPending* share = nullptr;   // reuse this launch's sort when it matches (same scalars, layout, table geometry)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -807,10 +866,11 @@ class MsmRunner {
   // launch on workspace slot `wslot`; the result is collected with finish_t
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, hipEvent_t gate = nullptr) {
+               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, hipEvent_t gate = nullptr,
+               const MsmPending* share = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate};
+    MsmTuning tune{bigsort_min, gate, share};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend);
   }
   template <class Fld>

@@ -117,6 +117,26 @@ do {                                                                           \
     if (_e != hipSuccess) return eng->hip_fail(_e, name);                      \
   }                                                                            \
 } while (0)
+  // another launch already sorted these scalars with this layout?
+  const MsmPending::Sort* sh = nullptr;
+  if (tune.share && tune.share->active) {
+    const MsmPending::Sort& s0 = tune.share->sort;
+    if (s0.scalars == scalars && s0.coef == (const void*)coef_d && s0.npts == npts && s0.part_len == (part_len ? part_len : npts) &&
+        s0.c == c && s0.nwin == nwin && s0.wide == wide && s0.seg == seg && s0.pre_stride == pre_stride &&
+        s0.pre_off == pre_off && s0.nkeys == nkeys && s0.max_segs == max_segs && tune.share->slot->ev_sort)
+      sh = &s0;
+  }
+  if (!slot.ev_sort) {
+    he = hipEventCreateWithFlags(&slot.ev_sort, hipEventDisableTiming);
+    if (he != hipSuccess) return eng->hip_fail(he, "msm event");
+  }
+  if (sh) {
+    MSM_HIP(hipStreamWaitEvent(st, tune.share->slot->ev_sort, 0));
+    sorted = const_cast<uint32_t*>(sh->sorted);
+    segs = const_cast<SegDesc*>(sh->segs);
+    offsets = const_cast<uint2*>(sh->offsets);
+    order = const_cast<uint32_t*>(sh->order);
+  } else {
   MSM_HIP(hipMemsetAsync(counts, 0, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
   dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
   const size_t plen = part_len ? part_len : npts;
@@ -163,6 +183,8 @@ do {                                                                           \
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
                                                 pre_off, nullptr, cursor, sorted);
   }
+  MSM_HIP(hipEventRecord(slot.ev_sort, st));
+  }
   MSM_STAGE("scatter");
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB);
@@ -173,8 +195,19 @@ do {                                                                           \
     const int cap = G2FLD ? cap_g2 : cap_g1;
     if (cap > 0 && acc_wgs > (size_t)cap) acc_wgs = (size_t)cap;
   }
-  msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
-      (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
+  static const bool pair_acc = !getenv("ZK_ACC_PAIR") || atoi(getenv("ZK_ACC_PAIR")) != 0;
+  bool launched = false;
+  if constexpr (G2FLD) {
+    if (pair_acc) {
+      // extension field: a pair of lanes per segment (two waves per SIMD instead of one; quad.hpp pair_madd)
+      msm_accumulate_pair_kernel<KF><<<dim3((unsigned)((max_segs + 63) / 64), NB), dim3(128), 0, st>>>(
+          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
+      launched = true;
+    }
+  }
+  if (!launched)
+    msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
+        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
   }
   MSM_STAGE("accumulate");
   {
@@ -208,6 +241,22 @@ do {                                                                           \
   pend->nb = (int)NB;
   pend->lo_bits = lo_bits;
   pend->slot = &slot;
+  pend->sort.scalars = scalars;
+  pend->sort.coef = (const void*)coef_d;
+  pend->sort.npts = npts;
+  pend->sort.part_len = part_len ? part_len : npts;
+  pend->sort.nkeys = nkeys;
+  pend->sort.max_segs = max_segs;
+  pend->sort.c = c;
+  pend->sort.nwin = nwin;
+  pend->sort.wide = wide;
+  pend->sort.seg = seg;
+  pend->sort.pre_stride = pre_stride;
+  pend->sort.pre_off = pre_off;
+  pend->sort.sorted = sorted;
+  pend->sort.order = order;
+  pend->sort.segs = segs;
+  pend->sort.offsets = offsets;
   pend->tab = std::move(tab);
   pend->tab2 = std::move(tab2);
   return ZK_OK;

@@ -120,6 +120,84 @@ ZK_D Fld qadd(const Fld& ca, const Fld& cb, int q) {
   return r;
 }
 
+// ---- mixed addition shared by a PAIR of lanes (the accumulate kernel of extension-field MSMs)
+// Lane A (even) holds X and ZZ of the running sum and x of the affine addend, lane B (odd) holds Y, ZZZ and y.  The ten
+// multiplications of madd-2008-s run as five rounds of one multiplication per lane -- every slot used:
+//   round 1   A: U2 = x2 ZZ1           B: S2 = y2 ZZZ1          A: P = U2 - X1      B: R = S2 - Y1
+//   round 2   A: PP = P^2              B: RR = R^2
+//   round 3   A: Q = X1 PP             B: PPP = P PP
+//   round 4   A: ZZ3 = ZZ1 PP          B: ZZZ3 = ZZZ1 PPP       A: X3 = RR - PPP - 2Q
+//   round 5   A: R (Q - X3)            B: Y1 PPP                B: Y3 = R (Q - X3) - Y1 PPP
+// A lane keeps half of a point (two coordinates) and half of the temporaries, so the Fq2 kernel that needed 453
+// registers and ran one wave per SIMD fits two.  Equal points (P = R = 0) are doubled from the AFFINE addend in the
+// same rounds by switching operands (mdbl-2008-s-1: U = 2y, V = U^2, W = U V, S = x V, M = 3 x^2, X3 = M^2 - 2S,
+// Y3 = M (S - X3) - W y, ZZ3 = V, ZZZ3 = W):
+//   round 2   A: XX = x^2              B: V = U^2
+//   round 3   A: S = x V               B: W = U V
+//   round 4   A: MM = M^2              B: -                     A: X3 = MM - 2S
+//   round 5   A: M (S - X3)            B: W y                   B: Y3 = M (S - X3) - W y
+template <class Fld>
+struct PairAcc {       // lane A: c0 = X, c1 = ZZ; lane B: c0 = Y, c1 = ZZZ
+  Fld c0, c1;
+};
+template <class Fld>
+ZK_D Fld pswap(const Fld& v) {        // the value held by the other lane of the pair
+  return qperm<1, 0, 3, 2>(v);
+}
+// acc += (x2, y2) where this lane holds `in` = x2 (lane A) or y2 (lane B); lb = lane & 1
+template <class Fld>
+ZK_D PairAcc<Fld> pair_madd(const PairAcc<Fld>& a, const Fld& in, bool lb) {
+  // identity of the running sum: ZZ (lane A's c1) is zero
+  const bool za = qperm<0, 0, 2, 2>(a.c1).is_zero();
+  // round 1
+  const Fld m1 = in * a.c1;                                  // A: U2        B: S2
+  const Fld d = m1 - a.c0;                                   // A: P         B: R
+  const Fld od = pswap(d);                                   // A: R         B: P
+  const bool D = d.is_zero() && od.is_zero() && !za;         // equal points: double the affine addend
+  const bool inv = (lb ? od.is_zero() && !d.is_zero() : d.is_zero() && !od.is_zero()) && !za;   // P = 0, R != 0
+  const Fld u = lb ? in.dbl() : in;                          // A: x         B: U = 2y
+  // round 2
+  const Fld s2 = D ? u : d;
+  const Fld m2 = s2.sqr();                                   // A: PP | XX   B: RR | V
+  const Fld o2 = pswap(m2);                                  // A: RR | V    B: PP | XX
+  // round 3
+  //   add: A: X1 * PP (own m2)      B: P (od) * PP (o2)
+  //   dbl: A: x * V (o2)            B: U * V (own m2)
+  const Fld a3 = D ? u : (lb ? od : a.c0);
+  const Fld b3 = D ? (lb ? m2 : o2) : (lb ? o2 : m2);
+  const Fld m3 = a3 * b3;                                    // A: Q | S     B: PPP | W
+  const Fld o3 = pswap(m3);                                  // A: PPP | W   B: Q | S
+  // round 4
+  //   add: A: ZZ1 * PP              B: ZZZ1 * PPP
+  //   dbl: A: M * M, M = 3 XX       B: (unused)
+  const Fld M = m2.dbl() + m2;                               // lane A, doubling: 3 x^2
+  const Fld a4 = D ? M : a.c1;
+  const Fld b4 = D ? M : (lb ? m3 : m2);
+  const Fld m4 = a4 * b4;                                    // A: ZZ3 | MM  B: ZZZ3 | -
+  // lane A: X3 = RR - PPP - 2Q  |  MM - 2S
+  const Fld X3 = D ? (m4 - m3.dbl()) : (o2 - o3 - m3.dbl());
+  // round 5
+  //   add: A: R (od) * (Q - X3)     B: Y1 * PPP (own m3)
+  //   dbl: A: M * (S - X3)          B: W (own m3) * y
+  const Fld a5 = lb ? (D ? m3 : a.c0) : (D ? M : od);
+  const Fld b5 = lb ? (D ? in : m3) : (m3 - X3);
+  const Fld m5 = a5 * b5;
+  const Fld o5 = pswap(m5);
+  PairAcc<Fld> r;
+  //   lane A: X3, ZZ3 (add: m4; dbl: V = o2)      lane B: Y3 = A's product - own product, ZZZ3 (add: m4; dbl: W = m3)
+  r.c0 = lb ? (o5 - m5) : X3;
+  r.c1 = D ? (lb ? m3 : o2) : m4;
+  if (inv) {                                                 // inverse points: the identity (X = Y = 1, ZZ = ZZZ = 0)
+    r.c0 = Fld::one();
+    r.c1 = Fld::zero();
+  }
+  if (za) {                                                  // running sum was the identity: the affine point itself
+    r.c0 = in;
+    r.c1 = Fld::one();
+  }
+  return r;
+}
+
 // Tree sum inside aligned sub-blocks of `nvl` (power of two) virtual lanes of a workgroup: every quad contributes the
 // point whose coordinates its lanes hold; afterwards the first quad of each sub-block holds the sub-block's total.
 // `sh` is LDS for blockDim.x / 4 points.  log2(nvl) dependent additions.
