@@ -1,9 +1,8 @@
-python -m pytest tests/test_gpu_groth16.py tests/test_gpu_configs.py tests/test_gpu_dist.py -m gpu -x -q 2>&1 | tail -4
-for cfg in "ZK_SHARE_SORT=1" "ZK_SHARE_SORT=0"; do
-  env $cfg python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-primitives 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$cfg', d['value'], d['ms_per_step'])"
-  env $cfg python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-primitives --no-tables 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('table-free $cfg', d['value'], d['ms_per_step'])"
-done
+python bench.py --no-cpu-baseline --no-primitives > gpurun_out/b_c4.json 2> gpurun_out/b_c4.err; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/b_c4.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], {k:v for k,v in d.items() if k in('table_free','pipelined')})
+PY
+python tools/c5_bls381.py 22 > gpurun_out/c5_22_new3.json 2> gpurun_out/c5_22_new3.err; tail -2 gpurun_out/c5_22_new3.err
+python -c "
+import json; d=json.load(open('gpurun_out/c5_22_new3.json')); print(d['prove_s'], d['all_parties_equal'], d['distributed_equals_local'])"

@@ -25,6 +25,13 @@
 #define ZK_HD_NOINLINE __attribute__((noinline))
 #endif
 
+// Fields of up to this many 32-bit limbs inline the Montgomery product at every call site; wider ones go through the
+// out-of-line copy.  A translation unit whose kernels are dominated by 12-limb products (the BLS12 G1 Pippenger kernels)
+// may raise it before including this header.
+#ifndef ZK_MUL_INLINE_LIMBS
+#define ZK_MUL_INLINE_LIMBS 8
+#endif
+
 namespace zk {
 
 template <class P>
@@ -133,7 +140,7 @@ struct Fp {
   // 8-limb fields inline it at every call site; 12-limb fields (BLS12 base fields) always go through the
   // out-of-line copy, which keeps kernels that chain dozens of them at a size the compiler handles well.
   ZK_HD friend Fp operator*(const Fp& a, const Fp& b) {
-    if constexpr (N > 8) return mul_ni(a, b);
+    if constexpr (N > ZK_MUL_INLINE_LIMBS) return mul_ni(a, b);
     else return mul_inline(a, b);
   }
   ZK_HD static Fp mul_inline(const Fp& a, const Fp& b) {

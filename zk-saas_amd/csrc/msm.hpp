@@ -425,8 +425,16 @@ static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __
 // between the field multiplications to shorten live ranges) was measured and rejected: 0.96 ms against 0.73 ms per
 // 52k-point launch -- with so few waves the multiplier needs the instruction-level parallelism across independent
 // field multiplications more than it needs a second wave.
+#ifndef ZK_ACC_WAVES_12
+#define ZK_ACC_WAVES_12 3
+#endif
+#ifndef ZK_PAIR_WAVES_12
+#define ZK_PAIR_WAVES_12 2
+#endif
 template <class Fld>
-constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : 3;
+constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : 3);
+template <class Fld>
+constexpr int PAIR_WAVES = sizeof(Fld) > 64 ? ZK_PAIR_WAVES_12 : 2;
 template <class Fld>
 __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases0,
                                                             const Affine<Fld>* __restrict__ bases1, size_t pstride,
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
 
 // Extension-field variant: one PAIR of lanes per segment (quad.hpp pair_madd): 128 threads = 64 segments per workgroup.
 template <class Fld>
-__global__ __launch_bounds__(128, 2) void msm_accumulate_pair_kernel(const Affine<Fld>* __restrict__ bases0,
+__global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kernel(const Affine<Fld>* __restrict__ bases0,
                                                                     const Affine<Fld>* __restrict__ bases1, size_t pstride,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const SegDesc* __restrict__ segs,
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(128, 2) void msm_accumulate_pair_kernel(const Affin
       // the identity sentinel is (0, 0): both coordinates zero (pair-uniform after the exchange)
       const bool ident = pt.is_zero() && pswap(pt).is_zero();
       if (!ident) {
-        Fld c = (lb && (e >> 31)) ? pt.neg() : pt;
+        const Fld c = qsel(lb && (e >> 31) != 0, pt.neg(), pt);
         acc = pair_madd(acc, c, lb);
       }
       e = e_next;
@@ -666,7 +674,7 @@ struct KernelField {
 };
 template <class P>
 struct KernelField<Fp2T<P, false>> {
-  using type = Fp2T<P, (P::N <= 8)>;
+  using type = Fp2T<P, (P::N <= ZK_MUL_INLINE_LIMBS)>;
 };
 
 // ---------------------------------------------------------------------------------------------------- host

@@ -1,4 +1,5 @@
 // Pippenger kernels for G2 of one curve (own translation unit: see msm_impl.hpp).
+#define ZK_MUL_INLINE_LIMBS 12
 #include "curves.hpp"
 #include "msm_impl.hpp"
 namespace zk {

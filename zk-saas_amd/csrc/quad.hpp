@@ -155,46 +155,41 @@ ZK_D PairAcc<Fld> pair_madd(const PairAcc<Fld>& a, const Fld& in, bool lb) {
   const Fld od = pswap(d);                                   // A: R         B: P
   const bool D = d.is_zero() && od.is_zero() && !za;         // equal points: double the affine addend
   const bool inv = (lb ? od.is_zero() && !d.is_zero() : d.is_zero() && !od.is_zero()) && !za;   // P = 0, R != 0
-  const Fld u = lb ? in.dbl() : in;                          // A: x         B: U = 2y
+  const Fld u = qsel(lb, in.dbl(), in);                         // A: x         B: U = 2y
   // round 2
-  const Fld s2 = D ? u : d;
+  const Fld s2 = qsel(D, u, d);
   const Fld m2 = s2.sqr();                                   // A: PP | XX   B: RR | V
   const Fld o2 = pswap(m2);                                  // A: RR | V    B: PP | XX
   // round 3
   //   add: A: X1 * PP (own m2)      B: P (od) * PP (o2)
   //   dbl: A: x * V (o2)            B: U * V (own m2)
-  const Fld a3 = D ? u : (lb ? od : a.c0);
-  const Fld b3 = D ? (lb ? m2 : o2) : (lb ? o2 : m2);
+  const Fld a3 = qsel(D, u, qsel(lb, od, a.c0));
+  const Fld b3 = qsel(D != lb, o2, m2);
   const Fld m3 = a3 * b3;                                    // A: Q | S     B: PPP | W
   const Fld o3 = pswap(m3);                                  // A: PPP | W   B: Q | S
   // round 4
   //   add: A: ZZ1 * PP              B: ZZZ1 * PPP
   //   dbl: A: M * M, M = 3 XX       B: (unused)
   const Fld M = m2.dbl() + m2;                               // lane A, doubling: 3 x^2
-  const Fld a4 = D ? M : a.c1;
-  const Fld b4 = D ? M : (lb ? m3 : m2);
+  const Fld a4 = qsel(D, M, a.c1);
+  const Fld b4 = qsel(D, M, qsel(lb, m3, m2));
   const Fld m4 = a4 * b4;                                    // A: ZZ3 | MM  B: ZZZ3 | -
   // lane A: X3 = RR - PPP - 2Q  |  MM - 2S
-  const Fld X3 = D ? (m4 - m3.dbl()) : (o2 - o3 - m3.dbl());
+  const Fld X3 = qsel(D, m4, o2 - o3) - m3.dbl();
   // round 5
   //   add: A: R (od) * (Q - X3)     B: Y1 * PPP (own m3)
   //   dbl: A: M * (S - X3)          B: W (own m3) * y
-  const Fld a5 = lb ? (D ? m3 : a.c0) : (D ? M : od);
-  const Fld b5 = lb ? (D ? in : m3) : (m3 - X3);
+  const Fld a5 = qsel(lb, qsel(D, m3, a.c0), qsel(D, M, od));
+  const Fld b5 = qsel(lb, qsel(D, in, m3), m3 - X3);
   const Fld m5 = a5 * b5;
   const Fld o5 = pswap(m5);
   PairAcc<Fld> r;
   //   lane A: X3, ZZ3 (add: m4; dbl: V = o2)      lane B: Y3 = A's product - own product, ZZZ3 (add: m4; dbl: W = m3)
-  r.c0 = lb ? (o5 - m5) : X3;
-  r.c1 = D ? (lb ? m3 : o2) : m4;
-  if (inv) {                                                 // inverse points: the identity (X = Y = 1, ZZ = ZZZ = 0)
-    r.c0 = Fld::one();
-    r.c1 = Fld::zero();
-  }
-  if (za) {                                                  // running sum was the identity: the affine point itself
-    r.c0 = in;
-    r.c1 = Fld::one();
-  }
+  r.c0 = qsel(lb, o5 - m5, X3);
+  r.c1 = qsel(D, qsel(lb, m3, o2), m4);
+  // inverse points: the identity (X = Y = 1, ZZ = ZZZ = 0); running sum was the identity: the affine point itself
+  r.c0 = qsel(za, in, qsel(inv, Fld::one(), r.c0));
+  r.c1 = qsel(za, Fld::one(), qsel(inv, Fld::zero(), r.c1));
   return r;
 }
 
