@@ -425,8 +425,9 @@ class Engine : public IEngine {
   }
   int vec_mul_sub(void* out, const void* a, const void* b, const void* c, size_t len, hipStream_t st) override {
     if (!len) return ZK_OK;
-    vec_mul_sub_kernel<Fr><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((Fr*)out, (const Fr*)a,
-                                                                                     (const Fr*)b, (const Fr*)c, len);
+    const unsigned bk = (unsigned)king_block(len);       // one-wave groups at proof sizes (see king_block)
+    vec_mul_sub_kernel<Fr><<<dim3((unsigned)((len + bk - 1) / bk)), dim3(bk), 0, st>>>((Fr*)out, (const Fr*)a,
+                                                                                      (const Fr*)b, (const Fr*)c, len);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -442,7 +443,7 @@ class Engine : public IEngine {
     if (rc) return rc;
     Fr* data = (Fr*)shares;
     size_t nvec = (size_t)1 << log_n;
-    if (log_n < NTT_TILE_BITS || force_simple_ntt) {
+    if (log_n < NTT_TILE_BITS_SMALL || force_simple_ntt) {
       for (int s = 1; s <= log_n; s++) {
         size_t work = (nvec / 2) * batch;
         ntt_stage_simple_kernel<Fr><<<dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st>>>(data, log_n, s, tw,
@@ -452,21 +453,29 @@ class Engine : public IEngine {
       if (add) return vec_add(shares, add, nvec * batch, st);
       return ZK_OK;
     }
-    NttPlan plan = make_ntt_plan(log_n);
+    if (ntt_tile_bits(log_n) == NTT_TILE_BITS_SMALL && (small_groups() || log_n < NTT_TILE_BITS))
+      return fft1_tiled<NTT_TILE_BITS_SMALL>(data, log_n, log_l, batch, tw, (const Fr*)add, st);
+    return fft1_tiled<NTT_TILE_BITS>(data, log_n, log_l, batch, tw, (const Fr*)add, st);
+  }
+  template <int TB>
+  int fft1_tiled(Fr* data, int log_n, int log_l, size_t batch, const Fr* tw, const Fr* add, hipStream_t st) {
+    constexpr size_t TILE = (size_t)1 << TB;
+    const size_t nvec = (size_t)1 << log_n;
+    NttPlan plan = make_ntt_plan(log_n, TB);
     for (int p = 0; p < plan.npass; p++) {
       const NttPass& ps = plan.pass[p];
       int rbits = ps.s1 - ps.s0;
-      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (NTT_TILE + ((size_t)1 << rbits) / 2 + 1);
-      static bool attr_set = false;
+      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (TILE + ((size_t)1 << rbits) / 2 + 1);
+      bool& attr_set = ntt_attr_set_[TB == NTT_TILE_BITS_SMALL ? 0 : 1];     // per engine, i.e. per device
       if (!attr_set) {
-        ZK_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<Fr>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)((sizeof(Fr) / 16) * 16 * (NTT_TILE + NTT_TILE / 2 + 1))));
+        ZK_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<Fr, TB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((sizeof(Fr) / 16) * 16 * (TILE + TILE / 2 + 1))));
         attr_set = true;
       }
-      dim3 grid((unsigned)(nvec >> NTT_TILE_BITS), (unsigned)batch);
+      dim3 grid((unsigned)(nvec >> TB), (unsigned)batch);
       ProfScope ps_(prof, PROF_NTT_PASS, st, (double)nvec * batch);
-      ntt_pass_kernel<Fr><<<grid, dim3(NTT_THREADS), lds, st>>>(data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l,
-                                                               p == plan.npass - 1 ? (const Fr*)add : nullptr);
+      ntt_pass_kernel<Fr, TB><<<grid, dim3((unsigned)(TILE / 4)), lds, st>>>(data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l,
+                                                                           p == plan.npass - 1 ? add : nullptr);
       ZK_HIP(hipGetLastError());
     }
     return ZK_OK;
@@ -477,9 +486,10 @@ class Engine : public IEngine {
   int king_l(const Fr* in, const KingBatch<Fr>& kb, int batch, int np, int log_lc, const Fr* U, const Fr* gen,
              const GTab* gt, const Fr* in_scale, int rearrange, uint64_t seed_, Fr* out, bool negate, hipStream_t st) {
     size_t Lc = (size_t)1 << log_lc;
-    size_t Wc = Lc < (size_t)KING_THREADS ? Lc : (size_t)KING_THREADS;
+    const size_t kbk = (size_t)king_block(Lc);
+    size_t Wc = Lc < kbk ? Lc : kbk;
     size_t lds = (size_t)L * Wc * sizeof(Fr);
-    dim3 grid((unsigned)(Lc / Wc), (unsigned)batch), block(KING_THREADS);
+    dim3 grid((unsigned)(Lc / Wc), (unsigned)batch), block((unsigned)kbk);
     ProfScope ps_(prof, PROF_KING, st, (double)Lc * batch);
     const RngSeed seed = rs(seed_, (uint64_t)batch);
     if (negate)
@@ -594,7 +604,8 @@ class Engine : public IEngine {
   template <int L>
   int degred_l(const Fr* in, const Fr* in_mask, int np, size_t len, const Fr* U, uint64_t seed, Fr* out,
                const Fr* out_mask, hipStream_t st) {
-    dim3 grid((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), block(KING_THREADS);
+    const size_t kbk = (size_t)king_block(len);
+    dim3 grid((unsigned)((len + kbk - 1) / kbk)), block((unsigned)kbk);
     ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
     king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, rs(seed), out, out_mask);
     ZK_HIP(hipGetLastError());
@@ -877,6 +888,7 @@ class Engine : public IEngine {
     zk_crs_share crs{};
     zk_groth16_masks mk{};
     bool has_mk = false, r_zero = false, split_v = false, full = true;
+    std::atomic<int> v_acc_flag{0};     // raised once V's accumulate has been enqueued (MsmGate)
     int first = 0, count = 0;
     Fr r, s;
     DevBuf hwork, hshare;
@@ -965,26 +977,32 @@ class Engine : public IEngine {
     j.split_v = count >= 2 && split_v_env;
     const int nh = j.split_v ? count / 2 : count;
     const Fr* cf = msm_.coef_d_ + first;
-    // ZK_GATE_ACC=1 (experiment): the accumulate launches of the witness MSMs wait until circom_h has left the chip
-    static const bool gate_acc = getenv("ZK_GATE_ACC") != nullptr;
-    hipEvent_t gate = nullptr;
-    bool h_done = false;
-    if (full && gate_acc) {
-      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
-      if (he != hipSuccess) return hip_fail(he, "h share buffer");
-      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
-      if (rc) return rc;
-      ZK_HIP(hipEventRecord(ev_gate_[j.slot], streams_[5]));
-      gate = ev_gate_[j.slot];
-      h_done = true;
+    // ZK_V_FIRST=1 (measured, off by default): the accumulate kernels of S/H and W wait for V's.  Issued together, the G1
+    // waves (168 registers, three per SIMD) keep the SIMDs they landed on -- a retiring one frees too few registers for
+    // a 256-register G2 wave, whatever the stream priorities say -- so the G2 accumulate takes 1.9 ms instead of ~1 ms
+    // and its 0.9 ms finalize/reduce tail runs on a nearly empty chip.  Ordering them hides that tail under the G1
+    // accumulates but gives up the overlap at the front: 283-285 vs 291-293 proofs/s with tables, 198-208 vs 208-225
+    // without.
+    static const bool v_first = getenv("ZK_V_FIRST") && atoi(getenv("ZK_V_FIRST")) != 0;
+    MsmGate gate_v{}, gate_g1{};
+    if (v_first) {
+      j.v_acc_flag.store(0, std::memory_order_relaxed);
+      gate_v.signal_ev = ev_gate_[j.slot];
+      gate_v.signal_flag = &j.v_acc_flag;
+      gate_g1.wait_ev = ev_gate_[j.slot];
+      gate_g1.wait_flag = &j.v_acc_flag;
     }
-    auto msm_task = [this, J, dev, gate](auto fld_tag, int which, const void* bases, const void* bases2, const void* scal,
-                                         size_t npts, const Fr* coef, size_t plen, hipStream_t stream, int wslot,
-                                         MsmPending* pend, auto* out1, auto* out2) {
+    auto msm_task = [this, J, dev, gate_v, gate_g1](auto fld_tag, int which, const void* bases, const void* bases2,
+                                                    const void* scal, size_t npts, const Fr* coef, size_t plen,
+                                                    hipStream_t stream, int wslot, MsmPending* pend, auto* out1,
+                                                    auto* out2) {
       using Fld = decltype(fld_tag);
       J->fut.push_back(pool_->submit([=]() {
         (void)hipSetDevice(dev);
-        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2, gate);
+        constexpr bool is_v = std::is_same<Fld, Fq2_>::value;
+        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2,
+                                              is_v ? gate_v : gate_g1);
+        if (is_v && which == 2) J->v_acc_flag.store(1, std::memory_order_release);   // also when the launch failed early
         if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
         J->rc[which] = rc2;
         if constexpr (std::is_same<Fld, Fq_>::value) {
@@ -1009,9 +1027,11 @@ class Engine : public IEngine {
       hipStream_t sv = streams_[2], ss = streams_[0];
       J->fut.push_back(pool_->submit([=]() {
         (void)hipSetDevice(dev);
-        int rc2 = msm_.template launch_t<Fq2_>(this, vb, as, npts, cf, cstride, sv, ws0 + 3, &J->pV0, nullptr, gate);
+        int rc2 = msm_.template launch_t<Fq2_>(this, vb, as, npts, cf, cstride, sv, ws0 + 3, &J->pV0, nullptr, gate_v);
+        J->v_acc_flag.store(1, std::memory_order_release);
         int rc3 = rc2 ? rc2
-                      : msm_.template launch_t<Fq_>(this, sd, as, npts, cf, cstride, ss, ws0 + 1, &J->pS, hd, gate, &J->pV0);
+                      : msm_.template launch_t<Fq_>(this, sd, as, npts, cf, cstride, ss, ws0 + 1, &J->pS, hd, gate_g1,
+                                                    &J->pV0);
         if (!rc3) rc3 = msm_.template finish_t<Fq_>(this, &J->pS, &J->S, &J->H);
         J->rc[0] = rc3;
         if (!rc3 && J->full) {                        // s*S and r*H off the tail (prove.rs:229-235, linearity)
@@ -1081,12 +1101,10 @@ class Engine : public IEngine {
     // measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
     if (full) {
       hipStream_t hs = streams_[5];
-      if (!h_done) {
-        hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
-        if (he != hipSuccess) return hip_fail(he, "h share buffer");
-        rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
-        if (rc) return rc;
-      }
+      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+      if (he != hipSuccess) return hip_fail(he, "h share buffer");
+      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
+      if (rc) return rc;
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
                                       ws0 + 0, &j.pU);
       if (rc) return rc;
@@ -2044,9 +2062,15 @@ class Engine : public IEngine {
     if (streams_ready_) return ZK_OK;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     // hi = numerically lowest = highest priority
+    // high priority: the G2 stream(s) and the circom_h -> U chain (short kernels the bulk accumulates would otherwise
+    // starve; measured 291 vs 242 proofs/s without priorities, a third level gains nothing).  ZK_STREAM_PRIO = six
+    // letters h / n / l overrides.
+    const char* pe = getenv("ZK_STREAM_PRIO");
+    const char* pdef = "llhlhh";
+    if (!pe || strlen(pe) != 6) pe = pdef;
     for (int i = 0; i < 6; i++) {
-      bool prio = (i == 2 || i == 4 || i == 5);      // the two G2 halves and the circom_h -> U chain
-      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, prio ? hi : lo));
+      int pr = pe[i] == 'h' ? hi : (pe[i] == 'l' ? lo : (lo + hi) / 2);
+      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, pr));
     }
     for (int i = 0; i < NJOBS; i++) {
       ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
@@ -2069,6 +2093,7 @@ class Engine : public IEngine {
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool streams_ready_ = false;
   bool force_simple_ntt = false;
+  bool ntt_attr_set_[2] = {false, false};
   std::map<std::string, void*> base_tables_;
   DevBuf hwork_;
   Fr* pmat_ = nullptr;

@@ -17,6 +17,8 @@
 //   8. host         : combines the few (S, A) pairs per window and folds windows high -> low
 //                     (254 sequential doublings: latency-bound on any one lane, cheap on a CPU core).
 #pragma once
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +85,23 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
       sorted[pos] = idx | (neg << 31);
     }
   }
+}
+
+// Workspace zeroing by one-wave workgroups: hipMemsetAsync's 256-thread fill kernel waits for four free wave slots on
+// one CU, which the concurrent accumulate kernels of a proof rarely leave (measured 1.0 ms for a 20 us fill).
+static __global__ __launch_bounds__(64) void msm_zero_kernel(uint32_t* __restrict__ p, size_t n_words) {
+  size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) * 4;
+  if (i + 4 <= n_words) {
+    *reinterpret_cast<uint4*>(p + i) = make_uint4(0, 0, 0, 0);
+  } else {
+    for (; i < n_words; i++) p[i] = 0;
+  }
+}
+inline hipError_t msm_zero(void* p, size_t bytes, hipStream_t st) {     // p 16-byte aligned, bytes % 4 == 0
+  const size_t words = bytes / 4;
+  if (!words) return hipSuccess;
+  msm_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(64), 0, st>>>((uint32_t*)p, words);
+  return hipGetLastError();
 }
 
 // -------------------------------------------------------------------------------------------------- big sort
@@ -724,9 +743,21 @@ struct MsmPending {
   } sort;
 };
 
+// Ordering between the accumulate kernels of concurrent launches (the Groth16 prover runs the G2 accumulate ahead of the
+// G1 ones: see engine_impl.hpp prove_begin).  The signalling launch records `signal_ev` right after its accumulate
+// kernel and then raises `signal_flag`; a waiting launch (its sort work still runs ahead) spins on `wait_flag` on the
+// host -- so that the event it then waits for on its stream is this proof's record, not a stale one -- before its own
+// accumulate kernel.
+struct MsmGate {
+  hipEvent_t wait_ev = nullptr;
+  std::atomic<int>* wait_flag = nullptr;
+  hipEvent_t signal_ev = nullptr;
+  std::atomic<int>* signal_flag = nullptr;
+};
+
 struct MsmTuning {
   size_t bigsort_min;
-  hipEvent_t gate = nullptr;      // if set: the accumulate launch waits for this event (sort work still runs ahead)
+  MsmGate gate;
   const MsmPending* share = nullptr;   // reuse this launch's sort when it matches (same scalars, layout, table geometry)
 };
 
@@ -874,7 +905,7 @@ class MsmRunner {
   // launch on workspace slot `wslot`; the result is collected with finish_t
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, hipEvent_t gate = nullptr,
+               hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, MsmGate gate = MsmGate{},
                const MsmPending* share = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");

@@ -137,7 +137,7 @@ do {                                                                           \
     offsets = const_cast<uint2*>(sh->offsets);
     order = const_cast<uint32_t*>(sh->order);
   } else {
-  MSM_HIP(hipMemsetAsync(counts, 0, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
+  MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
   dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
   const size_t plen = part_len ? part_len : npts;
   {
@@ -148,7 +148,7 @@ do {                                                                           \
     uint32_t* bin_base = bin_counts + nbins;
     uint32_t* bin_cursor = bin_base + nbins + 1;
     uint2* tmp = (uint2*)(ws + o_tmp);
-    MSM_HIP(hipMemsetAsync(bin_counts, 0, nbins * 4, st));
+    MSM_HIP(msm_zero(bin_counts, nbins * 4, st));
     // tile = BIG_THREADS * ppt points: ~1024 tiles for small MSMs, 16 points per thread for the multi-million ones
     int ppt = BIG_PTS_PER_THREAD;
     while (ppt > 1 && (npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt) < 1024) ppt >>= 1;
@@ -196,6 +196,11 @@ do {                                                                           \
     if (cap > 0 && acc_wgs > (size_t)cap) acc_wgs = (size_t)cap;
   }
   static const bool pair_acc = !getenv("ZK_ACC_PAIR") || atoi(getenv("ZK_ACC_PAIR")) != 0;
+  if (tune.gate.wait_ev) {
+    if (tune.gate.wait_flag)
+      while (!tune.gate.wait_flag->load(std::memory_order_acquire)) std::this_thread::yield();
+    MSM_HIP(hipStreamWaitEvent(st, tune.gate.wait_ev, 0));
+  }
   bool launched = false;
   if constexpr (G2FLD) {
     if (pair_acc) {
@@ -208,6 +213,10 @@ do {                                                                           \
   if (!launched)
     msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
         (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
+  if (tune.gate.signal_ev) {
+    MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
+    if (tune.gate.signal_flag) tune.gate.signal_flag->store(1, std::memory_order_release);
+  }
   }
   MSM_STAGE("accumulate");
   {

@@ -17,9 +17,12 @@
 
 namespace zk {
 
+// Two tile sizes.  2^11-element tiles (512 threads, 64 KB of LDS, 9..11 stages per pass) are the default for n >= 2^11.
+// 2^8-element tiles worked by ONE wave serve 2^8 <= n < 2^11 (one launch instead of one per stage) and, with
+// ZK_SMALL_GROUPS=1, every n <= 2^14: as many passes, 8x the workgroups (pss.hpp small_groups for the measurement).
 constexpr int NTT_TILE_BITS = 11;
-constexpr int NTT_TILE = 1 << NTT_TILE_BITS;
-constexpr int NTT_THREADS = NTT_TILE / 4;
+constexpr int NTT_TILE_BITS_SMALL = 8;
+constexpr int NTT_SMALL_MAX_LOG_N = 14;
 
 struct NttPass {
   int s0, s1;   // stages s0+1 .. s1
@@ -32,28 +35,32 @@ struct NttPlan {
   NttPass pass[4];
 };
 
-inline NttPlan make_ntt_plan(int k) {
+inline int ntt_tile_bits(int log_n) { return log_n <= NTT_SMALL_MAX_LOG_N ? NTT_TILE_BITS_SMALL : NTT_TILE_BITS; }
+
+// tb = tile bits; passes after the first take at most tb - 2 stages so that a tile keeps >= 4 adjacent columns
+inline NttPlan make_ntt_plan(int k, int tb = NTT_TILE_BITS) {
   NttPlan p{};
   p.log_n = k;
-  if (k <= NTT_TILE_BITS) {
+  if (k <= tb) {
     p.npass = 1;
     p.pass[0] = {0, k, 0};
     return p;
   }
-  int npass = 1 + (k - NTT_TILE_BITS + 8) / 9;
+  const int later = tb - 2;
+  int npass = 1 + (k - tb + later - 1) / later;
   int parts[4];
   int base = k / npass, rem = k % npass;
   for (int i = 0; i < npass; i++) parts[i] = base + (i < rem ? 1 : 0);
   for (int i = 1; i < npass; i++)
-    if (parts[i] > 9) {
-      parts[0] += parts[i] - 9;
-      parts[i] = 9;
+    if (parts[i] > later) {
+      parts[0] += parts[i] - later;
+      parts[i] = later;
     }
   p.npass = npass;
   int s = 0;
   for (int i = 0; i < npass; i++) {
     int rb = parts[i];
-    int cb = NTT_TILE_BITS - rb;
+    int cb = tb - rb;
     if (cb > s) cb = s;
     p.pass[i] = {s, s + rb, cb};
     s += rb;
@@ -103,17 +110,21 @@ struct LdsVec {
   }
 };
 
-// One pass of fft1 over a batch of vectors.  grid = (n / TILE, batch), block = NTT_THREADS.
+// One pass of fft1 over a batch of vectors.  grid = (n / TILE, batch), block = TILE / 4 threads, TILE = 2^TB.
 //   data     : [batch][n]
 //   tw_full  : w_m^e (direction of the transform), e in [0, m], m = n << log_l.  Stage twiddles
 //              w_{2^rbits}^j = tw_full[j << (log_m - rbits)] are staged into LDS; the pre-twiddle of a
 //              later pass is read from HBM/L2 once per element.
 //   pass 0 (s0 == 0) uses the shifted exponent k+1 and no pre-twiddle.
 //   add      : optional [batch][n] added at the final store (in_mask)
-template <class F>
-__global__ __launch_bounds__(NTT_THREADS, 4) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0, int s1,
-                                                              int cbits, const F* __restrict__ tw_full, int log_l,
-                                                              const F* __restrict__ add) {
+template <class F, int TB>
+__global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0,
+                                                                               int s1, int cbits,
+                                                                               const F* __restrict__ tw_full, int log_l,
+                                                                               const F* __restrict__ add) {
+  constexpr int NTT_TILE_BITS = TB;                  // shadow the namespace-level (large tile) constants
+  constexpr int NTT_TILE = 1 << TB;
+  constexpr int NTT_THREADS = NTT_TILE / 4;
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   extern __shared__ uint4 smem[];
   constexpr int H = sizeof(F) / 16;

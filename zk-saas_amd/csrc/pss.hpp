@@ -19,6 +19,17 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int KING_THREADS = 256;
+// ZK_SMALL_GROUPS=1 (measured, off by default): one-wave workgroups for the short kernels of a Groth16 proof (NTT passes
+// on 2^8-element tiles, king / deg_red / vec kernels, workspace zeroing), so that a workgroup fits any single wave slot
+// the concurrent MSM accumulate kernels free.  It works as intended -- the circom_h chain of the SHA-256 proof ends at
+// 1.36 ms instead of 2.77 ms (a 512-thread NTT group waited 1.9 ms for a CU to drain) -- but the proof is bound by the
+// chip's multiplier throughput, not by that chain: the earlier U-MSM only displaces the other accumulates.  290 vs 290
+// proofs/s with tables, 205 vs 220 without (profiles/r02_small_groups_timeline.txt).
+inline bool small_groups() {
+  static const bool on = getenv("ZK_SMALL_GROUPS") && atoi(getenv("ZK_SMALL_GROUPS")) != 0;
+  return on;
+}
+inline int king_block(size_t chunks) { return (small_groups() && chunks <= ((size_t)1 << 16)) ? 64 : KING_THREADS; }
 
 // The l = 2 kernels (the configuration every reference example runs) inline their multiplies; larger
 // packing factors call the out-of-line one to keep code size bounded.
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(KING_THREADS) void pss_unpack_kernel(const Fp<P>* _
 // twiddle gen^((l >> (s'+1)) * (k + 1 + Lc*(e & (2^s'-1)))).  Output chunk q packs positions q*l..q*l+l-1
 // (rearrange: written to chunk bitrev(q), slot i taking position q*l + bitrev_l(i)).
 //
-// One workgroup handles Wc = min(256, Lc) input chunks k0-1 .. k0+Wc-2 (mod Lc), which produce exactly
+// One workgroup handles Wc = min(blockDim.x, Lc) input chunks k0-1 .. k0+Wc-2 (mod Lc), which produce exactly
 // the positions {h*Lc + k0 .. h*Lc + k0 + Wc - 1 : h < l}; these are exchanged through LDS and packed.
 //   in     : [np][Lc] (+ in_mask, optional)   out: [n][Lc] (+ out_mask, optional)
 //   gentab : gen^e, e in [0, m]               gtab: c*g^e, e in [0, Lc] or nullptr (g = 1, c = 1)
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
   extern __shared__ uint4 smem[];
   const uint32_t Lc = 1u << log_lc;
-  const uint32_t Wc = Lc < (uint32_t)KING_THREADS ? Lc : (uint32_t)KING_THREADS;
+  const uint32_t Wc = Lc < blockDim.x ? Lc : blockDim.x;
   const uint32_t log_m = log_lc + LOGL;
   LdsVec<F> lds{smem, (int)(L * Wc)};
   const uint32_t tid = threadIdx.x;
