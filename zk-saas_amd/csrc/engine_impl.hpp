@@ -985,6 +985,22 @@ class Engine : public IEngine {
     // without.
     static const bool v_first = getenv("ZK_V_FIRST") && atoi(getenv("ZK_V_FIRST")) != 0;
     MsmGate gate_v{}, gate_g1{};
+    // ZK_H_FIRST_LOG_M=<k> (measured, off by default): for domains of 2^k and more circom_h goes first and the accumulate
+    // kernels of the witness MSMs wait for it.  Its NTT passes are 512-thread / 64 KB workgroups that need a whole CU to
+    // drain; next to four multi-hundred-millisecond accumulate kernels each pass waits ~78 ms (BLS12-381, m = 2^22)
+    // where the whole chain takes a few milliseconds alone.  Ordering it first removes that wait (5.5 ms per pass) and
+    // changes nothing: 0.667 vs 0.666 s per proof -- the proof is bound by the multiplier throughput of the five
+    // accumulates, whichever order they run in.
+    bool h_done = false;
+    if (full && !v_first && h_first(log_m)) {
+      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+      if (he != hipSuccess) return hip_fail(he, "h share buffer");
+      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
+      if (rc) return rc;
+      ZK_HIP(hipEventRecord(ev_gate_[j.slot], streams_[5]));
+      gate_v.wait_ev = gate_g1.wait_ev = ev_gate_[j.slot];      // recorded before any task runs: no host flag needed
+      h_done = true;
+    }
     if (v_first) {
       j.v_acc_flag.store(0, std::memory_order_relaxed);
       gate_v.signal_ev = ev_gate_[j.slot];
@@ -1097,19 +1113,27 @@ class Engine : public IEngine {
         }
     }
     // ---- circom_h and the U-MSM that depends on it form a long dependent chain: high-priority internal stream.
-    // Holding the other MSM streams (or only their accumulate launches) back until circom_h has finished was
-    // measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
+    // At the SHA-256 size, holding the other MSM streams (or only their accumulate launches) back until circom_h has
+    // finished was measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once (and at
+    // 2^22 it makes no difference: h_first above).
     if (full) {
       hipStream_t hs = streams_[5];
-      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
-      if (he != hipSuccess) return hip_fail(he, "h share buffer");
-      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
-      if (rc) return rc;
+      if (!h_done) {
+        hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+        if (he != hipSuccess) return hip_fail(he, "h share buffer");
+        rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
+        if (rc) return rc;
+      }
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
                                       ws0 + 0, &j.pU);
       if (rc) return rc;
     }
     return ZK_OK;
+  }
+
+  static bool h_first(int log_m) {
+    static const int h_first_min = getenv("ZK_H_FIRST_LOG_M") ? atoi(getenv("ZK_H_FIRST_LOG_M")) : 0;
+    return h_first_min > 0 && log_m >= h_first_min;
   }
 
   // the U-MSM of a partial job (h comes from the caller's king rounds)

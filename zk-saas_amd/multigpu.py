@@ -141,7 +141,8 @@ def bench(args, rank, local_rank, world):
     net = znet.StarNet(pp, rank, world, net_id, transport)
     first, k = net.first, net.k
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
-            "dtype": "u32 limbs (256-bit Montgomery)", "transport": transport, "parties_per_gpu": k}
+            "dtype": "u32 limbs (%s Montgomery)" % ("255-bit Fr / 381-bit Fq" if wl == "c5" else "256-bit"),
+            "transport": transport, "parties_per_gpu": k}
     eb = pp.fr.nbytes
     per = lambda dt: dt / args.steps
     if wl == "c2":
