@@ -69,3 +69,21 @@ def test_bench_two_ranks_as_the_driver_launches_it(workload):
     assert res["n_gpus"] == 2 and res["parties_per_gpu"] == 4 and res["value"] > 0
     if workload == "c4":
         assert res["proof_matches_single_gpu"] is True and res["config"]["masks"] is True
+
+
+def test_bench_falls_back_to_shared_memory_when_rccl_cannot_start():
+    """Two ranks on ONE GPU is a configuration RCCL refuses; the bench must notice before its timed region (probe round),
+    agree across ranks, and finish over the shared-memory transport with the fact recorded in its line."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, ZK_DIST_VIA_CPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ZK_NET", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", "c2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["value"] > 0
+    assert res["transport"] == "shm" and "rccl transport failed" in res["transport_note"]

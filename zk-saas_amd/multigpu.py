@@ -97,6 +97,44 @@ def _bootstrap(rank, world):
     return dist, box[0]
 
 
+def _open_net(pp, rank, world, dist, net_id, transport):
+    """The star network of the run.  RCCL between several ranks has never run on the 1-GPU boxes this was developed on, so
+    the multi-rank bench probes it with one small d_fft round before the timed region and -- if any rank reports a
+    failure -- every rank falls back to the shared-memory transport (same verbs staged through host memory; slower, and
+    said so in the result line) instead of losing the measurement.  Returns (net, note or None)."""
+    from .api import ZkError
+    err, net = None, None
+    try:
+        net = znet.StarNet(pp, rank, world, net_id, transport)
+        if world > 1:
+            net.lib.zk_net_set_timeout_ms(net.h, 20000)
+            log_m = 10
+            x = _rand_fr(pp, net.k * ((1 << log_m) // pp.l), 5 + rank)
+            znet.dist_d_fft(pp, net, 0, x, None, False, log_m, seed=1)
+            pp.sync()
+            net.lib.zk_net_set_timeout_ms(net.h, 30000)
+    except ZkError as e:
+        err = "%s" % (e,)
+    if world == 1 or transport != "rccl":
+        if err:
+            raise RuntimeError(err)
+        return net, None
+    import torch
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if not int(flag.item()):
+        return net, None
+    if net is not None:
+        net.close()
+    msgs = [None] * world
+    dist.all_gather_object(msgs, err)
+    why = next((m for m in msgs if m), "unknown")
+    box = [znet.StarNet.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    net = znet.StarNet(pp, rank, world, box[0], "shm")
+    return net, "rccl transport failed (%s): king rounds staged through host shared memory instead" % why[:200]
+
+
 def _timed(dist, torch, step, steps, warmup):
     """W untimed steps, barrier + device sync, K timed steps, device sync + barrier, max over ranks"""
     for i in range(warmup):
@@ -138,11 +176,15 @@ def bench(args, rank, local_rank, world):
     pp = zk.PackedSharingParams(curve, 2, device=local_rank)
     if pp.n % world:
         raise SystemExit("the number of GPUs must divide n = %d parties" % pp.n)
-    net = znet.StarNet(pp, rank, world, net_id, transport)
+    net, note = _open_net(pp, rank, world, dist, net_id, transport)
+    if note:
+        transport = "shm"
     first, k = net.first, net.k
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": "u32 limbs (%s Montgomery)" % ("255-bit Fr / 381-bit Fq" if wl == "c5" else "256-bit"),
             "transport": transport, "parties_per_gpu": k}
+    if note:
+        base["transport_note"] = note
     eb = pp.fr.nbytes
     per = lambda dt: dt / args.steps
     if wl == "c2":
