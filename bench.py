@@ -329,6 +329,9 @@ def main():
     ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c4 = SHA-256 Groth16 (default, the headline metric), c2 = d_fft 2^20, "
                          "c3 = d_msm 2^20 per party, c5 = BLS12-381 2^24-constraint synthetic Groth16")
+    ap.add_argument("--king", default="alltoall", choices=["alltoall", "star"],
+                    help="N > 1: how a king round runs -- every rank king of a chunk range (two all-to-all exchanges; "
+                         "default) or the reference's star through rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-masks", action="store_true", help="zero masks (the *::zero() variants the reference's "
                     "micro-benchmarks use); default: all twelve masks sampled, as groth16/examples/sha256.rs")

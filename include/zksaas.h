@@ -232,6 +232,9 @@ int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
 /* Tunables of this context (no reference counterpart).  "rng_replay": see "share randomness".  "msm_bigsort_min": point count from which zk_msm sorts with
  * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
  * "msm_table_c": window bits (8..20, default 16) of tables built by later zk_msm_precompute calls.
+ * "king_alltoall": 1 = the zk_dist_* king rounds of d_fft / d_ifft / deg_red (and everything composed of them) run as
+ * all-to-all: every present rank is king of a contiguous chunk range (zk_net_alltoall twice per round) instead of
+ * gather -> rank 0 -> scatter; identical results; every rank of a net must choose alike (default 0, or ZK_KING_ALLTOALL=1).
  * Unknown name -> ZK_ERR_BAD_INPUT. */
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
 /* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value
@@ -313,15 +316,20 @@ void zk_net_destroy(zk_net* net);
 const char* zk_net_last_error(zk_net* net, int* party);
 int zk_net_set_timeout_ms(zk_net* net, uint64_t ms);
 int zk_net_info(const zk_net* net, int info[4]);          /* rank, world, first party, parties per rank */
+int zk_net_stats(const zk_net* net, uint64_t stats[4]);   /* since creation: gathers, scatters, all-to-alls, bytes this rank sent */
 /* raw verbs (what the primitives below are made of; exposed for hosts that compose their own rounds).
  * zk_net_enter: join the next round on `sid`; *mask = ranks taking part.  gather = client_send_or_king_receive
  * (lib.rs:89-135): bytes_per_rank from every rank, the king's `full` receives the present ranks' blocks compacted in
  * rank order.  scatter = client_receive_or_king_send (:137-176): rank r receives block r of the king's `full`.
  * *_host move small host values (<= 4096 bytes) through the control block.  Transfers on a channel are enqueued on
- * the channel's stream; zk_net_sync waits for it with the timeout as deadline. */
+ * the channel's stream; zk_net_sync waits for it with the timeout as deadline.
+ * zk_net_alltoall (no counterpart in mpc-net, whose topology is a star: the exchange of the all-to-all king, option
+ * "king_alltoall"): the block for rank r is read at send + r*bytes_per_peer (indexed by RANK), the block from the i-th
+ * PRESENT rank lands at recv + i*bytes_per_peer (compacted, like gather). */
 int zk_net_enter(zk_net* net, int sid, uint32_t* mask);
 int zk_net_gather(zk_net* net, int sid, uint32_t mask, const void* local, size_t bytes_per_rank, void* full);
 int zk_net_scatter(zk_net* net, int sid, uint32_t mask, const void* full, size_t bytes_per_rank, void* local);
+int zk_net_alltoall(zk_net* net, int sid, uint32_t mask, const void* send, size_t bytes_per_peer, void* recv);
 int zk_net_gather_host(zk_net* net, int sid, uint32_t mask, const void* mine, size_t bytes, void* all);
 int zk_net_bcast_host(zk_net* net, int sid, uint32_t mask, void* buf, size_t bytes);
 int zk_net_sync(zk_net* net, int sid);

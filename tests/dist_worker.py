@@ -31,8 +31,13 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         from gpu_util import dec_jacobian
         from test_oracle_groth16 import small_r1cs
 
+        a2a = scenario.endswith("_a2a")          # the all-to-all king instead of the star (same results, bit for bit)
+        if a2a:
+            scenario = scenario[:-4]
         pp = zk.PackedSharingParams("bn254", 2)
         pp.set_option("msm_bigsort_min", 0 if rank % 2 else 1 << 30)      # both sort paths across the ranks
+        if a2a:
+            pp.set_option("king_alltoall", 1)
         net = znet.StarNet(pp, rank, world, net_id, transport, timeout_ms=1500 if scenario == "late" else 60000)
         first, k, n = net.first, net.k, pp.n
         eb = pp.fr.nbytes
@@ -57,7 +62,7 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         checks = {}
         if scenario == "late":
             # one party per rank (world = 8); the last rank enters after the timeout and is left out
-            log_m = 10
+            log_m = 13 if a2a else 10          # 16 king workgroup columns over the 7 present ranks: uneven ranges, one empty
             Lc = (1 << log_m) // 2
             sh = rand_fr(n * Lc)
             if rank == world - 1:
@@ -91,6 +96,7 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
             ref = zk.api.d_msm_parties(pp, ZK_G1, DeviceBuffer.from_numpy(pp, bases[: n - 1]),
                                        DeviceBuffer.from_numpy(pp, scal[: n - 1]), ln, present)
             checks["d_msm_dropout"] = G1.eq(dec_jacobian(pp, got[0]), dec_jacobian(pp, ref[first]))
+            checks["king_mode"] = (net.stats()["alltoalls"] > 0) == a2a
             q.put((rank, all(checks.values()), repr(checks)))
             net.close()
             return
@@ -179,6 +185,8 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         h = znet.dist_circom_h(pp, net, qap, wit.log_m, masks=mct, seed=4)
         pp.sync()
         checks["circom_h"] = same_rows(h, h_ref, (1 << wit.log_m) // 2)
+        st = net.stats()
+        checks["king_mode"] = (st["alltoalls"] >= 10 and world > 1) if a2a else st["alltoalls"] == 0
         q.put((rank, all(checks.values()), repr(checks)))
         net.close()
     except Exception as e:      # noqa: BLE001

@@ -52,6 +52,17 @@ def test_late_rank_is_left_out_on_the_gpu():
     _spawn(8, "late")
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_alltoall_king_equals_the_star_king(world):
+    """Option king_alltoall: every rank reconstructs and re-packs a contiguous chunk range (two all-to-all exchanges per
+    round instead of gather + scatter through rank 0); shares bit-identical to the single-context results."""
+    _spawn(world, "flow_a2a")
+
+
+def test_alltoall_king_with_a_late_rank():
+    _spawn(8, "late_a2a")
+
+
 @pytest.mark.parametrize("workload", ["c4", "c2", "c3"])
 def test_bench_two_ranks_as_the_driver_launches_it(workload):
     """bench.py --gpus 2 through torch.distributed.run, both ranks on the one GPU of this box (ZK_NET=shm); for c4
@@ -67,6 +78,7 @@ def test_bench_two_ranks_as_the_driver_launches_it(workload):
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["parties_per_gpu"] == 4 and res["value"] > 0
+    assert res["king"] == "alltoall" and "transport_note" not in res
     if workload == "c4":
         assert res["proof_matches_single_gpu"] is True and res["config"]["masks"] is True
 
@@ -86,4 +98,4 @@ def test_bench_falls_back_to_shared_memory_when_rccl_cannot_start():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["value"] > 0
-    assert res["transport"] == "shm" and "rccl transport failed" in res["transport_note"]
+    assert res["transport"] == "shm" and res["king"] == "star" and "rccl transport" in res["transport_note"]

@@ -92,6 +92,26 @@ def _worker(rank, world, net_id, scenario, q):
             net.bcast_host(3, mk, tot)
             ok = ok and int(tot[0]) == world * (world + 1) // 2
             q.put((rank, bool(ok), ""))
+        elif scenario == "a2a":
+            # the all-to-all of the second-stage king: multi-chunk blocks, slot reuse across rounds, a star verb in between
+            mask = net.enter(1)
+            nb = 1000                                            # bytes per peer: several sub-slot chunks
+
+            def block(src, dst, rnd):
+                return ((np.arange(nb, dtype=np.uint32) * 7 + src * 131 + dst * 17 + rnd) % 251).astype(np.uint8)
+            for rnd in range(3):
+                send = np.concatenate([block(rank, r, rnd) for r in range(world)])
+                recv = np.zeros(world * nb, dtype=np.uint8)
+                net.alltoall(1, mask, send, nb, recv)
+                for i in range(world):
+                    ok = ok and np.array_equal(recv[i * nb:(i + 1) * nb], block(i, rank, rnd))
+                if rnd == 1:
+                    g = np.full(8, rank, dtype=np.uint64)
+                    full = np.zeros(8 * world, dtype=np.uint64) if rank == 0 else None
+                    net.gather(1, mask, g, g.nbytes, full)
+                    if rank == 0:
+                        ok = ok and all(int(full[8 * r]) == r for r in range(world))
+            q.put((rank, bool(ok), ""))
         elif scenario == "late":
             # the last rank shows up after the timeout: everyone else continues without its parties (lagrange path)
             if rank == world - 1:
@@ -108,6 +128,11 @@ def _worker(rank, world, net_id, scenario, q):
                 parties = list(range((world - 1) * k))
                 want = od.d_fft(shares, [od.FftMask.zero(Lc)] * o.n, False, dom, o, seed=3, parties=parties)
                 ok = got == want[first:first + k]
+                # the all-to-all among the present ranks: blocks addressed by rank, received compacted
+                send = np.array([rank * 100 + r for r in range(world)], dtype=np.uint64)
+                recv = np.zeros(world - 1, dtype=np.uint64)
+                net.alltoall(0, mask, send, 8, recv)
+                ok = ok and [int(v) for v in recv] == [r * 100 + rank for r in range(world - 1)]
                 # reconstructs: the outputs of the present parties alone determine the transform (dropout tolerance)
                 q.put((rank, bool(ok), ""))
         net.close()
@@ -135,6 +160,11 @@ def _run(world, scenario):
 @pytest.mark.parametrize("world", [2, 4])
 def test_star_rounds_over_shared_memory(world):
     _run(world, "flow")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_alltoall_over_shared_memory(world):
+    _run(world, "a2a")
 
 
 def test_a_late_rank_is_left_out_and_the_king_continues():

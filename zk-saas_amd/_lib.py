@@ -16,7 +16,7 @@ SYMBOLS = [
     "zk_profile_slots", "zk_profile_name", "zk_profile_read", "zk_d_msm_local", "zk_group_add", "zk_groth16_assemble",
     "zk_groth16_msms_begin", "zk_groth16_msms_finish", "zk_groth16_prove_async", "zk_groth16_wait", "zk_groth16_abort",
     "zk_net_unique_id", "zk_net_create", "zk_net_destroy", "zk_net_last_error", "zk_net_set_timeout_ms", "zk_net_info",
-    "zk_net_enter", "zk_net_gather", "zk_net_scatter", "zk_net_gather_host", "zk_net_bcast_host", "zk_net_sync",
+    "zk_net_enter", "zk_net_gather", "zk_net_scatter", "zk_net_alltoall", "zk_net_stats", "zk_net_gather_host", "zk_net_bcast_host", "zk_net_sync",
     "zk_dist_d_fft", "zk_dist_d_ifft", "zk_dist_deg_red", "zk_dist_d_pp", "zk_dist_d_msm", "zk_dist_circom_h",
     "zk_dist_groth16_prove", "zk_chacha20_block", "zk_deg_red_points", "zk_degred_mask_sample_points",
     "zk_points_decompress", "zk_points_compress", "zk_libsnark_h", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
@@ -138,6 +138,8 @@ def load():
     lib.zk_net_enter.argtypes = [vp, i32, u32p]
     lib.zk_net_gather.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
     lib.zk_net_scatter.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
+    lib.zk_net_alltoall.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
+    lib.zk_net_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.zk_net_gather_host.argtypes = [vp, i32, C.c_uint32, vp, sz, vp]
     lib.zk_net_bcast_host.argtypes = [vp, i32, C.c_uint32, vp, sz]
     lib.zk_net_sync.argtypes = [vp, i32]

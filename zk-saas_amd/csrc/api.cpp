@@ -398,6 +398,15 @@ int zk_net_scatter(zk_net* net, int sid, uint32_t mask, const void* full, size_t
   if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
   return net->net.scatter(sid, mask, full, bytes_per_rank, local);
 }
+int zk_net_stats(const zk_net* net, uint64_t stats[4]) {
+  if (!net || !stats) return ZK_ERR_BAD_INPUT;
+  for (int i = 0; i < 4; i++) stats[i] = net->net.stats[i];
+  return ZK_OK;
+}
+int zk_net_alltoall(zk_net* net, int sid, uint32_t mask, const void* send, size_t bytes_per_peer, void* recv) {
+  if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
+  return net->net.alltoall(sid, mask, send, bytes_per_peer, recv);
+}
 int zk_net_gather_host(zk_net* net, int sid, uint32_t mask, const void* mine, size_t bytes, void* all) {
   if (!net || sid < 0 || sid >= zk::NET_NSID) return ZK_ERR_BAD_INPUT;
   return net->net.gather_host(sid, mask, mine, bytes, all);

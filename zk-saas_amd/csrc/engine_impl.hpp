@@ -484,22 +484,28 @@ class Engine : public IEngine {
   // ---------------------------------------------------------------- king of d_fft (dfft/mod.rs:264-304)
   template <int L>
   int king_l(const Fr* in, const KingBatch<Fr>& kb, int batch, int np, int log_lc, const Fr* U, const Fr* gen,
-             const GTab* gt, const Fr* in_scale, int rearrange, uint64_t seed_, Fr* out, bool negate, hipStream_t st) {
+             const GTab* gt, const Fr* in_scale, int rearrange, uint64_t seed_, Fr* out, bool negate, hipStream_t st,
+             const KingRange* range = nullptr) {
     size_t Lc = (size_t)1 << log_lc;
     const size_t kbk = (size_t)king_block(Lc);
     size_t Wc = Lc < kbk ? Lc : kbk;
     size_t lds = (size_t)L * Wc * sizeof(Fr);
-    dim3 grid((unsigned)(Lc / Wc), (unsigned)batch), block((unsigned)kbk);
-    ProfScope ps_(prof, PROF_KING, st, (double)Lc * batch);
+    const size_t cols = range ? range->cnt : Lc;          // king workgroup columns of this launch
+    if (range && (Wc == Lc || range->rs % Wc || range->seg % Wc || range->cnt % Wc || batch != 1))
+      return fail(ZK_ERR_GENERIC, "bad king range");
+    if (!cols) return ZK_OK;
+    dim3 grid((unsigned)(cols / Wc), (unsigned)batch), block((unsigned)kbk);
+    ProfScope ps_(prof, PROF_KING, st, (double)cols * batch);
     const RngSeed seed = rs(seed_, (uint64_t)batch);
+    const uint32_t rs_ = range ? range->rs : 0u, seg_ = range ? range->seg : 0u;
     if (negate)
       king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, kb, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                               in_scale, pack2_, rearrange, seed, out);
+                                                               in_scale, pack2_, rearrange, seed, out, rs_, seg_);
     else
       king_fft2_kernel<FrP, L, false><<<grid, block, lds, st>>>(in, kb, np, (uint32_t)log_lc, U, pmat_, gen,
                                                                 gt ? gt->tab : nullptr, gt ? gt->step : nullptr,
-                                                                in_scale, pack2_, rearrange, seed, out);
+                                                                in_scale, pack2_, rearrange, seed, out, rs_, seg_);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -507,7 +513,7 @@ class Engine : public IEngine {
   // share randomness seed + y
   int king_dispatch_batch(const Fr* in, const KingBatch<Fr>& kb, int batch, int np, int log_m, int inverse,
                           const Fr* U, const void* g, int scale, int rearrange, uint64_t seed, Fr* out, bool negate,
-                          hipStream_t st) {
+                          hipStream_t st, const KingRange* range = nullptr) {
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     if (batch < 1 || batch > KING_BATCH) return fail(ZK_ERR_BAD_INPUT, "bad king batch");
@@ -533,20 +539,20 @@ class Engine : public IEngine {
     }
     int log_lc = log_m - log_l;
     switch (l) {
-      case 1: return king_l<1>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
-      case 2: return king_l<2>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
-      case 4: return king_l<4>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
-      default: return king_l<8>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st);
+      case 1: return king_l<1>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st, range);
+      case 2: return king_l<2>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st, range);
+      case 4: return king_l<4>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st, range);
+      default: return king_l<8>(in, kb, batch, np, log_lc, U, gen, need ? &gt : nullptr, in_scale, rearrange, seed, out, negate, st, range);
     }
   }
   int king_dispatch(const Fr* in, const Fr* in_mask, int np, int log_m, int inverse, const Fr* U, const void* g,
                     int scale, int rearrange, uint64_t seed, Fr* out, const Fr* out_mask, bool negate,
-                    hipStream_t st) {
+                    hipStream_t st, const KingRange* range = nullptr) {
     KingBatch<Fr> kb{};
     kb.in_mask[0] = in_mask;
     kb.out_mask[0] = out_mask;
     kb.stride = 0;
-    return king_dispatch_batch(in, kb, 1, np, log_m, inverse, U, g, scale, rearrange, seed, out, negate, st);
+    return king_dispatch_batch(in, kb, 1, np, log_m, inverse, U, g, scale, rearrange, seed, out, negate, st, range);
   }
   int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
                 const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out, const void* out_mask,
@@ -603,25 +609,27 @@ class Engine : public IEngine {
   // ---------------------------------------------------------------- deg_red (deg_red.rs:80-126)
   template <int L>
   int degred_l(const Fr* in, const Fr* in_mask, int np, size_t len, const Fr* U, uint64_t seed, Fr* out,
-               const Fr* out_mask, hipStream_t st) {
+               const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0) {
+    if (!stride) stride = len;
     const size_t kbk = (size_t)king_block(len);
     dim3 grid((unsigned)((len + kbk - 1) / kbk)), block((unsigned)kbk);
     ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
-    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, rs(seed), out, out_mask);
+    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, rs(seed), out, out_mask,
+                                                       stride, j0);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
   int deg_red_np(const Fr* in, const Fr* in_mask, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
-                 const Fr* out_mask, hipStream_t st) {
+                 const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0) {
     if (!len) return ZK_OK;
     const Fr* U = nullptr;
     int rc = umat_for(parties, np, &U);
     if (rc) return rc;
     switch (l) {
-      case 1: return degred_l<1>(in, in_mask, np, len, U, seed, out, out_mask, st);
-      case 2: return degred_l<2>(in, in_mask, np, len, U, seed, out, out_mask, st);
-      case 4: return degred_l<4>(in, in_mask, np, len, U, seed, out, out_mask, st);
-      default: return degred_l<8>(in, in_mask, np, len, U, seed, out, out_mask, st);
+      case 1: return degred_l<1>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
+      case 2: return degred_l<2>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
+      case 4: return degred_l<4>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
+      default: return degred_l<8>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
     }
   }
   int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed, hipStream_t st) override {
@@ -1420,6 +1428,10 @@ class Engine : public IEngine {
       rng_replay_ = value != 0;
       return ZK_OK;
     }
+    if (!strcmp(name, "king_alltoall")) {         // every rank of a net must choose alike
+      king_a2a_ = value != 0;
+      return ZK_OK;
+    }
     if (!strcmp(name, "msm_table_c")) {
       if (value < 8 || value > 20) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be in 8..20");
       msm_.table_c = msm_.table_c_g2 = (int)value;
@@ -1778,6 +1790,72 @@ class Engine : public IEngine {
     return net_err(net, net->scatter(sid, mask, fout, bytes, local));
   }
 
+  // ---- second-stage king: every present rank is king of a contiguous range of chunks.  One all-to-all
+  // brings a range's input chunks of all parties to its owner, the king kernel runs on the range, a second all-to-all
+  // returns every party's output shares.  Per link a round carries 1/W of the star's bytes and no rank does more than
+  // 1/W of the king's arithmetic.  Option "king_alltoall" (or ZK_KING_ALLTOALL=1), set alike on every rank.
+  bool king_a2a_ = getenv("ZK_KING_ALLTOALL") && atoi(getenv("ZK_KING_ALLTOALL")) != 0;
+  DevBuf a2a_send_[NET_NSID], a2a_back_[NET_NSID];
+  struct A2aPlan {
+    A2aMap map;
+    int me;
+    uint32_t seg, rs, cnt;
+  };
+  // ranges of `gran`-aligned columns over the present ranks; false when there is less than one granule per rank
+  bool a2a_plan(const Net* net, uint32_t mask, size_t len, size_t gran, A2aPlan* pl) const {
+    pl->map.nranks = net->world;
+    pl->map.npresent = 0;
+    pl->me = -1;
+    for (int r = 0; r < 16; r++) pl->map.idx_of_rank[r] = -1;
+    for (int r = 0; r < net->world; r++)
+      if (mask & (1u << r)) {
+        if (r == net->rank) pl->me = pl->map.npresent;
+        pl->map.idx_of_rank[r] = pl->map.npresent++;
+      }
+    const size_t np_r = (size_t)pl->map.npresent;
+    if (pl->me < 0 || np_r < 2 || len / gran < np_r || len % gran) return false;
+    const size_t seg = ((len / gran + np_r - 1) / np_r) * gran;
+    if (seg > 0xffffffffull) return false;
+    pl->seg = (uint32_t)seg;
+    const size_t rs0 = (size_t)pl->me * seg;
+    pl->rs = (uint32_t)(rs0 < len ? rs0 : len);
+    pl->cnt = (uint32_t)(rs0 >= len ? 0 : (len - rs0 < seg ? len - rs0 : seg));
+    return true;
+  }
+  static constexpr int A2A_NOT_APPLICABLE = -1000;
+  // king(in [np][seg], parties, np, out [n][seg], plan, stream); shift / unpack: see pss.hpp a2a_*_kernel
+  template <class KingFn, class UnpackFn>
+  int king_round_a2a(Net* net, int sid, uint32_t mask, Fr* local, size_t len, size_t gran, uint32_t shift, KingFn king,
+                     UnpackFn unpack) {
+    A2aPlan pl;
+    if (!a2a_plan(net, mask, len, gran, &pl)) return A2A_NOT_APPLICABLE;
+    const int k = net->parties_per_rank();
+    const size_t blk = (size_t)k * pl.seg;                       // elements per (rank, rank) block
+    const int npres = pl.map.npresent;
+    hipStream_t s = net_stream(net, sid, nullptr);
+    ZK_HIP(a2a_send_[sid].ensure((size_t)net->world * blk * sizeof(Fr)));
+    ZK_HIP(a2a_back_[sid].ensure((size_t)npres * blk * sizeof(Fr)));
+    ZK_HIP(dist_in_[sid].ensure((size_t)npres * blk * sizeof(Fr)));
+    ZK_HIP(dist_out_[sid].ensure((size_t)n * pl.seg * sizeof(Fr)));
+    Fr* send = (Fr*)a2a_send_[sid].p;
+    Fr* back = (Fr*)a2a_back_[sid].p;
+    Fr* fin = (Fr*)dist_in_[sid].p;
+    Fr* fout = (Fr*)dist_out_[sid].p;
+    {
+      const size_t tot = (size_t)net->world * blk;
+      a2a_pack_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(local, k, len, pl.seg, shift, pl.map, send);
+      ZK_HIP(hipGetLastError());
+    }
+    int rc = net_err(net, net->alltoall(sid, mask, send, blk * sizeof(Fr), fin));
+    if (rc) return rc;
+    std::vector<uint32_t> ps = parties_of(net, mask);
+    rc = king(fin, ps.data(), (int)ps.size(), fout, pl, s);
+    if (rc) return rc;
+    rc = net_err(net, net->alltoall(sid, mask, fout, blk * sizeof(Fr), back));
+    if (rc) return rc;
+    return unpack(back, pl, s);
+  }
+
   int dist_d_fft_on(Net* net, int sid, uint32_t mask, Fr* shares, const Fr* in_mask, const Fr* out_mask, int rearrange,
                     int log_m, int inverse, const void* g, uint64_t seed, bool do_fft1) {
     const int k = net->parties_per_rank();
@@ -1799,6 +1877,30 @@ class Engine : public IEngine {
       if (rc) return rc;
     }
     const int scale = (inverse && !in_mask) ? 1 : 0;
+    rc = A2A_NOT_APPLICABLE;
+    if (king_a2a_ && net->transport != ZK_NET_LOCAL) {
+      const size_t kbk = (size_t)king_block(Lc);
+      const size_t Wc = Lc < kbk ? Lc : kbk;
+      const int log_lc = log_m - ilog2(l);
+      if (Wc < Lc)
+        rc = king_round_a2a(
+            net, sid, mask, shares, Lc, Wc, 1u,
+            [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const A2aPlan& pl, hipStream_t ks) {
+              const Fr* U = nullptr;
+              int r2 = umat_for(ps, np, &U);
+              if (r2) return r2;
+              KingRange rg{pl.rs, pl.seg, pl.cnt};
+              return king_dispatch(in, nullptr, np, log_m, inverse, U, g, scale, rearrange, seed, out, nullptr, false, ks, &rg);
+            },
+            [&](const Fr* back, const A2aPlan& pl, hipStream_t ks) {
+              const size_t tot = (size_t)pl.map.npresent * k * pl.seg;
+              a2a_unpack_fft_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ks>>>(
+                  back, k, (uint32_t)log_lc, pl.seg, l, ilog2(l), rearrange, pl.map.npresent, shares);
+              ZK_HIP(hipGetLastError());
+              return (int)ZK_OK;
+            });
+    }
+    if (rc == A2A_NOT_APPLICABLE)
     rc = king_round(net, sid, mask, shares, Lc, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
       const Fr* U = nullptr;
       int r2 = umat_for(ps, np, &U);
@@ -1833,9 +1935,24 @@ class Engine : public IEngine {
       rc = vec_add(x, in_mask, (size_t)k * len, s);
       if (rc) return rc;
     }
-    rc = king_round(net, sid, mask, x, len, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
-      return deg_red_np(in, nullptr, ps, np, len, seed, out, nullptr, ks);
-    });
+    rc = A2A_NOT_APPLICABLE;
+    if (king_a2a_ && net->transport != ZK_NET_LOCAL)
+      rc = king_round_a2a(
+          net, sid, mask, x, len, 1, 0u,
+          [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const A2aPlan& pl, hipStream_t ks) {
+            return deg_red_np(in, nullptr, ps, np, pl.cnt, seed, out, nullptr, ks, pl.seg, pl.rs);
+          },
+          [&](const Fr* back, const A2aPlan& pl, hipStream_t ks) {
+            const size_t tot = (size_t)pl.map.npresent * k * pl.seg;
+            a2a_unpack_rows_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ks>>>(back, k, len, pl.seg,
+                                                                                                pl.map.npresent, x);
+            ZK_HIP(hipGetLastError());
+            return (int)ZK_OK;
+          });
+    if (rc == A2A_NOT_APPLICABLE)
+      rc = king_round(net, sid, mask, x, len, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
+        return deg_red_np(in, nullptr, ps, np, len, seed, out, nullptr, ks);
+      });
     if (rc) return rc;
     if (out_mask) return vec_add(x, out_mask, (size_t)k * len, s);
     return ZK_OK;

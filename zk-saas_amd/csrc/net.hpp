@@ -54,6 +54,8 @@ struct NetChan {
   std::atomic<uint64_t> king_tick;               // king consumed the gather slots / filled the scatter slots
   std::atomic<uint64_t> pay_tick[NET_MAXR];
   std::atomic<uint64_t> pay_king;
+  std::atomic<uint64_t> a2a_post[NET_MAXR];      // all-to-all SHM: rank's outgoing blocks written / every block for it read
+  std::atomic<uint64_t> a2a_done[NET_MAXR];
   unsigned char payload[NET_MAXR][NET_PAYLOAD];
   unsigned char pay_out[NET_PAYLOAD];
 };
@@ -167,7 +169,7 @@ class Net {
       cap_ = shm_bytes_per_chan ? shm_bytes_per_chan : ((size_t)64 << 20);
       cap_ = (cap_ / world) & ~(size_t)255;       // per rank slot
       for (int s = 0; s < NET_NSID; s++)
-        if (!map_data(s)) return ZK_ERR_NOT_CONNECTED;
+        if (!map_data(s, data_, "_d") || !map_data(s, adata_, "_a")) return ZK_ERR_NOT_CONNECTED;
     } else {
       Rccl& R = Rccl::inst();
       if (!R.load(&err)) return ZK_ERR_NOT_CONNECTED;
@@ -217,13 +219,17 @@ class Net {
       stream_[s] = nullptr;
       ev_in_[s] = ev_out_[s] = nullptr;
       if (data_[s]) munmap(data_[s], cap_ * world);
-      data_[s] = nullptr;
+      if (adata_[s]) munmap(adata_[s], cap_ * world);
+      data_[s] = adata_[s] = nullptr;
     }
     if (ctl_) munmap(ctl_, sizeof(NetCtl));
     ctl_ = nullptr;
     if (rank == 0 && !name_.empty()) {
       shm_unlink(name_.c_str());
-      for (int s = 0; s < NET_NSID; s++) shm_unlink((name_ + "_d" + std::to_string(s)).c_str());
+      for (int s = 0; s < NET_NSID; s++) {
+        shm_unlink((name_ + "_d" + std::to_string(s)).c_str());
+        shm_unlink((name_ + "_a" + std::to_string(s)).c_str());
+      }
     }
     name_.clear();
   }
@@ -288,8 +294,13 @@ class Net {
 
   // ---- data plane.  bytes = bytes PER RANK (k parties' rows); the king's `full` holds the present ranks' blocks
   // compacted in rank order (so that a dropout leaves the [np][len] layout the king kernels take).
+  // verb counters since creation: gathers, scatters, all-to-alls, payload bytes this rank sent (zk_net_stats)
+  uint64_t stats[4] = {0, 0, 0, 0};
+
   int gather(int sid, uint32_t mask, const void* local, size_t bytes, void* full) {
     const int op = op_[sid]++;
+    stats[0]++;
+    if (rank != 0) stats[3] += bytes;
     if (transport == ZK_NET_LOCAL) return copy_dd(full, local, bytes, sid);
     if (transport == ZK_NET_RCCL) {
       Rccl& R = Rccl::inst();
@@ -338,6 +349,8 @@ class Net {
 
   int scatter(int sid, uint32_t mask, const void* full, size_t bytes, void* local) {
     const int op = op_[sid]++;
+    stats[1]++;
+    if (rank == 0) stats[3] += bytes * (size_t)(__builtin_popcount(mask) - 1);
     if (transport == ZK_NET_LOCAL) return copy_dd(local, full, bytes, sid);
     if (transport == ZK_NET_RCCL) {
       Rccl& R = Rccl::inst();
@@ -377,6 +390,77 @@ class Net {
       if (int rc = copy_in((char*)local + off, data_[sid] + (size_t)rank * cap_, len, sid)) return rc;
       if (int rc = sync(sid)) return rc;
       c.rank_tick[rank].store(t, std::memory_order_release);
+      if (bytes == 0) break;
+    }
+    return ZK_OK;
+  }
+
+  // All-to-all among the ranks of `mask` (the second-stage king: every rank is king of a contiguous chunk range).
+  //   send : block for rank r at send + r * bytes (indexed by RANK; blocks of absent ranks are ignored)
+  //   recv : block from the i-th PRESENT rank at recv + i * bytes (compacted in rank order: the [np][len] layout the king
+  //          kernels take after a dropout)
+  int alltoall(int sid, uint32_t mask, const void* send, size_t bytes, void* recv) {
+    const int op = op_[sid]++;
+    stats[2]++;
+    stats[3] += bytes * (size_t)(__builtin_popcount(mask) - 1);
+    if (transport == ZK_NET_LOCAL) return copy_dd(recv, send, bytes, sid);
+    int present[NET_MAXR], np_r = 0, me = -1;
+    for (int r = 0; r < world; r++)
+      if (mask & (1u << r)) {
+        if (r == rank) me = np_r;
+        present[np_r++] = r;
+      }
+    if (me < 0) return fail("this rank is not part of the round", ZK_ERR_PROTOCOL);
+    if (transport == ZK_NET_RCCL) {
+      Rccl& R = Rccl::inst();
+      int rc = R.GroupStart();
+      for (int i = 0; i < np_r && !rc; i++) {
+        const int r = present[i];
+        const char* src = (const char*)send + (size_t)r * bytes;
+        char* dst = (char*)recv + (size_t)i * bytes;
+        if (r == rank) {
+          rc = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+        } else {
+          rc = R.Send(src, bytes, 1, r, comm_[sid], stream_[sid]);
+          if (!rc) rc = R.Recv(dst, bytes, 1, r, comm_[sid], stream_[sid]);
+        }
+      }
+      int rc2 = R.GroupEnd();
+      if (rc || rc2) return rccl_fail(rc ? rc : rc2, "alltoall");
+      return ZK_OK;
+    }
+    // SHM: my segment slot holds one sub-slot per destination rank
+    NetChan& c = ctl_->chan[sid];
+    const size_t sub = (cap_ / (size_t)world) & ~(size_t)63;
+    if (!sub) return fail("shared segment too small for an all-to-all", ZK_ERR_BAD_INPUT);
+    for (size_t off = 0, ch = 0; off < bytes || (bytes == 0 && ch == 0); off += sub, ch++) {
+      const size_t len = bytes - off < sub ? bytes - off : sub;
+      const uint64_t t = tick(sid, op, ch);
+      // my sub-slots are free once every present rank has read what I posted last
+      for (int i = 0; i < np_r; i++)
+        if (!wait_ge(c.a2a_done[present[i]], last_a_[sid], "peer (all-to-all slot)")) return ZK_ERR_NOT_CONNECTED;
+      for (int i = 0; i < np_r; i++) {
+        const int r = present[i];
+        if (r == rank) continue;
+        if (int rc = copy_out_async(adata_[sid] + (size_t)rank * cap_ + (size_t)r * sub, (const char*)send + (size_t)r * bytes + off,
+                                    len, sid))
+          return rc;
+      }
+      if (int rc = sync(sid)) return rc;
+      c.a2a_post[rank].store(t, std::memory_order_release);
+      for (int i = 0; i < np_r; i++) {
+        const int r = present[i];
+        char* dst = (char*)recv + (size_t)i * bytes + off;
+        if (r == rank) {
+          if (int rc = copy_dd(dst, (const char*)send + (size_t)r * bytes + off, len, sid)) return rc;
+          continue;
+        }
+        if (!wait_ge(c.a2a_post[r], t, "peer (all-to-all)")) return ZK_ERR_NOT_CONNECTED;
+        if (int rc = copy_in(dst, adata_[sid] + (size_t)r * cap_ + (size_t)rank * sub, len, sid)) return rc;
+      }
+      if (int rc = sync(sid)) return rc;
+      c.a2a_done[rank].store(t, std::memory_order_release);
+      last_a_[sid] = t;
       if (bytes == 0) break;
     }
     return ZK_OK;
@@ -510,8 +594,8 @@ class Net {
     ctl_ = (NetCtl*)p;      // a fresh segment is zero-filled: all sequence words start at 0
     return true;
   }
-  bool map_data(int s) {
-    std::string nm = name_ + "_d" + std::to_string(s);
+  bool map_data(int s, char** seg, const char* suffix) {
+    std::string nm = name_ + suffix + std::to_string(s);
     int fd = shm_open(nm.c_str(), O_CREAT | O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)(cap_ * world)) != 0) {
       if (fd >= 0) ::close(fd);
@@ -524,7 +608,7 @@ class Net {
       fail("mmap data segment", ZK_ERR_NOT_CONNECTED);
       return false;
     }
-    data_[s] = (char*)p;
+    seg[s] = (char*)p;
     return true;
   }
   int copy_dd(void* dst, const void* src, size_t bytes, int sid) {
@@ -547,6 +631,15 @@ class Net {
     if (hipMemcpyAsync(shm, src, len, hipMemcpyDeviceToHost, stream_[sid]) != hipSuccess) return fail("hipMemcpy d2h");
     return sync(sid);
   }
+  int copy_out_async(char* shm, const char* src, size_t len, int sid) {     // caller syncs
+    if (!len) return ZK_OK;
+    if (host_mode) {
+      memcpy(shm, src, len);
+      return ZK_OK;
+    }
+    if (hipMemcpyAsync(shm, src, len, hipMemcpyDeviceToHost, stream_[sid]) != hipSuccess) return fail("hipMemcpy d2h");
+    return ZK_OK;
+  }
   int copy_in(char* dst, const char* shm, size_t len, int sid) {
     if (!len) return ZK_OK;
     if (host_mode) {
@@ -564,6 +657,9 @@ class Net {
   std::string name_;
   NetCtl* ctl_ = nullptr;
   char* data_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
+  char* adata_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};     // all-to-all staging (own segment: no slot is shared
+                                                                    // with the star verbs)
+  uint64_t last_a_[NET_NSID] = {0, 0, 0, 0};
   size_t cap_ = 0;
   void* comm_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t stream_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};

@@ -164,7 +164,12 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     const Fp<P>* __restrict__ in0, KingBatch<Fp<P>> kb, int np, uint32_t log_lc,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
     const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
-    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, RngSeed seed0, Fp<P>* __restrict__ out0) {
+    const PackL2<Fp<P>>* __restrict__ k2, int rearrange, RngSeed seed0, Fp<P>* __restrict__ out0, uint32_t rs,
+    uint32_t seg) {
+  // seg != 0: the all-to-all king.  This launch covers the workgroups k0 = rs + blockIdx.x * Wc of ONE rank's chunk
+  // range; `in` is [np][seg] holding input chunks rs-1 .. (column c = chunk rs - 1 + c), `out` is [n][seg] in range-local
+  // order: the l runs of seg/l output chunks the range produces, one after the other (a2a_unpack_fft_kernel places them).
+  // Twiddles, g^pos and the share randomness use the GLOBAL chunk indices, so the shares equal the star king's.
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
   const F* __restrict__ in = in0 + blockIdx.y * kb.stride;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
   const uint32_t log_m = log_lc + LOGL;
   LdsVec<F> lds{smem, (int)(L * Wc)};
   const uint32_t tid = threadIdx.x;
-  const uint32_t k0 = blockIdx.x * Wc;
+  const uint32_t k0 = rs + blockIdx.x * Wc;
 
   if (tid < Wc) {
     // ---- phase 1: chunk k = k0 - 1 + tid (mod Lc), i.e. k + 1 = k0 + tid (or Lc when that is 0)
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     for (int i = 0; i < L; i++) v[i] = F::zero();
 #pragma unroll 1
     for (int s = 0; s < np; s++) {
-      F x = load_elem(in + ((size_t)s << log_lc) + k);
+      F x = seg ? load_elem(in + (size_t)s * seg + (blockIdx.x * Wc + tid)) : load_elem(in + ((size_t)s << log_lc) + k);
       // d_ifft scales the share by 1/m BEFORE the mask is added (dfft/mod.rs:159 then :254-258); without a
       // mask the factor is folded into gtab instead.
       if (in_scale) x = mulsel<L>(x, load_elem(in_scale));
@@ -245,13 +250,14 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
   __syncthreads();
   if (tid < Wc) {
     // ---- phase 2: one output chunk per thread
-    uint32_t q;
+    uint32_t q, ql = 0;
     if (Wc == Lc) {
       q = tid;
     } else {
       uint32_t per_region = Wc / L;
       uint32_t h = tid / per_region, jj = tid % per_region;
       q = (h * Lc + k0) / L + jj;
+      ql = h * (seg / L) + (blockIdx.x * Wc) / L + jj;
     }
     F sec[L + T];
 #pragma unroll
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
     for (int p = 0; p < N; p++) {
-      size_t o = ((size_t)p << log_lc) + j;
+      size_t o = seg ? (size_t)p * seg + ql : ((size_t)p << log_lc) + j;
       F acc = sh[p];
       if (out_mask) acc = acc + load_elem(out_mask + o);
       store_elem(out + o, acc);
@@ -276,12 +282,71 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
   }
 }
 
+// ---- exchange layouts of the all-to-all king (engine_impl.hpp king_round_a2a).  Rank index i of the PRESENT ranks owns the
+// king workgroups k0 in [i*seg, (i+1)*seg) (d_fft) or the chunks [i*seg, (i+1)*seg) (deg_red); `shift` = 1 for d_fft,
+// whose workgroup k0 reads the input chunks k0-1 .. k0+Wc-2.
+//   pack  : send[r][p][c] = local[p][(idx(r)*seg + c - shift) mod len]       (block of rank r at r*k*seg; c < count(r))
+//   unpack: local[p][dest] = recv[i][p][c]                                    (blocks compacted over present ranks)
+// `idx_of_rank[r]` = index of rank r among the present ranks or -1.
+struct KingRange {      // a rank's share of the king workgroup columns: [rs, rs + cnt) of the [i*seg, (i+1)*seg) it owns
+  uint32_t rs, seg, cnt;
+};
+struct A2aMap {
+  int idx_of_rank[16];
+  int nranks, npresent;
+};
+template <class F>
+__global__ void a2a_pack_kernel(const F* __restrict__ local, int k, size_t len, uint32_t seg, uint32_t shift, A2aMap map,
+                                F* __restrict__ send) {
+  const size_t per = (size_t)k * seg;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * map.nranks) return;
+  const int r = (int)(t / per);
+  const int i = map.idx_of_rank[r];
+  if (i < 0) return;
+  const uint32_t p = (uint32_t)((t % per) / seg), c = (uint32_t)(t % seg);
+  const size_t g = (size_t)i * seg + c;          // d_fft: king workgroup column k0 + tid; deg_red: chunk
+  if (g >= len) return;                          // beyond the last range
+  const size_t src = (g + len - shift) % len;
+  store_elem(send + t, load_elem(local + (size_t)p * len + src));
+}
+// d_fft: the range of present rank i produced, for h < l, the output chunks q = (h*len + i*seg)/l + e, e < seg/l, at
+// range-local position h*(seg/l) + e; they land at chunk q (or bitrev(q) when rearranged)
+template <class F>
+__global__ void a2a_unpack_fft_kernel(const F* __restrict__ recv, int k, uint32_t log_lc, uint32_t seg, int l_, int log_l,
+                                      int rearrange, int npresent, F* __restrict__ local) {
+  const size_t per = (size_t)k * seg;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * npresent) return;
+  const uint32_t i = (uint32_t)(t / per), p = (uint32_t)((t % per) / seg), c = (uint32_t)(t % seg);
+  const size_t len = (size_t)1 << log_lc;
+  const uint32_t run = seg / l_;
+  const uint32_t h = c / run, e = c % run;
+  if ((size_t)i * seg + (size_t)e * l_ >= len) return;         // workgroups beyond the last range were not launched
+  const uint32_t q = (uint32_t)(((size_t)h * len + (size_t)i * seg) >> log_l) + e;
+  const uint32_t j = rearrange ? bitrev32(q, log_lc) : q;
+  store_elem(local + ((size_t)p << log_lc) + j, load_elem(recv + t));
+}
+template <class F>
+__global__ void a2a_unpack_rows_kernel(const F* __restrict__ recv, int k, size_t len, uint32_t seg, int npresent,
+                                       F* __restrict__ local) {
+  const size_t per = (size_t)k * seg;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * npresent) return;
+  const uint32_t i = (uint32_t)(t / per), p = (uint32_t)((t % per) / seg), c = (uint32_t)(t % seg);
+  const size_t g = (size_t)i * seg + c;
+  if (g >= len) return;
+  store_elem(local + (size_t)p * len + g, load_elem(recv + t));
+}
+
 // King closure of deg_red (deg_red.rs:103-111): unpack_missing_shares then pack, per chunk.
 template <class P, int L>
 __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
-    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask) {
+    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask, size_t stride, size_t j0) {
+  // stride = row pitch of in / out (len for whole vectors); j0 = global index of column 0 (share randomness of a chunk
+  // range of the all-to-all king must be the one the star king would draw)
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
@@ -292,18 +357,18 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
   for (int i = 0; i < L; i++) sec[i] = F::zero();
 #pragma unroll 1
   for (int s = 0; s < np; s++) {
-    F x = load_elem(in + (size_t)s * len + j);
-    if (in_mask) x = x + load_elem(in_mask + (size_t)s * len + j);
+    F x = load_elem(in + (size_t)s * stride + j);
+    if (in_mask) x = x + load_elem(in_mask + (size_t)s * stride + j);
 #pragma unroll
     for (int i = 0; i < L; i++) sec[i] = sec[i] + mulsel<L>(U[i * np + s], x);
   }
 #pragma unroll
-  for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
+  for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)(j0 + j) * T + i);
   F sh[N];
   pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
   for (int p = 0; p < N; p++) {
-    size_t o = (size_t)p * len + j;
+    size_t o = (size_t)p * stride + j;
     F acc = sh[p];
     if (out_mask) acc = acc + load_elem(out_mask + o);
     store_elem(out + o, acc);

@@ -97,42 +97,57 @@ def _bootstrap(rank, world):
     return dist, box[0]
 
 
-def _open_net(pp, rank, world, dist, net_id, transport):
-    """The star network of the run.  RCCL between several ranks has never run on the 1-GPU boxes this was developed on, so
-    the multi-rank bench probes it with one small d_fft round before the timed region and -- if any rank reports a
-    failure -- every rank falls back to the shared-memory transport (same verbs staged through host memory; slower, and
-    said so in the result line) instead of losing the measurement.  Returns (net, note or None)."""
+def _open_net(pp, rank, world, dist, net_id, transport, king):
+    """The star network of the run and the king mode it runs in.  RCCL between several ranks has never run on the 1-GPU
+    boxes this was developed on, so the multi-rank bench probes its configuration with one small d_fft round before the
+    timed region; if any rank reports a failure every rank moves to the next configuration -- (rccl, all-to-all king) ->
+    (rccl, star king) -> (shared memory, star king; the same verbs staged through host memory: slower, and said so in
+    the result line) -- instead of losing the measurement.  Returns (net, transport, king, note or None)."""
     from .api import ZkError
-    err, net = None, None
-    try:
-        net = znet.StarNet(pp, rank, world, net_id, transport)
-        if world > 1:
+    if world == 1:
+        return znet.StarNet(pp, rank, world, net_id, transport), transport, "star", None
+    import torch
+    chain = [(transport, king)]
+    if king == "alltoall":
+        chain.append((transport, "star"))
+    if transport == "rccl":
+        chain.append(("shm", "star"))
+    notes = []
+    net = None
+    for attempt, (tr, kg) in enumerate(chain):
+        err = None
+        try:
+            if net is None or tr != net_tr:
+                if net is not None:
+                    net.close()
+                    net = None
+                if attempt:
+                    box = [znet.StarNet.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    net_id = box[0]
+                net = znet.StarNet(pp, rank, world, net_id, tr)
+                net_tr = tr
+            pp.set_option("king_alltoall", 1 if kg == "alltoall" else 0)
             net.lib.zk_net_set_timeout_ms(net.h, 20000)
-            log_m = 10
+            log_m = 14                                   # 32 king workgroup columns: enough for 8 chunk ranges
             x = _rand_fr(pp, net.k * ((1 << log_m) // pp.l), 5 + rank)
             znet.dist_d_fft(pp, net, 0, x, None, False, log_m, seed=1)
             pp.sync()
+            net.sync(0)
             net.lib.zk_net_set_timeout_ms(net.h, 30000)
-    except ZkError as e:
-        err = "%s" % (e,)
-    if world == 1 or transport != "rccl":
-        if err:
-            raise RuntimeError(err)
-        return net, None
-    import torch
-    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    if not int(flag.item()):
-        return net, None
-    if net is not None:
-        net.close()
-    msgs = [None] * world
-    dist.all_gather_object(msgs, err)
-    why = next((m for m in msgs if m), "unknown")
-    box = [znet.StarNet.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    net = znet.StarNet(pp, rank, world, box[0], "shm")
-    return net, "rccl transport failed (%s): king rounds staged through host shared memory instead" % why[:200]
+        except ZkError as e:
+            err = "%s" % (e,)
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if not int(flag.item()):
+            return net, tr, kg, ("; ".join(notes) or None)
+        msgs = [None] * world
+        dist.all_gather_object(msgs, err)
+        notes.append("%s transport with the %s king failed (%s)" % (tr, kg, next((m for m in msgs if m), "unknown")[:160]))
+        if net is not None and err and "net:" in err:     # a failed collective leaves the channel state undefined
+            net.close()
+            net = None
+    raise RuntimeError("no working transport: " + "; ".join(notes))
 
 
 def _timed(dist, torch, step, steps, warmup):
@@ -176,13 +191,12 @@ def bench(args, rank, local_rank, world):
     pp = zk.PackedSharingParams(curve, 2, device=local_rank)
     if pp.n % world:
         raise SystemExit("the number of GPUs must divide n = %d parties" % pp.n)
-    net, note = _open_net(pp, rank, world, dist, net_id, transport)
-    if note:
-        transport = "shm"
+    king = os.environ.get("ZK_KING", getattr(args, "king", "alltoall"))
+    net, transport, king, note = _open_net(pp, rank, world, dist, net_id, transport, king)
     first, k = net.first, net.k
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": "u32 limbs (%s Montgomery)" % ("255-bit Fr / 381-bit Fq" if wl == "c5" else "256-bit"),
-            "transport": transport, "parties_per_gpu": k}
+            "transport": transport, "king": king, "parties_per_gpu": k}
     if note:
         base["transport_note"] = note
     eb = pp.fr.nbytes

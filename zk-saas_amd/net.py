@@ -47,6 +47,12 @@ class StarNet:
             raise ZkError(rc, "zk_net_unique_id failed")
         return bytes(buf)
 
+    def stats(self):
+        """dict(gathers, scatters, alltoalls, bytes_sent) since creation"""
+        st = (C.c_uint64 * 4)()
+        self.lib.zk_net_stats(self.h, st)
+        return {"gathers": st[0], "scatters": st[1], "alltoalls": st[2], "bytes_sent": st[3]}
+
     def close(self):
         if self.h:
             self.lib.zk_net_destroy(self.h)
@@ -77,6 +83,10 @@ class StarNet:
 
     def scatter(self, sid, mask, full, bytes_per_rank, local):
         self._check(self.lib.zk_net_scatter(self.h, sid, mask, self._p(full), bytes_per_rank, self._p(local)))
+
+    def alltoall(self, sid, mask, send, bytes_per_peer, recv):
+        """block for rank r read at send + r * bytes_per_peer; block from the i-th present rank written at recv + i * ..."""
+        self._check(self.lib.zk_net_alltoall(self.h, sid, mask, self._p(send), bytes_per_peer, self._p(recv)))
 
     def gather_host(self, sid, mask, mine, all_out):
         self._check(self.lib.zk_net_gather_host(self.h, sid, mask, mine.ctypes.data, mine.nbytes,
