@@ -63,21 +63,24 @@ def test_alltoall_king_with_a_late_rank():
     _spawn(8, "late_a2a")
 
 
-@pytest.mark.parametrize("workload", ["c4", "c2", "c3"])
-def test_bench_two_ranks_as_the_driver_launches_it(workload):
-    """bench.py --gpus 2 through torch.distributed.run, both ranks on the one GPU of this box (ZK_NET=shm); for c4
-    bench.py itself compares the sharded proof with the single-context proof."""
+@pytest.mark.parametrize("workload,ranks", [("c4", 2), ("c4", 4), ("c2", 2), ("c3", 2)])
+def test_bench_ranks_as_the_driver_launches_it(workload, ranks):
+    """bench.py --gpus N through torch.distributed.run, all ranks on the one GPU of this box (ZK_NET=shm), WITHOUT the
+    replay stream the other tests run on (the driver does not set it: every rank's context then has its own production
+    stream, and the bench has to deal its inputs from one dealer all the same); for c4 bench.py itself compares the
+    sharded proof with the single-context proof."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, ZK_NET="shm", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+    env.pop("ZK_RNG_REPLAY", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2",
            "--warmup", "1", "--workload", workload]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["n_gpus"] == 2 and res["parties_per_gpu"] == 4 and res["value"] > 0
+    assert res["n_gpus"] == ranks and res["parties_per_gpu"] == 8 // ranks and res["value"] > 0
     assert res["king"] == "alltoall" and "transport_note" not in res
     if workload == "c4":
         assert res["proof_matches_single_gpu"] is True and res["config"]["masks"] is True
@@ -91,6 +94,7 @@ def test_bench_falls_back_to_shared_memory_when_rccl_cannot_start():
         port = sk.getsockname()[1]
     env = dict(os.environ, ZK_DIST_VIA_CPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ZK_NET", None)
+    env.pop("ZK_RNG_REPLAY", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--workload", "c2"]

@@ -201,6 +201,17 @@ def bench(args, rank, local_rank, world):
         base["transport_note"] = note
     eb = pp.fr.nbytes
     per = lambda dt: dt / args.steps
+    # ONE dealer: every rank derives the same dealing (witness / QAP shares, masks) from the seeds below and keeps its
+    # parties' rows, so the dealing runs on the replayable stream; a context's production stream is keyed from
+    # /dev/urandom and two ranks would otherwise hold rows of two different sharings (found by running 4 ranks without
+    # ZK_RNG_REPLAY: every rank's proof shares were right for ITS dealing and the assembled proof was not a proof).
+    # The timed proofs run on the production stream again (the kings' share randomness need not agree).
+    pp.set_option("rng_replay", 1)
+
+    def timed(step):
+        if not os.environ.get("ZK_RNG_REPLAY"):
+            pp.set_option("rng_replay", 0)
+        return _timed(dist, torch, step, args.steps, args.warmup)
     if wl == "c2":
         log_m = 20
         m = 1 << log_m
@@ -209,8 +220,7 @@ def bench(args, rank, local_rank, world):
         full_mask = None if args.no_masks else FftMask.sample(pp, False, None, 0, log_m, 11)
         mk = FftMask.zero() if full_mask is None else FftMask(rows(full_mask.in_mask, first, k, Lc * eb),
                                                              rows(full_mask.out_mask, first, k, Lc * eb))
-        dt = _timed(dist, torch, lambda i: znet.dist_d_fft(pp, net, 0, sh, mk, False, log_m, seed=i), args.steps,
-                    args.warmup)
+        dt = timed(lambda i: znet.dist_d_fft(pp, net, 0, sh, mk, False, log_m, seed=i))
         alg = (32 if full_mask is not None else 16) * m * 32          # all parties, with / without masks
         gbs = alg / per(dt) / 1e9
         res = dict(base, metric="d_fft per second (m = 2^20, BN254 Fr, l = 2, n = 8)", value=round(args.steps / dt, 3),
@@ -226,7 +236,7 @@ def bench(args, rank, local_rank, world):
         g1 = pp.fq.encode([1, 2]).reshape(-1)
         bases = DeviceBuffer.from_numpy(pp, np.tile(g1, (k * ln, 1)))
         sc = _rand_fr(pp, k * ln, 200 + rank)
-        dt = _timed(dist, torch, lambda i: znet.dist_d_msm(pp, net, 0, ZK_G1, bases, sc, ln), args.steps, args.warmup)
+        dt = timed(lambda i: znet.dist_d_msm(pp, net, 0, ZK_G1, bases, sc, ln))
         alg = pp.n * ln * 96
         from .api import msm_plan
         plan = msm_plan(pp, ZK_G1, k * ln)
@@ -257,7 +267,7 @@ def bench(args, rank, local_rank, world):
             out["proof"] = znet.dist_prove(pp, net, lcrs.ct, qap, a_sh, ax_sh, r, s, wit.log_m, masks=mct, seed=2000 + i)
         step(0)
         pp._check(pp.lib.zk_profile_enable(pp.h, 1))
-        dt = _timed(dist, torch, step, args.steps, args.warmup)
+        dt = timed(step)
         prof = read_profile(pp)
         pp._check(pp.lib.zk_profile_enable(pp.h, 0))
         # untimed cross-check: the ranks' shares put together reconstruct the single-context proof
@@ -304,7 +314,7 @@ def bench(args, rank, local_rank, world):
 
         def step(i):
             out["proof"] = znet.dist_prove(pp, net, inst.crs.ct, wit.qap, wit.a_share, wit.ax_share, r, s, log_m, seed=7 + i)
-        dt = _timed(dist, torch, step, args.steps, args.warmup)
+        dt = timed(step)
         res = dict(base, metric="Groth16 proofs/sec (BLS12-381, 2^%d - 2 constraints)" % log_m,
                    value=round(args.steps / dt, 4), unit="proofs/s", ms_per_step=round(per(dt) * 1e3, 2), scaling="strong",
                    constraints_per_sec=round(inst.nc * args.steps / dt, 1),
