@@ -447,11 +447,14 @@ static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __
 #ifndef ZK_ACC_WAVES_12
 #define ZK_ACC_WAVES_12 3
 #endif
+#ifndef ZK_ACC_WAVES_8
+#define ZK_ACC_WAVES_8 3
+#endif
 #ifndef ZK_PAIR_WAVES_12
 #define ZK_PAIR_WAVES_12 2
 #endif
 template <class Fld>
-constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : 3);
+constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8);
 template <class Fld>
 constexpr int PAIR_WAVES = sizeof(Fld) > 64 ? ZK_PAIR_WAVES_12 : 2;
 template <class Fld>
