@@ -19,6 +19,8 @@ from bench import build_inputs              # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 pp = zk.PackedSharingParams("bn254", 2)
+if os.environ.get("ZK_TABLE_C"):
+    pp.set_option("msm_table_c", int(os.environ["ZK_TABLE_C"]))
 r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
 Lc = (1 << wit.log_m) // pp.l
 h_full = pp.alloc_fr(pp.n * Lc)
