@@ -227,10 +227,22 @@ do {                                                                           \
   MSM_STAGE("finalize");
   // quads per group: few groups (one bucket set) -> whole workgroups per group, shortest dependent chain; many groups
   // (one bucket set per window) -> 4 quads per group, waves stay full
+  // As many quads per group as keep the whole launch resident at once (a second generation of workgroups doubles a
+  // kernel that is one dependent chain): the chip holds 1024 SIMDs x (2 waves of the extension-field kernels, 3 of the
+  // base-field ones) x 16 quads.  ZK_RED_NVL_A / _B override (experiments).
   const size_t tot_groups = (size_t)red_groups * NB * kwin;
-  const int nvl_a = tot_groups <= 1024 ? QUAD_VL : (tot_groups <= 4096 ? 16 : 4);
   const size_t tot_slices = (size_t)nslices * NB * kwin;
-  const int nvl_b = tot_slices <= 256 ? QUAD_VL : 16;
+  const size_t cap_quads = (size_t)1024 * (G2FLD ? 2 : 3) * 16;
+  auto pick_nvl = [&](size_t groups) {
+    int v = QUAD_VL;
+    while (v > 4 && groups * (size_t)v > cap_quads) v >>= 1;
+    return v;
+  };
+  static const int env_a = getenv("ZK_RED_NVL_A") ? atoi(getenv("ZK_RED_NVL_A")) : 0;
+  static const int env_b = getenv("ZK_RED_NVL_B") ? atoi(getenv("ZK_RED_NVL_B")) : 0;
+  int nvl_a = pick_nvl(tot_groups), nvl_b = pick_nvl(tot_slices);
+  if (env_a == 4 || env_a == 8 || env_a == 16 || env_a == 32 || env_a == 64) nvl_a = env_a;
+  if (env_b == 4 || env_b == 8 || env_b == 16 || env_b == 32 || env_b == 64) nvl_b = env_b;
   const unsigned gpw_a = QUAD_VL / nvl_a, gpw_b = QUAD_VL / nvl_b;
   msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)kwin), dim3(QUAD_THREADS), quad_lds, st>>>(
       buckets, B, lo_bits, nvl_a, rc);
