@@ -111,6 +111,9 @@ def _worker(rank, world, net_id, scenario, q):
                     net.gather(1, mask, g, g.nbytes, full)
                     if rank == 0:
                         ok = ok and all(int(full[8 * r]) == r for r in range(world))
+            st = net.stats()
+            ok = ok and st["alltoalls"] == 3 and st["gathers"] == 1 and st["scatters"] == 0
+            ok = ok and st["bytes_sent"] == 3 * nb * (world - 1) + (64 if rank else 0)
             q.put((rank, bool(ok), ""))
         elif scenario == "late":
             # the last rank shows up after the timeout: everyone else continues without its parties (lagrange path)
