@@ -81,18 +81,19 @@ struct Fp {
     return borrow != 0;
   }
 
+  // The carry chains below are written with clang's __builtin_addc / __builtin_subc: on the device they become one
+  // v_addc_co / v_subb_co per limb.  The portable form ((uint64_t)a - b - borrow, borrow = t >> 63) compiled to two
+  // 64-bit adds, a shift and a move per limb -- 60 instructions for a conditional subtraction that needs 18; measured
+  // with tools/mulbench.hip and on the NTT (one addition and one subtraction per multiplication).
+
   // r = a - p if a >= p (a < 2p assumed); `carry` is the bit above limb N-1 of a.
   ZK_HD static Fp reduce_once(const Fp& a, uint32_t carry = 0) {
     Fp d;
-    uint32_t borrow = 0;
+    unsigned borrow = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)a.v[i] - P::MOD[i] - borrow;
-      d.v[i] = (uint32_t)t;
-      borrow = (uint32_t)(t >> 63);
-    }
+    for (int i = 0; i < N; i++) d.v[i] = __builtin_subc(a.v[i], P::MOD[i], borrow, &borrow);
     // a >= p  <=>  carry set, or no borrow
-    bool ge = carry | (borrow ^ 1u);
+    const bool ge = (carry | (borrow ^ 1u)) != 0;
     Fp r;
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = ge ? d.v[i] : a.v[i];
@@ -101,35 +102,23 @@ struct Fp {
 
   ZK_HD friend Fp operator+(const Fp& a, const Fp& b) {
     Fp s;
-    uint32_t c = 0;
+    unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
-      s.v[i] = (uint32_t)t;
-      c = (uint32_t)(t >> 32);
-    }
+    for (int i = 0; i < N; i++) s.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
     return reduce_once(s, c);
   }
 
   ZK_HD friend Fp operator-(const Fp& a, const Fp& b) {
     Fp d;
-    uint32_t borrow = 0;
+    unsigned borrow = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
-      d.v[i] = (uint32_t)t;
-      borrow = (uint32_t)(t >> 63);
-    }
+    for (int i = 0; i < N; i++) d.v[i] = __builtin_subc(a.v[i], b.v[i], borrow, &borrow);
     // add p back if we borrowed
-    uint32_t mask = 0u - borrow;
-    uint32_t c = 0;
+    const uint32_t mask = 0u - borrow;
+    unsigned c = 0;
     Fp r;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)d.v[i] + (P::MOD[i] & mask) + c;
-      r.v[i] = (uint32_t)t;
-      c = (uint32_t)(t >> 32);
-    }
+    for (int i = 0; i < N; i++) r.v[i] = __builtin_addc(d.v[i], P::MOD[i] & mask, c, &c);
     return r;
   }
 
