@@ -10,7 +10,8 @@ using namespace zk;
 template <class F, int VAR>
 __device__ __forceinline__ F mulv(const F& a, const F& b) {
   if constexpr (VAR == 0) return F::mul_ref(a, b);
-  else return F::mul_inline(a, b);
+  else if constexpr (VAR == 2) return F::mul_fips(a, b);
+  else return F::mul_pairs(a, b);
 }
 
 template <class F, int VAR>
@@ -28,8 +29,9 @@ __global__ void check(const F* x, const F* y, int* bad, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   F r0 = F::mul_ref(x[i], y[i]);
-  F r1 = F::mul_inline(x[i], y[i]);
-  if (r0 != r1) atomicAdd(bad, 1);
+  F r1 = F::mul_pairs(x[i], y[i]);
+  F r2 = F::mul_fips(x[i], y[i]);
+  if (r0 != r1 || r0 != r2) atomicAdd(bad, 1);
 }
 
 template <class F>
@@ -66,11 +68,12 @@ void run(const char* name) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 200;
-  for (int var = 0; var < 2; var++) {
+  for (int var = 0; var < 3; var++) {
     for (int rep = 0; rep < 2; rep++) {
       hipMemcpy(dx, hx.data(), n * sizeof(F), hipMemcpyHostToDevice);
       hipEventRecord(e0);
       if (var == 0) chain<F, 0><<<n / 256, 256>>>(dx, dy, iters);
+      else if (var == 2) chain<F, 2><<<n / 256, 256>>>(dx, dy, iters);
       else chain<F, 1><<<n / 256, 256>>>(dx, dy, iters);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
@@ -81,9 +84,10 @@ void run(const char* name) {
     }
   }
   // single-wave latency: 64 lanes only
-  for (int var = 0; var < 2; var++) {
+  for (int var = 0; var < 3; var++) {
     hipEventRecord(e0);
     if (var == 0) chain<F, 0><<<1, 64>>>(dx, dy, 2000);
+    else if (var == 2) chain<F, 2><<<1, 64>>>(dx, dy, 2000);
     else chain<F, 1><<<1, 64>>>(dx, dy, 2000);
     hipEventRecord(e1);
     hipEventSynchronize(e1);

@@ -176,7 +176,7 @@ struct Fp {
     }
     return reduce_once(r, (uint32_t)t[M]);
 #else
-    return mul_pairs(a, b);
+    return mul_fips(a, b);
 #endif
   }
 
@@ -293,6 +293,62 @@ struct Fp {
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = t[i];
     return reduce_once(r, t[N]);
+#else
+    return mul_ref(a, b);
+#endif
+  }
+
+  // THE device multiply.  Product-scanning (FIPS) Montgomery with one 96-bit column accumulator: each v_mad_u64_u32 adds
+  // its product into the 64-bit pair and the carry-out bit (an SGPR lane mask) is counted in the third word -- one carry
+  // instruction per mad (128 for 8 limbs) where the row-wise form below (mul_pairs, round 1's multiplier, kept for the
+  // cross-check in tools/mulbench.hip) needs ~190 plus the moves that pack limb pairs, and no carry instruction feeds
+  // the next one (gfx950 wants two wait states between a VALU that writes a carry and the VALU that reads it).
+  // Measured (profiles/r02_mulbench.txt): 123.8 vs 98.1 G products/s on BN254 Fq (80 % of the v_mad_u64_u32 issue
+  // bound), 59.6 vs 47.4 on the 12-limb BLS12-381 Fq, 0.76 vs 1.00 us per dependent product for a lone wave.
+  ZK_HD static Fp mul_fips(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m[N], r[N];
+    uint64_t acc = 0, cy;
+    uint32_t acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc = madc(a.v[i], b.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      m[k] = (uint32_t)acc * P::N0INV;
+      acc = madc_k(m[k], P::MOD[0], acc, &cy);
+      acc2 = add_cy(acc2, cy);
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc = madc(a.v[i], b.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      r[k - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+    r[N - 1] = (uint32_t)acc;
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = r[i];
+    return reduce_once(o, (uint32_t)(acc >> 32));
 #else
     return mul_ref(a, b);
 #endif
