@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB
 # ALU view.  v_mad_u64_u32 issues at quarter rate on gfx950 (measured, tools/mulbench.hip: a wave64 instruction
 # occupies its SIMD for 8 cycles): 256 CUs x 4 SIMDs x 2.4 GHz x 64 lanes / 8 cycles = 19.7 T mad/s; an 8-limb
 # Montgomery product is 128 of them => 153.6 G products/s is the INSTRUCTION-ISSUE BOUND every fraction below is
-# quoted against.  Our multiplier (field.hpp mul_pairs) reaches 99 G/s of it on BN254 Fq (profiles/r02_mulbench.txt; 93 in round 1).
+# quoted against.  Our multiplier (field.hpp mul_fips) reaches 123.8 G/s of it on BN254 Fq (profiles/r02_mulbench.txt; 93 in round 1).
 MAD_ISSUE_BOUND_G = 256 * 4 * 2.4e9 * 64 / 8 / 128 / 1e9
-MUL_MEASURED_G = 99.0
+MUL_MEASURED_G = 123.8
 
 # algorithmic bytes per unit of each timed slot (DESIGN.md "Measurement")
 #   ntt_pass      : fft1 as ONE ideal pass moves 2 x 32 B per element; with P passes each launch is charged 64/P
