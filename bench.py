@@ -211,8 +211,12 @@ def primitives(pp, zk):
             "frac_mad_issue_bound": round(modmul / t / 1e9 / MAD_ISSUE_BOUND_G, 3)}
     del sh, dst, mask
     ln = 1 << 20
-    g1 = pp.fq.encode([1, 2]).reshape(-1)
-    bases = zk.DeviceBuffer.from_numpy(pp, np.tile(g1, (pp.n * ln, 1)))
+    # DISTINCT bases (seeded random multiples of the generator, as a CRS is).  Round 1 and most of round 2 tiled ONE point
+    # 8 x 2^20 times: then every bucket's second addition is a doubling and negated digits cancel -- the rare branches of
+    # the mixed addition become the common ones, taken by different lanes at different steps, and the accumulate kernel
+    # ran with 64 % of its lanes active (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU).
+    from zksaas_amd import groth16 as zg
+    bases = zg.base_points(pp, ZK_G1, rand_fr(pp.n * ln), pp.n * ln)
     sc = rand_fr(pp.n * ln)
     t = med(pp, lambda: zk.d_msm(pp, ZK_G1, bases, sc, ln), 3)
     alg = pp.n * ln * 96

@@ -50,9 +50,11 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
                                   c-1 */, uint32_t pre_stride /* fixed-base table: rows of this many points, one per
                                   window; all windows share ONE bucket set; 0 = no table */, uint32_t pre_off,
                                   uint32_t* __restrict__ counts /* [nwin*B] */,
-                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
+                                  const uint32_t* __restrict__ skip /* bit i: base i is the identity */) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
+  if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return;
   Fp<FrP> s = load_elem(scalars + i);
   if (coef) s = s * coef[i / part_len];
   s = s.from_mont();
@@ -104,6 +106,26 @@ inline hipError_t msm_zero(void* p, size_t bytes, hipStream_t st) {     // p 16-
   return hipGetLastError();
 }
 
+// Identity bases contribute nothing: bit i of `skip` is set when base i is the identity in EVERY base vector of the
+// launch, and the sort then emits no entry for point i.  A Groth16 CRS is full of them -- b_query holds the identity for
+// every wire that no B-row mentions (59 % of the SHA-256 circuit's wires; half of the PACKED shares) -- and a lane
+// that loads an identity idles while its wave adds (measured: 49 % of the lanes of the G2 accumulate active).
+template <class Fld>
+__global__ __launch_bounds__(256) void msm_skip_mask_kernel(const Affine<Fld>* __restrict__ bases0,
+                                                            const Affine<Fld>* __restrict__ bases1, size_t npts,
+                                                            uint32_t* __restrict__ skip) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool id = false;
+  if (i < npts) {
+    id = load_elem(bases0 + i).is_identity();
+    if (id && bases1) id = load_elem(bases1 + i).is_identity();
+  }
+  const uint64_t m = __ballot(id);
+  const int lane = threadIdx.x & 63;
+  if (lane == 0 && i < npts) skip[i >> 5] = (uint32_t)m;
+  if (lane == 32 && i < npts) skip[i >> 5] = (uint32_t)(m >> 32);
+}
+
 // -------------------------------------------------------------------------------------------------- big sort
 // For multi-million-point MSMs the two atomics-per-(point, window) passes above dominate (measured at 8 x 2^20
 // points: 4.7 ms histogram + 12.2 ms scatter against 15.6 ms of accumulate).  The big-sort path is a two-level
@@ -147,7 +169,8 @@ __device__ __forceinline__ void msm_for_each_digit(Fp<FrP> s, int c, int nwin, i
 
 template <class FrP>
 __device__ __forceinline__ Fp<FrP> msm_load_scalar(const Fp<FrP>* scalars, const Fp<FrP>* coef, size_t part_len,
-                                                   size_t i) {
+                                                   size_t i, const uint32_t* skip) {
+  if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return Fp<FrP>::zero();      // identity base: no digit, no entry
   Fp<FrP> s = load_elem(scalars + i);
   if (coef) s = s * coef[i / part_len];
   return s.from_mont();
@@ -160,7 +183,8 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP
                                                                     int ppt /* points per thread */,
                                                                     uint32_t wmask /* 0: fixed-base table, all windows
                                                                     share one bucket set; ~0: one set per window */,
-                                                                    uint32_t* __restrict__ bin_counts) {
+                                                                    uint32_t* __restrict__ bin_counts,
+                                                                    const uint32_t* __restrict__ skip) {
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) big_lds[b] = 0;
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP
   for (int k = 0; k < ppt; k++) {
     size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (i >= npts) break;
-    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i), c, nwin, wide,
+    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i, skip), c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[(((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits)], 1u); });
   }
   __syncthreads();
@@ -214,7 +238,8 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
                                                                        int lo_bits, int ppt, uint32_t wmask,
                                                                        uint32_t pre_stride, uint32_t pre_off,
                                                                        uint32_t* __restrict__ bin_cursor,
-                                                                       uint2* __restrict__ tmp) {
+                                                                       uint2* __restrict__ tmp,
+                                                                       const uint32_t* __restrict__ skip) {
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
   uint32_t* cnt = big_lds;            // per-bin count of this tile, then the running local rank
@@ -225,7 +250,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
   for (int k = 0; k < ppt; k++) {
     size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (i >= npts) break;
-    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i), c, nwin, wide,
+    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i, skip), c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[(((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits)], 1u); });
   }
   __syncthreads();
@@ -239,7 +264,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
   for (int k = 0; k < ppt; k++) {
     size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (i >= npts) break;
-    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i), c, nwin, wide,
+    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i, skip), c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t neg) {
                               uint32_t bin = (((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits);
                               uint32_t r = atomicAdd(&cnt[bin], 1u);

@@ -16,6 +16,8 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   if (npts == 0) return ZK_OK;
   if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
   constexpr bool G2FLD = IsExtField<Fld>::value;
+  const void* const bases_in = bases;            // the caller's points (the skip mask reads them, not the table rows)
+  const void* const bases2_in = bases2;
   // fixed-base table registered for this base vector (and the same window layout / offset for the second one)?
   size_t toff = 0, toff2 = 0;
   std::shared_ptr<const MsmTable> tab = TableRegistry::inst().find(bases, npts, sizeof(Affine<Fld>), FrP::BITS, &toff), tab2;
@@ -72,6 +74,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     const int sort_lo = c - 1 - BIG_HI;
   const bool big = npts >= tune.bigsort_min && sort_lo >= 1 && sort_lo <= 12;
   const int kbin = tab ? 1 : nwin;                 // window components of the sort bins
+  const size_t o_skip = take(((npts + 63) / 64) * 8);
   size_t o_bins = 0, o_tmp = 0;
   if (big) {
     o_bins = take((3 * ((size_t)kbin << BIG_HI) + 1) * 4);
@@ -119,7 +122,8 @@ do {                                                                           \
 } while (0)
   // another launch already sorted these scalars with this layout?
   const MsmPending::Sort* sh = nullptr;
-  if (tune.share && tune.share->active) {
+  // (a shared sort leaves out the identities of the launch that built it: only valid when identity skipping is off)
+  if (tune.share && tune.share->active && getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0) {
     const MsmPending::Sort& s0 = tune.share->sort;
     if (s0.scalars == scalars && s0.coef == (const void*)coef_d && s0.npts == npts && s0.part_len == (part_len ? part_len : npts) &&
         s0.c == c && s0.nwin == nwin && s0.wide == wide && s0.seg == seg && s0.pre_stride == pre_stride &&
@@ -139,6 +143,13 @@ do {                                                                           \
   } else {
   MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
   dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
+  // identity bases are left out of the sort (msm_skip_mask_kernel); ZK_MSM_SKIP_IDENTITY=0 keeps them (A/B runs)
+  static const bool skip_on = !(getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0);
+  uint32_t* skip = nullptr;
+  if (skip_on) {
+    skip = (uint32_t*)(ws + o_skip);
+    msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip);
+  }
   const size_t plen = part_len ? part_len : npts;
   {
   ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts);
@@ -156,16 +167,17 @@ do {                                                                           \
     const uint32_t wmask = tab ? 0u : ~0u;
     msm_part_hist_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d, plen,
                                                                                 c, nwin, wide, sort_lo, ppt, wmask,
-                                                                                bin_counts);
+                                                                                bin_counts, skip);
     msm_bin_scan_kernel<<<dim3(1), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor);
     msm_part_scatter_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp);
+        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp,
+        skip);
     msm_bin_sort_kernel<<<dim3(nbins), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_lo, (uint32_t)(c - 1), counts,
                                                                    sorted);
     MSM_STAGE("big sort");
   } else {
     msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                pre_off, counts, nullptr, nullptr);
+                                                pre_off, counts, nullptr, nullptr, skip);
     MSM_STAGE("digits/count");
   }
   iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
@@ -181,7 +193,7 @@ do {                                                                           \
   MSM_STAGE("expand");
   if (!big)
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                pre_off, nullptr, cursor, sorted);
+                                                pre_off, nullptr, cursor, sorted, skip);
   }
   MSM_HIP(hipEventRecord(slot.ev_sort, st));
   }
