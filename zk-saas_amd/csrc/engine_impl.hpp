@@ -900,7 +900,7 @@ class Engine : public IEngine {
     int first = 0, count = 0;
     Fr r, s;
     DevBuf hwork, hshare;
-    MsmPending pS, pV0, pV1, pW, pU;
+    MsmPending pS, pH, pV0, pV1, pW, pU;
     P1 S, H, W, U, sS, rH;
     P2 V0, V1;
     P1 rN, sK, rsM, s_cA, r_cB1;
@@ -1030,9 +1030,9 @@ class Engine : public IEngine {
         if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
         J->rc[which] = rc2;
         if constexpr (std::is_same<Fld, Fq_>::value) {
-          if (!rc2 && which == 0 && J->full) {        // s*S and r*H off the tail (prove.rs:229-235, linearity)
-            J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
-            if (!J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
+          if (!rc2 && J->full) {                      // s*S and r*H off the tail (prove.rs:229-235, linearity)
+            if (which == 0) J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
+            if ((which == 4 || (which == 0 && out2 != nullptr)) && !J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
           }
         }
       }));
@@ -1071,9 +1071,22 @@ class Engine : public IEngine {
       if (j.split_v)
         msm_task(Fq2_{}, 3, vb + (size_t)nh * cstride * sizeof(Affine<Fq2_>), nullptr, as + (size_t)nh * cstride * sizeof(Fr),
                  (size_t)(count - nh) * cstride, cf + nh, cstride, streams_[4], ws0 + 5, &j.pV1, &j.V1, (P2*)nullptr);
-      // S and H multiply two base vectors by the same witness shares: one sort, shared launches
-      msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride, streams_[0],
-               ws0 + 1, &j.pS, &j.S, &j.H);
+      // S and H multiply two base vectors by the same witness shares: ONE launch over both vectors (one sort).  The sort
+      // leaves out identity bases, and the two vectors' identities differ -- b_query is the identity for every wire no
+      // B-row mentions (59 % in the SHA-256 circuit), a_query for 7 % -- so the fused launch skips almost nothing and the
+      // H half of its accumulate idles on those lanes.  Running them as two MSMs with their own sorts (ZK_SPLIT_SH=1) does
+      // fewer additions and was still slower, measured: 391 vs 464 proofs/s with tables, 300 vs 351 without -- a sixth
+      // concurrent chain starves circom_h's kernels further (timeline: the U-MSM then ends 0.6 ms after everything else).
+      static const bool fuse_sh = !(getenv("ZK_SPLIT_SH") && atoi(getenv("ZK_SPLIT_SH")) != 0);
+      if (fuse_sh || j.r_zero) {
+        msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride,
+                 streams_[0], ws0 + 1, &j.pS, &j.S, j.r_zero ? (P1*)nullptr : &j.H);
+      } else {
+        msm_task(Fq_{}, 0, crs->s_d, nullptr, a_share, (size_t)count * cstride, cf, cstride, streams_[0], ws0 + 1, &j.pS,
+                 &j.S, (P1*)nullptr);
+        msm_task(Fq_{}, 4, crs->h_d, nullptr, a_share, (size_t)count * cstride, cf, cstride, streams_[1], ws0 + 2, &j.pH,
+                 &j.H, (P1*)nullptr);
+      }
     }
     msm_task(Fq_{}, 1, crs->w_d, nullptr, ax_share, (size_t)count * crs->len_w, cf, crs->len_w, streams_[3], ws0 + 4,
              &j.pW, &j.W, (P1*)nullptr);
@@ -1274,7 +1287,7 @@ class Engine : public IEngine {
   // joins a job's tasks and device work and marks it free (after an error, or zk_groth16_abort)
   void abort_job(ProveJob& j) {
     drain(j);
-    MsmPending* ps[5] = {&j.pS, &j.pV0, &j.pV1, &j.pW, &j.pU};
+    MsmPending* ps[6] = {&j.pS, &j.pH, &j.pV0, &j.pV1, &j.pW, &j.pU};
     for (MsmPending* p : ps)
       if (p->active) {
         (void)hipEventSynchronize(p->slot->ev);
