@@ -1,7 +1,7 @@
 """Per-stream kernel timeline of one proof from a rocprofv3 --kernel-trace result (rocpd sqlite database or csv).
 
-usage: python tools/timeline.py gpurun_out/prof/p_results.db [proof_index_from_end]
-Proof boundaries: gaps of more than 150 us with no kernel running.
+usage: python tools/timeline.py gpurun_out/prof/p_results.db [proof_index_from_end [gap_us]]
+Proof boundaries: gaps of more than gap_us (default 70) with no kernel running.
 """
 import csv
 import re
@@ -11,6 +11,7 @@ from collections import defaultdict
 
 path = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+gap_ns = int(float(sys.argv[3]) * 1000) if len(sys.argv) > 3 else 70_000
 if path.endswith(".db"):
     cur = sqlite3.connect(path).cursor()
     rows = [{"Kernel_Name": r[0], "Start_Timestamp": r[1], "End_Timestamp": r[2], "Stream_Id": r[3], "Grid_Size_X": r[4]}
@@ -33,7 +34,7 @@ def short(n):
 bounds, end = [0], 0
 for i, r in enumerate(rows):
     st = int(r["Start_Timestamp"])
-    if i and st - end > 150_000:
+    if i and st - end > gap_ns:
         bounds.append(i)
     end = max(end, int(r["End_Timestamp"]))
 bounds.append(len(rows))
