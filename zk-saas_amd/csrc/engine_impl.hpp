@@ -2222,9 +2222,20 @@ class Engine : public IEngine {
     const char* pe = getenv("ZK_STREAM_PRIO");
     const char* pdef = "llhlhh";
     if (!pe || strlen(pe) != 6) pe = pdef;
+    // ZK_CU_RESERVE=<n> (experiment): the MSM streams 0..4 are kept off n of the chip's CUs (spread evenly), which stay
+    // free for the circom_h -> U chain on stream 5 (its multi-wave workgroups otherwise wait for a CU to drain)
+    const int reserve = getenv("ZK_CU_RESERVE") ? atoi(getenv("ZK_CU_RESERVE")) : 0;
     for (int i = 0; i < 6; i++) {
       int pr = pe[i] == 'h' ? hi : (pe[i] == 'l' ? lo : (lo + hi) / 2);
-      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, pr));
+      if (reserve > 0 && reserve < 256 && i < 5) {
+        uint32_t mask[8];
+        for (int w = 0; w < 8; w++) mask[w] = 0xffffffffu;
+        const int step = 256 / reserve;
+        for (int cu = 0; cu < 256; cu += step) mask[cu >> 5] &= ~(1u << (cu & 31));
+        ZK_HIP(hipExtStreamCreateWithCUMask(&streams_[i], 8, mask));
+      } else {
+        ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, pr));
+      }
     }
     for (int i = 0; i < NJOBS; i++) {
       ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
