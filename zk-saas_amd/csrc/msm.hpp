@@ -38,6 +38,12 @@ namespace zk {
 constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
 constexpr int MSM_WS = 12;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate streams)
 
+// Sort-stage arrays of a launch over TWO base vectors with per-vector sorts (their identity bases differ) live in two
+// copies of one workspace region; blockIdx.y picks the copy: every sort-stage kernel shifts its array pointers by
+// blockIdx.y * ys bytes (ys = 0: one sort shared by both vectors).
+#define ZK_YSHIFT(p) \
+  if (p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.y * ys)
+
 struct SegDesc {
   uint32_t bucket, start, end;
 };
@@ -51,7 +57,11 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
                                   window; all windows share ONE bucket set; 0 = no table */, uint32_t pre_off,
                                   uint32_t* __restrict__ counts /* [nwin*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
-                                  const uint32_t* __restrict__ skip /* bit i: base i is the identity */) {
+                                  const uint32_t* __restrict__ skip /* bit i: base i is the identity */, size_t ys) {
+  ZK_YSHIFT(counts);
+  ZK_YSHIFT(cursor);
+  ZK_YSHIFT(sorted);
+  ZK_YSHIFT(skip);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
   if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return;
@@ -91,7 +101,8 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
 
 // Workspace zeroing by one-wave workgroups: hipMemsetAsync's 256-thread fill kernel waits for four free wave slots on
 // one CU, which the concurrent accumulate kernels of a proof rarely leave (measured 1.0 ms for a 20 us fill).
-static __global__ __launch_bounds__(64) void msm_zero_kernel(uint32_t* __restrict__ p, size_t n_words) {
+static __global__ __launch_bounds__(64) void msm_zero_kernel(uint32_t* __restrict__ p, size_t n_words, size_t ys) {
+  ZK_YSHIFT(p);
   size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) * 4;
   if (i + 4 <= n_words) {
     *reinterpret_cast<uint4*>(p + i) = make_uint4(0, 0, 0, 0);
@@ -99,10 +110,10 @@ static __global__ __launch_bounds__(64) void msm_zero_kernel(uint32_t* __restric
     for (; i < n_words; i++) p[i] = 0;
   }
 }
-inline hipError_t msm_zero(void* p, size_t bytes, hipStream_t st) {     // p 16-byte aligned, bytes % 4 == 0
+inline hipError_t msm_zero(void* p, size_t bytes, hipStream_t st, unsigned ny = 1, size_t ys = 0) {   // p 16-byte aligned
   const size_t words = bytes / 4;
   if (!words) return hipSuccess;
-  msm_zero_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(64), 0, st>>>((uint32_t*)p, words);
+  msm_zero_kernel<<<dim3((unsigned)((words + 255) / 256), ny), dim3(64), 0, st>>>((uint32_t*)p, words, ys);
   return hipGetLastError();
 }
 
@@ -113,12 +124,18 @@ inline hipError_t msm_zero(void* p, size_t bytes, hipStream_t st) {     // p 16-
 template <class Fld>
 __global__ __launch_bounds__(256) void msm_skip_mask_kernel(const Affine<Fld>* __restrict__ bases0,
                                                             const Affine<Fld>* __restrict__ bases1, size_t npts,
-                                                            uint32_t* __restrict__ skip) {
+                                                            uint32_t* __restrict__ skip, size_t ys) {
+  // ys != 0 (grid.y = 2): one mask per base vector; ys == 0: one mask, set where EVERY vector holds the identity
+  ZK_YSHIFT(skip);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool id = false;
   if (i < npts) {
-    id = load_elem(bases0 + i).is_identity();
-    if (id && bases1) id = load_elem(bases1 + i).is_identity();
+    if (ys) {
+      id = load_elem((blockIdx.y ? bases1 : bases0) + i).is_identity();
+    } else {
+      id = load_elem(bases0 + i).is_identity();
+      if (id && bases1) id = load_elem(bases1 + i).is_identity();
+    }
   }
   const uint64_t m = __ballot(id);
   const int lane = threadIdx.x & 63;
@@ -184,7 +201,9 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP
                                                                     uint32_t wmask /* 0: fixed-base table, all windows
                                                                     share one bucket set; ~0: one set per window */,
                                                                     uint32_t* __restrict__ bin_counts,
-                                                                    const uint32_t* __restrict__ skip) {
+                                                                    const uint32_t* __restrict__ skip, size_t ys) {
+  ZK_YSHIFT(bin_counts);
+  ZK_YSHIFT(skip);
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) big_lds[b] = 0;
@@ -205,7 +224,10 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP
 static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_scan_kernel(const uint32_t* __restrict__ bin_counts,
                                                                           uint32_t nbins,
                                                                           uint32_t* __restrict__ bin_base,
-                                                                          uint32_t* __restrict__ bin_cursor) {
+                                                                          uint32_t* __restrict__ bin_cursor, size_t ys) {
+  ZK_YSHIFT(bin_counts);
+  ZK_YSHIFT(bin_base);
+  ZK_YSHIFT(bin_cursor);
   __shared__ uint32_t sh[BIG_THREADS];
   const uint32_t per = (nbins + BIG_THREADS - 1) / BIG_THREADS;
   const uint32_t b0 = threadIdx.x * per;
@@ -239,7 +261,10 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
                                                                        uint32_t pre_stride, uint32_t pre_off,
                                                                        uint32_t* __restrict__ bin_cursor,
                                                                        uint2* __restrict__ tmp,
-                                                                       const uint32_t* __restrict__ skip) {
+                                                                       const uint32_t* __restrict__ skip, size_t ys) {
+  ZK_YSHIFT(bin_cursor);
+  ZK_YSHIFT(tmp);
+  ZK_YSHIFT(skip);
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
   uint32_t* cnt = big_lds;            // per-bin count of this tile, then the running local rank
@@ -279,7 +304,11 @@ static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_sort_kernel(const 
                                                                           const uint32_t* __restrict__ bin_base,
                                                                           int lo_bits, uint32_t keys_per_window_log2,
                                                                           uint32_t* __restrict__ counts,
-                                                                          uint32_t* __restrict__ sorted) {
+                                                                          uint32_t* __restrict__ sorted, size_t ys) {
+  ZK_YSHIFT(tmp);
+  ZK_YSHIFT(bin_base);
+  ZK_YSHIFT(counts);
+  ZK_YSHIFT(sorted);
   __shared__ uint32_t cur[1 << 12];
   const uint32_t nlo = 1u << lo_bits;
   const uint32_t bin = blockIdx.x;
@@ -350,8 +379,12 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const
                                                                    uint2* __restrict__ block_tot,
                                                                    const uint2* __restrict__ carry,
                                                                    uint2* __restrict__ offsets, int mode,
-                                                                   uint32_t seg) {
+                                                                   uint32_t seg, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(counts);
+  ZK_YSHIFT(block_tot);
+  ZK_YSHIFT(carry);
+  ZK_YSHIFT(offsets);
   __shared__ uint2 sh[ISCAN_THREADS];
   size_t base = (size_t)blockIdx.x * ISCAN_BLOCK + (size_t)threadIdx.x * ISCAN_PER;
   uint2 loc[ISCAN_PER];
@@ -377,8 +410,10 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const
     offsets[len] = make_uint2(cr.x + tot.x, cr.y + tot.y);
 }
 
-static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint2* __restrict__ bt, size_t nblocks) {
+static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint2* __restrict__ bt, size_t nblocks,
+                                                                           size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(bt);
   __shared__ uint2 sh[ISCAN_THREADS];
   uint2 running = make_uint2(0, 0);
   for (size_t b0 = 0; b0 < nblocks; b0 += ISCAN_BLOCK) {
@@ -411,8 +446,12 @@ __device__ __forceinline__ uint32_t seg_bin(uint32_t len, uint32_t seg) { return
 static __global__ __launch_bounds__(256) void msm_expand_kernel(const uint2* __restrict__ offsets, size_t nkeys,
                                                                 uint32_t* __restrict__ cursor,
                                                                 SegDesc* __restrict__ segs, uint32_t seg,
-                                                                uint32_t* __restrict__ lenhist) {
+                                                                uint32_t* __restrict__ lenhist, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(cursor);
+  ZK_YSHIFT(segs);
+  ZK_YSHIFT(lenhist);
   __shared__ uint32_t lh[SEG_BINS];
   if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
   __syncthreads();
@@ -440,8 +479,13 @@ static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __
                                                                const uint2* __restrict__ offsets, size_t nkeys,
                                                                uint32_t seg, const uint32_t* __restrict__ lenhist,
                                                                uint32_t* __restrict__ bincur,
-                                                               uint32_t* __restrict__ order) {
+                                                               uint32_t* __restrict__ order, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(segs);
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(lenhist);
+  ZK_YSHIFT(bincur);
+  ZK_YSHIFT(order);
   __shared__ uint32_t lh[SEG_BINS], base[SEG_BINS];
   if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
   __syncthreads();
@@ -489,7 +533,11 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
                                                             const SegDesc* __restrict__ segs,
                                                             const uint2* __restrict__ offsets, size_t nkeys,
                                                             const uint32_t* __restrict__ order,
-                                                            XYZZ<Fld>* __restrict__ partial0) {
+                                                            XYZZ<Fld>* __restrict__ partial0, size_t ys) {
+  ZK_YSHIFT(sorted);
+  ZK_YSHIFT(segs);
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(order);
   // blockIdx.y: which of the (up to two) base vectors that share this scalar vector -- and therefore the sort
   const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
   XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
@@ -529,7 +577,11 @@ __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kern
                                                                     const SegDesc* __restrict__ segs,
                                                                     const uint2* __restrict__ offsets, size_t nkeys,
                                                                     const uint32_t* __restrict__ order,
-                                                                    XYZZ<Fld>* __restrict__ partial0) {
+                                                                    XYZZ<Fld>* __restrict__ partial0, size_t ys) {
+  ZK_YSHIFT(sorted);
+  ZK_YSHIFT(segs);
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(order);
   const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
   XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
   const uint32_t nseg = offsets[nkeys].y;
@@ -587,8 +639,9 @@ constexpr int QUAD_VL = QUAD_THREADS / 4;
 template <class Fld>
 __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
                                                                    const uint2* __restrict__ offsets, size_t nkeys,
-                                                                   XYZZ<Fld>* __restrict__ buckets0) {
+                                                                   XYZZ<Fld>* __restrict__ buckets0, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(offsets);
   const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
   extern __shared__ uint4 smem_fin[];

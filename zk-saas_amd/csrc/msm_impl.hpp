@@ -65,11 +65,16 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
+  // identity bases are left out of the sort (msm_skip_mask_kernel); ZK_MSM_SKIP_IDENTITY=0 keeps them (A/B runs).
+  // Two base vectors over the same scalars then get their OWN sorts (their identities differ: a fused sort could only
+  // skip a point that is the identity in both) -- same kernels, grid.y = 2, the sort-stage arrays in two copies of one
+  // workspace region (ZK_YSHIFT in the kernels); ZK_MSM_ONE_SORT=1 keeps the single shared sort.
+  static const bool skip_on = !(getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0);
+  static const bool one_sort = getenv("ZK_MSM_ONE_SORT") && atoi(getenv("ZK_MSM_ONE_SORT")) != 0;
+  const unsigned NS = (NB == 2 && skip_on && !one_sort) ? 2u : 1u;       // sorts of this launch
+  // ---- sort region (replicated NS times)
   size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
-         o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc)),
-         o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
-         o_rc = take(NB * (size_t)kwin * red_groups * sizeof(XYZZ<Fld>)),
-         o_out = take(NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>));
+         o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc));
   // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
     const int sort_lo = c - 1 - BIG_HI;
   const bool big = npts >= tune.bigsort_min && sort_lo >= 1 && sort_lo <= 12;
@@ -80,6 +85,13 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     o_bins = take((3 * ((size_t)kbin << BIG_HI) + 1) * 4);
     o_tmp = take(max_sorted * sizeof(uint2));
   }
+  const size_t sort_region = off;
+  const size_t ys = NS == 2 ? sort_region : 0;     // byte distance between the two copies
+  off = sort_region * NS;
+  // ---- per base vector
+  size_t o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
+         o_rc = take(NB * (size_t)kwin * red_groups * sizeof(XYZZ<Fld>)),
+         o_out = take(NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>));
   hipError_t he = slot.ws.ensure(off);
   if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
   const size_t out_bytes = NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>);
@@ -141,14 +153,12 @@ do {                                                                           \
     offsets = const_cast<uint2*>(sh->offsets);
     order = const_cast<uint32_t*>(sh->order);
   } else {
-  MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st));   // counts and lenhist
-  dim3 pg((unsigned)((npts + 255) / 256)), pb(256);
-  // identity bases are left out of the sort (msm_skip_mask_kernel); ZK_MSM_SKIP_IDENTITY=0 keeps them (A/B runs)
-  static const bool skip_on = !(getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0);
+  MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st, NS, ys));   // counts and lenhist
+  dim3 pg((unsigned)((npts + 255) / 256), NS), pb(256);
   uint32_t* skip = nullptr;
   if (skip_on) {
     skip = (uint32_t*)(ws + o_skip);
-    msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip);
+    msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip, ys);
   }
   const size_t plen = part_len ? part_len : npts;
   {
@@ -159,41 +169,41 @@ do {                                                                           \
     uint32_t* bin_base = bin_counts + nbins;
     uint32_t* bin_cursor = bin_base + nbins + 1;
     uint2* tmp = (uint2*)(ws + o_tmp);
-    MSM_HIP(msm_zero(bin_counts, nbins * 4, st));
+    MSM_HIP(msm_zero(bin_counts, nbins * 4, st, NS, ys));
     // tile = BIG_THREADS * ppt points: ~1024 tiles for small MSMs, 16 points per thread for the multi-million ones
     int ppt = BIG_PTS_PER_THREAD;
     while (ppt > 1 && (npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt) < 1024) ppt >>= 1;
     const unsigned tiles = (unsigned)((npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
     const uint32_t wmask = tab ? 0u : ~0u;
-    msm_part_hist_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d, plen,
-                                                                                c, nwin, wide, sort_lo, ppt, wmask,
-                                                                                bin_counts, skip);
-    msm_bin_scan_kernel<<<dim3(1), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor);
-    msm_part_scatter_kernel<FrP><<<dim3(tiles), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
+    msm_part_hist_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d,
+                                                                                    plen, c, nwin, wide, sort_lo, ppt,
+                                                                                    wmask, bin_counts, skip, ys);
+    msm_bin_scan_kernel<<<dim3(1, NS), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor, ys);
+    msm_part_scatter_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
         (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp,
-        skip);
-    msm_bin_sort_kernel<<<dim3(nbins), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_lo, (uint32_t)(c - 1), counts,
-                                                                   sorted);
+        skip, ys);
+    msm_bin_sort_kernel<<<dim3(nbins, NS), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_lo, (uint32_t)(c - 1), counts,
+                                                                       sorted, ys);
     MSM_STAGE("big sort");
   } else {
     msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                pre_off, counts, nullptr, nullptr, skip);
+                                                pre_off, counts, nullptr, nullptr, skip, ys);
     MSM_STAGE("digits/count");
   }
-  iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
-                                                                                   nullptr, 0, seg);
-  iscan_carry_kernel<<<dim3(1), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks);
-  iscan_block_kernel<<<dim3((unsigned)iscan_blocks), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
-                                                                                   offsets, 1, seg);
+  iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
+                                                                                       nullptr, 0, seg, ys);
+  iscan_carry_kernel<<<dim3(1, NS), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks, ys);
+  iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
+                                                                                       offsets, 1, seg, ys);
   MSM_STAGE("scan");
-  msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg,
-                                                                                 lenhist);
-  msm_order_kernel<<<dim3((unsigned)((max_segs + 255) / 256)), dim3(256), 0, st>>>(segs, offsets, nkeys, seg, lenhist,
-                                                                                   lenhist + SEG_BINS, order);
+  msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256), NS), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg,
+                                                                                     lenhist, ys);
+  msm_order_kernel<<<dim3((unsigned)((max_segs + 255) / 256), NS), dim3(256), 0, st>>>(
+      segs, offsets, nkeys, seg, lenhist, lenhist + SEG_BINS, order, ys);
   MSM_STAGE("expand");
   if (!big)
     msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                pre_off, nullptr, cursor, sorted, skip);
+                                                pre_off, nullptr, cursor, sorted, skip, ys);
   }
   MSM_HIP(hipEventRecord(slot.ev_sort, st));
   }
@@ -218,13 +228,14 @@ do {                                                                           \
     if (pair_acc) {
       // extension field: a pair of lanes per segment (two waves per SIMD instead of one; quad.hpp pair_madd)
       msm_accumulate_pair_kernel<KF><<<dim3((unsigned)((max_segs + 63) / 64), NB), dim3(128), 0, st>>>(
-          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
+          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial,
+          ys);
       launched = true;
     }
   }
   if (!launched)
     msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial);
+        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial, ys);
   if (tune.gate.signal_ev) {
     MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
     if (tune.gate.signal_flag) tune.gate.signal_flag->store(1, std::memory_order_release);
@@ -235,7 +246,7 @@ do {                                                                           \
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_REDUCE_G2 : PROF_MSM_REDUCE, st, (double)nkeys * NB);   // units: buckets
   const size_t quad_lds = QUAD_VL * sizeof(XYZZ<Fld>);
   msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + QUAD_VL - 1) / QUAD_VL), NB), dim3(QUAD_THREADS), quad_lds, st>>>(
-      partial, max_segs, offsets, nkeys, buckets);
+      partial, max_segs, offsets, nkeys, buckets, ys);
   MSM_STAGE("finalize");
   // quads per group: few groups (one bucket set) -> whole workgroups per group, shortest dependent chain; many groups
   // (one bucket set per window) -> 4 quads per group, waves stay full
