@@ -17,9 +17,10 @@
 
 namespace zk {
 
-// Two tile sizes.  2^11-element tiles (512 threads, 64 KB of LDS, 9..11 stages per pass) are the default for n >= 2^11.
-// 2^8-element tiles worked by ONE wave serve 2^8 <= n < 2^11 (one launch instead of one per stage) and, with
-// ZK_SMALL_GROUPS=1, every n <= 2^14: as many passes, 8x the workgroups (pss.hpp small_groups for the measurement).
+// Two tile sizes.  2^11-element tiles (512 threads, 64 KB of LDS, 9..11 stages per pass) for n > 2^14; 2^8-element tiles
+// worked by ONE wave for 2^8 <= n <= 2^14 (the Groth16 circuits of the reference): as many passes, 8x the workgroups,
+// and a workgroup that fits any single wave slot (pss.hpp small_groups for the measurement; ZK_SMALL_GROUPS=0 keeps the
+// large tile from n = 2^11 up).
 constexpr int NTT_TILE_BITS = 11;
 constexpr int NTT_TILE_BITS_SMALL = 8;
 constexpr int NTT_SMALL_MAX_LOG_N = 14;

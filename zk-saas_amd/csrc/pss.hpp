@@ -19,14 +19,15 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int KING_THREADS = 256;
-// ZK_SMALL_GROUPS=1 (measured, off by default): one-wave workgroups for the short kernels of a Groth16 proof (NTT passes
-// on 2^8-element tiles, king / deg_red / vec kernels, workspace zeroing), so that a workgroup fits any single wave slot
-// the concurrent MSM accumulate kernels free.  It works as intended -- the circom_h chain of the SHA-256 proof ends at
-// 1.36 ms instead of 2.77 ms (a 512-thread NTT group waited 1.9 ms for a CU to drain) -- but the proof is bound by the
-// chip's multiplier throughput, not by that chain: the earlier U-MSM only displaces the other accumulates.  290 vs 290
-// proofs/s with tables, 205 vs 220 without (profiles/r02_small_groups_timeline.txt).
+// One-wave workgroups for the short kernels of a Groth16 proof (NTT passes on 2^8-element tiles, king / deg_red / vec
+// kernels, workspace zeroing), so that a workgroup fits any single wave slot the concurrent MSM accumulate kernels free:
+// a 512-thread / 64 KB NTT workgroup needs a whole CU to drain and waited 0.7-1.9 ms for a 0.07 ms pass.  While the proof
+// was bound by the chip's multiplier throughput this changed nothing (the earlier U-MSM only displaced the other
+// accumulates: 290 vs 290 proofs/s, profiles/r02_small_groups_timeline.txt); with the faster multiplier and the
+// identity-free sorts the circom_h -> U chain became the last to finish and it is worth +8.6 % (500 vs 460 proofs/s with
+// tables, 366 vs 360 without).  ZK_SMALL_GROUPS=0 restores the wide groups.
 inline bool small_groups() {
-  static const bool on = getenv("ZK_SMALL_GROUPS") && atoi(getenv("ZK_SMALL_GROUPS")) != 0;
+  static const bool on = !(getenv("ZK_SMALL_GROUPS") && atoi(getenv("ZK_SMALL_GROUPS")) == 0);
   return on;
 }
 inline int king_block(size_t chunks) { return (small_groups() && chunks <= ((size_t)1 << 16)) ? 64 : KING_THREADS; }
