@@ -58,6 +58,7 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
                                   uint32_t* __restrict__ counts /* [nwin*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
                                   const uint32_t* __restrict__ skip /* bit i: base i is the identity */, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(counts);
   ZK_YSHIFT(cursor);
   ZK_YSHIFT(sorted);
@@ -102,6 +103,7 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
 // Workspace zeroing by one-wave workgroups: hipMemsetAsync's 256-thread fill kernel waits for four free wave slots on
 // one CU, which the concurrent accumulate kernels of a proof rarely leave (measured 1.0 ms for a 20 us fill).
 static __global__ __launch_bounds__(64) void msm_zero_kernel(uint32_t* __restrict__ p, size_t n_words, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(p);
   size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) * 4;
   if (i + 4 <= n_words) {
@@ -125,6 +127,7 @@ template <class Fld>
 __global__ __launch_bounds__(256) void msm_skip_mask_kernel(const Affine<Fld>* __restrict__ bases0,
                                                             const Affine<Fld>* __restrict__ bases1, size_t npts,
                                                             uint32_t* __restrict__ skip, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   // ys != 0 (grid.y = 2): one mask per base vector; ys == 0: one mask, set where EVERY vector holds the identity
   ZK_YSHIFT(skip);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP
                                                                     share one bucket set; ~0: one set per window */,
                                                                     uint32_t* __restrict__ bin_counts,
                                                                     const uint32_t* __restrict__ skip, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bin_counts);
   ZK_YSHIFT(skip);
   extern __shared__ uint32_t big_lds[];
@@ -225,6 +229,7 @@ static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_scan_kernel(const 
                                                                           uint32_t nbins,
                                                                           uint32_t* __restrict__ bin_base,
                                                                           uint32_t* __restrict__ bin_cursor, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bin_counts);
   ZK_YSHIFT(bin_base);
   ZK_YSHIFT(bin_cursor);
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
                                                                        uint32_t* __restrict__ bin_cursor,
                                                                        uint2* __restrict__ tmp,
                                                                        const uint32_t* __restrict__ skip, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bin_cursor);
   ZK_YSHIFT(tmp);
   ZK_YSHIFT(skip);
@@ -305,6 +311,7 @@ static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_sort_kernel(const 
                                                                           int lo_bits, uint32_t keys_per_window_log2,
                                                                           uint32_t* __restrict__ counts,
                                                                           uint32_t* __restrict__ sorted, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(tmp);
   ZK_YSHIFT(bin_base);
   ZK_YSHIFT(counts);

@@ -287,12 +287,14 @@ __global__ void powers_kernel(F* __restrict__ out, F base, size_t count, F scale
 
 template <class F>
 __global__ void vec_add_kernel(F* __restrict__ x, const F* __restrict__ y, size_t len) {
+  __builtin_amdgcn_s_setprio(3);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < len) store_elem(x + i, load_elem(x + i) + load_elem(y + i));
 }
 
 template <class F>
 __global__ void vec_scale_kernel(F* __restrict__ x, F k, size_t len) {
+  __builtin_amdgcn_s_setprio(3);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < len) store_elem(x + i, load_elem(x + i) * k);
 }
@@ -300,6 +302,7 @@ __global__ void vec_scale_kernel(F* __restrict__ x, F k, size_t len) {
 template <class F>
 __global__ void vec_mul_sub_kernel(F* __restrict__ out, const F* __restrict__ a, const F* __restrict__ b,
                                    const F* __restrict__ c, size_t len) {
+  __builtin_amdgcn_s_setprio(3);   // on the circom_h chain: win issue arbitration against the bulk accumulate waves
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < len) store_elem(out + i, load_elem(a + i) * load_elem(b + i) - load_elem(c + i));
 }
