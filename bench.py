@@ -164,7 +164,10 @@ def proof_alu(prof, pp, table_windows, steps, dt):
             continue
         g2 = "G2" in e["kernel"]
         plan = msm_plan(pp, ZK_G2 if g2 else ZK_G1, int(e["units"] / e["launches"]))
-        windows = table_windows if table_windows else plan["windows"]
+        if isinstance(table_windows, dict):
+            windows = table_windows["g2" if g2 else "g1"]
+        else:
+            windows = table_windows if table_windows else plan["windows"]
         muls += e["units"] / steps * windows * (28 if g2 else 10)
     rate = muls / (dt / steps) / 1e9
     return {"modmuls_per_proof": int(muls), "achieved": round(rate, 2), "unit": "G modmul/s over the proof's wall time",
@@ -372,12 +375,14 @@ def main():
     r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
     masks = None if args.no_masks else zg.ProofMasks(pp, wit.log_m, seed=77)
     table_windows = None
+    table_windows_by_group = None
     if not args.no_tables:
         from zksaas_amd import api
         if os.environ.get("ZK_TABLE_C"):
             pp.set_option("msm_table_c", int(os.environ["ZK_TABLE_C"]))
         crs.precompute()
         table_windows = api.msm_table_info(pp, api.ZK_G1, crs.s)["windows"]
+        table_windows_by_group = {"g1": table_windows, "g2": api.msm_table_info(pp, api.ZK_G2, crs.v)["windows"]}
     dt, prof, proof = timed(pp, zg, crs, wit, r, s, masks, args.steps, args.warmup, torch)
 
     proofs_per_s = args.steps / dt
@@ -396,7 +401,7 @@ def main():
                    "fixed_base_tables": not args.no_tables},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
         "roofline": roofline_of(prof, ntt_passes=2, masks_on=masks is not None, pp=pp, table_windows=table_windows),
-        "proof_alu": proof_alu(prof, pp, table_windows, args.steps, dt),
+        "proof_alu": proof_alu(prof, pp, table_windows_by_group, args.steps, dt),
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
     if not args.no_primitives:
