@@ -1,6 +1,7 @@
 // Engine<Cfg>: per-curve implementation of IEngine (included by exactly one .hip file per curve).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
 
@@ -1027,14 +1028,25 @@ class Engine : public IEngine {
         int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2,
                                               is_v ? gate_v : gate_g1);
         if (is_v && which == 2) J->v_acc_flag.store(1, std::memory_order_release);   // also when the launch failed early
+        static const bool trace = getenv("ZK_TRACE_HOST") != nullptr;
+        auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (trace && !rc2) {
+          (void)hipEventSynchronize(pend->slot->ev);
+          t0 = now_us();
+        }
         if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
+        if (trace) t1 = now_us();
         J->rc[which] = rc2;
         if constexpr (std::is_same<Fld, Fq_>::value) {
           if (!rc2 && J->full) {                      // s*S and r*H off the tail (prove.rs:229-235, linearity)
             if (which == 0) J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
+            if (trace) t2 = now_us();
             if ((which == 4 || (which == 0 && out2 != nullptr)) && !J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
+            if (trace) t3 = now_us();
           }
         }
+        if (trace) fprintf(stderr, "[zk host] msm %d: gpu done %.0f, fold %.0f us, s*S %.0f us, r*H %.0f us\n", which, t0, t1 - t0, t2 ? t2 - t1 : 0.0, t3 ? t3 - t2 : 0.0);
       }));
     };
     const char* vb = (const char*)crs->v_d;

@@ -41,8 +41,10 @@ constexpr int MSM_WS = 12;            // independent workspaces: 6 per proof in 
 // Sort-stage arrays of a launch over TWO base vectors with per-vector sorts (their identity bases differ) live in two
 // copies of one workspace region; blockIdx.y picks the copy: every sort-stage kernel shifts its array pointers by
 // blockIdx.y * ys bytes (ys = 0: one sort shared by both vectors).
-#define ZK_YSHIFT(p) \
-  if (p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.y * ys)
+#define ZK_YSHIFT(p)                                                                                        \
+  do {                                                                                                      \
+    if (p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.y * ys);      \
+  } while (0)
 
 struct SegDesc {
   uint32_t bucket, start, end;
