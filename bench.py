@@ -152,11 +152,23 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None):
             "share_of_slot_time": round(best["total_ms"] / sum(e["total_ms"] for e in cands), 3)}
 
 
+def identity_fractions(pp, crs):
+    """Share of identity points in each packed query vector of the CRS (what the MSM sort leaves out).  It is a property
+    of the circuit: b_query holds the identity for every wire no B-row mentions."""
+    out = {}
+    for name, buf, width in (("a_query(S)", crs.s, 8), ("b_g1_query(H)", crs.h, 8), ("b_g2_query(V)", crs.v, 16),
+                             ("l_query(W)", crs.w, 8), ("h_query(U)", crs.u, 8)):
+        a = buf.to_numpy().reshape(-1, width)
+        out[name] = round(float((~a.any(axis=1)).mean()), 3)
+    return out
+
+
 def proof_alu(prof, pp, table_windows, steps, dt):
     """Whole-proof multiplier utilisation: the base-field products of all accumulate launches of one proof (points x
     windows x products per mixed addition: 10 in G1, 28 in G2 = 8 Fq2 products + 2 Fq2 squarings) over the proof's
     WALL time.  The per-kernel figure in `roofline.alu` divides one launch's products by that launch's duration while
-    three or four other MSMs share the chip with it; this one does not depend on how the launches overlap."""
+    three or four other MSMs share the chip with it; this one does not depend on how the launches overlap.  It counts
+    the additions of ALL points, also of the identity bases the sort leaves out (config.crs_identity_fraction)."""
     from zksaas_amd.api import ZK_G1, ZK_G2, msm_plan
     muls = 0.0
     for e in prof:
@@ -398,7 +410,8 @@ def main():
                    "masks": masks is not None, "constraints": r1.num_constraints,
                    "wires": r1.num_variables, "domain": 1 << wit.log_m, "len_a": crs.len_a, "len_w": crs.len_w,
                    "len_u": crs.len_u, "parties": pp.n, "packing_factor": pp.l,
-                   "fixed_base_tables": not args.no_tables},
+                   "fixed_base_tables": not args.no_tables,
+                   "crs_identity_fraction": identity_fractions(pp, crs)},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
         "roofline": roofline_of(prof, ntt_passes=2, masks_on=masks is not None, pp=pp, table_windows=table_windows),
         "proof_alu": proof_alu(prof, pp, table_windows_by_group, args.steps, dt),
