@@ -286,6 +286,13 @@ __global__ void powers_kernel(F* __restrict__ out, F base, size_t count, F scale
 }
 
 template <class F>
+__global__ void vec_sum_kernel(F* __restrict__ out, const F* __restrict__ a, const F* __restrict__ b, size_t len) {
+  __builtin_amdgcn_s_setprio(3);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) store_elem(out + i, load_elem(a + i) + load_elem(b + i));
+}
+
+template <class F>
 __global__ void vec_add_kernel(F* __restrict__ x, const F* __restrict__ y, size_t len) {
   __builtin_amdgcn_s_setprio(3);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
