@@ -118,3 +118,34 @@ def test_production_share_randomness_is_fresh_per_call_and_ignores_the_seed():
     finally:
         pp.close()
         pp2.close()
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_377", "bls12_381"])
+def test_field_arithmetic_edge_values(curve):
+    """out = a*b - c (zk_vec_mul_sub), x += y (zk_vec_add) and x *= k (zk_vec_scale) on the values a Montgomery multiplier
+    and the carry chains get wrong first: 0, 1, p-1, p-2, 2^k +- 1, all-ones limbs below p, R mod p, plus random ones --
+    against Python integers (the device multiplier is the product-scanning form of csrc/field.hpp, the adder / subtracter
+    the carry-builtin chains)."""
+    import zksaas_amd as zk
+    pp, o = ctx(curve, 2), opp(curve, 2)
+    p = o.p
+    nb = p.bit_length()
+    edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 32) - 1, 1 << 32, (1 << 64) - 1, 1 << 64,
+            (1 << 128) - 1, (1 << (nb - 1)) - 1, (1 << (nb - 1)) % p, (1 << 256) % p, ((1 << 256) - 1) % p,
+            pow(2, 256, p) * pow(2, 256, p) % p, p - ((1 << 256) % p)]
+    edge = [e % p for e in edge]
+    rnd = rand_vec(91, 400, p)
+    a = [x for x in edge for _ in edge] + rnd
+    b = [y for _ in edge for y in edge] + rand_vec(92, 400, p)
+    c = [edge[(i * 7) % len(edge)] for i in range(len(edge) ** 2)] + rand_vec(93, 400, p)
+    n = len(a)
+    out = pp.alloc_fr(n)
+    zk.api.vec_mul_sub(pp, out, up(pp, a), up(pp, b), up(pp, c), n)
+    assert pp.download_fr(out) == [(x * y - z) % p for x, y, z in zip(a, b, c)]
+    xs = up(pp, a)
+    pp._check(pp.lib.zk_vec_add(pp.h, xs.ptr, up(pp, b).ptr, n, None))
+    assert pp.download_fr(xs) == [(x + y) % p for x, y in zip(a, b)]
+    for k in (0, 1, p - 1, (1 << 256) % p, rnd[0]):
+        xs = up(pp, a)
+        zk.api.vec_scale(pp, xs, k, n)
+        assert pp.download_fr(xs) == [x * k % p for x in a]
