@@ -13,6 +13,7 @@
 #include "field.hpp"
 #include "ntt.hpp"
 #include "pss.hpp"
+#include "hostpool.hpp"
 #include "net.hpp"
 
 namespace zk {
@@ -171,6 +172,8 @@ class TableRegistry {
 class IEngine {
  public:
   virtual ~IEngine() {}
+  // the context's host worker pool (nullptr before the first prover call): msm_fold splits a table-free fold over it
+  virtual HostPool* host_pool() { return nullptr; }
   Profiler prof;
   int l = 0, n = 0, t = 0, device = 0;
   Status last;

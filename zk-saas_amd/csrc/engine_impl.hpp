@@ -2286,6 +2286,7 @@ class Engine : public IEngine {
     return ZK_OK;
   }
   std::unique_ptr<HostPool> pool_;
+  HostPool* host_pool() override { return pool_.get(); }
   hipEvent_t ev_in_[NJOBS] = {nullptr, nullptr};
   hipEvent_t ev_gate_[NJOBS] = {nullptr, nullptr};
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

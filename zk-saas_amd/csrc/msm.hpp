@@ -18,6 +18,7 @@
 //                     (254 sequential doublings: latency-bound on any one lane, cheap on a CPU core).
 #pragma once
 #include <atomic>
+#include <future>
 #include <thread>
 #include <algorithm>
 #include <cstdio>
@@ -939,9 +940,11 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
   const int kwin = p.kwin, c = p.c, wide = p.wide, lo_bits = p.lo_bits, nslices = p.c;
   const int hb = c - 1 - lo_bits;                  // row slices 0..hb come first, then lo_bits column slices
   const XYZZ<Fld>* hall = (const XYZZ<Fld>*)p.slot->pinned;
-  auto fold = [&](const XYZZ<Fld>* h) -> XYZZ<Fld> {
+  // windows [w_lo, w_hi] of one vector, high to low, doublings only INSIDE the range:
+  // sum_w 2^(start_w - start_w_lo) X_w with X_w = sum_j 2^(j + lo_bits) TR_j + sum_j 2^j TC_j
+  auto fold_range = [&](const XYZZ<Fld>* h, int w_hi, int w_lo) -> XYZZ<Fld> {
     XYZZ<Fld> total = XYZZ<Fld>::identity();
-    for (int w = kwin - 1; w >= 0; w--) {
+    for (int w = w_hi; w >= w_lo; w--) {
       const XYZZ<Fld>* sl = h + (size_t)w * nslices;
       const int cw = (kwin == 1 || w < wide) ? c : c - 1;
       for (int t = cw - 1; t >= 0; t--) {
@@ -952,8 +955,50 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
     }
     return total;
   };
-  *result = fold(hall);
-  if (p.nb == 2 && result2) *result2 = fold(hall + (size_t)kwin * nslices);
+  auto width_of = [&](int w_hi, int w_lo) {
+    int bits = 0;
+    for (int w = w_hi; w >= w_lo; w--) bits += (kwin == 1 || w < wide) ? c : c - 1;
+    return bits;
+  };
+  // Table-free MSMs have one bucket set per window: ~250 doublings + ~2c additions per window on one host thread
+  // (0.4 ms for G2, the gap between two table-free proofs).  With the context's worker pool the windows are folded in
+  // FOLD_PARTS contiguous groups in parallel and the groups joined by one walk of doublings: the additions leave the
+  // critical path.  (With a fixed-base table there is one window and nothing to split.)
+  constexpr int FOLD_PARTS = 4;
+  HostPool* pool = eng->host_pool();
+  static const bool par_fold = !(getenv("ZK_PAR_FOLD") && atoi(getenv("ZK_PAR_FOLD")) == 0);
+  const int nvec = (p.nb == 2 && result2) ? 2 : 1;
+  if (!pool || !par_fold || kwin < 2 * FOLD_PARTS) {
+    *result = fold_range(hall, kwin - 1, 0);
+    if (nvec == 2) *result2 = fold_range(hall + (size_t)kwin * nslices, kwin - 1, 0);
+    return ZK_OK;
+  }
+  XYZZ<Fld> part[2][FOLD_PARTS];
+  int lo_w[FOLD_PARTS], hi_w[FOLD_PARTS];
+  for (int g = 0; g < FOLD_PARTS; g++) {          // group 0 = the highest windows
+    hi_w[g] = kwin - 1 - (int)((long)kwin * g / FOLD_PARTS);
+    lo_w[g] = kwin - (int)((long)kwin * (g + 1) / FOLD_PARTS);
+  }
+  std::vector<std::future<void>> futs;
+  for (int v = 0; v < nvec; v++)
+    for (int g = 0; g < FOLD_PARTS; g++) {
+      if (v == 0 && g == 0) continue;              // this thread's share
+      const XYZZ<Fld>* h = hall + (size_t)v * kwin * nslices;
+      XYZZ<Fld>* dst = &part[v][g];
+      const int a = hi_w[g], b = lo_w[g];
+      futs.push_back(pool->submit([=, &fold_range]() { *dst = fold_range(h, a, b); }));
+    }
+  part[0][0] = fold_range(hall, hi_w[0], lo_w[0]);
+  for (auto& f : futs) f.get();
+  for (int v = 0; v < nvec; v++) {
+    XYZZ<Fld> total = part[v][0];
+    for (int g = 1; g < FOLD_PARTS; g++) {
+      const int bits = width_of(hi_w[g], lo_w[g]);
+      for (int i = 0; i < bits; i++) total = xyzz_dbl_ni(total);
+      total = xyzz_add_ni(total, part[v][g]);
+    }
+    *(v == 0 ? result : result2) = total;
+  }
   return ZK_OK;
 }
 
