@@ -38,7 +38,9 @@ for i, r in enumerate(rows):
         bounds.append(i)
     end = max(end, int(r["End_Timestamp"]))
 bounds.append(len(rows))
-lo, hi = bounds[-1 - back], bounds[-back]
+# windows that are whole proofs (the table build, a lone copy between two proofs etc. are not)
+wins = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i + 1] - bounds[i] >= 40]
+lo, hi = wins[-back] if len(wins) >= back else wins[0]
 sel = rows[lo:hi]
 t0 = int(sel[0]["Start_Timestamp"])
 print(f"proof window: {len(sel)} launches, {(max(int(r['End_Timestamp']) for r in sel) - t0) / 1e6:.3f} ms busy, "
