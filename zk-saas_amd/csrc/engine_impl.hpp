@@ -427,8 +427,9 @@ class Engine : public IEngine {
   int vec_mul_sub(void* out, const void* a, const void* b, const void* c, size_t len, hipStream_t st) override {
     if (!len) return ZK_OK;
     const unsigned bk = (unsigned)king_block(len);       // one-wave groups at proof sizes (see king_block)
-    vec_mul_sub_kernel<Fr><<<dim3((unsigned)((len + bk - 1) / bk)), dim3(bk), 0, st>>>((Fr*)out, (const Fr*)a,
-                                                                                      (const Fr*)b, (const Fr*)c, len);
+    size_t wgs = (len + bk - 1) / bk;
+    if (bk == 64 && wgs > 512) wgs = 512;                // grid-stride inside (see the kernel)
+    vec_mul_sub_kernel<Fr><<<dim3((unsigned)wgs), dim3(bk), 0, st>>>((Fr*)out, (const Fr*)a, (const Fr*)b, (const Fr*)c, len);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
