@@ -5,6 +5,7 @@
 // multiples of CRS constants and of the out-masks in prove.rs:40-56, 99-110, 229-235, and the final window fold of an
 // MSM.  All of it is submitted when a proof starts and runs beside the device work; nothing spawns threads per call.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -30,7 +31,9 @@ class HostPool {
             job = std::move(q_.front());
             q_.pop_front();
           }
+          busy_.fetch_add(1, std::memory_order_relaxed);
           job();
+          busy_.fetch_sub(1, std::memory_order_relaxed);
         }
       });
   }
@@ -53,6 +56,9 @@ class HostPool {
     return f;
   }
   int size() const { return (int)workers_.size(); }
+  // workers not running a task right now (a task that fans out to the pool and waits checks this first: waiting for
+  // sub-tasks that no free worker can pick up would be a deadlock)
+  int idle() const { return (int)workers_.size() - busy_.load(std::memory_order_relaxed); }
 
  private:
   std::mutex mu_;
@@ -60,6 +66,7 @@ class HostPool {
   std::deque<std::packaged_task<void()>> q_;
   std::vector<std::thread> workers_;
   bool stop_ = false;
+  std::atomic<int> busy_{0};
 };
 
 }  // namespace zk

@@ -968,7 +968,9 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
   HostPool* pool = eng->host_pool();
   static const bool par_fold = !(getenv("ZK_PAR_FOLD") && atoi(getenv("ZK_PAR_FOLD")) == 0);
   const int nvec = (p.nb == 2 && result2) ? 2 : 1;
-  if (!pool || !par_fold || kwin < 2 * FOLD_PARTS) {
+  // only with free workers for every sub-task: this may itself be a pool task, and waiting for sub-tasks that nobody can
+  // pick up would deadlock the pool
+  if (!pool || !par_fold || kwin < 2 * FOLD_PARTS || pool->idle() < 2 * FOLD_PARTS) {
     *result = fold_range(hall, kwin - 1, 0);
     if (nvec == 2) *result2 = fold_range(hall + (size_t)kwin * nslices, kwin - 1, 0);
     return ZK_OK;
