@@ -611,27 +611,29 @@ class Engine : public IEngine {
   // ---------------------------------------------------------------- deg_red (deg_red.rs:80-126)
   template <int L>
   int degred_l(const Fr* in, const Fr* in_mask, int np, size_t len, const Fr* U, uint64_t seed, Fr* out,
-               const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0) {
+               const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
+               const Fr* sub_c = nullptr) {
     if (!stride) stride = len;
     const size_t kbk = (size_t)king_block(len);
     dim3 grid((unsigned)((len + kbk - 1) / kbk)), block((unsigned)kbk);
     ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
     king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, rs(seed), out, out_mask,
-                                                       stride, j0);
+                                                       stride, j0, mul_b, sub_c);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
   int deg_red_np(const Fr* in, const Fr* in_mask, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
-                 const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0) {
+                 const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
+                 const Fr* sub_c = nullptr) {
     if (!len) return ZK_OK;
     const Fr* U = nullptr;
     int rc = umat_for(parties, np, &U);
     if (rc) return rc;
     switch (l) {
-      case 1: return degred_l<1>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
-      case 2: return degred_l<2>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
-      case 4: return degred_l<4>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
-      default: return degred_l<8>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0);
+      case 1: return degred_l<1>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
+      case 2: return degred_l<2>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
+      case 4: return degred_l<4>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
+      default: return degred_l<8>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
     }
   }
   int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed, hipStream_t st) override {
@@ -875,11 +877,9 @@ class Engine : public IEngine {
     if (rc) return rc;
     rc = king3(W1, mk, 3, log_m, 0, nullptr, 0, 0, seed + 3, W0, per, st);
     if (rc) return rc;
-    // h = a*b - c share-wise, then deg_red     (ext_wit.rs:173-179)
-    rc = vec_mul_sub(h, W0, W0 + per, W0 + 2 * per, per, st);
-    if (rc) return rc;
-    return deg_red_np((const Fr*)h, mk ? (const Fr*)mk->degred_in : nullptr, nullptr, n, Lc, seed + 6, (Fr*)h,
-                      mk ? (const Fr*)mk->degred_out : nullptr, st);
+    // h = a*b - c share-wise, then deg_red     (ext_wit.rs:173-179): the product is formed at deg_red's load
+    return deg_red_np(W0, mk ? (const Fr*)mk->degred_in : nullptr, nullptr, n, Lc, seed + 6, (Fr*)h,
+                      mk ? (const Fr*)mk->degred_out : nullptr, st, 0, 0, W0 + per, W0 + 2 * per);
   }
 
   // ---------------------------------------------------------------- prover (prove.rs, sha256.rs:32-129)

@@ -345,9 +345,12 @@ template <class P, int L>
 __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
     const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
-    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask, size_t stride, size_t j0) {
+    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask, size_t stride, size_t j0,
+    const Fp<P>* __restrict__ mul_b, const Fp<P>* __restrict__ sub_c) {
   // stride = row pitch of in / out (len for whole vectors); j0 = global index of column 0 (share randomness of a chunk
-  // range of the all-to-all king must be the one the star king would draw)
+  // range of the all-to-all king must be the one the star king would draw).  mul_b / sub_c (optional, same layout as
+  // `in`): the input share is in * mul_b - sub_c, i.e. circom_h's a*b - c (ext_wit.rs:173-177) computed at the load
+  // instead of by a kernel of its own on the proof's critical chain.
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
 #pragma unroll 1
   for (int s = 0; s < np; s++) {
     F x = load_elem(in + (size_t)s * stride + j);
+    if (mul_b) x = x * load_elem(mul_b + (size_t)s * stride + j) - load_elem(sub_c + (size_t)s * stride + j);
     if (in_mask) x = x + load_elem(in_mask + (size_t)s * stride + j);
 #pragma unroll
     for (int i = 0; i < L; i++) sec[i] = sec[i] + mulsel<L>(U[i * np + s], x);
