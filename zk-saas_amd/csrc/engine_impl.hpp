@@ -436,6 +436,10 @@ class Engine : public IEngine {
 
   // ---------------------------------------------------------------- fft1 (dfft/mod.rs:178-208)
   int fft1(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st) override {
+    return fft1_src(shares, log_m, inverse, batch, add, st, NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1});
+  }
+  // src (optional): the first pass reads vector y from src.p[y / src.per] instead of from `shares` (out of place)
+  int fft1_src(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st, NttSrc<Fr> src) {
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     int log_n = log_m - log_l;
@@ -445,6 +449,11 @@ class Engine : public IEngine {
     if (rc) return rc;
     Fr* data = (Fr*)shares;
     size_t nvec = (size_t)1 << log_n;
+    if ((log_n < NTT_TILE_BITS_SMALL || force_simple_ntt) && src.p[0]) {
+      for (size_t y = 0; y < batch; y += src.per)
+        ZK_HIP(hipMemcpyAsync(data + y * nvec, src.p[y / src.per], (size_t)src.per * nvec * sizeof(Fr),
+                              hipMemcpyDeviceToDevice, st));
+    }
     if (log_n < NTT_TILE_BITS_SMALL || force_simple_ntt) {
       for (int s = 1; s <= log_n; s++) {
         size_t work = (nvec / 2) * batch;
@@ -456,11 +465,12 @@ class Engine : public IEngine {
       return ZK_OK;
     }
     if (ntt_tile_bits(log_n) == NTT_TILE_BITS_SMALL && (small_groups() || log_n < NTT_TILE_BITS))
-      return fft1_tiled<NTT_TILE_BITS_SMALL>(data, log_n, log_l, batch, tw, (const Fr*)add, st);
-    return fft1_tiled<NTT_TILE_BITS>(data, log_n, log_l, batch, tw, (const Fr*)add, st);
+      return fft1_tiled<NTT_TILE_BITS_SMALL>(data, log_n, log_l, batch, tw, (const Fr*)add, st, src);
+    return fft1_tiled<NTT_TILE_BITS>(data, log_n, log_l, batch, tw, (const Fr*)add, st, src);
   }
   template <int TB>
-  int fft1_tiled(Fr* data, int log_n, int log_l, size_t batch, const Fr* tw, const Fr* add, hipStream_t st) {
+  int fft1_tiled(Fr* data, int log_n, int log_l, size_t batch, const Fr* tw, const Fr* add, hipStream_t st,
+                 NttSrc<Fr> src) {
     constexpr size_t TILE = (size_t)1 << TB;
     const size_t nvec = (size_t)1 << log_n;
     NttPlan plan = make_ntt_plan(log_n, TB);
@@ -476,8 +486,9 @@ class Engine : public IEngine {
       }
       dim3 grid((unsigned)(nvec >> TB), (unsigned)batch);
       ProfScope ps_(prof, PROF_NTT_PASS, st, (double)nvec * batch);
-      ntt_pass_kernel<Fr, TB><<<grid, dim3((unsigned)(TILE / 4)), lds, st>>>(data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l,
-                                                                           p == plan.npass - 1 ? add : nullptr);
+      ntt_pass_kernel<Fr, TB><<<grid, dim3((unsigned)(TILE / 4)), lds, st>>>(
+          data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l, p == plan.npass - 1 ? add : nullptr,
+          p == 0 ? src : NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1});
       ZK_HIP(hipGetLastError());
     }
     return ZK_OK;
@@ -863,12 +874,10 @@ class Engine : public IEngine {
     ZK_HIP(hwork.ensure(6 * per * sizeof(Fr)));
     Fr* W0 = (Fr*)hwork.p;
     Fr* W1 = W0 + 3 * per;
-    const void* q[3] = {qa, qb, qc};
-    for (int k = 0; k < 3; k++)
-      ZK_HIP(hipMemcpyAsync(W0 + k * per, q[k], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     Fr w2m = root_of_unity(log_m + 1);     // Radix2EvaluationDomain::new(2m).element(1), ext_wit.rs:120-125
-    // 3 x d_ifft(rearrange = true, g = w_2m)   (ext_wit.rs:127-159)
-    int rc = fft1(W0, log_m, 1, 3 * (size_t)n, nullptr, st);
+    // 3 x d_ifft(rearrange = true, g = w_2m)   (ext_wit.rs:127-159); the first pass reads the caller's vectors (no copy)
+    int rc = fft1_src(W0, log_m, 1, 3 * (size_t)n, nullptr, st,
+                      NttSrc<Fr>{{(const Fr*)qa, (const Fr*)qb, (const Fr*)qc}, (uint32_t)n});
     if (rc) return rc;
     rc = king3(W0, mk, 0, log_m, 1, &w2m, 1, 1, seed, W1, per, st);
     if (rc) return rc;

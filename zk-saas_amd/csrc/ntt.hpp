@@ -118,11 +118,18 @@ struct LdsVec {
 //              later pass is read from HBM/L2 once per element.
 //   pass 0 (s0 == 0) uses the shifted exponent k+1 and no pre-twiddle.
 //   add      : optional [batch][n] added at the final store (in_mask)
+// optional read-only sources of the FIRST pass: vector y of the batch is read from p[y / per] + (y % per) * n instead of
+// from `data` (circom_h transforms the caller's three QAP vectors into its work buffer without copying them first)
+template <class F>
+struct NttSrc {
+  const F* p[3];
+  uint32_t per;
+};
 template <class F, int TB>
 __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0,
                                                                                int s1, int cbits,
                                                                                const F* __restrict__ tw_full, int log_l,
-                                                                               const F* __restrict__ add) {
+                                                                               const F* __restrict__ add, NttSrc<F> src) {
   constexpr int NTT_TILE_BITS = TB;                  // shadow the namespace-level (large tile) constants
   constexpr int NTT_TILE = 1 << TB;
   constexpr int NTT_THREADS = NTT_TILE / 4;
@@ -138,6 +145,7 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
   const int tid = threadIdx.x;
   const size_t n = (size_t)1 << log_n;
   F* vec = data + (size_t)blockIdx.y * n;
+  const F* vin = src.p[0] ? src.p[blockIdx.y / src.per] + (size_t)(blockIdx.y % src.per) * n : vec;
   const F* addv = add ? add + (size_t)blockIdx.y * n : nullptr;
 
   // tile origin
@@ -165,7 +173,7 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
     uint32_t r = (x >> cbits) & (R - 1);
     uint32_t hb = x >> (cbits + rbits);
     size_t gi = ((h0 + hb) << s1) + ((size_t)r << s0) + c0 + c;
-    F v = load_elem(vec + gi);
+    F v = load_elem(vin + gi);
     if (!shifted) {
       // w_{2^s1}^((c0+c+1)*rev(r)) = w_m^(e << (log_m - s1))
       uint64_t e = (uint64_t)(c0 + c + 1) * bitrev32(r, rbits);
