@@ -109,6 +109,7 @@ struct MsmTable {
   int c = 0, nwin = 0, wide = 0, bits = 0, device = 0;
   const void* owner = nullptr;    // the engine that built it (dropped with it)
   void* data = nullptr;           // [nwin][len] affine
+  bool any_identity = true;       // false: no base of the vector is the identity (MSMs over it need no skip mask)
   ~MsmTable() {
     if (data) (void)hipFree(data);
   }

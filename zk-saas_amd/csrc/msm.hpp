@@ -1229,6 +1229,24 @@ class MsmRunner {
     if (rc) return rc;
     he = hipStreamSynchronize(st);
     if (he != hipSuccess) return eng->hip_fail(he, "msm_table_kernel");
+    {
+      // does the vector hold any identity at all?  (once, here: an MSM over a vector without one skips the mask kernel)
+      using KF = typename KernelField<Fld>::type;
+      const size_t words = ((len + 63) / 64) * 2;
+      uint32_t* mask_d = nullptr;
+      he = hipMalloc(&mask_d, words * 4);
+      if (he != hipSuccess) return eng->hip_fail(he, "identity mask");
+      msm_skip_mask_kernel<KF><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>((const Affine<KF>*)bases, nullptr, len,
+                                                                                       mask_d, 0);
+      std::vector<uint32_t> mask_h(words);
+      he = hipMemcpyAsync(mask_h.data(), mask_d, words * 4, hipMemcpyDeviceToHost, st);
+      if (he == hipSuccess) he = hipStreamSynchronize(st);
+      (void)hipFree(mask_d);
+      if (he != hipSuccess) return eng->hip_fail(he, "identity mask");
+      bool any = false;
+      for (size_t i = 0; i < (len + 31) / 32 && !any; i++) any = mask_h[i] != 0;
+      t->any_identity = any;
+    }
     TableRegistry::inst().add(std::move(t));
     return ZK_OK;
   }

@@ -71,7 +71,9 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   // workspace region (ZK_YSHIFT in the kernels); ZK_MSM_ONE_SORT=1 keeps the single shared sort.
   static const bool skip_on = !(getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0);
   static const bool one_sort = getenv("ZK_MSM_ONE_SORT") && atoi(getenv("ZK_MSM_ONE_SORT")) != 0;
-  const unsigned NS = (NB == 2 && skip_on && !one_sort) ? 2u : 1u;       // sorts of this launch
+  // registered vectors know whether they hold an identity at all (zk_msm_precompute): without one there is no mask
+  const bool none = tab && !tab->any_identity && (NB == 1 || (tab2 && !tab2->any_identity));
+  const unsigned NS = (NB == 2 && skip_on && !one_sort && !none) ? 2u : 1u;       // sorts of this launch
   // ---- sort region (replicated NS times)
   size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
          o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc));
@@ -156,7 +158,7 @@ do {                                                                           \
   MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st, NS, ys));   // counts and lenhist
   dim3 pg((unsigned)((npts + 255) / 256), NS), pb(256);
   uint32_t* skip = nullptr;
-  if (skip_on) {
+  if (skip_on && !none) {
     skip = (uint32_t*)(ws + o_skip);
     msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip, ys);
   }
