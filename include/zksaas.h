@@ -292,6 +292,36 @@ int zk_groth16_wait(zk_ctx* ctx, int handle, void* pi_a, void* pi_b, void* pi_c)
 int zk_groth16_abort(zk_ctx* ctx, int handle);
 int zk_groth16_assemble(zk_ctx* ctx, const zk_crs_share* crs, const void* r, const void* s, const void* const* sums,
                         const zk_groth16_masks* masks, void* pi_a, void* pi_b, void* pi_c);
+/* A BATCH of proofs against one packed CRS in one pass -- what a proving service does with the reference by spawning
+ * concurrent dsha256 runs (mpc-net/src/multi.rs:317-327 runs the parties as concurrent tasks; groth16/examples/
+ * sha256.rs:316-360 is one such run): nproofs (1..16) witnesses, each with its own QAP shares, witness shares, (r, s)
+ * and masks, same CRS and domain.  Every one of the five d_msm is ONE sort / accumulate / reduce chain over nproofs
+ * scalar vectors against the shared base vector, circom_h one launch chain over 3 nproofs vectors; the results are the
+ * group elements nproofs calls of zk_groth16_prove give.  Pointer arrays are host arrays of device pointers; r, s:
+ * nproofs Montgomery Fr each (host, contiguous); masks: nproofs entries or NULL; pi_a / pi_c: [nproofs][n] Jacobian G1,
+ * pi_b: [nproofs][n] Jacobian G2 (host).  Replay mode: proof b draws the share randomness zk_groth16_prove draws with
+ * seed + 16 b. */
+int zk_groth16_prove_batch(zk_ctx* ctx, const zk_crs_share* crs, int nproofs, const void* const* qap_a_d,
+                           const void* const* qap_b_d, const void* const* qap_c_d, const void* const* a_share_d,
+                           const void* const* ax_share_d, const void* r, const void* s, int log2_m,
+                           const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c, void* stream);
+/* G::msm of ONE base vector bases_d [len] against nvec (1..16) scalar vectors scalars_d[v] [len] (dmsm/mod.rs:73 called
+ * once per witness): one Pippenger pass with bucket sets per scalar vector.  out: nvec Jacobian points (host). */
+int zk_msm_batch(zk_ctx* ctx, int group, const void* bases_d, size_t len, const void* const* scalars_d, int nvec,
+                 void* out, void* stream);
+/* unpack / unpack2 over GROUP elements (secret-sharing/src/pss.rs:125-166 with T = curve point; lagrange_unpack
+ * :170-221 for a party subset): shares_d [nparties][nchunks] affine points of the listed parties (ascending ids, NULL =
+ * 0..nparties-1) -> out_d [nchunks][l] affine.  zk_pss_unpack_points needs all n parties. */
+int zk_pss_unpack_points(zk_ctx* ctx, int group, const void* shares_d, size_t nchunks, void* out_d, void* stream);
+int zk_pss_unpack2_points(zk_ctx* ctx, int group, const void* shares_d, const uint32_t* parties, int nparties,
+                          size_t nchunks, void* out_d, void* stream);
+/* The last step of the reference's run (groth16/examples/sha256.rs:375-377): (a, b, c) = pp.unpack2(shares)[0] over the
+ * parties' proof shares.  pi_a / pi_c: nparties Jacobian G1, pi_b: nparties Jacobian G2 (host) of the listed parties
+ * (ascending ids, NULL = all n; a subset goes through lagrange_unpack and needs more than 2 (t + l - 1) of them).
+ * proof_affine (optional, host): A (G1) | B (G2) | C (G1) as affine Montgomery points; proof_bytes (optional, host):
+ * ark_groth16::Proof::serialize_compressed, 4 |Fq| bytes (128 for BN254; BLS12-381: 192 in the zcash form). */
+int zk_groth16_reconstruct(zk_ctx* ctx, const void* pi_a, const void* pi_b, const void* pi_c, const uint32_t* parties,
+                           int nparties, void* proof_affine, void* proof_bytes, void* stream);
 
 /* ---- the star network on one multi-GPU node (mpc-net/src/lib.rs:43-53, 89-176 `MpcNet`; ser_net.rs:16-120) -------
  * One process per GPU; rank rho drives the k = n / world parties [rho*k, (rho+1)*k) (party p -> rank p / k is the only
@@ -325,7 +355,12 @@ int zk_net_stats(const zk_net* net, uint64_t stats[4]);   /* since creation: gat
  * the channel's stream; zk_net_sync waits for it with the timeout as deadline.
  * zk_net_alltoall (no counterpart in mpc-net, whose topology is a star: the exchange of the all-to-all king, option
  * "king_alltoall"): the block for rank r is read at send + r*bytes_per_peer (indexed by RANK), the block from the i-th
- * PRESENT rank lands at recv + i*bytes_per_peer (compacted, like gather). */
+ * PRESENT rank lands at recv + i*bytes_per_peer (compacted, like gather).
+ * Waiting: the zk_dist_* calls return with their device work enqueued and make the caller's stream wait for the channel
+ * streams.  A host that wants the timeout to hold for the data plane as well (a peer that dies mid-round, a hung RCCL
+ * collective) calls zk_net_sync(net, sid) BEFORE synchronising its own stream: zk_net_sync waits with the timeout as a
+ * deadline, aborts the communicators on expiry and returns ZK_ERR_PROTOCOL; a plain stream synchronise would block
+ * behind the hung collective forever.  After a PROTOCOL / NOT_CONNECTED result the net must be destroyed and rebuilt. */
 int zk_net_enter(zk_net* net, int sid, uint32_t* mask);
 int zk_net_gather(zk_net* net, int sid, uint32_t mask, const void* local, size_t bytes_per_rank, void* full);
 int zk_net_scatter(zk_net* net, int sid, uint32_t mask, const void* full, size_t bytes_per_rank, void* local);

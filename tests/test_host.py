@@ -37,6 +37,17 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert e.value.code == 3
 
 
+def test_load_then_import_torch_exits_cleanly():
+    """loading the library (which shares torch's HIP runtime) and importing torch afterwards must not abort
+    the interpreter at exit (a global preload of torch's librccl did: 'double free or corruption', exit 134)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import zksaas_amd as zk; zk.load(); "
+            "from zksaas_amd import net; net.StarNet.unique_id(); import torch; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stderr[-400:])
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "zk-saas_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -21,6 +21,7 @@ SYMBOLS = [
     "zk_dist_groth16_prove", "zk_chacha20_block", "zk_deg_red_points", "zk_degred_mask_sample_points",
     "zk_points_decompress", "zk_points_compress", "zk_libsnark_h", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
+    "zk_groth16_prove_batch", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct",
 ]
 
 _lib = None
@@ -46,13 +47,16 @@ def _share_hip_runtime_with_torch():
         spec = None
     if spec is None or not spec.origin:
         return
-    for name in ("libamdhip64.so", "librccl.so"):      # one HIP runtime and one RCCL per process
-        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
-        if os.path.exists(cand):
-            try:
-                C.CDLL(cand, mode=C.RTLD_GLOBAL)
-            except OSError:
-                pass
+    # Only the HIP runtime.  RCCL is NOT preloaded: net.hpp's Rccl::load finds torch's copy with RTLD_NOLOAD once torch
+    # is imported and dlopens it lazily otherwise, and only for the RCCL transport -- a global preload of torch's
+    # librccl before `import torch` made the process abort at exit on a box without a GPU (double free in the two
+    # copies' static destructors; tests/test_host.py::test_load_then_import_torch_exits_cleanly).
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -154,6 +158,12 @@ def load():
     lib.zk_deg_red_parties.argtypes = [vp, vp, C.POINTER(C.c_uint32), i32, vp, vp, sz, u64, vp, vp]
     lib.zk_d_msm_parties.argtypes = [vp, i32, vp, vp, sz, C.POINTER(C.c_uint32), i32, vp, vp, vp, vp]
     lib.zk_pss_pack_points.argtypes = [vp, i32, vp, sz, i32, vp, vp]
+    lib.zk_groth16_prove_batch.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                           C.POINTER(vp), vp, vp, i32, vp, u64, vp, vp, vp, vp]
+    lib.zk_msm_batch.argtypes = [vp, i32, vp, sz, C.POINTER(vp), i32, vp, vp]
+    lib.zk_pss_unpack_points.argtypes = [vp, i32, vp, sz, vp, vp]
+    lib.zk_pss_unpack2_points.argtypes = [vp, i32, vp, C.POINTER(C.c_uint32), i32, sz, vp, vp]
+    lib.zk_groth16_reconstruct.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_uint32), i32, vp, vp, vp]
     lib.zk_profile_enable.argtypes = [vp, i32]
     lib.zk_profile_slots.argtypes = []
     lib.zk_profile_name.argtypes = [i32]

@@ -272,6 +272,33 @@ def msm(pp, group, bases_d, scalars_d, length, len_scalars=None, stream=None):
     return out
 
 
+def msm_batch(pp, group, bases_d, scalar_vectors, length, stream=None):
+    """zk_msm_batch: ONE base vector against several scalar vectors (G::msm once per witness, one Pippenger pass):
+    returns [nvec][3 * coord limbs] Jacobian points."""
+    nl = pp.fq.nl * (2 if group == ZK_G2 else 1)
+    nv = len(scalar_vectors)
+    out = np.zeros((nv, 3 * nl), dtype=np.uint64)
+    arr = (C.c_void_p * nv)(*[_ptr(v) for v in scalar_vectors])
+    pp._check(pp.lib.zk_msm_batch(pp.h, group, _ptr(bases_d), length, arr, nv, out.ctypes.data, stream))
+    return out
+
+
+def unpack_points(pp, group, shares_d, nchunks, parties=None, two=True, out=None, stream=None):
+    """pss.rs:125-166 over group elements: shares_d [nparties][nchunks] affine -> [nchunks][l] affine (device).
+    two=False: unpack (all n parties); parties: ascending ids of the shares present (lagrange_unpack)."""
+    width = pp.fq.nl * (4 if group == ZK_G2 else 2) * 8
+    out = out or DeviceBuffer(pp, nchunks * pp.l * width)
+    if not two:
+        pp._check(pp.lib.zk_pss_unpack_points(pp.h, group, _ptr(shares_d), nchunks, _ptr(out), stream))
+        return out
+    if parties is None:
+        pp._check(pp.lib.zk_pss_unpack2_points(pp.h, group, _ptr(shares_d), None, pp.n, nchunks, _ptr(out), stream))
+    else:
+        ids = (C.c_uint32 * len(parties))(*parties)
+        pp._check(pp.lib.zk_pss_unpack2_points(pp.h, group, _ptr(shares_d), ids, len(parties), nchunks, _ptr(out), stream))
+    return out
+
+
 def fr_to_bytes(pp, x_d, count, stream=None):
     """ark-serialize CanonicalSerialize of `count` Fr elements of a device vector: bytes (32 or 48 per element,
     little-endian canonical integers) -- the payload of an mpc-net frame (ser_net.rs:24-25)."""

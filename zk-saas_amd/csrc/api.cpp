@@ -294,6 +294,33 @@ int zk_groth16_prove_async(zk_ctx* ctx, const zk_crs_share* crs, const void* qap
   return e->groth16_prove_async(crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
                                 S(stream), handle);
 }
+int zk_groth16_prove_batch(zk_ctx* ctx, const zk_crs_share* crs, int nproofs, const void* const* qap_a_d,
+                           const void* const* qap_b_d, const void* const* qap_c_d, const void* const* a_share_d,
+                           const void* const* ax_share_d, const void* r, const void* s, int log2_m,
+                           const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c, void* stream) {
+  CTX_OR_FAIL();
+  return e->groth16_prove_batch(crs, nproofs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
+                                pi_a, pi_b, pi_c, S(stream));
+}
+int zk_msm_batch(zk_ctx* ctx, int group, const void* bases_d, size_t len, const void* const* scalars_d, int nvec,
+                 void* out, void* stream) {
+  CTX_OR_FAIL();
+  return e->msm_batch(group, bases_d, len, scalars_d, nvec, out, S(stream));
+}
+int zk_pss_unpack_points(zk_ctx* ctx, int group, const void* shares_d, size_t nchunks, void* out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->pss_unpack_points(group, shares_d, nullptr, e->n, nchunks, 0, out_d, S(stream));
+}
+int zk_pss_unpack2_points(zk_ctx* ctx, int group, const void* shares_d, const uint32_t* parties, int nparties,
+                          size_t nchunks, void* out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->pss_unpack_points(group, shares_d, parties, nparties, nchunks, 1, out_d, S(stream));
+}
+int zk_groth16_reconstruct(zk_ctx* ctx, const void* pi_a, const void* pi_b, const void* pi_c, const uint32_t* parties,
+                           int nparties, void* proof_affine, void* proof_bytes, void* stream) {
+  CTX_OR_FAIL();
+  return e->groth16_reconstruct(pi_a, pi_b, pi_c, parties, parties ? nparties : e->n, proof_affine, proof_bytes, S(stream));
+}
 int zk_groth16_wait(zk_ctx* ctx, int handle, void* pi_a, void* pi_b, void* pi_c) {
   CTX_OR_FAIL();
   return e->groth16_wait(handle, pi_a, pi_b, pi_c);

@@ -242,6 +242,16 @@ class IEngine {
                                   const void* a_share, const void* ax_share, const void* r, const void* s, int log_m,
                                   const zk_groth16_masks* masks, uint64_t seed, hipStream_t st, int* handle) = 0;
   virtual int groth16_wait(int handle, void* pi_a, void* pi_b, void* pi_c) = 0;
+  virtual int groth16_prove_batch(const zk_crs_share* crs, int nb, const void* const* qa, const void* const* qb,
+                                  const void* const* qc, const void* const* a_share, const void* const* ax_share,
+                                  const void* r, const void* s, int log_m, const zk_groth16_masks* masks, uint64_t seed,
+                                  void* pi_a, void* pi_b, void* pi_c, hipStream_t st) = 0;
+  virtual int pss_unpack_points(int group, const void* shares, const uint32_t* parties, int np, size_t nchunks, int two,
+                                void* out, hipStream_t st) = 0;
+  virtual int groth16_reconstruct(const void* pi_a, const void* pi_b, const void* pi_c, const uint32_t* parties, int np,
+                                  void* proof_affine, void* proof_bytes, hipStream_t st) = 0;
+  virtual int msm_batch(int group, const void* bases, size_t len, const void* const* scalars, int nb, void* out,
+                        hipStream_t st) = 0;
   virtual int groth16_abort(int handle) = 0;
   virtual int deg_red_points(int group, const void* x, const void* in_mask, const void* out_mask, size_t len,
                              const void* gen_affine, uint64_t seed, void* out, hipStream_t st) = 0;

@@ -51,6 +51,8 @@ class Engine : public IEngine {
   ~Engine() override {
     for (auto& j : jobs_)
       if (j.active) abort_job(j);
+    if (bjob_.active) abort_batch(bjob_);
+    if (ev_batch_in_) (void)hipEventDestroy(ev_batch_in_);
     pool_.reset();                                   // joins the host workers before anything they use goes away
     TableRegistry::inst().forget_owner(this);
     for (auto& kv : gentabs_) (void)hipFree(kv.second);
@@ -68,6 +70,7 @@ class Engine : public IEngine {
     if (err_flag_) (void)hipFree(err_flag_);
     if (rng_key_d_) (void)hipFree(rng_key_d_);
     if (u2c_) (void)hipFree(u2c_);
+    for (auto& kv : ucanon_) (void)hipFree(kv.second);
     if (pmc_) (void)hipFree(pmc_);
   }
 
@@ -509,7 +512,7 @@ class Engine : public IEngine {
     if (!cols) return ZK_OK;
     dim3 grid((unsigned)(cols / Wc), (unsigned)batch), block((unsigned)kbk);
     ProfScope ps_(prof, PROF_KING, st, (double)cols * batch);
-    const RngSeed seed = rs(seed_, (uint64_t)batch);
+    const RngSeed seed = rs(seed_, kb.seed_off((uint32_t)batch - 1) + 1);
     const uint32_t rs_ = range ? range->rs : 0u, seg_ = range ? range->seg : 0u;
     if (negate)
       king_fft2_kernel<FrP, L, true><<<grid, block, lds, st>>>(in, kb, np, (uint32_t)log_lc, U, pmat_, gen,
@@ -621,31 +624,42 @@ class Engine : public IEngine {
 
   // ---------------------------------------------------------------- deg_red (deg_red.rs:80-126)
   template <int L>
-  int degred_l(const Fr* in, const Fr* in_mask, int np, size_t len, const Fr* U, uint64_t seed, Fr* out,
-               const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
+  int degred_l(const Fr* in, const DegredBatch<Fr>& db, int batch, int np, size_t len, const Fr* U, uint64_t seed,
+               Fr* out, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
                const Fr* sub_c = nullptr) {
     if (!stride) stride = len;
     const size_t kbk = (size_t)king_block(len);
-    dim3 grid((unsigned)((len + kbk - 1) / kbk)), block((unsigned)kbk);
-    ProfScope ps_(prof, PROF_DEGRED, st, (double)len);
-    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, in_mask, np, len, U, pmat_, pack2_, rs(seed), out, out_mask,
-                                                       stride, j0, mul_b, sub_c);
+    dim3 grid((unsigned)((len + kbk - 1) / kbk), (unsigned)batch), block((unsigned)kbk);
+    ProfScope ps_(prof, PROF_DEGRED, st, (double)len * batch);
+    const uint64_t span = batch > 1 ? (uint64_t)(batch - 1) * db.seed_step + 1 : 1;
+    king_degred_kernel<FrP, L><<<grid, block, 0, st>>>(in, db, np, len, U, pmat_, pack2_, rs(seed, span), out, stride, j0,
+                                                       mul_b, sub_c);
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
-  int deg_red_np(const Fr* in, const Fr* in_mask, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
-                 const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
-                 const Fr* sub_c = nullptr) {
-    if (!len) return ZK_OK;
+  // `batch` independent vectors (the proofs of a batch): see DegredBatch
+  int deg_red_batch(const Fr* in, const DegredBatch<Fr>& db, int batch, const uint32_t* parties, int np, size_t len,
+                    uint64_t seed, Fr* out, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
+                    const Fr* sub_c = nullptr) {
+    if (!len || batch < 1) return ZK_OK;
+    if (batch > DEGRED_BATCH) return fail(ZK_ERR_BAD_INPUT, "bad deg_red batch");
     const Fr* U = nullptr;
     int rc = umat_for(parties, np, &U);
     if (rc) return rc;
     switch (l) {
-      case 1: return degred_l<1>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
-      case 2: return degred_l<2>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
-      case 4: return degred_l<4>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
-      default: return degred_l<8>(in, in_mask, np, len, U, seed, out, out_mask, st, stride, j0, mul_b, sub_c);
+      case 1: return degred_l<1>(in, db, batch, np, len, U, seed, out, st, stride, j0, mul_b, sub_c);
+      case 2: return degred_l<2>(in, db, batch, np, len, U, seed, out, st, stride, j0, mul_b, sub_c);
+      case 4: return degred_l<4>(in, db, batch, np, len, U, seed, out, st, stride, j0, mul_b, sub_c);
+      default: return degred_l<8>(in, db, batch, np, len, U, seed, out, st, stride, j0, mul_b, sub_c);
     }
+  }
+  int deg_red_np(const Fr* in, const Fr* in_mask, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
+                 const Fr* out_mask, hipStream_t st, size_t stride = 0, size_t j0 = 0, const Fr* mul_b = nullptr,
+                 const Fr* sub_c = nullptr) {
+    DegredBatch<Fr> db{};
+    db.in_mask[0] = in_mask;
+    db.out_mask[0] = out_mask;
+    return deg_red_batch(in, db, 1, parties, np, len, seed, out, st, stride, j0, mul_b, sub_c);
   }
   int deg_red(void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed, hipStream_t st) override {
     if (len && !x) return fail(ZK_ERR_BAD_INPUT, "null pointer");
@@ -891,6 +905,82 @@ class Engine : public IEngine {
                       mk ? (const Fr*)mk->degred_out : nullptr, st, 0, 0, W0 + per, W0 + 2 * per);
   }
 
+  // circom_h of `nb` proofs as ONE launch chain (zk_groth16_prove_batch): the 3 nb vectors go through every NTT pass,
+  // king and deg_red launch together (grid.y), so the chain's dozen dependent launches are paid once per batch.
+  // q*[b]: [n][Lc]; mk: nb mask sets or nullptr; h: [nb][n][Lc]; proof b draws the randomness a single circom_h with
+  // seed + PROOF_SEED_STEP * b draws.
+  static constexpr uint32_t PROOF_SEED_STEP = 16;
+  int circom_h_batch(int nb, const void* const* qa, const void* const* qb, const void* const* qc, int log_m,
+                     const zk_groth16_masks* mk, uint64_t seed, Fr* h, DevBuf& hwork, hipStream_t st) {
+    int log_l = ilog2(l);
+    if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large for this field");
+    if (nb < 1 || 3 * nb > KING_BATCH || nb > DEGRED_BATCH) return fail(ZK_ERR_BAD_INPUT, "bad batch size");
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
+    // one launch needs the in-masks of a stage all present or all absent across the batch; otherwise proof by proof
+    bool uniform = true;
+    if (mk)
+      for (int k = 0; k < 6 && uniform; k++)
+        for (int b = 1; b < nb; b++)
+          if ((mk[b].fft_in[k] != nullptr) != (mk[0].fft_in[k] != nullptr)) uniform = false;
+    if (mk && uniform)
+      for (int k = 0; k < 6 && uniform; k += 3)
+        if ((mk[0].fft_in[k] != nullptr) != (mk[0].fft_in[k + 1] != nullptr) ||
+            (mk[0].fft_in[k] != nullptr) != (mk[0].fft_in[k + 2] != nullptr))
+          uniform = false;
+    if (!uniform) {
+      for (int b = 0; b < nb; b++) {
+        int rc = circom_h_ws(qa[b], qb[b], qc[b], log_m, &mk[b], seed + (uint64_t)PROOF_SEED_STEP * b, h + b * per, hwork, st);
+        if (rc) return rc;
+      }
+      return ZK_OK;
+    }
+    ZK_HIP(hwork.ensure(6 * per * nb * sizeof(Fr)));
+    Fr* W0 = (Fr*)hwork.p;
+    Fr* W1 = W0 + 3 * per * nb;
+    Fr w2m = root_of_unity(log_m + 1);
+    NttSrc<Fr> src{};
+    src.per = (uint32_t)n;
+    for (int b = 0; b < nb; b++) {
+      if (!qa[b] || !qb[b] || !qc[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+      src.p[3 * b] = (const Fr*)qa[b];
+      src.p[3 * b + 1] = (const Fr*)qb[b];
+      src.p[3 * b + 2] = (const Fr*)qc[b];
+    }
+    int rc = fft1_src(W0, log_m, 1, 3 * (size_t)n * nb, nullptr, st, src);
+    if (rc) return rc;
+    const Fr* U = nullptr;
+    rc = umat_for(nullptr, n, &U);
+    if (rc) return rc;
+    auto king = [&](const Fr* in, int first, int inverse, const void* g, int scale, int rearrange, uint64_t sd, Fr* out) {
+      KingBatch<Fr> kb{};
+      kb.stride = per;
+      kb.items_per = 3;
+      kb.seed_step = PROOF_SEED_STEP;
+      for (int b = 0; b < nb; b++)
+        for (int k = 0; k < 3; k++) {
+          kb.in_mask[3 * b + k] = mk ? (const Fr*)mk[b].fft_in[first + k] : nullptr;
+          kb.out_mask[3 * b + k] = mk ? (const Fr*)mk[b].fft_out[first + k] : nullptr;
+        }
+      return king_dispatch_batch(in, kb, 3 * nb, n, log_m, inverse, U, g, scale, rearrange, sd, out, false, st);
+    };
+    rc = king(W0, 0, 1, &w2m, 1, 1, seed, W1);
+    if (rc) return rc;
+    rc = fft1(W1, log_m, 0, 3 * (size_t)n * nb, nullptr, st);
+    if (rc) return rc;
+    rc = king(W1, 3, 0, nullptr, 0, 0, seed + 3, W0);
+    if (rc) return rc;
+    DegredBatch<Fr> db{};
+    for (int b = 0; b < nb; b++) {
+      db.in_mask[b] = mk ? (const Fr*)mk[b].degred_in : nullptr;
+      db.out_mask[b] = mk ? (const Fr*)mk[b].degred_out : nullptr;
+    }
+    db.in_step = 3 * per;
+    db.out_step = per;
+    db.seed_step = PROOF_SEED_STEP;
+    return deg_red_batch(W0, db, nb, nullptr, n, Lc, seed + 6, h, st, 0, 0, W0 + per, W0 + 2 * per);
+  }
+
   // ---------------------------------------------------------------- prover (prove.rs, sha256.rs:32-129)
   // One proof in flight = one ProveJob: its device scratch, the pending MSMs and the host-side terms.  Everything the
   // host contributes (scalar multiples of CRS constants, of the out-masks and of the in-mask sums, MSM window folds)
@@ -953,13 +1043,22 @@ class Engine : public IEngine {
 
   // Starts one proof (full = all n parties and the assembly; otherwise the five partial d_msm sums of parties
   // [first, first + count) for the multi-GPU flow, where circom_h is driven by the caller and h arrives in finish).
+  // A failure after the job has been marked active leaves pool tasks and MSMs in flight that reference the caller's
+  // buffers: every such return goes through abort_job (the job is free again, the error message is kept).
   int prove_begin(ProveJob& j, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
                   const void* a_share, const void* ax_share, const Fr& r, const Fr& s, int log_m,
                   const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st) {
-    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     if (j.active) return fail(ZK_ERR_BAD_INPUT, "a proof is already in flight on this slot");
-    int rc = ensure_streams();
-    if (rc) return rc;
+    int rc = prove_begin_impl(j, crs, qa, qb, qc, a_share, ax_share, r, s, log_m, mk, seed, full, first, count, st);
+    if (rc && j.active) {
+      Status keep = last;
+      abort_job(j);
+      last = keep;
+    }
+    return rc;
+  }
+  void init_job(ProveJob& j, const zk_crs_share* crs, const zk_groth16_masks* mk, const Fr& r, const Fr& s, bool full,
+                int first, int count) {
     j.crs = *crs;
     j.has_mk = mk != nullptr;
     j.mk = mk ? *mk : zk_groth16_masks{};
@@ -976,6 +1075,14 @@ class Engine : public IEngine {
     for (int k = 0; k < 5; k++) j.in1[k] = P1::identity();
     j.s_om0.assign(n, P1::identity());
     j.r_om1.assign(n, P1::identity());
+  }
+  int prove_begin_impl(ProveJob& j, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                       const void* a_share, const void* ax_share, const Fr& r, const Fr& s, int log_m,
+                       const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st) {
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    int rc = ensure_streams();
+    if (rc) return rc;
+    init_job(j, crs, mk, r, s, full, first, count);
     const size_t Lc = ((size_t)1 << log_m) / l;
     const int dev = device;
     const int ws0 = j.slot * 6;
@@ -1112,49 +1219,7 @@ class Engine : public IEngine {
     }
     msm_task(Fq_{}, 1, crs->w_d, nullptr, ax_share, (size_t)count * crs->len_w, cf, crs->len_w, streams_[3], ws0 + 4,
              &j.pW, &j.W, (P1*)nullptr);
-    // ---- host terms that depend on nothing but the inputs
-    if (full) {
-      j.fut.push_back(pool_->submit([J]() {
-        P1 d1 = aff1(J->crs.delta_g1);
-        J->rN = host_scalar_mul<FrP, Fq_>(d1, J->r);
-        J->s_cA = host_scalar_mul<FrP, Fq_>(xyzz_add_ni(xyzz_add_ni(aff1(J->crs.a_query0), J->rN), aff1(J->crs.alpha_g1)), J->s);
-      }));
-      j.fut.push_back(pool_->submit([J]() {
-        P1 d1 = aff1(J->crs.delta_g1);
-        J->sK = host_scalar_mul<FrP, Fq_>(d1, J->s);
-        J->r_cB1 = host_scalar_mul<FrP, Fq_>(xyzz_add_ni(xyzz_add_ni(aff1(J->crs.b_g1_query0), J->sK), aff1(J->crs.beta_g1)), J->r);
-      }));
-      j.fut.push_back(pool_->submit([J]() { J->rsM = host_scalar_mul<FrP, Fq_>(aff1(J->crs.delta_g1), J->r * J->s); }));
-      j.fut.push_back(pool_->submit([J]() { J->sK2 = host_scalar_mul<FrP, Fq2_>(aff2(J->crs.delta_g2), J->s); }));
-    }
-    if (mk) {
-      // in-mask terms sum_p coef_p * mask_p (the king's unpack2 + sum over the masked points, dmsm/mod.rs:85-86)
-      for (int k = 0; k < 5; k++) {
-        if (!mk->msm_in[k] || (k == 1 && j.r_zero)) continue;
-        const void* im = mk->msm_in[k];
-        j.fut.push_back(pool_->submit([this, J, k, im, first, count]() {
-          if (k == 2) {
-            J->in2 = msm_.template mask_term<Fq2_>(im, first, count);
-          } else {
-            J->in1[k] = msm_.template mask_term<Fq_>(im, first, count);
-            if (k == 0 && J->full) J->s_in0 = host_scalar_mul<FrP, Fq_>(J->in1[0], J->s);
-            if (k == 1 && J->full) J->r_in1 = host_scalar_mul<FrP, Fq_>(J->in1[1], J->r);
-          }
-        }));
-      }
-      // per-party multiples of the out-masks of A and B1 that enter C = s*A + r*B1 + ...
-      if (full)
-        for (int p = 0; p < n; p++) {
-          if (mk->msm_out[0])
-            j.fut.push_back(pool_->submit([J, p]() {
-              J->s_om0[p] = host_scalar_mul<FrP, Fq_>(jacobian_to_xyzz(((const Jacobian<Fq_>*)J->mk.msm_out[0])[p]), J->s);
-            }));
-          if (mk->msm_out[1] && !j.r_zero)
-            j.fut.push_back(pool_->submit([J, p]() {
-              J->r_om1[p] = host_scalar_mul<FrP, Fq_>(jacobian_to_xyzz(((const Jacobian<Fq_>*)J->mk.msm_out[1])[p]), J->r);
-            }));
-        }
-    }
+    submit_host_terms(J, j.fut, full, first, count);
     // ---- circom_h and the U-MSM that depends on it form a long dependent chain: high-priority internal stream.
     // At the SHA-256 size, holding the other MSM streams (or only their accumulate launches) back until circom_h has
     // finished was measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once (and at
@@ -1172,6 +1237,54 @@ class Engine : public IEngine {
       if (rc) return rc;
     }
     return ZK_OK;
+  }
+
+  // Host-side terms of one proof that depend on nothing but its inputs (scalar multiples of CRS constants, in-mask sums,
+  // per-party multiples of the out-masks): tasks of the worker pool, running beside the device work.
+  void submit_host_terms(ProveJob* J, std::vector<std::future<void>>& fut, bool full, int first, int count) {
+    if (full) {
+      fut.push_back(pool_->submit([J]() {
+        P1 d1 = aff1(J->crs.delta_g1);
+        J->rN = host_scalar_mul<FrP, Fq_>(d1, J->r);
+        J->s_cA = host_scalar_mul<FrP, Fq_>(xyzz_add_ni(xyzz_add_ni(aff1(J->crs.a_query0), J->rN), aff1(J->crs.alpha_g1)), J->s);
+      }));
+      fut.push_back(pool_->submit([J]() {
+        P1 d1 = aff1(J->crs.delta_g1);
+        J->sK = host_scalar_mul<FrP, Fq_>(d1, J->s);
+        J->r_cB1 = host_scalar_mul<FrP, Fq_>(xyzz_add_ni(xyzz_add_ni(aff1(J->crs.b_g1_query0), J->sK), aff1(J->crs.beta_g1)), J->r);
+      }));
+      fut.push_back(pool_->submit([J]() { J->rsM = host_scalar_mul<FrP, Fq_>(aff1(J->crs.delta_g1), J->r * J->s); }));
+      fut.push_back(pool_->submit([J]() { J->sK2 = host_scalar_mul<FrP, Fq2_>(aff2(J->crs.delta_g2), J->s); }));
+    }
+    const zk_groth16_masks* mk = J->has_mk ? &J->mk : nullptr;
+    if (mk) {
+      // in-mask terms sum_p coef_p * mask_p (the king's unpack2 + sum over the masked points, dmsm/mod.rs:85-86)
+      for (int k = 0; k < 5; k++) {
+        if (!mk->msm_in[k] || (k == 1 && J->r_zero)) continue;
+        const void* im = mk->msm_in[k];
+        fut.push_back(pool_->submit([this, J, k, im, first, count]() {
+          if (k == 2) {
+            J->in2 = msm_.template mask_term<Fq2_>(im, first, count);
+          } else {
+            J->in1[k] = msm_.template mask_term<Fq_>(im, first, count);
+            if (k == 0 && J->full) J->s_in0 = host_scalar_mul<FrP, Fq_>(J->in1[0], J->s);
+            if (k == 1 && J->full) J->r_in1 = host_scalar_mul<FrP, Fq_>(J->in1[1], J->r);
+          }
+        }));
+      }
+      // per-party multiples of the out-masks of A and B1 that enter C = s*A + r*B1 + ...
+      if (full)
+        for (int p = 0; p < n; p++) {
+          if (mk->msm_out[0])
+            fut.push_back(pool_->submit([J, p]() {
+              J->s_om0[p] = host_scalar_mul<FrP, Fq_>(jacobian_to_xyzz(((const Jacobian<Fq_>*)J->mk.msm_out[0])[p]), J->s);
+            }));
+          if (mk->msm_out[1] && !J->r_zero)
+            fut.push_back(pool_->submit([J, p]() {
+              J->r_om1[p] = host_scalar_mul<FrP, Fq_>(jacobian_to_xyzz(((const Jacobian<Fq_>*)J->mk.msm_out[1])[p]), J->r);
+            }));
+        }
+    }
   }
 
   static bool h_first(int log_m) {
@@ -1210,6 +1323,11 @@ class Engine : public IEngine {
     P2 V;
     int rc = prove_join(j, &S, &H, &V, &W, &U);
     if (rc) return rc;
+    return assemble_job(j, S, H, V, W, U, pi_a, pi_b, pi_c);
+  }
+  // the n parties' (A, B, C) shares of one proof from its five MSM totals (in-mask terms included) and the host terms
+  int assemble_job(ProveJob& j, const P1& S, const P1& H, const P2& V, const P1& W, const P1& U, void* pi_a, void* pi_b,
+                   void* pi_c) {
     const zk_groth16_masks* mk = j.has_mk ? &j.mk : nullptr;
     // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party; C = s*A + r*B1 - rs*delta + W + U by linearity:
     //   s*A_p = s*(a0 + r*delta + alpha) + s*S + s*in0 + s*om0_p     (every term was computed beside the device work)
@@ -1323,6 +1441,203 @@ class Engine : public IEngine {
     if (handle < 0 || handle >= NJOBS) return fail(ZK_ERR_BAD_INPUT, "bad handle");
     abort_job(jobs_[handle]);
     return ZK_OK;
+  }
+
+  // ---------------------------------------------------------------- a batch of proofs against one CRS
+  // zk_groth16_prove_batch: `nb` witnesses proved against the SAME packed CRS in one pass.  The reference runs its
+  // parties as concurrent tasks and a service runs proofs concurrently (mpc-net/src/multi.rs:317-327,
+  // groth16/examples/sha256.rs:316-360); one proof of the SHA-256 circuit leaves most of the chip idle (a dozen short
+  // dependent launches per MSM, 2.3 waves per SIMD in the accumulate), so the batch goes through every stage TOGETHER:
+  // each of the five MSMs is ONE sort / accumulate / finalize / reduce chain over nb scalar vectors against one base
+  // vector (msm.hpp MsmScalars: bucket sets indexed by (proof, window)), circom_h is one launch chain over 3 nb
+  // vectors.  Host terms (scalar multiples of masks and CRS constants) are per proof, on the worker pool as before.
+  static constexpr int MAX_PROOF_BATCH = MSM_MAXB;
+  struct BatchJob {
+    bool active = false;
+    int nb = 0;
+    std::vector<std::unique_ptr<ProveJob>> pj;      // per proof: host terms and the five MSM totals
+    MsmPending pSH, pV, pW, pU;
+    DevBuf hwork, hshare;
+    std::vector<std::future<void>> fut;
+    int rc[4] = {0, 0, 0, 0};
+  };
+  BatchJob bjob_;
+  hipEvent_t ev_batch_in_ = nullptr;
+
+  void abort_batch(BatchJob& B) {
+    for (auto& f : B.fut)
+      if (f.valid()) f.wait();
+    B.fut.clear();
+    MsmPending* ps[4] = {&B.pSH, &B.pV, &B.pW, &B.pU};
+    for (MsmPending* p : ps)
+      if (p->active) {
+        (void)hipEventSynchronize(p->slot->ev);
+        p->active = false;
+        p->tab.reset();
+        p->tab2.reset();
+      }
+    B.active = false;
+  }
+
+  int groth16_prove_batch(const zk_crs_share* crs, int nb, const void* const* qa, const void* const* qb,
+                          const void* const* qc, const void* const* a_share, const void* const* ax_share, const void* r_,
+                          const void* s_, int log_m, const zk_groth16_masks* mk, uint64_t seed, void* pi_a, void* pi_b,
+                          void* pi_c, hipStream_t st) override {
+    if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    int rc = check_prove_args(crs, r_, s_, log_m);
+    if (rc) return rc;
+    if (nb < 1 || nb > MAX_PROOF_BATCH || 3 * nb > KING_BATCH || nb > DEGRED_BATCH)
+      return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MAX_PROOF_BATCH));
+    if (!qa || !qb || !qc || !a_share || !ax_share || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    for (int b = 0; b < nb; b++)
+      if (!qa[b] || !qb[b] || !qc[b] || !a_share[b] || !ax_share[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    BatchJob& B = bjob_;
+    if (B.active) return fail(ZK_ERR_BAD_INPUT, "a batch is already in flight");
+    rc = ensure_streams();
+    if (rc) return rc;
+    if (!ev_batch_in_) ZK_HIP(hipEventCreateWithFlags(&ev_batch_in_, hipEventDisableTiming));
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
+    ZK_HIP(B.hshare.ensure(per * nb * sizeof(Fr)));
+    B.nb = nb;
+    while ((int)B.pj.size() < nb) B.pj.emplace_back(new ProveJob());
+    bool all_r_zero = true;
+    for (int b = 0; b < nb; b++) {
+      Fr r = Fr::from_limbs((const uint32_t*)r_ + (size_t)b * FrP::N), s = Fr::from_limbs((const uint32_t*)s_ + (size_t)b * FrP::N);
+      init_job(*B.pj[b], crs, mk ? &mk[b] : nullptr, r, s, true, 0, n);
+      all_r_zero = all_r_zero && r.is_zero();
+    }
+    for (int i = 0; i < 4; i++) B.rc[i] = 0;
+    ZK_HIP(hipEventRecord(ev_batch_in_, st));
+    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_batch_in_, 0));
+    B.active = true;
+    BatchJob* BJ = &B;
+    const int dev = device;
+    const int ws0 = 12;                                 // the batch's own MSM workspaces (msm.hpp MSM_WS)
+    const Fr* cf = msm_.coef_d_;
+    MsmBatchArg ba_a, ba_x;
+    ba_a.nb = ba_x.nb = nb;
+    for (int b = 0; b < nb; b++) {
+      ba_a.p[b] = a_share[b];
+      ba_x.p[b] = ax_share[b];
+    }
+    // ---- the witness MSMs: V (G2) first on its high-priority stream, S + H as one launch over both base vectors, W
+    B.fut.push_back(pool_->submit([=]() {
+      (void)hipSetDevice(dev);
+      int rc2 = msm_.template launch_t<Fq2_>(this, crs->v_d, nullptr, (size_t)n * crs->len_a, cf, crs->len_a, streams_[2],
+                                            ws0 + 3, &BJ->pV, nullptr, MsmGate{}, nullptr, &ba_a);
+      std::vector<P2> res((size_t)nb);
+      if (!rc2) rc2 = msm_fold_batch<Fq2_>(this, BJ->pV, res.data(), 1);
+      BJ->rc[1] = rc2;
+      if (!rc2)
+        for (int b = 0; b < nb; b++) BJ->pj[b]->V0 = res[b];
+    }));
+    const void* hd = all_r_zero ? nullptr : crs->h_d;
+    B.fut.push_back(pool_->submit([=]() {
+      (void)hipSetDevice(dev);
+      int rc2 = msm_.template launch_t<Fq_>(this, crs->s_d, nullptr, (size_t)n * crs->len_a, cf, crs->len_a, streams_[0],
+                                           ws0 + 1, &BJ->pSH, hd, MsmGate{}, nullptr, &ba_a);
+      std::vector<P1> res((size_t)nb * 2);
+      if (!rc2) rc2 = msm_fold_batch<Fq_>(this, BJ->pSH, res.data(), hd ? 2 : 1);
+      BJ->rc[0] = rc2;
+      if (rc2) return;
+      // s*S and r*H per proof (prove.rs:229-235, linearity): spread over the pool, this task takes proof 0
+      std::vector<std::future<void>> sub;
+      auto fin = [=, &res](int b) {
+        ProveJob* J = BJ->pj[b].get();
+        J->S = res[b];
+        J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
+        if (hd && !J->r_zero) {
+          J->H = res[(size_t)nb + b];
+          J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
+        }
+      };
+      for (int b = 1; b < nb; b++) sub.push_back(pool_->submit([=]() { fin(b); }));
+      fin(0);
+      for (auto& f : sub) f.get();
+    }));
+    B.fut.push_back(pool_->submit([=]() {
+      (void)hipSetDevice(dev);
+      int rc2 = msm_.template launch_t<Fq_>(this, crs->w_d, nullptr, (size_t)n * crs->len_w, cf, crs->len_w, streams_[3],
+                                           ws0 + 4, &BJ->pW, nullptr, MsmGate{}, nullptr, &ba_x);
+      std::vector<P1> res((size_t)nb);
+      if (!rc2) rc2 = msm_fold_batch<Fq_>(this, BJ->pW, res.data(), 1);
+      BJ->rc[2] = rc2;
+      if (!rc2)
+        for (int b = 0; b < nb; b++) BJ->pj[b]->W = res[b];
+    }));
+    // ---- host terms of every proof
+    for (int b = 0; b < nb; b++) submit_host_terms(B.pj[b].get(), B.fut, true, 0, n);
+    // ---- circom_h of the whole batch and the U-MSM behind it
+    auto bail = [&](int code) {
+      Status keep = last;
+      abort_batch(B);
+      last = keep;
+      return code;
+    };
+    hipStream_t hs = streams_[5];
+    rc = circom_h_batch(nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, B.hwork, hs);
+    if (rc) return bail(rc);
+    MsmBatchArg ba_h;
+    ba_h.nb = nb;
+    for (int b = 0; b < nb; b++) ba_h.p[b] = (const Fr*)B.hshare.p + (size_t)b * per;
+    rc = msm_.template launch_t<Fq_>(this, crs->u_d, nullptr, (size_t)n * crs->len_u, cf, crs->len_u, hs, ws0 + 0, &B.pU,
+                                    nullptr, MsmGate{}, nullptr, &ba_h);
+    if (rc) return bail(rc);
+    std::vector<P1> ures((size_t)nb);
+    rc = msm_fold_batch<Fq_>(this, B.pU, ures.data(), 1);
+    if (rc) return bail(rc);
+    for (auto& f : B.fut)
+      if (f.valid()) f.wait();
+    B.fut.clear();
+    B.active = false;
+    for (int i = 0; i < 4; i++)
+      if (B.rc[i]) return B.rc[i];
+    for (int b = 0; b < nb; b++) {
+      ProveJob& j = *B.pj[b];
+      if (j.err.code) return fail(j.err.code, j.err.msg);
+      const P1 S = xyzz_add_ni(j.S, j.in1[0]);
+      const P1 H = j.r_zero ? P1::identity() : xyzz_add_ni(j.H, j.in1[1]);
+      const P2 V = xyzz_add_ni(j.V0, j.in2);
+      const P1 W = xyzz_add_ni(j.W, j.in1[3]);
+      const P1 U = xyzz_add_ni(ures[b], j.in1[4]);
+      rc = assemble_job(j, S, H, V, W, U, (char*)pi_a + (size_t)b * n * sizeof(Jacobian<Fq_>),
+                        (char*)pi_b + (size_t)b * n * sizeof(Jacobian<Fq2_>), (char*)pi_c + (size_t)b * n * sizeof(Jacobian<Fq_>));
+      if (rc) return rc;
+    }
+    return ZK_OK;
+  }
+
+  // zk_msm_batch: G::msm of ONE base vector against `nb` scalar vectors (the sort / accumulate / reduce chain of
+  // msm.hpp runs once for the batch); out: nb Jacobian points (host).
+  int msm_batch(int group, const void* bases, size_t len, const void* const* scalars, int nb, void* out,
+                hipStream_t st) override {
+    if (nb < 1 || nb > MSM_MAXB) return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MSM_MAXB));
+    if (!out || !scalars || (len && !bases)) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    MsmBatchArg ba;
+    ba.nb = nb;
+    for (int b = 0; b < nb; b++) {
+      if (len && !scalars[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+      ba.p[b] = scalars[b];
+    }
+    auto run = [&](auto tag) -> int {
+      using Fld = decltype(tag);
+      MsmPending pend;
+      int rc = msm_.template launch_t<Fld>(this, bases, nullptr, len, nullptr, 1, st, 0, &pend, nullptr, MsmGate{}, nullptr, &ba);
+      if (rc) return rc;
+      std::vector<XYZZ<Fld>> res((size_t)nb);
+      rc = msm_fold_batch<Fld>(this, pend, res.data(), 1);
+      if (rc) return rc;
+      for (int b = 0; b < nb; b++) {
+        Jacobian<Fld> j = xyzz_to_jacobian(res[b]);
+        memcpy((char*)out + (size_t)b * sizeof(j), &j, sizeof(j));
+      }
+      return ZK_OK;
+    };
+    if (group == ZK_G1) return run(Fq_{});
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2) return run(Fq2_{});
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
   }
 
   // sum over the listed local parties of coef_p * (msm_p + in_mask_p): one rank's contribution to the king's
@@ -1706,6 +2021,146 @@ class Engine : public IEngine {
     rc = base_mul(group, gen_affine, si, cnt, in_mask, st);
     if (rc) return rc;
     return base_mul(group, gen_affine, so, cnt, out_mask, st);
+  }
+
+  // ---------------------------------------------------------------- unpack / unpack2 over group elements
+  // secret-sharing/src/pss.rs:125-166 with T = curve point (`T: DomainCoeff<F>`), used by the reference to turn the n
+  // parties' proof shares into the proof (groth16/examples/sha256.rs:375-377: pp.unpack2(shares)[0]).  The maps are the
+  // same l x np matrices as over Fr (unpack: U1; unpack2: U2, or the Lagrange form for a party subset,
+  // pss.rs:170-221), applied by points_lincomb_kernel with canonical scalars.
+  std::map<uint64_t, Fr*> ucanon_;
+  // host copy (Montgomery) of the l x np matrix: kind 1 = unpack (all n parties), 2 = unpack2 / lagrange_unpack
+  int umat_host(const uint32_t* parties, int np, int kind, std::vector<Fr>& U, uint32_t* mask_out) {
+    if (np <= 0 || np > n) return fail(ZK_ERR_BAD_INPUT, "bad party count");
+    uint32_t mask = 0;
+    std::vector<uint32_t> ids((size_t)np);
+    for (int i = 0; i < np; i++) {
+      ids[i] = parties ? parties[i] : (uint32_t)i;
+      if (ids[i] >= (uint32_t)n || (i > 0 && ids[i] <= ids[i - 1]))
+        return fail(ZK_ERR_BAD_INPUT, "party ids must be ascending and < n");
+      mask |= 1u << ids[i];
+    }
+    if (kind == 1 && np != n) return fail(ZK_ERR_BAD_INPUT, "unpack needs all n shares");
+    if (np < n && np <= 2 * (t + l - 1)) return fail(ZK_ERR_PROTOCOL, "Not enough shares to reconstruct", 0);   // pss.rs:183-186
+    *mask_out = mask;
+    std::vector<Fr> x, y, z;
+    points(x, y, z);
+    U.assign((size_t)l * np, Fr::zero());
+    if (np == n) {
+      Fr ninv = Fr::from_u64((uint64_t)n).inverse();
+      const int k = l + t;
+      for (int kk = 0; kk < l; kk++)
+        for (int p = 0; p < n; p++) {
+          Fr ratio = (kind == 1 ? y[kk] : z[2 * kk]) * x[p].inverse(), acc = Fr::zero(), c = Fr::one();
+          for (int d = 0; d < (kind == 1 ? k : n); d++) {
+            acc = acc + c;
+            c = c * ratio;
+          }
+          U[(size_t)kk * n + p] = acc * ninv;
+        }
+      return ZK_OK;
+    }
+    for (int kk = 0; kk < l; kk++)
+      for (int i = 0; i < np; i++) {
+        Fr num = Fr::one(), den = Fr::one();
+        for (int j = 0; j < np; j++)
+          if (j != i) {
+            num = num * (z[2 * kk] - x[ids[j]]);
+            den = den * (x[ids[i]] - x[ids[j]]);
+          }
+        U[(size_t)kk * np + i] = num * den.inverse();
+      }
+    return ZK_OK;
+  }
+  template <class Fld>
+  int unpack_points_t(const void* shares, const uint32_t* parties, int np, size_t nchunks, int kind, void* out,
+                      hipStream_t st) {
+    if (!nchunks) return ZK_OK;
+    if (!shares || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    std::vector<Fr> U;
+    uint32_t mask = 0;
+    int rc = umat_host(parties, np, kind, U, &mask);
+    if (rc) return rc;
+    Fr* Ud = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = ucanon_.find(key_u(mask, kind));
+      if (it != ucanon_.end()) Ud = it->second;
+    }
+    if (!Ud) {
+      for (auto& v : U) v = v.from_mont();
+      rc = upload(U, &Ud);
+      if (rc) return rc;
+      std::lock_guard<std::mutex> lk(mu_);
+      ucanon_[key_u(mask, kind)] = Ud;
+    }
+    using A = Affine<Fld>;
+    PtGroup<Fld> g0{(const A*)shares, 1, nchunks, np, 0};
+    const size_t total = nchunks * (size_t)l;
+    points_lincomb_kernel<FrP, Fld><<<dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st>>>(
+        g0, g0, 1, Ud, np, l, nchunks, nullptr, 0, (A*)out, 1, (size_t)l);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  // shares: [np][nchunks] affine (device); out: [nchunks][l] affine (device).  two = 0: unpack (np must be n).
+  int pss_unpack_points(int group, const void* shares, const uint32_t* parties, int np, size_t nchunks, int two, void* out,
+                        hipStream_t st) override {
+    if (group == ZK_G1) return unpack_points_t<Fq_>(shares, parties, np, nchunks, two ? 2 : 1, out, st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2) return unpack_points_t<Fq2_>(shares, parties, np, nchunks, two ? 2 : 1, out, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+  // sha256.rs:375-377: (a, b, c) = pp.unpack2(shares)[0] for the three proof elements, from the parties' Jacobian
+  // outputs (host).  proof_affine (optional): A (G1) | B (G2) | C (G1) affine Montgomery; proof_bytes (optional):
+  // ark_groth16::Proof::serialize_compressed (a | b | c; 4 |Fq| bytes).  Three points: evaluated on the host
+  // (Straus over the np shares), compressed by the device codec.
+  DevBuf recon_;
+  int groth16_reconstruct(const void* pi_a, const void* pi_b, const void* pi_c, const uint32_t* parties, int np,
+                          void* proof_affine, void* proof_bytes, hipStream_t st) override {
+    if constexpr (!Cfg::HAS_G2) {
+      return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    } else {
+      if (!pi_a || !pi_b || !pi_c || (!proof_affine && !proof_bytes)) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+      std::vector<Fr> U;
+      uint32_t mask = 0;
+      int rc = umat_host(parties, np, 2, U, &mask);
+      if (rc) return rc;
+      auto one = [&](auto tag, const void* jac) {
+        using Fld = decltype(tag);
+        const Jacobian<Fld>* j = (const Jacobian<Fld>*)jac;
+        std::vector<XYZZ<Fld>> pts((size_t)np);
+        for (int p = 0; p < np; p++) pts[p] = jacobian_to_xyzz(j[p]);
+        return xyzz_to_affine(host_straus<FrP, Fld>(pts.data(), U.data(), np));      // row 0 of the matrix: secret 0
+      };
+      struct Out {
+        Affine<Fq_> a;
+        Affine<Fq2_> b;
+        Affine<Fq_> c;
+      } o{one(Fq_{}, pi_a), one(Fq2_{}, pi_b), one(Fq_{}, pi_c)};
+      static_assert(sizeof(Out) == 4 * sizeof(Affine<Fq_>), "proof layout");
+      if (proof_affine) memcpy(proof_affine, &o, sizeof(o));
+      if (!proof_bytes) return ZK_OK;
+      constexpr size_t NB = (Cfg::FqP::BITS + 7) / 8;
+      ZK_HIP(recon_.ensure(sizeof(o) + 4 * NB));
+      char* d = (char*)recon_.p;
+      Affine<Fq_> g1s[2] = {o.a, o.c};
+      ZK_HIP(hipMemcpyAsync(d, g1s, sizeof(g1s), hipMemcpyHostToDevice, st));
+      ZK_HIP(hipMemcpyAsync(d + sizeof(g1s), &o.b, sizeof(o.b), hipMemcpyHostToDevice, st));
+      char* bytes_d = d + sizeof(o);
+      rc = points_codec_t<Fq_>(d, 2, bytes_d, 0, Fq_::zero(), st);                    // a, c -> bytes [0, 2 NB)
+      if (rc) return rc;
+      rc = points_codec_t<Fq2_>(d + sizeof(g1s), 1, bytes_d + 2 * NB, 0, Fq2_{}, st);  // b -> bytes [2 NB, 4 NB)
+      if (rc) return rc;
+      std::vector<uint8_t> hb(4 * NB);
+      ZK_HIP(hipMemcpyAsync(hb.data(), bytes_d, 4 * NB, hipMemcpyDeviceToHost, st));
+      ZK_HIP(hipStreamSynchronize(st));
+      uint8_t* ob = (uint8_t*)proof_bytes;
+      memcpy(ob, hb.data(), NB);                       // a
+      memcpy(ob + NB, hb.data() + 2 * NB, 2 * NB);     // b
+      memcpy(ob + 3 * NB, hb.data() + NB, NB);         // c
+      return ZK_OK;
+    }
   }
 
   // ---------------------------------------------------------------- compressed point vectors (ser_net.rs:111-120)
@@ -2224,7 +2679,10 @@ class Engine : public IEngine {
       return code;
     };
     if (rc) return bail(rc);
-    ZK_HIP(dist_h_.ensure((size_t)k * Lc * sizeof(Fr)));
+    {
+      hipError_t he = dist_h_.ensure((size_t)k * Lc * sizeof(Fr));
+      if (he != hipSuccess) return bail(hip_fail(he, "h share buffer"));
+    }
     rc = dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, dist_h_.p, st);
     if (rc) return bail(rc);
     rc = prove_launch_u(j, dist_h_.p, st);

@@ -37,7 +37,8 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
-constexpr int MSM_WS = 12;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate streams)
+constexpr int MSM_WS = 18;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
+                                      // streams) + 6 for a batch of proofs (zk_groth16_prove_batch)
 
 // Sort-stage arrays of a launch over TWO base vectors with per-vector sorts (their identity bases differ) live in two
 // copies of one workspace region; blockIdx.y picks the copy: every sort-stage kernel shifts its array pointers by
@@ -51,14 +52,28 @@ struct SegDesc {
   uint32_t bucket, start, end;
 };
 
+// A launch multiplies ONE base vector (or two) by a BATCH of scalar vectors -- the same query of a CRS against the
+// witnesses of several proofs (zk_groth16_prove_batch).  Vector b of the batch gets its own bucket sets: everything
+// downstream of the sort sees `nb * sets_per` bucket sets where a single MSM has `sets_per` (1 with a fixed-base table,
+// one per window without), so the sort, accumulate, finalize and reduce launches are paid once per batch and every
+// launch carries nb times the lanes.
+constexpr int MSM_MAXB = 16;
+template <class F>
+struct MsmScalars {
+  const F* p[MSM_MAXB];   // scalar vector b of the batch, npts elements each
+  uint32_t npts;          // points per vector (= length of the base vector)
+  uint32_t nb;            // vectors in the batch
+  uint32_t sets_per;      // bucket sets per vector
+};
+
 // -------------------------------------------------------------------------------------------------- digits
 // pass 0: histogram; pass 1: scatter.  coef (optional): per-part multiplier, part = i / part_len.
 template <class FrP, int PASS>
-__global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t npts, const Fp<FrP>* __restrict__ coef,
+__global__ void msm_digits_kernel(MsmScalars<Fp<FrP>> sc, const Fp<FrP>* __restrict__ coef,
                                   size_t part_len, int c, int nwin, int wide /* windows [0, wide) have c bits, the rest
                                   c-1 */, uint32_t pre_stride /* fixed-base table: rows of this many points, one per
                                   window; all windows share ONE bucket set; 0 = no table */, uint32_t pre_off,
-                                  uint32_t* __restrict__ counts /* [nwin*B] */,
+                                  uint32_t* __restrict__ counts /* [nsets*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
                                   const uint32_t* __restrict__ skip /* bit i: base i is the identity */, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
@@ -66,13 +81,14 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
   ZK_YSHIFT(cursor);
   ZK_YSHIFT(sorted);
   ZK_YSHIFT(skip);
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npts) return;
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)sc.npts * sc.nb) return;
+  const uint32_t vb = (uint32_t)(g / sc.npts), i = (uint32_t)(g % sc.npts);
   if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return;
-  Fp<FrP> s = load_elem(scalars + i);
+  Fp<FrP> s = load_elem(sc.p[vb] + i);
   if (coef) s = s * coef[i / part_len];
   s = s.from_mont();
-  const uint32_t B = 1u << (c - 1);
+  const uint32_t set0 = vb * sc.sets_per;
   uint32_t carry = 0;
   constexpr int N = FrP::N;
   for (int w = 0; w < nwin; w++) {
@@ -92,12 +108,12 @@ __global__ void msm_digits_kernel(const Fp<FrP>* __restrict__ scalars, size_t np
     if (d == 0) continue;
     uint32_t neg = d < 0 ? 1u : 0u;
     uint32_t b = (uint32_t)(neg ? -d : d) - 1;
-    uint32_t key = pre_stride ? b : (uint32_t)w * B + b;
+    uint32_t key = ((set0 + (pre_stride ? 0u : (uint32_t)w)) << (c - 1)) + b;
     if (PASS == 0) {
       atomicAdd(counts + key, 1u);
     } else {
       uint32_t pos = atomicAdd(cursor + key, 1u);
-      uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + (uint32_t)i : (uint32_t)i;
+      uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
       sorted[pos] = idx | (neg << 31);
     }
   }
@@ -161,10 +177,16 @@ __global__ __launch_bounds__(256) void msm_skip_mask_kernel(const Affine<Fld>* _
 //   bin_sort    : one workgroup per bin: counts of the 2^lo low-bit buckets (written out as the per-key counts the
 //                 rest of the pipeline scans), LDS scan, second sweep places index|sign into sorted[]
 // The order inside a bucket is arbitrary, as before; bucket sums do not depend on it.
-constexpr int BIG_HI = 8;
+constexpr int BIG_HI = 8;                 // top bucket bits of a bin (fewer when a batch has many bucket sets: msm_big_hi)
+constexpr int BIG_MAX_BINS = 8192;        // LDS: 4 B per bin in part_hist, 8 B in part_scatter
 constexpr int BIG_THREADS = 256;
 constexpr int BIG_PTS_PER_THREAD = 16;   // points per thread for multi-million-point MSMs; fewer for small ones so that
                                          // the tiles (BIG_THREADS * points-per-thread points each) still fill the chip
+inline int msm_big_hi(size_t nsets) {
+  int hi = BIG_HI;
+  while (hi > 0 && (nsets << hi) > (size_t)BIG_MAX_BINS) hi--;
+  return hi;
+}
 
 // signed-digit walk over one scalar (shared by all sort kernels): fn(window, bucket index, negative)
 template <class FrP, class Fn>
@@ -190,19 +212,23 @@ __device__ __forceinline__ void msm_for_each_digit(Fp<FrP> s, int c, int nwin, i
   }
 }
 
+// scalar of global entry g = (vector vb of the batch, point i); identity bases and out-of-range entries give zero
 template <class FrP>
-__device__ __forceinline__ Fp<FrP> msm_load_scalar(const Fp<FrP>* scalars, const Fp<FrP>* coef, size_t part_len,
-                                                   size_t i, const uint32_t* skip) {
+__device__ __forceinline__ Fp<FrP> msm_load_scalar(const MsmScalars<Fp<FrP>>& sc, const Fp<FrP>* coef, size_t part_len,
+                                                   size_t g, const uint32_t* skip, uint32_t* vb_out, uint32_t* i_out) {
+  const uint32_t vb = (uint32_t)(g / sc.npts), i = (uint32_t)(g % sc.npts);
+  *vb_out = vb;
+  *i_out = i;
   if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return Fp<FrP>::zero();      // identity base: no digit, no entry
-  Fp<FrP> s = load_elem(scalars + i);
+  Fp<FrP> s = load_elem(sc.p[vb] + i);
   if (coef) s = s * coef[i / part_len];
   return s.from_mont();
 }
 
 template <class FrP>
-__global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP>* __restrict__ scalars, size_t npts,
+__global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(MsmScalars<Fp<FrP>> sc,
                                                                     const Fp<FrP>* __restrict__ coef, size_t part_len,
-                                                                    int c, int nwin, int wide, int lo_bits,
+                                                                    int c, int nwin, int wide, int hi_bits, int lo_bits,
                                                                     int ppt /* points per thread */,
                                                                     uint32_t wmask /* 0: fixed-base table, all windows
                                                                     share one bucket set; ~0: one set per window */,
@@ -212,15 +238,19 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(const Fp<FrP
   ZK_YSHIFT(bin_counts);
   ZK_YSHIFT(skip);
   extern __shared__ uint32_t big_lds[];
-  const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
+  const uint32_t nbins = (sc.nb * sc.sets_per) << hi_bits;
+  const size_t total = (size_t)sc.npts * sc.nb;
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) big_lds[b] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * BIG_THREADS * ppt;
   for (int k = 0; k < ppt; k++) {
-    size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
-    if (i >= npts) break;
-    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i, skip), c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[(((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits)], 1u); });
+    size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
+    if (g >= total) break;
+    uint32_t vb, i;
+    Fp<FrP> s = msm_load_scalar<FrP>(sc, coef, part_len, g, skip, &vb, &i);
+    const uint32_t set0 = vb * sc.sets_per;
+    msm_for_each_digit<FrP>(s, c, nwin, wide,
+                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits)], 1u); });
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS)
@@ -262,10 +292,10 @@ static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_scan_kernel(const 
 }
 
 template <class FrP>
-__global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<FrP>* __restrict__ scalars,
-                                                                       size_t npts, const Fp<FrP>* __restrict__ coef,
+__global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(MsmScalars<Fp<FrP>> sc,
+                                                                       const Fp<FrP>* __restrict__ coef,
                                                                        size_t part_len, int c, int nwin, int wide,
-                                                                       int lo_bits, int ppt, uint32_t wmask,
+                                                                       int hi_bits, int lo_bits, int ppt, uint32_t wmask,
                                                                        uint32_t pre_stride, uint32_t pre_off,
                                                                        uint32_t* __restrict__ bin_cursor,
                                                                        uint2* __restrict__ tmp,
@@ -275,17 +305,21 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
   ZK_YSHIFT(tmp);
   ZK_YSHIFT(skip);
   extern __shared__ uint32_t big_lds[];
-  const uint32_t nbins = (wmask ? (uint32_t)nwin : 1u) << BIG_HI;
+  const uint32_t nbins = (sc.nb * sc.sets_per) << hi_bits;
+  const size_t total = (size_t)sc.npts * sc.nb;
   uint32_t* cnt = big_lds;            // per-bin count of this tile, then the running local rank
   uint32_t* gbase = big_lds + nbins;  // start of this tile's range inside the bin
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) cnt[b] = 0;
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * BIG_THREADS * ppt;
   for (int k = 0; k < ppt; k++) {
-    size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
-    if (i >= npts) break;
-    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i, skip), c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[(((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits)], 1u); });
+    size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
+    if (g >= total) break;
+    uint32_t vb, i;
+    Fp<FrP> s = msm_load_scalar<FrP>(sc, coef, part_len, g, skip, &vb, &i);
+    const uint32_t set0 = vb * sc.sets_per;
+    msm_for_each_digit<FrP>(s, c, nwin, wide,
+                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits)], 1u); });
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) {
@@ -296,22 +330,26 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(const Fp<
   __syncthreads();
   const uint32_t lo_mask = (1u << lo_bits) - 1;
   for (int k = 0; k < ppt; k++) {
-    size_t i = base + (size_t)k * BIG_THREADS + threadIdx.x;
-    if (i >= npts) break;
-    msm_for_each_digit<FrP>(msm_load_scalar<FrP>(scalars, coef, part_len, i, skip), c, nwin, wide,
+    size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
+    if (g >= total) break;
+    uint32_t vb, i;
+    Fp<FrP> s = msm_load_scalar<FrP>(sc, coef, part_len, g, skip, &vb, &i);
+    const uint32_t set0 = vb * sc.sets_per;
+    msm_for_each_digit<FrP>(s, c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t neg) {
-                              uint32_t bin = (((uint32_t)w & wmask) << BIG_HI) | (b >> lo_bits);
+                              uint32_t bin = ((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits);
                               uint32_t r = atomicAdd(&cnt[bin], 1u);
-                              uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + (uint32_t)i : (uint32_t)i;
+                              uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
                               tmp[gbase[bin] + r] = make_uint2(idx | (neg << 31), b & lo_mask);
                             });
   }
 }
 
-// one workgroup per bin; the bin's keys are [bin << lo_bits, (bin + 1) << lo_bits) in the (window-major) key order
+// one workgroup per bin; the bin's keys are [bin << lo_bits, (bin + 1) << lo_bits) in the (set-major) key order
 static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_sort_kernel(const uint2* __restrict__ tmp,
                                                                           const uint32_t* __restrict__ bin_base,
-                                                                          int lo_bits, uint32_t keys_per_window_log2,
+                                                                          int hi_bits, int lo_bits,
+                                                                          uint32_t keys_per_set_log2,
                                                                           uint32_t* __restrict__ counts,
                                                                           uint32_t* __restrict__ sorted, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
@@ -322,8 +360,8 @@ static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_sort_kernel(const 
   __shared__ uint32_t cur[1 << 12];
   const uint32_t nlo = 1u << lo_bits;
   const uint32_t bin = blockIdx.x;
-  const uint32_t w = bin >> BIG_HI, hi = bin & ((1u << BIG_HI) - 1);
-  const size_t key0 = ((size_t)w << keys_per_window_log2) + ((size_t)hi << lo_bits);
+  const uint32_t w = bin >> hi_bits, hi = bin & ((1u << hi_bits) - 1);
+  const size_t key0 = ((size_t)w << keys_per_set_log2) + ((size_t)hi << lo_bits);
   const uint32_t e0 = bin_base[bin], e1 = bin_base[bin + 1];
   for (uint32_t j = threadIdx.x; j < nlo; j += BIG_THREADS) cur[j] = 0;
   __syncthreads();
@@ -814,9 +852,16 @@ struct MsmSlot {
 
 // A launched MSM (or two sharing one sort) whose (S, A) pairs are on their way to the slot's pinned buffer.
 // msm_fold() waits for the event and folds on the host.
+// the scalar vectors of a batched launch (host side of MsmScalars)
+struct MsmBatchArg {
+  int nb = 1;
+  const void* p[16] = {nullptr};
+};
+
 struct MsmPending {
   bool active = false;
   int kwin = 0, c = 0, wide = 0, nb = 1, lo_bits = 0;
+  int batch = 1;                                 // scalar vectors of the launch (results: [base vector][batch])
   MsmSlot* slot = nullptr;
   std::shared_ptr<const MsmTable> tab, tab2;     // keep the tables alive while the kernels run
   // the sort this launch produced (device pointers into the slot's workspace): another MSM over the SAME scalars with
@@ -918,7 +963,7 @@ inline void msm_plan_of(size_t npts, bool g2, int* out) {
 template <class FrP, class Fld>
 int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* bases, const void* bases2,
                const void* scalars, size_t npts, const Fp<FrP>* coef_d, size_t part_len, hipStream_t st,
-               MsmPending* out);
+               MsmPending* out, const MsmBatchArg* batch = nullptr);
 // zk_msm_precompute's table kernel (same translation units)
 template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,
@@ -927,10 +972,11 @@ int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwi
 // Wait for a launched MSM and fold on the host.  The device left, per window, the c bit slices of the weighted bucket
 // sum (msm_reduce_b_kernel): X_w = sum_j 2^(j + lo_bits) TR_j + sum_j 2^j TC_j, and the result is sum_w 2^(start of w)
 // X_w -- one Horner walk over all bit positions from the top: a doubling per bit and an addition per slice.
+// results: [base vector v < nvec][scalar vector b < batch] at results[v * batch + b]
 template <class Fld>
-int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2) {
-  *result = XYZZ<Fld>::identity();
-  if (result2) *result2 = XYZZ<Fld>::identity();
+int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
+  const int batch = p.batch;
+  for (int i = 0; i < nvec * batch; i++) results[i] = XYZZ<Fld>::identity();
   if (!p.active) return ZK_OK;
   p.active = false;
   hipError_t he = hipEventSynchronize(p.slot->ev);
@@ -940,6 +986,7 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
   const int kwin = p.kwin, c = p.c, wide = p.wide, lo_bits = p.lo_bits, nslices = p.c;
   const int hb = c - 1 - lo_bits;                  // row slices 0..hb come first, then lo_bits column slices
   const XYZZ<Fld>* hall = (const XYZZ<Fld>*)p.slot->pinned;
+  if (nvec > p.nb) nvec = p.nb;
   // windows [w_lo, w_hi] of one vector, high to low, doublings only INSIDE the range:
   // sum_w 2^(start_w - start_w_lo) X_w with X_w = sum_j 2^(j + lo_bits) TR_j + sum_j 2^j TC_j
   auto fold_range = [&](const XYZZ<Fld>* h, int w_hi, int w_lo) -> XYZZ<Fld> {
@@ -967,12 +1014,29 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
   constexpr int FOLD_PARTS = 4;
   HostPool* pool = eng->host_pool();
   static const bool par_fold = !(getenv("ZK_PAR_FOLD") && atoi(getenv("ZK_PAR_FOLD")) == 0);
-  const int nvec = (p.nb == 2 && result2) ? 2 : 1;
+  // bucket sets of (base vector v, scalar vector b) start at hall + ((v * batch + b) * kwin) * nslices
+  auto sets_of = [&](int v, int b) { return hall + ((size_t)v * batch + b) * kwin * nslices; };
   // only with free workers for every sub-task: this may itself be a pool task, and waiting for sub-tasks that nobody can
   // pick up would deadlock the pool
+  if (batch > 1) {
+    // a batch: one fold per (v, b); table-free folds (kwin > 1) are spread over free workers
+    const int jobs = nvec * batch;
+    if (kwin > 1 && pool && par_fold && pool->idle() >= jobs) {
+      std::vector<std::future<void>> futs;
+      for (int i = 1; i < jobs; i++) {
+        XYZZ<Fld>* dst = results + i;
+        const XYZZ<Fld>* h = sets_of(i / batch, i % batch);
+        futs.push_back(pool->submit([=, &fold_range]() { *dst = fold_range(h, kwin - 1, 0); }));
+      }
+      results[0] = fold_range(sets_of(0, 0), kwin - 1, 0);
+      for (auto& f : futs) f.get();
+    } else {
+      for (int i = 0; i < jobs; i++) results[i] = fold_range(sets_of(i / batch, i % batch), kwin - 1, 0);
+    }
+    return ZK_OK;
+  }
   if (!pool || !par_fold || kwin < 2 * FOLD_PARTS || pool->idle() < 2 * FOLD_PARTS) {
-    *result = fold_range(hall, kwin - 1, 0);
-    if (nvec == 2) *result2 = fold_range(hall + (size_t)kwin * nslices, kwin - 1, 0);
+    for (int v = 0; v < nvec; v++) results[v] = fold_range(sets_of(v, 0), kwin - 1, 0);
     return ZK_OK;
   }
   XYZZ<Fld> part[2][FOLD_PARTS];
@@ -985,7 +1049,7 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
   for (int v = 0; v < nvec; v++)
     for (int g = 0; g < FOLD_PARTS; g++) {
       if (v == 0 && g == 0) continue;              // this thread's share
-      const XYZZ<Fld>* h = hall + (size_t)v * kwin * nslices;
+      const XYZZ<Fld>* h = sets_of(v, 0);
       XYZZ<Fld>* dst = &part[v][g];
       const int a = hi_w[g], b = lo_w[g];
       futs.push_back(pool->submit([=, &fold_range]() { *dst = fold_range(h, a, b); }));
@@ -999,9 +1063,20 @@ int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2)
       for (int i = 0; i < bits; i++) total = xyzz_dbl_ni(total);
       total = xyzz_add_ni(total, part[v][g]);
     }
-    *(v == 0 ? result : result2) = total;
+    results[v] = total;
   }
   return ZK_OK;
+}
+
+// single scalar vector: result (and result2 for the second base vector of the launch)
+template <class Fld>
+int msm_fold(IEngine* eng, MsmPending& p, XYZZ<Fld>* result, XYZZ<Fld>* result2) {
+  if (p.active && p.batch != 1) return eng->fail(ZK_ERR_GENERIC, "msm_fold on a batched launch");
+  XYZZ<Fld> r[2];
+  int rc = msm_fold_batch<Fld>(eng, p, r, result2 ? 2 : 1);
+  *result = r[0];
+  if (result2) *result2 = r[1];
+  return rc;
 }
 
 // sum_p k_p * P_p for a handful of points by Straus' interleaving (4-bit windows, one shared doubling chain):
@@ -1043,11 +1118,12 @@ class MsmRunner {
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
                hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, MsmGate gate = MsmGate{},
-               const MsmPending* share = nullptr) {
+               const MsmPending* share = nullptr, const MsmBatchArg* batch = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
     MsmTuning tune{bigsort_min, gate, share};
-    return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend);
+    return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
+                                batch);
   }
   template <class Fld>
   int finish_t(IEngine* eng, MsmPending* pend, XYZZ<Fld>* result, XYZZ<Fld>* result2 = nullptr) {

@@ -9,12 +9,15 @@ namespace zk {
 template <class FrP, class Fld>
 int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* bases, const void* bases2,
                const void* scalars, size_t npts, const Fp<FrP>* coef_d, size_t part_len, hipStream_t st,
-               MsmPending* pend) {
+               MsmPending* pend, const MsmBatchArg* ba) {
   using Fr = Fp<FrP>;
   pend->active = false;
   const unsigned NB = bases2 ? 2u : 1u;
+  const size_t batch = ba ? (size_t)ba->nb : 1;    // scalar vectors multiplied against the same base vector(s)
+  if (batch < 1 || batch > (size_t)MSM_MAXB) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm batch");
+  pend->batch = (int)batch;
   if (npts == 0) return ZK_OK;
-  if (npts >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
+  if (npts * batch >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
   constexpr bool G2FLD = IsExtField<Fld>::value;
   const void* const bases_in = bases;            // the caller's points (the skip mask reads them, not the table rows)
   const void* const bases2_in = bases2;
@@ -36,9 +39,10 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const int c = (T + nwin - 1) / nwin;            // widest window
   const int wide = T - nwin * (c - 1);            // 1 <= wide <= nwin
   const uint32_t B = 1u << (c - 1);
-  const int kwin = tab ? 1 : nwin;                // bucket sets: with a table all windows share one
-  const size_t nkeys = (size_t)kwin * B;
-  const size_t max_sorted = npts * nwin;
+  const int kwin = tab ? 1 : nwin;                // bucket sets per scalar vector: with a table all windows share one
+  const size_t nsets = batch * (size_t)kwin;      // bucket sets of the launch
+  const size_t nkeys = nsets * B;
+  const size_t max_sorted = npts * batch * nwin;
   if (max_sorted >= ((size_t)1 << 32)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large (points x windows >= 2^32)");
   const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
   uint32_t seg = msm_pick_seg(npts, G2FLD);
@@ -50,6 +54,12 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     while ((size_t)want * 4 < avg && want < 1024) want <<= 1;
     const bool overridden = getenv("ZK_MSM_SEG") || (G2FLD && getenv("ZK_MSM_SEG_G2"));
     if (!overridden && want > seg) seg = want;
+    // a batch has lanes to spare (batch x the segments of one MSM): longer segments leave fewer partial sums to the
+    // finalize kernel.  ZK_MSM_SEG_BATCH overrides (measured in DESIGN.md "batched proving").
+    if (batch > 1) {
+      static const int seg_batch = getenv("ZK_MSM_SEG_BATCH") ? atoi(getenv("ZK_MSM_SEG_BATCH")) : 0;
+      if (seg_batch >= 1 && seg_batch <= 1024) seg = (uint32_t)seg_batch;
+    }
   }
   const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
@@ -78,13 +88,14 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
          o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc));
   // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
-    const int sort_lo = c - 1 - BIG_HI;
-  const bool big = npts >= tune.bigsort_min && sort_lo >= 1 && sort_lo <= 12;
-  const int kbin = tab ? 1 : nwin;                 // window components of the sort bins
+  const int sort_hi = msm_big_hi(nsets);
+  const int sort_lo = c - 1 - sort_hi;
+  const bool big = npts * batch >= tune.bigsort_min && sort_hi >= 1 && sort_lo >= 1 && sort_lo <= 12;
+  const size_t kbin = nsets;                       // set components of the sort bins
   const size_t o_skip = take(((npts + 63) / 64) * 8);
   size_t o_bins = 0, o_tmp = 0;
   if (big) {
-    o_bins = take((3 * ((size_t)kbin << BIG_HI) + 1) * 4);
+    o_bins = take((3 * (kbin << sort_hi) + 1) * 4);
     o_tmp = take(max_sorted * sizeof(uint2));
   }
   const size_t sort_region = off;
@@ -92,11 +103,11 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   off = sort_region * NS;
   // ---- per base vector
   size_t o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
-         o_rc = take(NB * (size_t)kwin * red_groups * sizeof(XYZZ<Fld>)),
-         o_out = take(NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>));
+         o_rc = take(NB * nsets * red_groups * sizeof(XYZZ<Fld>)),
+         o_out = take(NB * nsets * nslices * sizeof(XYZZ<Fld>));
   hipError_t he = slot.ws.ensure(off);
   if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
-  const size_t out_bytes = NB * (size_t)kwin * nslices * sizeof(XYZZ<Fld>);
+  const size_t out_bytes = NB * nsets * nslices * sizeof(XYZZ<Fld>);
   he = slot.ensure_pinned(out_bytes);
   if (he != hipSuccess) return eng->hip_fail(he, "msm pinned buffer");
   if (!slot.ev) {
@@ -137,7 +148,7 @@ do {                                                                           \
   // another launch already sorted these scalars with this layout?
   const MsmPending::Sort* sh = nullptr;
   // (a shared sort leaves out the identities of the launch that built it: only valid when identity skipping is off)
-  if (tune.share && tune.share->active && getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0) {
+  if (batch == 1 && tune.share && tune.share->active && getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0) {
     const MsmPending::Sort& s0 = tune.share->sort;
     if (s0.scalars == scalars && s0.coef == (const void*)coef_d && s0.npts == npts && s0.part_len == (part_len ? part_len : npts) &&
         s0.c == c && s0.nwin == nwin && s0.wide == wide && s0.seg == seg && s0.pre_stride == pre_stride &&
@@ -157,6 +168,12 @@ do {                                                                           \
   } else {
   MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st, NS, ys));   // counts and lenhist
   dim3 pg((unsigned)((npts + 255) / 256), NS), pb(256);
+  dim3 pgb((unsigned)((npts * batch + 255) / 256), NS);     // one thread per (scalar vector, point)
+  MsmScalars<Fr> sc{};
+  for (size_t b = 0; b < batch; b++) sc.p[b] = (const Fr*)(ba ? ba->p[b] : scalars);
+  sc.npts = (uint32_t)npts;
+  sc.nb = (uint32_t)batch;
+  sc.sets_per = (uint32_t)kwin;
   uint32_t* skip = nullptr;
   if (skip_on && !none) {
     skip = (uint32_t*)(ws + o_skip);
@@ -164,9 +181,9 @@ do {                                                                           \
   }
   const size_t plen = part_len ? part_len : npts;
   {
-  ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts);
+  ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts * batch);
   if (big) {
-    const uint32_t nbins = (uint32_t)kbin << BIG_HI;
+    const uint32_t nbins = (uint32_t)(kbin << sort_hi);
     uint32_t* bin_counts = (uint32_t*)(ws + o_bins);
     uint32_t* bin_base = bin_counts + nbins;
     uint32_t* bin_cursor = bin_base + nbins + 1;
@@ -174,22 +191,22 @@ do {                                                                           \
     MSM_HIP(msm_zero(bin_counts, nbins * 4, st, NS, ys));
     // tile = BIG_THREADS * ppt points: ~1024 tiles for small MSMs, 16 points per thread for the multi-million ones
     int ppt = BIG_PTS_PER_THREAD;
-    while (ppt > 1 && (npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt) < 1024) ppt >>= 1;
-    const unsigned tiles = (unsigned)((npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
+    const size_t tot = npts * batch;
+    while (ppt > 1 && (tot + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt) < 1024) ppt >>= 1;
+    const unsigned tiles = (unsigned)((tot + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
     const uint32_t wmask = tab ? 0u : ~0u;
-    msm_part_hist_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), nbins * 4, st>>>((const Fr*)scalars, npts, coef_d,
-                                                                                    plen, c, nwin, wide, sort_lo, ppt,
-                                                                                    wmask, bin_counts, skip, ys);
+    msm_part_hist_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), nbins * 4, st>>>(sc, coef_d, plen, c, nwin, wide,
+                                                                                    sort_hi, sort_lo, ppt, wmask,
+                                                                                    bin_counts, skip, ys);
     msm_bin_scan_kernel<<<dim3(1, NS), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor, ys);
     msm_part_scatter_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-        (const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp,
-        skip, ys);
-    msm_bin_sort_kernel<<<dim3(nbins, NS), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_lo, (uint32_t)(c - 1), counts,
-                                                                       sorted, ys);
+        sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp, skip, ys);
+    msm_bin_sort_kernel<<<dim3(nbins, NS), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_hi, sort_lo, (uint32_t)(c - 1),
+                                                                       counts, sorted, ys);
     MSM_STAGE("big sort");
   } else {
-    msm_digits_kernel<FrP, 0><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                pre_off, counts, nullptr, nullptr, skip, ys);
+    msm_digits_kernel<FrP, 0><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, counts, nullptr,
+                                                 nullptr, skip, ys);
     MSM_STAGE("digits/count");
   }
   iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
@@ -204,14 +221,14 @@ do {                                                                           \
       segs, offsets, nkeys, seg, lenhist, lenhist + SEG_BINS, order, ys);
   MSM_STAGE("expand");
   if (!big)
-    msm_digits_kernel<FrP, 1><<<pg, pb, 0, st>>>((const Fr*)scalars, npts, coef_d, plen, c, nwin, wide, pre_stride,
-                                                pre_off, nullptr, cursor, sorted, skip, ys);
+    msm_digits_kernel<FrP, 1><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, nullptr, cursor,
+                                                 sorted, skip, ys);
   }
   MSM_HIP(hipEventRecord(slot.ev_sort, st));
   }
   MSM_STAGE("scatter");
   {
-  ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB);
+  ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB * batch);
   size_t acc_wgs = (max_segs + 127) / 128;
   {
     static const int cap_g1 = getenv("ZK_ACC_WGS_G1") ? atoi(getenv("ZK_ACC_WGS_G1")) : 0;
@@ -255,8 +272,8 @@ do {                                                                           \
   // As many quads per group as keep the whole launch resident at once (a second generation of workgroups doubles a
   // kernel that is one dependent chain): the chip holds 1024 SIMDs x (2 waves of the extension-field kernels, 3 of the
   // base-field ones) x 16 quads.  ZK_RED_NVL_A / _B override (experiments).
-  const size_t tot_groups = (size_t)red_groups * NB * kwin;
-  const size_t tot_slices = (size_t)nslices * NB * kwin;
+  const size_t tot_groups = (size_t)red_groups * NB * nsets;
+  const size_t tot_slices = (size_t)nslices * NB * nsets;
   const size_t cap_quads = (size_t)1024 * (G2FLD ? 2 : 3) * 16;
   auto pick_nvl = [&](size_t groups) {
     int v = QUAD_VL;
@@ -269,9 +286,9 @@ do {                                                                           \
   if (env_a == 4 || env_a == 8 || env_a == 16 || env_a == 32 || env_a == 64) nvl_a = env_a;
   if (env_b == 4 || env_b == 8 || env_b == 16 || env_b == 32 || env_b == 64) nvl_b = env_b;
   const unsigned gpw_a = QUAD_VL / nvl_a, gpw_b = QUAD_VL / nvl_b;
-  msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)kwin), dim3(QUAD_THREADS), quad_lds, st>>>(
+  msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)nsets), dim3(QUAD_THREADS), quad_lds, st>>>(
       buckets, B, lo_bits, nvl_a, rc);
-  msm_reduce_b_kernel<KF><<<dim3(((unsigned)nslices + gpw_b - 1) / gpw_b, NB * (unsigned)kwin), dim3(QUAD_THREADS), quad_lds,
+  msm_reduce_b_kernel<KF><<<dim3(((unsigned)nslices + gpw_b - 1) / gpw_b, NB * (unsigned)nsets), dim3(QUAD_THREADS), quad_lds,
                             st>>>(rc, B, lo_bits, nvl_b, out);
   }
   MSM_HIP(hipGetLastError());
@@ -321,7 +338,7 @@ int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwi
 
 #define ZK_INSTANTIATE_MSM(FRP, FLD)                                                                              \
   template int msm_launch<FRP, FLD>(IEngine*, MsmSlot&, const MsmTuning&, const void*, const void*, const void*, \
-                                    size_t, const Fp<FRP>*, size_t, hipStream_t, MsmPending*);                   \
+                                    size_t, const Fp<FRP>*, size_t, hipStream_t, MsmPending*, const MsmBatchArg*);  \
   template int msm_table_launch<FRP, FLD>(IEngine*, const void*, size_t, int, int, int, void*, hipStream_t);
 
 }  // namespace zk

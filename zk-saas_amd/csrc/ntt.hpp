@@ -120,9 +120,11 @@ struct LdsVec {
 //   add      : optional [batch][n] added at the final store (in_mask)
 // optional read-only sources of the FIRST pass: vector y of the batch is read from p[y / per] + (y % per) * n instead of
 // from `data` (circom_h transforms the caller's three QAP vectors into its work buffer without copying them first)
+// (a batch of proofs passes three per proof: NTT_SRC_MAX = 3 x 16)
+constexpr int NTT_SRC_MAX = 48;
 template <class F>
 struct NttSrc {
-  const F* p[3];
+  const F* p[NTT_SRC_MAX];
   uint32_t per;
 };
 template <class F, int TB>

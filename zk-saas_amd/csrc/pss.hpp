@@ -152,12 +152,19 @@ __global__ __launch_bounds__(KING_THREADS) void pss_unpack_kernel(const Fp<P>* _
 //   gstep  : g^(Lc*e), e < l                  in_scale: optional factor applied to every input share
 // Batched form: blockIdx.y selects one of up to KING_BATCH independent vectors (the a, b, c polynomials of
 // circom_h): input / output at y * stride, masks per item, share randomness stream seed + y.
-constexpr int KING_BATCH = 3;
+// A batch of proofs (zk_groth16_prove_batch) makes that 3 vectors per proof: item y = 3 b + k; its share randomness is
+// stream seed + (y / items_per) * seed_step + y % items_per, so that proof b of a batch draws what a single proof with
+// seed + seed_step * b draws (items_per == 0: stream seed + y).
+constexpr int KING_BATCH = 48;
 template <class F>
 struct KingBatch {
   const F* in_mask[KING_BATCH];
   const F* out_mask[KING_BATCH];
   size_t stride;
+  uint32_t items_per, seed_step;
+  ZK_HD uint64_t seed_off(uint32_t y) const {
+    return items_per ? (uint64_t)(y / items_per) * seed_step + y % items_per : (uint64_t)y;
+  }
 };
 
 template <class P, int L, bool NEGATE>
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
   F* __restrict__ out = out0 + blockIdx.y * kb.stride;
   const F* __restrict__ in_mask = kb.in_mask[blockIdx.y];
   const F* __restrict__ out_mask = kb.out_mask[blockIdx.y];
-  const RngSeed seed = seed0.plus(blockIdx.y);
+  const RngSeed seed = seed0.plus(kb.seed_off(blockIdx.y));
   constexpr int T = L, N = 4 * L;
   constexpr int LOGL = (L == 1) ? 0 : (L == 2) ? 1 : (L == 4) ? 2 : (L == 8) ? 3 : 4;
   extern __shared__ uint4 smem[];
@@ -341,12 +348,31 @@ __global__ void a2a_unpack_rows_kernel(const F* __restrict__ recv, int k, size_t
 }
 
 // King closure of deg_red (deg_red.rs:103-111): unpack_missing_shares then pack, per chunk.
+// Batched form (blockIdx.y = item, the proofs of zk_groth16_prove_batch): item y reads in / mul_b / sub_c at
+// + y * in_step, writes out at + y * out_step, uses masks[y] and the randomness stream seed + y * seed_step.
+constexpr int DEGRED_BATCH = 16;
+template <class F>
+struct DegredBatch {
+  const F* in_mask[DEGRED_BATCH];
+  const F* out_mask[DEGRED_BATCH];
+  size_t in_step, out_step;
+  uint32_t seed_step;
+};
 template <class P, int L>
 __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
-    const Fp<P>* __restrict__ in, const Fp<P>* __restrict__ in_mask, int np, size_t len,
+    const Fp<P>* __restrict__ in, DegredBatch<Fp<P>> db, int np, size_t len,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
-    Fp<P>* __restrict__ out, const Fp<P>* __restrict__ out_mask, size_t stride, size_t j0,
+    Fp<P>* __restrict__ out, size_t stride, size_t j0,
     const Fp<P>* __restrict__ mul_b, const Fp<P>* __restrict__ sub_c) {
+  const Fp<P>* __restrict__ in_mask = db.in_mask[blockIdx.y];
+  const Fp<P>* __restrict__ out_mask = db.out_mask[blockIdx.y];
+  in += blockIdx.y * db.in_step;
+  out += blockIdx.y * db.out_step;
+  if (mul_b) {
+    mul_b += blockIdx.y * db.in_step;
+    sub_c += blockIdx.y * db.in_step;
+  }
+  seed = seed.plus((uint64_t)blockIdx.y * db.seed_step);
   // stride = row pitch of in / out (len for whole vectors); j0 = global index of column 0 (share randomness of a chunk
   // range of the all-to-all king must be the one the star king would draw).  mul_b / sub_c (optional, same layout as
   // `in`): the input share is in * mul_b - sub_c, i.e. circom_h's a*b - c (ext_wit.rs:173-177) computed at the load

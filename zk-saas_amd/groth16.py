@@ -311,6 +311,49 @@ def prove(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
     return pa, pb, pc
 
 
+def prove_batch(pp, crs, wits, rs, ss, masks=None, seed=0, stream=None):
+    """zk_groth16_prove_batch: len(wits) proofs against one CRS in one pass (each witness with its own r, s and
+    masks).  Returns a list of (pi_a, pi_b, pi_c) as prove() gives them."""
+    nb, nl = len(wits), pp.fq.nl
+    assert len(rs) == nb and len(ss) == nb and (masks is None or len(masks) == nb)
+    pa = np.zeros((nb, pp.n, 3 * nl), dtype=np.uint64)
+    pb = np.zeros((nb, pp.n, 6 * nl), dtype=np.uint64)
+    pc = np.zeros((nb, pp.n, 3 * nl), dtype=np.uint64)
+    rr = np.ascontiguousarray(np.stack([pp.fr.encode_one(v) for v in rs]))
+    sv = np.ascontiguousarray(np.stack([pp.fr.encode_one(v) for v in ss]))
+    for w in wits:
+        assert crs.len_a == w.len_a and crs.len_w == w.len_w and w.log_m == wits[0].log_m
+    arr = lambda f: (C.c_void_p * nb)(*[f(w) for w in wits])
+    mk = None
+    if masks is not None:
+        mk = (Masks * nb)()
+        for b, m in enumerate(masks):
+            src = m.ct if isinstance(m, ProofMasks) else m
+            C.memmove(C.byref(mk, b * C.sizeof(Masks)), C.byref(src), C.sizeof(Masks))
+    pp._check(pp.lib.zk_groth16_prove_batch(
+        pp.h, C.byref(crs.ct), nb, arr(lambda w: w.qap[0].ptr), arr(lambda w: w.qap[1].ptr), arr(lambda w: w.qap[2].ptr),
+        arr(lambda w: w.a_share.ptr), arr(lambda w: w.ax_share.ptr), rr.ctypes.data, sv.ctypes.data, wits[0].log_m,
+        None if mk is None else C.cast(mk, C.c_void_p), seed, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data, stream))
+    return [(pa[b], pb[b], pc[b]) for b in range(nb)]
+
+
+def reconstruct(pp, proof, parties=None, want_bytes=True, stream=None):
+    """zk_groth16_reconstruct (groth16/examples/sha256.rs:375-377): (a, b, c) = pp.unpack2(shares)[0] over the parties'
+    shares of one proof.  proof = (pi_a, pi_b, pi_c) rows of the listed parties (all n when parties is None).  Returns
+    (affine, bytes): affine = uint64 array [8 * |Fq| limbs] = A (x, y) | B (x.c0, x.c1, y.c0, y.c1) | C (x, y) in
+    Montgomery form; bytes = ark_groth16::Proof::serialize_compressed."""
+    nl = pp.fq.nl
+    pa, pb, pc = (np.ascontiguousarray(x, dtype=np.uint64) for x in proof)
+    aff = np.zeros(8 * nl, dtype=np.uint64)
+    raw = np.zeros(4 * pp.fq.nbytes, dtype=np.uint8)
+    ids, count = None, pp.n
+    if parties is not None:
+        ids, count = (C.c_uint32 * len(parties))(*parties), len(parties)
+    pp._check(pp.lib.zk_groth16_reconstruct(pp.h, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data, ids, count,
+                                            aff.ctypes.data, raw.ctypes.data if want_bytes else None, stream))
+    return aff, (raw.tobytes() if want_bytes else None)
+
+
 class ProofInFlight:
     """A proof started with prove_async (zk_groth16_prove_async); wait() joins it and returns the shares."""
 

@@ -132,8 +132,11 @@ def _open_net(pp, rank, world, dist, net_id, transport, king):
             log_m = 14                                   # 32 king workgroup columns: enough for 8 chunk ranges
             x = _rand_fr(pp, net.k * ((1 << log_m) // pp.l), 5 + rank)
             znet.dist_d_fft(pp, net, 0, x, None, False, log_m, seed=1)
-            pp.sync()
+            # the channel first: zk_net_sync waits with the timeout as a DEADLINE (a hung RCCL collective is aborted
+            # there and reported); a plain stream synchronise on the caller's stream -- which zk_dist_d_fft has made
+            # wait for the channel stream -- would block forever behind the same hung collective
             net.sync(0)
+            pp.sync()
             net.lib.zk_net_set_timeout_ms(net.h, 30000)
         except ZkError as e:
             err = "%s" % (e,)
