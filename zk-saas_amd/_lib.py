@@ -21,7 +21,7 @@ SYMBOLS = [
     "zk_dist_groth16_prove", "zk_chacha20_block", "zk_deg_red_points", "zk_degred_mask_sample_points",
     "zk_points_decompress", "zk_points_compress", "zk_libsnark_h", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
-    "zk_groth16_prove_batch", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct",
+    "zk_groth16_prove_batch", "zk_groth16_prove_batch_async", "zk_groth16_batch_wait", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct",
 ]
 
 _lib = None
@@ -160,6 +160,9 @@ def load():
     lib.zk_pss_pack_points.argtypes = [vp, i32, vp, sz, i32, vp, vp]
     lib.zk_groth16_prove_batch.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                            C.POINTER(vp), vp, vp, i32, vp, u64, vp, vp, vp, vp]
+    lib.zk_groth16_prove_batch_async.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                 C.POINTER(vp), vp, vp, i32, vp, u64, vp, C.POINTER(i32)]
+    lib.zk_groth16_batch_wait.argtypes = [vp, i32, vp, vp, vp]
     lib.zk_msm_batch.argtypes = [vp, i32, vp, sz, C.POINTER(vp), i32, vp, vp]
     lib.zk_pss_unpack_points.argtypes = [vp, i32, vp, sz, vp, vp]
     lib.zk_pss_unpack2_points.argtypes = [vp, i32, vp, C.POINTER(C.c_uint32), i32, sz, vp, vp]

@@ -302,6 +302,18 @@ int zk_groth16_prove_batch(zk_ctx* ctx, const zk_crs_share* crs, int nproofs, co
   return e->groth16_prove_batch(crs, nproofs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
                                 pi_a, pi_b, pi_c, S(stream));
 }
+int zk_groth16_prove_batch_async(zk_ctx* ctx, const zk_crs_share* crs, int nproofs, const void* const* qap_a_d,
+                                 const void* const* qap_b_d, const void* const* qap_c_d, const void* const* a_share_d,
+                                 const void* const* ax_share_d, const void* r, const void* s, int log2_m,
+                                 const zk_groth16_masks* masks, uint64_t seed, void* stream, int* handle) {
+  CTX_OR_FAIL();
+  return e->groth16_prove_batch_async(crs, nproofs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks,
+                                      seed, S(stream), handle);
+}
+int zk_groth16_batch_wait(zk_ctx* ctx, int handle, void* pi_a, void* pi_b, void* pi_c) {
+  CTX_OR_FAIL();
+  return e->groth16_batch_wait(handle, pi_a, pi_b, pi_c);
+}
 int zk_msm_batch(zk_ctx* ctx, int group, const void* bases_d, size_t len, const void* const* scalars_d, int nvec,
                  void* out, void* stream) {
   CTX_OR_FAIL();

@@ -250,6 +250,11 @@ class IEngine {
                                 void* out, hipStream_t st) = 0;
   virtual int groth16_reconstruct(const void* pi_a, const void* pi_b, const void* pi_c, const uint32_t* parties, int np,
                                   void* proof_affine, void* proof_bytes, hipStream_t st) = 0;
+  virtual int groth16_prove_batch_async(const zk_crs_share* crs, int nb, const void* const* qa, const void* const* qb,
+                                        const void* const* qc, const void* const* a_share,
+                                        const void* const* ax_share, const void* r, const void* s, int log_m,
+                                        const zk_groth16_masks* masks, uint64_t seed, hipStream_t st, int* handle) = 0;
+  virtual int groth16_batch_wait(int handle, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int msm_batch(int group, const void* bases, size_t len, const void* const* scalars, int nb, void* out,
                         hipStream_t st) = 0;
   virtual int groth16_abort(int handle) = 0;

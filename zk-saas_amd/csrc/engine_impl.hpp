@@ -51,8 +51,13 @@ class Engine : public IEngine {
   ~Engine() override {
     for (auto& j : jobs_)
       if (j.active) abort_job(j);
-    if (bjob_.active) abort_batch(bjob_);
-    if (ev_batch_in_) (void)hipEventDestroy(ev_batch_in_);
+    for (auto& b : bjobs_) {
+      if (b.active) abort_batch(b);
+      if (b.ev_in) (void)hipEventDestroy(b.ev_in);
+      if (b.slot != 0)
+        for (hipStream_t s_ : b.st)
+          if (s_) (void)hipStreamDestroy(s_);
+    }
     pool_.reset();                                   // joins the host workers before anything they use goes away
     TableRegistry::inst().forget_owner(this);
     for (auto& kv : gentabs_) (void)hipFree(kv.second);
@@ -1461,8 +1466,17 @@ class Engine : public IEngine {
     std::vector<std::future<void>> fut;
     int rc[4] = {0, 0, 0, 0};
   };
-  BatchJob bjob_;
-  hipEvent_t ev_batch_in_ = nullptr;
+  // Two batches may be in flight (zk_groth16_prove_batch_async): each has its own MSM workspaces, scratch and stream
+  // set, so that the sort phase of one batch runs under the accumulate kernels of the other and the reduction tails of one
+  // under the other's accumulates -- one batch alone leaves the chip partly idle for ~1 ms at either end.
+  static constexpr int NBATCH = 2;
+  struct BatchJobX : BatchJob {
+    zk_crs_share crs{};
+    int slot = 0;
+    hipEvent_t ev_in = nullptr;
+    hipStream_t st[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  };
+  BatchJobX bjobs_[NBATCH];
 
   void abort_batch(BatchJob& B) {
     for (auto& f : B.fut)
@@ -1483,19 +1497,51 @@ class Engine : public IEngine {
                           const void* const* qc, const void* const* a_share, const void* const* ax_share, const void* r_,
                           const void* s_, int log_m, const zk_groth16_masks* mk, uint64_t seed, void* pi_a, void* pi_b,
                           void* pi_c, hipStream_t st) override {
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int h = -1;
+    int rc = groth16_prove_batch_async(crs, nb, qa, qb, qc, a_share, ax_share, r_, s_, log_m, mk, seed, st, &h);
+    if (rc) return rc;
+    return groth16_batch_wait(h, pi_a, pi_b, pi_c);
+  }
+  int groth16_prove_batch_async(const zk_crs_share* crs_in, int nb, const void* const* qa, const void* const* qb,
+                                const void* const* qc, const void* const* a_share, const void* const* ax_share,
+                                const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk, uint64_t seed,
+                                hipStream_t st, int* handle) override {
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
-    int rc = check_prove_args(crs, r_, s_, log_m);
+    int rc = check_prove_args(crs_in, r_, s_, log_m);
     if (rc) return rc;
     if (nb < 1 || nb > MAX_PROOF_BATCH || 3 * nb > KING_BATCH || nb > DEGRED_BATCH)
       return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MAX_PROOF_BATCH));
-    if (!qa || !qb || !qc || !a_share || !ax_share || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (!qa || !qb || !qc || !a_share || !ax_share || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     for (int b = 0; b < nb; b++)
       if (!qa[b] || !qb[b] || !qc[b] || !a_share[b] || !ax_share[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    BatchJob& B = bjob_;
-    if (B.active) return fail(ZK_ERR_BAD_INPUT, "a batch is already in flight");
+    int slot = -1;
+    for (int i = 0; i < NBATCH; i++)
+      if (!bjobs_[i].active) {
+        slot = i;
+        break;
+      }
+    if (slot < 0) return fail(ZK_ERR_BAD_INPUT, "too many batches in flight (zk_groth16_batch_wait one first)");
+    BatchJobX& B = bjobs_[slot];
+    B.slot = slot;
     rc = ensure_streams();
     if (rc) return rc;
-    if (!ev_batch_in_) ZK_HIP(hipEventCreateWithFlags(&ev_batch_in_, hipEventDisableTiming));
+    if (!B.ev_in) {
+      ZK_HIP(hipEventCreateWithFlags(&B.ev_in, hipEventDisableTiming));
+      for (int i = 0; i < 6; i++) {
+        if (slot == 0) {
+          B.st[i] = streams_[i];                     // batch slot 0 shares the single-proof stream set
+        } else {
+          int pr = 0;
+          ZK_HIP(hipStreamGetPriority(streams_[i], &pr));
+          ZK_HIP(hipStreamCreateWithPriority(&B.st[i], hipStreamNonBlocking, pr));
+        }
+      }
+    }
+    B.crs = *crs_in;
+    const zk_crs_share* crs = &B.crs;
+    hipStream_t* const streams_ = B.st;              // this batch's stream set
+    hipEvent_t const ev_batch_in_ = B.ev_in;
     const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
     ZK_HIP(B.hshare.ensure(per * nb * sizeof(Fr)));
     B.nb = nb;
@@ -1508,11 +1554,11 @@ class Engine : public IEngine {
     }
     for (int i = 0; i < 4; i++) B.rc[i] = 0;
     ZK_HIP(hipEventRecord(ev_batch_in_, st));
-    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_batch_in_, 0));
+    for (int i = 0; i < 6; i++) ZK_HIP(hipStreamWaitEvent(streams_[i], ev_batch_in_, 0));
     B.active = true;
     BatchJob* BJ = &B;
     const int dev = device;
-    const int ws0 = 12;                                 // the batch's own MSM workspaces (msm.hpp MSM_WS)
+    const int ws0 = 12 + 6 * slot;                      // the batch's own MSM workspaces (msm.hpp MSM_WS)
     const Fr* cf = msm_.coef_d_;
     MsmBatchArg ba_a, ba_x;
     ba_a.nb = ba_x.nb = nb;
@@ -1583,8 +1629,22 @@ class Engine : public IEngine {
     rc = msm_.template launch_t<Fq_>(this, crs->u_d, nullptr, (size_t)n * crs->len_u, cf, crs->len_u, hs, ws0 + 0, &B.pU,
                                     nullptr, MsmGate{}, nullptr, &ba_h);
     if (rc) return bail(rc);
+    *handle = slot;
+    return ZK_OK;
+  }
+  int groth16_batch_wait(int handle, void* pi_a, void* pi_b, void* pi_c) override {
+    if (handle < 0 || handle >= NBATCH || !bjobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no batch in flight on this handle");
+    BatchJobX& B = bjobs_[handle];
+    auto bail = [&](int code) {
+      Status keep = last;
+      abort_batch(B);
+      last = keep;
+      return code;
+    };
+    if (!pi_a || !pi_b || !pi_c) return bail(fail(ZK_ERR_BAD_INPUT, "null pointer"));
+    const int nb = B.nb;
     std::vector<P1> ures((size_t)nb);
-    rc = msm_fold_batch<Fq_>(this, B.pU, ures.data(), 1);
+    int rc = msm_fold_batch<Fq_>(this, B.pU, ures.data(), 1);
     if (rc) return bail(rc);
     for (auto& f : B.fut)
       if (f.valid()) f.wait();

@@ -37,8 +37,8 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
-constexpr int MSM_WS = 18;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
-                                      // streams) + 6 for a batch of proofs (zk_groth16_prove_batch)
+constexpr int MSM_WS = 24;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
+                                      // streams) + 6 per batch of proofs in flight (zk_groth16_prove_batch)
 
 // Sort-stage arrays of a launch over TWO base vectors with per-vector sorts (their identity bases differ) live in two
 // copies of one workspace region; blockIdx.y picks the copy: every sort-stage kernel shifts its array pointers by

@@ -57,8 +57,8 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     // a batch has lanes to spare (batch x the segments of one MSM): longer segments leave fewer partial sums to the
     // finalize kernel.  ZK_MSM_SEG_BATCH overrides (measured in DESIGN.md "batched proving").
     if (batch > 1) {
-      static const int seg_batch = getenv("ZK_MSM_SEG_BATCH") ? atoi(getenv("ZK_MSM_SEG_BATCH")) : 0;
-      if (seg_batch >= 1 && seg_batch <= 1024) seg = (uint32_t)seg_batch;
+      static const int seg_batch = getenv("ZK_MSM_SEG_BATCH") ? atoi(getenv("ZK_MSM_SEG_BATCH")) : 128;
+      if (seg_batch >= 1 && seg_batch <= 1024 && !overridden) seg = (uint32_t)seg_batch;
     }
   }
   const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments

@@ -311,14 +311,33 @@ def prove(pp, crs, wit, r, s, masks=None, seed=0, stream=None):
     return pa, pb, pc
 
 
+class BatchInFlight:
+    """A batch started with prove_batch_async (zk_groth16_prove_batch_async); wait() joins it and returns the list of
+    (pi_a, pi_b, pi_c)."""
+
+    def __init__(self, pp, handle, nb, keep):
+        self.pp, self.handle, self.nb, self._keep = pp, handle, nb, keep
+
+    def wait(self):
+        pp, nb, nl = self.pp, self.nb, self.pp.fq.nl
+        pa = np.zeros((nb, pp.n, 3 * nl), dtype=np.uint64)
+        pb = np.zeros((nb, pp.n, 6 * nl), dtype=np.uint64)
+        pc = np.zeros((nb, pp.n, 3 * nl), dtype=np.uint64)
+        pp._check(pp.lib.zk_groth16_batch_wait(pp.h, self.handle, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data))
+        self._keep = None
+        return [(pa[b], pb[b], pc[b]) for b in range(nb)]
+
+
 def prove_batch(pp, crs, wits, rs, ss, masks=None, seed=0, stream=None):
     """zk_groth16_prove_batch: len(wits) proofs against one CRS in one pass (each witness with its own r, s and
     masks).  Returns a list of (pi_a, pi_b, pi_c) as prove() gives them."""
-    nb, nl = len(wits), pp.fq.nl
+    return prove_batch_async(pp, crs, wits, rs, ss, masks=masks, seed=seed, stream=stream).wait()
+
+
+def prove_batch_async(pp, crs, wits, rs, ss, masks=None, seed=0, stream=None):
+    """zk_groth16_prove_batch_async: enqueue a batch and return at once; up to two batches may be in flight."""
+    nb = len(wits)
     assert len(rs) == nb and len(ss) == nb and (masks is None or len(masks) == nb)
-    pa = np.zeros((nb, pp.n, 3 * nl), dtype=np.uint64)
-    pb = np.zeros((nb, pp.n, 6 * nl), dtype=np.uint64)
-    pc = np.zeros((nb, pp.n, 3 * nl), dtype=np.uint64)
     rr = np.ascontiguousarray(np.stack([pp.fr.encode_one(v) for v in rs]))
     sv = np.ascontiguousarray(np.stack([pp.fr.encode_one(v) for v in ss]))
     for w in wits:
@@ -330,11 +349,12 @@ def prove_batch(pp, crs, wits, rs, ss, masks=None, seed=0, stream=None):
         for b, m in enumerate(masks):
             src = m.ct if isinstance(m, ProofMasks) else m
             C.memmove(C.byref(mk, b * C.sizeof(Masks)), C.byref(src), C.sizeof(Masks))
-    pp._check(pp.lib.zk_groth16_prove_batch(
+    h = C.c_int(-1)
+    pp._check(pp.lib.zk_groth16_prove_batch_async(
         pp.h, C.byref(crs.ct), nb, arr(lambda w: w.qap[0].ptr), arr(lambda w: w.qap[1].ptr), arr(lambda w: w.qap[2].ptr),
         arr(lambda w: w.a_share.ptr), arr(lambda w: w.ax_share.ptr), rr.ctypes.data, sv.ctypes.data, wits[0].log_m,
-        None if mk is None else C.cast(mk, C.c_void_p), seed, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data, stream))
-    return [(pa[b], pb[b], pc[b]) for b in range(nb)]
+        None if mk is None else C.cast(mk, C.c_void_p), seed, stream, C.byref(h)))
+    return BatchInFlight(pp, h.value, nb, (crs, wits, masks, mk))
 
 
 def reconstruct(pp, proof, parties=None, want_bytes=True, stream=None):
