@@ -410,6 +410,10 @@ int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, con
  * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the
  * number of timed launches since zk_profile_enable. */
 int zk_profile_enable(zk_ctx* ctx, int on);
+/* MSM work counters of this context since creation (measurement only): stats[0] / [1] = mixed additions the G1 / G2
+ * accumulate kernels performed (= sorted (point, window) entries: identity bases and zero digits leave none), stats[2] /
+ * [3] = (point, window) pairs offered to the sorts.  Counted when an MSM's result is collected. */
+int zk_msm_stats(zk_ctx* ctx, uint64_t stats[4]);
 int zk_profile_slots(void);
 const char* zk_profile_name(int slot);
 int zk_profile_read(zk_ctx* ctx, int slot, double* total_ms, double* units, long* calls);

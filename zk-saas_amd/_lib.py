@@ -21,7 +21,7 @@ SYMBOLS = [
     "zk_dist_groth16_prove", "zk_chacha20_block", "zk_deg_red_points", "zk_degred_mask_sample_points",
     "zk_points_decompress", "zk_points_compress", "zk_libsnark_h", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
-    "zk_groth16_prove_batch", "zk_groth16_prove_batch_async", "zk_groth16_batch_wait", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct",
+    "zk_groth16_prove_batch", "zk_groth16_prove_batch_async", "zk_groth16_batch_wait", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct", "zk_msm_stats",
 ]
 
 _lib = None
@@ -167,6 +167,7 @@ def load():
     lib.zk_pss_unpack_points.argtypes = [vp, i32, vp, sz, vp, vp]
     lib.zk_pss_unpack2_points.argtypes = [vp, i32, vp, C.POINTER(C.c_uint32), i32, sz, vp, vp]
     lib.zk_groth16_reconstruct.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_uint32), i32, vp, vp, vp]
+    lib.zk_msm_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.zk_profile_enable.argtypes = [vp, i32]
     lib.zk_profile_slots.argtypes = []
     lib.zk_profile_name.argtypes = [i32]

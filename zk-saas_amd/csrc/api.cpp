@@ -515,6 +515,15 @@ int zk_profile_enable(zk_ctx* ctx, int on) {
   e->prof.on = on != 0;
   return ZK_OK;
 }
+int zk_msm_stats(zk_ctx* ctx, uint64_t stats[4]) {
+  CTX_OR_FAIL();
+  if (!stats) return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  stats[0] = e->msm_adds[0].load();
+  stats[1] = e->msm_adds[1].load();
+  stats[2] = e->msm_offered[0].load();
+  stats[3] = e->msm_offered[1].load();
+  return ZK_OK;
+}
 int zk_profile_slots(void) { return zk::PROF_NSLOTS; }
 const char* zk_profile_name(int slot) { return slot >= 0 && slot < zk::PROF_NSLOTS ? kSlotNames[slot] : ""; }
 int zk_profile_read(zk_ctx* ctx, int slot, double* total_ms, double* units, long* calls) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -176,6 +177,8 @@ class IEngine {
   // the context's host worker pool (nullptr before the first prover call): msm_fold splits a table-free fold over it
   virtual HostPool* host_pool() { return nullptr; }
   Profiler prof;
+  // MSM statistics since creation (zk_msm_stats): mixed additions performed and (point, window) pairs offered, G1 / G2
+  std::atomic<uint64_t> msm_adds[2] = {{0}, {0}}, msm_offered[2] = {{0}, {0}};
   int l = 0, n = 0, t = 0, device = 0;
   Status last;
   std::mutex last_mu;               // host worker tasks report failures too

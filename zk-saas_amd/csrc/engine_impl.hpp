@@ -54,7 +54,9 @@ class Engine : public IEngine {
     for (auto& b : bjobs_) {
       if (b.active) abort_batch(b);
       if (b.ev_in) (void)hipEventDestroy(b.ev_in);
-      if (b.slot != 0)
+      for (hipEvent_t e_ : b.ev_acc)
+        if (e_) (void)hipEventDestroy(e_);
+      if (b.own_streams)
         for (hipStream_t s_ : b.st)
           if (s_) (void)hipStreamDestroy(s_);
     }
@@ -1173,33 +1175,9 @@ class Engine : public IEngine {
     };
     const char* vb = (const char*)crs->v_d;
     const char* as = (const char*)a_share;
-    // Measured and rejected as a default (kept behind ZK_SHARE_SORT=1): S, H (G1) and V (G2) multiply three base vectors
-    // by the SAME witness shares with the same window layout, so V can sort (on its high-priority stream) and S/H run
-    // their accumulate on V's sort (msm_impl.hpp "share").  One sort less per proof (0.11 ms of chip time), but S/H then
-    // wait for another stream: 291 vs 289 proofs/s with tables, 215 vs 222 without -- within noise / slightly worse.
-    static const bool share_sort = getenv("ZK_SHARE_SORT") && atoi(getenv("ZK_SHARE_SORT")) != 0;
-    if (!j.split_v && share_sort) {
-      const void* sd = crs->s_d;
-      const void* hd = j.r_zero ? nullptr : crs->h_d;
-      const size_t npts = (size_t)count * cstride;
-      hipStream_t sv = streams_[2], ss = streams_[0];
-      J->fut.push_back(pool_->submit([=]() {
-        (void)hipSetDevice(dev);
-        int rc2 = msm_.template launch_t<Fq2_>(this, vb, as, npts, cf, cstride, sv, ws0 + 3, &J->pV0, nullptr, gate_v);
-        J->v_acc_flag.store(1, std::memory_order_release);
-        int rc3 = rc2 ? rc2
-                      : msm_.template launch_t<Fq_>(this, sd, as, npts, cf, cstride, ss, ws0 + 1, &J->pS, hd, gate_g1,
-                                                    &J->pV0);
-        if (!rc3) rc3 = msm_.template finish_t<Fq_>(this, &J->pS, &J->S, &J->H);
-        J->rc[0] = rc3;
-        if (!rc3 && J->full) {                        // s*S and r*H off the tail (prove.rs:229-235, linearity)
-          J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
-          if (!J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
-        }
-        if (!rc2) rc2 = msm_.template finish_t<Fq2_>(this, &J->pV0, &J->V0, (P2*)nullptr);
-        J->rc[2] = rc2;
-      }));
-    } else {
+    // (Round 2 measured sharing V's sort with S/H -- ZK_SHARE_SORT -- at 291 vs 289 proofs/s; the experiment went away
+    // with the segment descriptors it shared.)
+    {
       msm_task(Fq2_{}, 2, vb, nullptr, as, (size_t)nh * cstride, cf, cstride, streams_[2], ws0 + 3, &j.pV0, &j.V0,
                (P2*)nullptr);
       if (j.split_v)
@@ -1474,6 +1452,9 @@ class Engine : public IEngine {
     zk_crs_share crs{};
     int slot = 0;
     hipEvent_t ev_in = nullptr;
+    bool own_streams = false;
+    hipEvent_t ev_acc[4] = {nullptr, nullptr, nullptr, nullptr};      // V, S+H, W, U: recorded behind the accumulate kernel
+    std::atomic<int> acc_flag[4];                                     // ... once that record has been enqueued (MsmGate)
     hipStream_t st[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   };
   BatchJobX bjobs_[NBATCH];
@@ -1528,9 +1509,21 @@ class Engine : public IEngine {
     if (rc) return rc;
     if (!B.ev_in) {
       ZK_HIP(hipEventCreateWithFlags(&B.ev_in, hipEventDisableTiming));
+      for (int i = 0; i < 4; i++) ZK_HIP(hipEventCreateWithFlags(&B.ev_acc[i], hipEventDisableTiming));
+      // ZK_BATCH_V_CUS=<n> (experiment): the chip is split between the G2 MSM (stream 2: n of the 256 CUs) and
+      // everything else (the other CUs), so that the 256-register G2 waves and the 168-register G1 waves never compete
+      // for the same SIMDs (see DESIGN.md "batched proving")
+      static const int v_cus = getenv("ZK_BATCH_V_CUS") ? atoi(getenv("ZK_BATCH_V_CUS")) : 0;
+      B.own_streams = slot != 0 || (v_cus > 0 && v_cus < 256);
       for (int i = 0; i < 6; i++) {
-        if (slot == 0) {
+        if (!B.own_streams) {
           B.st[i] = streams_[i];                     // batch slot 0 shares the single-proof stream set
+        } else if (v_cus > 0 && v_cus < 256) {
+          uint32_t mask[8];
+          for (int w = 0; w < 8; w++) mask[w] = 0;
+          for (int cu = 0; cu < 256; cu++)
+            if ((cu < v_cus) == (i == 2)) mask[cu >> 5] |= 1u << (cu & 31);
+          ZK_HIP(hipExtStreamCreateWithCUMask(&B.st[i], 8, mask));
         } else {
           int pr = 0;
           ZK_HIP(hipStreamGetPriority(streams_[i], &pr));
@@ -1566,11 +1559,40 @@ class Engine : public IEngine {
       ba_a.p[b] = a_share[b];
       ba_x.p[b] = ax_share[b];
     }
+    // Order of the accumulate kernels.  Each accumulate of a batch fills the chip by itself (two or more rounds of
+    // waves), so running them ONE AFTER THE OTHER loses nothing -- the sorts, finalizes and reductions of the other MSMs
+    // run beside it -- and spares them each other: issued together, four kernels' waves interleave on every SIMD, the
+    // 256-register G2 waves are crowded out by the 168-register G1 waves (which fit any slot a G1 wave frees) and V's
+    // accumulate ends alone long after the others with its reduction tail on an empty chip
+    // (profiles/r03_b8_timeline_*.txt).  ZK_BATCH_ORDER: letters of the chain in order, V S W U (S = the S + H launch);
+    // an MSM not named runs unchained; "-" = no chain.
+    static const std::string order_env = getenv("ZK_BATCH_ORDER") ? getenv("ZK_BATCH_ORDER") : "";
+    // (a small batch does not fill the chip with one accumulate: its kernels run side by side as in a single proof)
+    const std::string order = !order_env.empty() ? order_env : (nb >= 4 ? "VSWU" : "-");
+    MsmGate gates[4];                                  // V, S, W, U
+    {
+      int prev = -1;
+      for (char ch : order) {
+        const int id = ch == 'V' ? 0 : ch == 'S' ? 1 : ch == 'W' ? 2 : ch == 'U' ? 3 : -1;
+        if (id < 0 || gates[id].signal_ev) continue;
+        B.acc_flag[id].store(0, std::memory_order_relaxed);
+        gates[id].signal_ev = B.ev_acc[id];
+        gates[id].signal_flag = &B.acc_flag[id];
+        if (prev >= 0) {
+          gates[id].wait_ev = B.ev_acc[prev];
+          gates[id].wait_flag = &B.acc_flag[prev];
+        }
+        prev = id;
+      }
+    }
+    const MsmGate gate_v = gates[0], gate_s = gates[1], gate_w = gates[2], gate_u = gates[3];
+    std::atomic<int>* aflag = B.acc_flag;
     // ---- the witness MSMs: V (G2) first on its high-priority stream, S + H as one launch over both base vectors, W
     B.fut.push_back(pool_->submit([=]() {
       (void)hipSetDevice(dev);
       int rc2 = msm_.template launch_t<Fq2_>(this, crs->v_d, nullptr, (size_t)n * crs->len_a, cf, crs->len_a, streams_[2],
-                                            ws0 + 3, &BJ->pV, nullptr, MsmGate{}, nullptr, &ba_a);
+                                            ws0 + 3, &BJ->pV, nullptr, gate_v, &ba_a);
+      aflag[0].store(1, std::memory_order_release);        // also when the launch failed early (waiters must not hang)
       std::vector<P2> res((size_t)nb);
       if (!rc2) rc2 = msm_fold_batch<Fq2_>(this, BJ->pV, res.data(), 1);
       BJ->rc[1] = rc2;
@@ -1581,7 +1603,8 @@ class Engine : public IEngine {
     B.fut.push_back(pool_->submit([=]() {
       (void)hipSetDevice(dev);
       int rc2 = msm_.template launch_t<Fq_>(this, crs->s_d, nullptr, (size_t)n * crs->len_a, cf, crs->len_a, streams_[0],
-                                           ws0 + 1, &BJ->pSH, hd, MsmGate{}, nullptr, &ba_a);
+                                           ws0 + 1, &BJ->pSH, hd, gate_s, &ba_a);
+      aflag[1].store(1, std::memory_order_release);
       std::vector<P1> res((size_t)nb * 2);
       if (!rc2) rc2 = msm_fold_batch<Fq_>(this, BJ->pSH, res.data(), hd ? 2 : 1);
       BJ->rc[0] = rc2;
@@ -1604,7 +1627,8 @@ class Engine : public IEngine {
     B.fut.push_back(pool_->submit([=]() {
       (void)hipSetDevice(dev);
       int rc2 = msm_.template launch_t<Fq_>(this, crs->w_d, nullptr, (size_t)n * crs->len_w, cf, crs->len_w, streams_[3],
-                                           ws0 + 4, &BJ->pW, nullptr, MsmGate{}, nullptr, &ba_x);
+                                           ws0 + 4, &BJ->pW, nullptr, gate_w, &ba_x);
+      aflag[2].store(1, std::memory_order_release);
       std::vector<P1> res((size_t)nb);
       if (!rc2) rc2 = msm_fold_batch<Fq_>(this, BJ->pW, res.data(), 1);
       BJ->rc[2] = rc2;
@@ -1627,7 +1651,8 @@ class Engine : public IEngine {
     ba_h.nb = nb;
     for (int b = 0; b < nb; b++) ba_h.p[b] = (const Fr*)B.hshare.p + (size_t)b * per;
     rc = msm_.template launch_t<Fq_>(this, crs->u_d, nullptr, (size_t)n * crs->len_u, cf, crs->len_u, hs, ws0 + 0, &B.pU,
-                                    nullptr, MsmGate{}, nullptr, &ba_h);
+                                    nullptr, gate_u, &ba_h);
+    aflag[3].store(1, std::memory_order_release);
     if (rc) return bail(rc);
     *handle = slot;
     return ZK_OK;
@@ -1682,7 +1707,7 @@ class Engine : public IEngine {
     auto run = [&](auto tag) -> int {
       using Fld = decltype(tag);
       MsmPending pend;
-      int rc = msm_.template launch_t<Fld>(this, bases, nullptr, len, nullptr, 1, st, 0, &pend, nullptr, MsmGate{}, nullptr, &ba);
+      int rc = msm_.template launch_t<Fld>(this, bases, nullptr, len, nullptr, 1, st, 0, &pend, nullptr, MsmGate{}, &ba);
       if (rc) return rc;
       std::vector<XYZZ<Fld>> res((size_t)nb);
       rc = msm_fold_batch<Fld>(this, pend, res.data(), 1);

@@ -8,10 +8,9 @@
 //   1. digits+count : scalar -> canonical integer -> signed c-bit digits; histogram per (window, |digit|)
 //   2. scan         : exclusive scan of {count, #segments} pairs
 //   3. scatter      : counting sort of point indices by bucket (sign in bit 31)
-//   4. expand       : segment descriptors (a bucket longer than SEG points is cut into segments, so that a
-//                     degenerate scalar distribution cannot serialise on one lane)
-//   5. accumulate   : one lane per segment, mixed XYZZ additions                     <- dominant kernel
-//   6. finalize     : one lane per bucket sums its segments
+//   4. (gone)       : round 2 cut buckets into segments and ordered them by length; see "balanced partition"
+//   5. accumulate   : equal contiguous ranges of the sorted entries, one per lane, mixed XYZZ additions   <- dominant
+//   6. finalize     : buckets that straddle a lane boundary are summed from the lanes' edge partials
 //   7. reduce       : sum_b (b+1) * bucket_b per window with per-lane suffix sums + an LDS tree across the
 //                     workgroup ("wavefront-level bucket reduction"); one (S, A) pair per workgroup
 //   8. host         : combines the few (S, A) pairs per window and folds windows high -> low
@@ -26,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "ec.hpp"
@@ -36,21 +36,24 @@
 namespace zk {
 #if defined(__HIPCC__)
 
-constexpr int MSM_SEG_MAX = 16;       // max points per accumulate lane (smaller for small MSMs, see pick_seg)
+constexpr size_t MSM_RANGE_MIN = 20, MSM_RANGE = 32;        // entries per accumulate lane: fewest (small MSMs), most
+constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 20;  // ... per lane pair of the extension-field kernel
+constexpr uint32_t FIN_SEQ = 16;      // a bucket spread over more accumulate lanes than this is summed by a workgroup
 constexpr int MSM_WS = 24;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
                                       // streams) + 6 per batch of proofs in flight (zk_groth16_prove_batch)
 
 // Sort-stage arrays of a launch over TWO base vectors with per-vector sorts (their identity bases differ) live in two
 // copies of one workspace region; blockIdx.y picks the copy: every sort-stage kernel shifts its array pointers by
 // blockIdx.y * ys bytes (ys = 0: one sort shared by both vectors).
-#define ZK_YSHIFT(p)                                                                                        \
-  do {                                                                                                      \
-    if (p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.y * ys);      \
-  } while (0)
-
-struct SegDesc {
-  uint32_t bucket, start, end;
-};
+// (pointer arithmetic on the pointer itself, never through an integer: a pointer rebuilt from an integer is a GENERIC
+// pointer to the compiler, its loads become flat_load and every wait on one of them waits for all memory traffic of the
+// wave -- found in the accumulate kernel's ISA, where it serialised the index load, the gather and the bucket flush)
+template <class T>
+__device__ __forceinline__ T* zk_yshift(T* p, size_t bytes) {
+  using C = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return p ? reinterpret_cast<T*>(reinterpret_cast<C*>(p) + bytes) : p;
+}
+#define ZK_YSHIFT(p) p = zk_yshift(p, (size_t)blockIdx.y * ys)
 
 // A launch multiplies ONE base vector (or two) by a BATCH of scalar vectors -- the same query of a CRS against the
 // witnesses of several proofs (zk_groth16_prove_batch).  Vector b of the batch gets its own bucket sets: everything
@@ -75,19 +78,28 @@ __global__ void msm_digits_kernel(MsmScalars<Fp<FrP>> sc, const Fp<FrP>* __restr
                                   window; all windows share ONE bucket set; 0 = no table */, uint32_t pre_off,
                                   uint32_t* __restrict__ counts /* [nsets*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
-                                  const uint32_t* __restrict__ skip /* bit i: base i is the identity */, size_t ys) {
+                                  const uint32_t* __restrict__ skip /* bit i: base i is the identity */,
+                                  Fp<FrP>* __restrict__ canon /* canonical scalars: written by pass 0, read by pass 1 */,
+                                  size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(counts);
   ZK_YSHIFT(cursor);
   ZK_YSHIFT(sorted);
   ZK_YSHIFT(skip);
+  ZK_YSHIFT(canon);
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)sc.npts * sc.nb) return;
   const uint32_t vb = (uint32_t)(g / sc.npts), i = (uint32_t)(g % sc.npts);
   if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return;
-  Fp<FrP> s = load_elem(sc.p[vb] + i);
-  if (coef) s = s * coef[i / part_len];
-  s = s.from_mont();
+  Fp<FrP> s;
+  if (PASS == 0) {
+    s = load_elem(sc.p[vb] + i);
+    if (coef) s = s * coef[i / part_len];
+    s = s.from_mont();
+    store_elem(canon + g, s);
+  } else {
+    s = load_elem(canon + g);
+  }
   const uint32_t set0 = vb * sc.sets_per;
   uint32_t carry = 0;
   constexpr int N = FrP::N;
@@ -213,16 +225,24 @@ __device__ __forceinline__ void msm_for_each_digit(Fp<FrP> s, int c, int nwin, i
 }
 
 // scalar of global entry g = (vector vb of the batch, point i); identity bases and out-of-range entries give zero
-template <class FrP>
+// The canonical integer (times the party coefficient) costs two field multiplications: the histogram pass computes it
+// once and leaves it in `canon`, the scatter pass reads it back (FIRST = false).
+template <class FrP, bool FIRST>
 __device__ __forceinline__ Fp<FrP> msm_load_scalar(const MsmScalars<Fp<FrP>>& sc, const Fp<FrP>* coef, size_t part_len,
-                                                   size_t g, const uint32_t* skip, uint32_t* vb_out, uint32_t* i_out) {
+                                                   size_t g, const uint32_t* skip, Fp<FrP>* canon, uint32_t* vb_out,
+                                                   uint32_t* i_out) {
   const uint32_t vb = (uint32_t)(g / sc.npts), i = (uint32_t)(g % sc.npts);
   *vb_out = vb;
   *i_out = i;
-  if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return Fp<FrP>::zero();      // identity base: no digit, no entry
-  Fp<FrP> s = load_elem(sc.p[vb] + i);
-  if (coef) s = s * coef[i / part_len];
-  return s.from_mont();
+  if (!FIRST) return load_elem(canon + g);
+  Fp<FrP> s = Fp<FrP>::zero();                                                // identity base: no digit, no entry
+  if (!(skip && ((skip[i >> 5] >> (i & 31)) & 1u))) {
+    s = load_elem(sc.p[vb] + i);
+    if (coef) s = s * coef[i / part_len];
+    s = s.from_mont();
+  }
+  store_elem(canon + g, s);
+  return s;
 }
 
 template <class FrP>
@@ -233,10 +253,12 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(MsmScalars<F
                                                                     uint32_t wmask /* 0: fixed-base table, all windows
                                                                     share one bucket set; ~0: one set per window */,
                                                                     uint32_t* __restrict__ bin_counts,
-                                                                    const uint32_t* __restrict__ skip, size_t ys) {
+                                                                    const uint32_t* __restrict__ skip,
+                                                                    Fp<FrP>* __restrict__ canon, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bin_counts);
   ZK_YSHIFT(skip);
+  ZK_YSHIFT(canon);
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbins = (sc.nb * sc.sets_per) << hi_bits;
   const size_t total = (size_t)sc.npts * sc.nb;
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(MsmScalars<F
     size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (g >= total) break;
     uint32_t vb, i;
-    Fp<FrP> s = msm_load_scalar<FrP>(sc, coef, part_len, g, skip, &vb, &i);
+    Fp<FrP> s = msm_load_scalar<FrP, true>(sc, coef, part_len, g, skip, canon, &vb, &i);
     const uint32_t set0 = vb * sc.sets_per;
     msm_for_each_digit<FrP>(s, c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits)], 1u); });
@@ -299,11 +321,11 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(MsmScalar
                                                                        uint32_t pre_stride, uint32_t pre_off,
                                                                        uint32_t* __restrict__ bin_cursor,
                                                                        uint2* __restrict__ tmp,
-                                                                       const uint32_t* __restrict__ skip, size_t ys) {
+                                                                       Fp<FrP>* __restrict__ canon, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bin_cursor);
   ZK_YSHIFT(tmp);
-  ZK_YSHIFT(skip);
+  ZK_YSHIFT(canon);
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbins = (sc.nb * sc.sets_per) << hi_bits;
   const size_t total = (size_t)sc.npts * sc.nb;
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(MsmScalar
     size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (g >= total) break;
     uint32_t vb, i;
-    Fp<FrP> s = msm_load_scalar<FrP>(sc, coef, part_len, g, skip, &vb, &i);
+    Fp<FrP> s = msm_load_scalar<FrP, false>(sc, coef, part_len, g, nullptr, canon, &vb, &i);
     const uint32_t set0 = vb * sc.sets_per;
     msm_for_each_digit<FrP>(s, c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits)], 1u); });
@@ -333,7 +355,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(MsmScalar
     size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
     if (g >= total) break;
     uint32_t vb, i;
-    Fp<FrP> s = msm_load_scalar<FrP>(sc, coef, part_len, g, skip, &vb, &i);
+    Fp<FrP> s = msm_load_scalar<FrP, false>(sc, coef, part_len, g, nullptr, canon, &vb, &i);
     const uint32_t set0 = vb * sc.sets_per;
     msm_for_each_digit<FrP>(s, c, nwin, wide,
                             [&](int w, uint32_t b, uint32_t neg) {
@@ -396,163 +418,91 @@ static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_sort_kernel(const 
 }
 
 // -------------------------------------------------------------------------------------------------- scan
-// Exclusive scan of pairs {count, nseg(count)} over `len` keys in three launches.
+// Exclusive scan of the per-key counts over `len` keys in three launches: offsets[k] = first sorted entry of key k,
+// offsets[len] = number of entries.
 constexpr int ISCAN_THREADS = 256;
 constexpr int ISCAN_PER = 8;
 constexpr int ISCAN_BLOCK = ISCAN_THREADS * ISCAN_PER;
 
-ZK_D uint32_t nseg_of(uint32_t cnt, uint32_t seg) { return (cnt + seg - 1) / seg; }
-
-ZK_D uint2 block_scan_u2(uint2 v, uint2* sh, uint2* total) {
+ZK_D uint32_t block_scan_u32(uint32_t v, uint32_t* sh, uint32_t* total) {
   int tid = threadIdx.x;
   sh[tid] = v;
   __syncthreads();
   for (int off = 1; off < ISCAN_THREADS; off <<= 1) {
-    uint2 t = sh[tid];
-    if (tid >= off) {
-      t.x += sh[tid - off].x;
-      t.y += sh[tid - off].y;
-    }
+    uint32_t t = sh[tid];
+    if (tid >= off) t += sh[tid - off];
     __syncthreads();
     sh[tid] = t;
     __syncthreads();
   }
-  uint2 ex = tid ? sh[tid - 1] : make_uint2(0, 0);
+  uint32_t ex = tid ? sh[tid - 1] : 0u;
   *total = sh[ISCAN_THREADS - 1];
   return ex;
 }
 
-// mode 0: write block totals; mode 1: write exclusive scans (offsets.x = point offset, offsets.y = seg offset)
+// mode 0: write block totals; mode 1: write the exclusive scan (and, for the global-atomics sort, a copy as the scatter
+// cursors)
 static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_block_kernel(const uint32_t* __restrict__ counts, size_t len,
-                                                                   uint2* __restrict__ block_tot,
-                                                                   const uint2* __restrict__ carry,
-                                                                   uint2* __restrict__ offsets, int mode,
-                                                                   uint32_t seg, size_t ys) {
+                                                                   uint32_t* __restrict__ block_tot,
+                                                                   const uint32_t* __restrict__ carry,
+                                                                   uint32_t* __restrict__ offsets,
+                                                                   uint32_t* __restrict__ cursor, int mode, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(counts);
   ZK_YSHIFT(block_tot);
   ZK_YSHIFT(carry);
   ZK_YSHIFT(offsets);
-  __shared__ uint2 sh[ISCAN_THREADS];
+  ZK_YSHIFT(cursor);
+  __shared__ uint32_t sh[ISCAN_THREADS];
   size_t base = (size_t)blockIdx.x * ISCAN_BLOCK + (size_t)threadIdx.x * ISCAN_PER;
-  uint2 loc[ISCAN_PER];
-  uint2 acc = make_uint2(0, 0);
+  uint32_t loc[ISCAN_PER];
+  uint32_t acc = 0;
 #pragma unroll
   for (int i = 0; i < ISCAN_PER; i++) {
     uint32_t cnt = base + i < len ? counts[base + i] : 0u;
     loc[i] = acc;
-    acc.x += cnt;
-    acc.y += nseg_of(cnt, seg);
+    acc += cnt;
   }
-  uint2 tot;
-  uint2 ex = block_scan_u2(acc, sh, &tot);
+  uint32_t tot;
+  uint32_t ex = block_scan_u32(acc, sh, &tot);
   if (mode == 0) {
     if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
     return;
   }
-  uint2 cr = carry[blockIdx.x];
+  uint32_t cr = carry[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < ISCAN_PER; i++)
-    if (base + i < len) offsets[base + i] = make_uint2(cr.x + ex.x + loc[i].x, cr.y + ex.y + loc[i].y);
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == ISCAN_THREADS - 1)
-    offsets[len] = make_uint2(cr.x + tot.x, cr.y + tot.y);
+    if (base + i < len) {
+      offsets[base + i] = cr + ex + loc[i];
+      if (cursor) cursor[base + i] = cr + ex + loc[i];
+    }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == ISCAN_THREADS - 1) offsets[len] = cr + tot;
 }
 
-static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint2* __restrict__ bt, size_t nblocks,
+static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint32_t* __restrict__ bt, size_t nblocks,
                                                                            size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bt);
-  __shared__ uint2 sh[ISCAN_THREADS];
-  uint2 running = make_uint2(0, 0);
+  __shared__ uint32_t sh[ISCAN_THREADS];
+  uint32_t running = 0;
   for (size_t b0 = 0; b0 < nblocks; b0 += ISCAN_BLOCK) {
     size_t base = b0 + (size_t)threadIdx.x * ISCAN_PER;
-    uint2 loc[ISCAN_PER];
-    uint2 acc = make_uint2(0, 0);
+    uint32_t loc[ISCAN_PER];
+    uint32_t acc = 0;
 #pragma unroll
     for (int i = 0; i < ISCAN_PER; i++) {
-      uint2 v = base + i < nblocks ? bt[base + i] : make_uint2(0, 0);
+      uint32_t v = base + i < nblocks ? bt[base + i] : 0u;
       loc[i] = acc;
-      acc.x += v.x;
-      acc.y += v.y;
+      acc += v;
     }
-    uint2 tot;
-    uint2 ex = block_scan_u2(acc, sh, &tot);
+    uint32_t tot;
+    uint32_t ex = block_scan_u32(acc, sh, &tot);
 #pragma unroll
     for (int i = 0; i < ISCAN_PER; i++)
-      if (base + i < nblocks)
-        bt[base + i] = make_uint2(running.x + ex.x + loc[i].x, running.y + ex.y + loc[i].y);
-    running.x += tot.x;
-    running.y += tot.y;
+      if (base + i < nblocks) bt[base + i] = running + ex + loc[i];
+    running += tot;
     __syncthreads();
   }
-}
-
-// cursor[key] = offsets[key].x ; segment descriptors for every bucket; histogram of the segment lengths
-constexpr int SEG_BINS = 65;
-__device__ __forceinline__ uint32_t seg_bin(uint32_t len, uint32_t seg) { return (len * 64u + seg - 1) / seg; }
-
-static __global__ __launch_bounds__(256) void msm_expand_kernel(const uint2* __restrict__ offsets, size_t nkeys,
-                                                                uint32_t* __restrict__ cursor,
-                                                                SegDesc* __restrict__ segs, uint32_t seg,
-                                                                uint32_t* __restrict__ lenhist, size_t ys) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
-  ZK_YSHIFT(offsets);
-  ZK_YSHIFT(cursor);
-  ZK_YSHIFT(segs);
-  ZK_YSHIFT(lenhist);
-  __shared__ uint32_t lh[SEG_BINS];
-  if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
-  __syncthreads();
-  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < nkeys) {
-    uint2 o = offsets[k], o1 = offsets[k + 1];
-    cursor[k] = o.x;
-    uint32_t s = o.y;
-    uint32_t full = (o1.x - o.x) / seg, rem = (o1.x - o.x) % seg;
-    for (uint32_t p = o.x; p < o1.x; p += seg, s++) {
-      uint32_t e = p + seg < o1.x ? p + seg : o1.x;
-      segs[s] = {(uint32_t)k, p, e};
-    }
-    if (full) atomicAdd(&lh[64], full);
-    if (rem) atomicAdd(&lh[seg_bin(rem, seg)], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < SEG_BINS && lh[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], lh[threadIdx.x]);
-}
-
-// order[] = the segment indices sorted by descending length (counting sort over SEG_BINS length classes), so that
-// the 64 lanes of an accumulate wave walk chains of equal length: bucket sizes are Poisson-like and an unsorted
-// launch idles ~25% of its lanes (every wave runs for its longest lane).
-static __global__ __launch_bounds__(256) void msm_order_kernel(const SegDesc* __restrict__ segs,
-                                                               const uint2* __restrict__ offsets, size_t nkeys,
-                                                               uint32_t seg, const uint32_t* __restrict__ lenhist,
-                                                               uint32_t* __restrict__ bincur,
-                                                               uint32_t* __restrict__ order, size_t ys) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
-  ZK_YSHIFT(segs);
-  ZK_YSHIFT(offsets);
-  ZK_YSHIFT(lenhist);
-  ZK_YSHIFT(bincur);
-  ZK_YSHIFT(order);
-  __shared__ uint32_t lh[SEG_BINS], base[SEG_BINS];
-  if (threadIdx.x < SEG_BINS) lh[threadIdx.x] = 0;
-  __syncthreads();
-  uint32_t nseg = offsets[nkeys].y;
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t bin = 0, r = 0;
-  if (s < nseg) {
-    SegDesc d = segs[s];
-    bin = seg_bin(d.end - d.start, seg);
-    r = atomicAdd(&lh[bin], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < SEG_BINS) {
-    uint32_t b = threadIdx.x, before = 0;
-    for (uint32_t j = b + 1; j < SEG_BINS; j++) before += lenhist[j];
-    base[b] = before + (lh[b] ? atomicAdd(&bincur[b], lh[b]) : 0u);
-  }
-  __syncthreads();
-  if (s < nseg) order[base[bin] + r] = s;
 }
 
 // -------------------------------------------------------------------------------------------------- accumulate
@@ -574,93 +524,245 @@ template <class Fld>
 constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8);
 template <class Fld>
 constexpr int PAIR_WAVES = sizeof(Fld) > 64 ? ZK_PAIR_WAVES_12 : 2;
+// BALANCED PARTITION.  The sorted entry array (offsets[nkeys] entries, grouped by bucket) is cut into `nlanes`
+// contiguous ranges of T = ceil(entries / nlanes) entries, one per lane (per lane pair in G2), whatever the bucket
+// boundaries are: every lane of the launch performs the same number of mixed additions, so a wave has no idle lanes
+// waiting for its longest chain, there is no tail of short waves, and the sort needs no per-bucket segment
+// descriptors nor a by-length ordering pass (round 2 cut buckets into segments of <= 16..64 points and counting-sorted
+// the segments by length: two more launches on every MSM's dependent chain, 1.33 rounds of waves on a batch of eight).
+// A lane walks its range and flushes its running sum whenever the bucket changes:
+//   * a bucket that lies wholly inside the range        -> buckets[k] (final: the finalize kernel does not touch it)
+//   * the first run when its bucket began in an earlier lane (whether or not it ends here) -> head[lane]
+//   * the last run when its bucket continues in the next lane (and began here)             -> tail[lane]
+// so bucket k, spanning lanes l0 = offsets[k] / T .. l1 = (offsets[k+1] - 1) / T with l1 > l0, is tail[l0] +
+// head[l0+1] + .. + head[l1] (msm_finalize_kernel, which also writes the identity into empty buckets): one extra
+// addition per lane boundary, ~1/T of the accumulate's.  Buckets spread over more than FIN_SEQ lanes (degenerate
+// scalars: all ones) are summed by whole workgroups (msm_heavy_kernel) from a list the accumulate lanes leave.
+// entries per lane: the launch has `nlanes` lanes for the most entries the sort could have produced; when it produced
+// fewer (identity bases, zero digits) the ranges stay at least `tmin` long and the surplus lanes have nothing to do --
+// every lane boundary costs a full addition in the finalize kernel
+// Stores of the accumulate kernels' partial sums, written as inline assembly ON PURPOSE.  gfx950 counts vector loads and
+// stores in one counter (vmcnt) and the compiler, seeing both kinds pending, can no longer wait for "all but the N
+// newest" operations: every wait inside the loop -- for the index fetched two points ahead, for a bucket boundary --
+// became s_waitcnt vmcnt(0), i.e. a wait for the point gather issued a moment earlier (read in the ISA; in a batch
+// the accumulate kernels ran 20 % slower than round 2's, which stored once, after its loop).  A store the compiler does
+// not see leaves its bookkeeping to loads, which return in order; the hardware still counts the store, so a wait can
+// only be longer than computed, never shorter, and the data registers are read when the store issues.
+typedef uint32_t zk_u32x4 __attribute__((ext_vector_type(4)));
+template <int I, int N>
+__device__ __forceinline__ void zk_store_chunks(const void* p, const zk_u32x4* v) {
+  if constexpr (I < N) {
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2" : : "v"(p), "v"(v[I]), "n"(16 * I) : "memory");
+    zk_store_chunks<I + 1, N>(p, v);
+  }
+}
+template <class F>
+__device__ __forceinline__ void store_elem_untracked(F* p, const F& v) {
+  static_assert(sizeof(F) % 16 == 0 && sizeof(F) <= 4096, "element must be a multiple of 16 bytes");
+  zk_u32x4 c[sizeof(F) / 16];
+  __builtin_memcpy(c, &v, sizeof(F));
+  zk_store_chunks<0, (int)(sizeof(F) / 16)>((const void*)p, c);
+}
+
+ZK_D uint32_t msm_range_len(uint32_t entries, uint32_t nlanes, uint32_t tmin) {
+  uint32_t T = (entries + nlanes - 1) / nlanes;
+  return T > tmin ? T : tmin;
+}
+// bucket that contains entry a (offsets[k] <= a < offsets[k+1]; empty buckets are skipped by construction)
+ZK_D uint32_t msm_bucket_of(const uint32_t* __restrict__ offsets, uint32_t nkeys, uint32_t a) {
+  uint32_t lo = 0, hi = nkeys;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets[mid + 1] <= a) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// first bucket of every lane's range, by one thread per lane ahead of the accumulate kernel: inside it the 18 dependent
+// loads of the search would open every wave (measured in a batch of eight with four MSMs in flight: accumulate slots
+// 17.6 + 10.2 ms with the search inside against 14.8 + 8.2 ms for round 2's per-bucket segments)
+static __global__ __launch_bounds__(256) void msm_lane_start_kernel(const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                                    uint32_t nlanes, uint32_t tmin,
+                                                                    uint32_t* __restrict__ k0, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(k0);
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= nlanes) return;
+  const uint32_t total = offsets[nkeys];
+  const uint32_t T = msm_range_len(total, nlanes, tmin);
+  if ((uint64_t)lane * T >= total) return;
+  k0[lane] = msm_bucket_of(offsets, nkeys, lane * T);
+}
+
 template <class Fld>
 __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases0,
-                                                            const Affine<Fld>* __restrict__ bases1, size_t pstride,
+                                                            const Affine<Fld>* __restrict__ bases1,
                                                             const uint32_t* __restrict__ sorted,
-                                                            const SegDesc* __restrict__ segs,
-                                                            const uint2* __restrict__ offsets, size_t nkeys,
-                                                            const uint32_t* __restrict__ order,
-                                                            XYZZ<Fld>* __restrict__ partial0, size_t ys) {
+                                                            const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                            uint32_t nlanes, uint32_t tmin,
+                                                            XYZZ<Fld>* __restrict__ buckets0,
+                                                            XYZZ<Fld>* __restrict__ edge0 /* [NB][2][nlanes]: head, tail */,
+                                                            uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
+                                                            const uint32_t* __restrict__ k0, size_t ys) {
   ZK_YSHIFT(sorted);
-  ZK_YSHIFT(segs);
   ZK_YSHIFT(offsets);
-  ZK_YSHIFT(order);
+  ZK_YSHIFT(heavy);
+  ZK_YSHIFT(k0);
   // blockIdx.y: which of the (up to two) base vectors that share this scalar vector -- and therefore the sort
   const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
-  XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
-  // bounded grid + grid-stride loop: every workgroup of the launch is resident at once, so the launch does not sit
-  // in its hardware queue waiting for wave slots (which stalls every other stream mapped to the same pipe)
-  const uint32_t nseg = offsets[nkeys].y;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nseg; t += (size_t)gridDim.x * blockDim.x) {
-    const uint32_t s = order[t];
-    SegDesc d = segs[s];
-    XYZZ<Fld> acc = XYZZ<Fld>::identity();
-    // software pipeline: the next point's index and coordinates are in flight while the current one is added
-    uint32_t e = sorted[d.start];
-    Affine<Fld> pt = load_elem(bases + (e & 0x7fffffffu));
-    for (uint32_t p = d.start; p < d.end; p++) {
-      uint32_t e_next = e;
-      Affine<Fld> pt_next = pt;
-      if (p + 1 < d.end) {
-        e_next = sorted[p + 1];
-        pt_next = load_elem(bases + (e_next & 0x7fffffffu));
+  XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
+  XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
+  XYZZ<Fld>* __restrict__ tail = head + nlanes;
+  const uint32_t total = offsets[nkeys];
+  const uint32_t T = msm_range_len(total, nlanes, tmin);
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= nlanes || (uint64_t)lane * T >= total) return;
+  const uint32_t a = lane * T, b = a + T < total ? a + T : total;
+  uint32_t k = k0[lane];
+  bool cont = offsets[k] < a;
+  XYZZ<Fld> acc = XYZZ<Fld>::identity();
+  // Software pipeline.  The affine point is needed by the first two of the ten multiplications of a mixed addition
+  // only (U2 = x ZZ, S2 = y ZZZ): the NEXT point's coordinates are requested right after them, INTO THE SAME REGISTERS,
+  // and arrive under the other eight; the index is fetched two points ahead.  (Loading the next point into a second
+  // set of registers and moving it over at the end of the step -- round 2's form -- makes the compiler wait for the
+  // gather before the moves: s_waitcnt vmcnt(0) at the bottom of every iteration, no overlap at all.)
+  uint32_t e = sorted[a];
+  uint32_t e1 = sorted[a + 1 < b ? a + 1 : a];
+  Affine<Fld> pt = load_elem(bases + (e & 0x7fffffffu));
+  for (uint32_t p = a; p < b; p++) {
+    const uint32_t e_cur = e;
+    // end of the current bucket: requested here, looked at after the addition (the same word for a whole run, so it
+    // comes from L1); nothing loaded is carried from one step to the next -- a value loaded inside the flush block and
+    // carried over costs a move there, and the move a wait for ALL loads of the wave, the gather included, on the two
+    // steps out of three on which some lane of a wave meets a bucket boundary
+    uint32_t end_k = offsets[k + 1];
+    const bool skip_pt = pt.is_identity();           // only when the sort kept identity bases (ZK_MSM_SKIP_IDENTITY=0)
+    const bool was_id = acc.is_identity();
+    Fld U2 = Fld::zero(), S2 = Fld::zero();
+    {
+      const Fld y2 = (e_cur >> 31) ? pt.y.neg() : pt.y;
+      if (!skip_pt) {
+        if (was_id) {
+          acc = XYZZ<Fld>{pt.x, y2, Fld::one(), Fld::one()};
+        } else {
+          U2 = pt.x * acc.ZZ;
+          S2 = y2 * acc.ZZZ;
+        }
       }
-      if (!pt.is_identity()) {
-        Fld y = (e >> 31) ? pt.y.neg() : pt.y;
-        acc = xyzz_madd(acc, pt.x, y);
-      }
-      e = e_next;
-      pt = pt_next;
     }
-    store_elem(partial + s, acc);
+    // pt is dead from here on: the next point's coordinates land in its registers.  Both loads are UNCONDITIONAL (the
+    // last steps of a range fetch its last entry again): behind a branch the compiler does not know how many loads
+    // are in flight and turns the next wait into a wait for all of them
+    e = e1;
+    pt = load_elem(bases + (e & 0x7fffffffu));
+    e1 = sorted[p + 2 < b ? p + 2 : b - 1];
+    if (!skip_pt && !was_id) {
+      const Fld P = U2 - acc.X;
+      const Fld R = S2 - acc.Y;
+      if (P.is_zero()) {
+        if (R.is_zero()) {                           // the same point again (degenerate inputs): fetch it once more
+          const Affine<Fld> q = load_elem(bases + (e_cur & 0x7fffffffu));
+          acc = xyzz_dbl_affine(q.x, (e_cur >> 31) ? q.y.neg() : q.y);
+        } else {
+          acc = XYZZ<Fld>::identity();
+        }
+      } else {
+        const Fld PP = P.sqr();
+        const Fld PPP = P * PP;
+        const Fld Q = acc.X * PP;
+        const Fld X3 = R.sqr() - PPP - Q.dbl();
+        const Fld Y3 = R * (Q - X3) - acc.Y * PPP;
+        acc = XYZZ<Fld>{X3, Y3, acc.ZZ * PP, acc.ZZZ * PPP};
+      }
+    }
+    while (end_k <= p) {                            // empty buckets behind the last flush (rare)
+      k++;
+      end_k = offsets[k + 1];
+    }
+    if (p + 1 == end_k || p + 1 == b) {             // the run ends: with its bucket, or with the range
+      XYZZ<Fld>* dst = cont ? head + lane : (p + 1 == end_k ? buckets + k : tail + lane);
+      store_elem_untracked(dst, acc);
+      // the lane in which a bucket BEGINS reports it when it spreads over many lanes (once per bucket and sort)
+      if (!cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
+        heavy[1 + atomicAdd(heavy, 1u)] = k;        // at most nlanes / FIN_SEQ such buckets: the list's capacity
+      acc = XYZZ<Fld>::identity();
+      cont = false;
+      k += p + 1 == end_k ? 1u : 0u;                // (the last step of the range may leave k one past: unused)
+    }
   }
 }
 
-// Extension-field variant: one PAIR of lanes per segment (quad.hpp pair_madd): 128 threads = 64 segments per workgroup.
+// Extension-field variant: one PAIR of lanes per range (quad.hpp pair_madd): 128 threads = 64 ranges per workgroup.
 template <class Fld>
 __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kernel(const Affine<Fld>* __restrict__ bases0,
-                                                                    const Affine<Fld>* __restrict__ bases1, size_t pstride,
+                                                                    const Affine<Fld>* __restrict__ bases1,
                                                                     const uint32_t* __restrict__ sorted,
-                                                                    const SegDesc* __restrict__ segs,
-                                                                    const uint2* __restrict__ offsets, size_t nkeys,
-                                                                    const uint32_t* __restrict__ order,
-                                                                    XYZZ<Fld>* __restrict__ partial0, size_t ys) {
+                                                                    const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                                    uint32_t nlanes, uint32_t tmin,
+                                                                    XYZZ<Fld>* __restrict__ buckets0,
+                                                                    XYZZ<Fld>* __restrict__ edge0,
+                                                                    uint32_t* __restrict__ heavy,
+                                                                    const uint32_t* __restrict__ k0, size_t ys) {
   ZK_YSHIFT(sorted);
-  ZK_YSHIFT(segs);
   ZK_YSHIFT(offsets);
-  ZK_YSHIFT(order);
+  ZK_YSHIFT(heavy);
+  ZK_YSHIFT(k0);
   const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
-  XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
-  const uint32_t nseg = offsets[nkeys].y;
+  XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
+  XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
+  XYZZ<Fld>* __restrict__ tail = head + nlanes;
+  const uint32_t total = offsets[nkeys];
+  const uint32_t T = msm_range_len(total, nlanes, tmin);
   const bool lb = (threadIdx.x & 1) != 0;
-  const size_t npairs = (size_t)gridDim.x * (blockDim.x / 2);
-  for (size_t t = (size_t)blockIdx.x * (blockDim.x / 2) + (threadIdx.x >> 1); t < nseg; t += npairs) {
-    const uint32_t s = order[t];
-    SegDesc d = segs[s];
-    PairAcc<Fld> acc{Fld::one(), Fld::zero()};               // the identity: X = Y = 1, ZZ = ZZZ = 0
-    uint32_t e = sorted[d.start];
-    // my coordinate of the affine point: x for the even lane, y for the odd one (a pair reads one whole point)
-    Fld pt = load_elem(reinterpret_cast<const Fld*>(bases + (e & 0x7fffffffu)) + (lb ? 1 : 0));
-    for (uint32_t p = d.start; p < d.end; p++) {
-      uint32_t e_next = e;
-      Fld pt_next = pt;
-      if (p + 1 < d.end) {
-        e_next = sorted[p + 1];
-        pt_next = load_elem(reinterpret_cast<const Fld*>(bases + (e_next & 0x7fffffffu)) + (lb ? 1 : 0));
-      }
-      // the identity sentinel is (0, 0): both coordinates zero (pair-uniform after the exchange)
-      const bool ident = pt.is_zero() && pswap(pt).is_zero();
-      if (!ident) {
-        const Fld c = qsel(lb && (e >> 31) != 0, pt.neg(), pt);
-        acc = pair_madd(acc, c, lb);
-      }
-      e = e_next;
-      pt = pt_next;
+  const uint32_t lane = blockIdx.x * (blockDim.x / 2) + (threadIdx.x >> 1);      // pair index = range index
+  if (lane >= nlanes || (uint64_t)lane * T >= total) return;
+  const uint32_t a = lane * T, b = a + T < total ? a + T : total;
+  uint32_t k = k0[lane];
+  bool cont = offsets[k] < a;
+  uint32_t end_k = offsets[k + 1];
+  // (this kernel requests the next point at the top of a step and has the whole 28-multiplication addition to receive
+  // it, so the simpler bookkeeping -- the end of the next bucket fetched one bucket ahead, ordinary stores -- costs it
+  // nothing: measured 83 G multiplications/s alone against 74 with msm_accumulate_kernel's form)
+  uint32_t end_n = offsets[k + 2 <= nkeys ? k + 2 : nkeys];
+  PairAcc<Fld> acc{Fld::one(), Fld::zero()};               // the identity: X = Y = 1, ZZ = ZZZ = 0
+  uint32_t e = sorted[a];
+  uint32_t e1 = a + 1 < b ? sorted[a + 1] : e;
+  // my coordinate of the affine point: x for the even lane, y for the odd one (a pair reads one whole point)
+  Fld pt = load_elem(reinterpret_cast<const Fld*>(bases + (e & 0x7fffffffu)) + (lb ? 1 : 0));
+  for (uint32_t p = a; p < b; p++) {
+    const uint32_t e_next = e1;
+    if (p + 2 < b) e1 = sorted[p + 2];
+    Fld pt_next = pt;
+    if (p + 1 < b) pt_next = load_elem(reinterpret_cast<const Fld*>(bases + (e_next & 0x7fffffffu)) + (lb ? 1 : 0));
+    // the identity sentinel is (0, 0): both coordinates zero (pair-uniform after the exchange)
+    const bool ident = pt.is_zero() && pswap(pt).is_zero();
+    if (!ident) {
+      const Fld c = qsel(lb && (e >> 31) != 0, pt.neg(), pt);
+      acc = pair_madd(acc, c, lb);
     }
-    Fld* o = reinterpret_cast<Fld*>(partial + s);            // X, Y, ZZ, ZZZ
-    store_elem(o + (lb ? 1 : 0), acc.c0);
-    store_elem(o + (lb ? 3 : 2), acc.c1);
+    if (p + 1 == end_k || p + 1 == b) {
+      XYZZ<Fld>* dst = cont ? head + lane : (p + 1 == end_k ? buckets + k : tail + lane);
+      Fld* o = reinterpret_cast<Fld*>(dst);                  // X, Y, ZZ, ZZZ
+      store_elem(o + (lb ? 1 : 0), acc.c0);
+      store_elem(o + (lb ? 3 : 2), acc.c1);
+      if (!lb && !cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
+        heavy[1 + atomicAdd(heavy, 1u)] = k;
+      acc = PairAcc<Fld>{Fld::one(), Fld::zero()};
+      cont = false;
+      if (p + 1 < b) {
+        k++;
+        end_k = end_n;
+        while (end_k == p + 1) {                    // empty buckets in between (rare)
+          k++;
+          end_k = offsets[k + 1];
+        }
+        end_n = offsets[k + 2 <= nkeys ? k + 2 : nkeys];
+      }
+    }
+    e = e_next;
+    pt = pt_next;
   }
 }
 
@@ -680,48 +782,85 @@ __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kern
 //                   the walk over the windows (msm_fold): 2 c group operations per window on single points
 // The dependent depth is (LO/64 - 1 + 6) + ~8 quad additions instead of the 27 full additions of a running-sum
 // reduction, and the work stays at ~2 additions per bucket.
-constexpr uint32_t FIN_SEQ = 16;
-constexpr int QUAD_THREADS = 256;                 // 64 points per workgroup: one wave per SIMD of a CU
+constexpr int QUAD_THREADS = 256;                 // most: 64 points per workgroup, one wave per SIMD of a CU
 constexpr int QUAD_VL = QUAD_THREADS / 4;
+// Threads per workgroup of the heavy / reduce kernels.  256 (64 quads: shortest trees) when an MSM runs alone; 64 -- ONE
+// wave -- by default: a four-wave workgroup needs four free wave slots with registers on ONE CU at the same moment, and
+// among the accumulate waves of a BATCH's MSMs it waits for them (profiles/r03_b8_timeline_wide_tails.txt: 1.0-1.3 ms
+// for a heavy-bucket launch that reads one word and exits, 0.6-1.8 ms per reduce stage).  ZK_QUAD_THREADS overrides.
+inline int quad_threads(bool batched) {
+  static const int v = getenv("ZK_QUAD_THREADS") ? atoi(getenv("ZK_QUAD_THREADS")) : 0;
+  if (v == 64 || v == 128 || v == 256) return v;
+  return batched ? 64 : 256;          // one proof at a time: 256 measured better (451 vs 409 proofs/s)
+}
 
+// Buckets spread over more than FIN_SEQ accumulate lanes (listed by the lanes they begin in): a whole workgroup sums one
+// at a time -- strided accumulation over its 64 quads, then a tree -- so that no quad walks a long chain.  The list is
+// empty for well-spread scalars and the launch ends at once.  grid.y = base vector; with two sorts (ys != 0) each has
+// its own list, with one shared sort both vectors use list 0.
 template <class Fld>
-__global__ __launch_bounds__(QUAD_THREADS, 2) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ partial0, size_t pstride,
-                                                                   const uint2* __restrict__ offsets, size_t nkeys,
-                                                                   XYZZ<Fld>* __restrict__ buckets0, size_t ys) {
+__global__ __launch_bounds__(QUAD_THREADS, 2) void msm_heavy_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes,
+                                                                uint32_t tmin,
+                                                                const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                                XYZZ<Fld>* __restrict__ buckets0,
+                                                                const uint32_t* __restrict__ heavy, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(offsets);
-  const XYZZ<Fld>* __restrict__ partial = partial0 + blockIdx.y * pstride;
-  XYZZ<Fld>* __restrict__ buckets = buckets0 + blockIdx.y * nkeys;
+  ZK_YSHIFT(heavy);
+  const uint32_t nh = heavy[0];
+  if (blockIdx.x >= nh) return;
+  const XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
+  const XYZZ<Fld>* __restrict__ tail = head + nlanes;
+  XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
-  __shared__ uint32_t nheavy, heavy[QUAD_VL];
-  if (threadIdx.x == 0) nheavy = 0;
-  __syncthreads();
+  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin);
   const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
-  const size_t k = (size_t)blockIdx.x * QUAD_VL + vl;
-  if (k < nkeys) {
-    const uint32_t s0 = offsets[k].y, s1 = offsets[k + 1].y;
-    if (s1 - s0 > FIN_SEQ) {
-      if (q == 0) heavy[atomicAdd(&nheavy, 1u)] = (uint32_t)vl;
-    } else {
-      Fld acc = qidentity<Fld>(q);
-      if (s1 > s0) acc = qload(partial + s0, q);
-      for (uint32_t s = s0 + 1; s < s1; s++) acc = qadd(acc, qload(partial + s, q), q);
-      qstore(buckets + k, q, acc);
-    }
-  }
-  __syncthreads();
-  // buckets with many segments (degenerate scalars): the whole workgroup sums one at a time -- strided accumulation
-  // over its 64 quads, then a tree -- so that no quad walks a long chain.  Empty for well-spread scalars.
-  const uint32_t nh = nheavy;
-  for (uint32_t h = 0; h < nh; h++) {
-    const size_t kh = (size_t)blockIdx.x * QUAD_VL + heavy[h];
-    const uint32_t s0 = offsets[kh].y, s1 = offsets[kh + 1].y;
-    Fld acc = qidentity<Fld>(q);
-    for (uint32_t s = s0 + vl; s < s1; s += QUAD_VL) acc = qadd(acc, qload(partial + s, q), q);
-    acc = wg_quad_sum(acc, sh, vl, q, QUAD_VL);
+  for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+    const uint32_t kh = heavy[1 + h];
+    const uint32_t o0 = offsets[kh], o1 = offsets[kh + 1];
+    const uint32_t l0 = o0 / T, l1 = (o1 - 1) / T;
+    Fld acc = vl == 0 ? qload(tail + l0, q) : qidentity<Fld>(q);
+    const int nq = (int)blockDim.x / 4;                 // quads of this workgroup
+    for (uint32_t l = l0 + 1 + vl; l <= l1; l += (uint32_t)nq) acc = qadd(acc, qload(head + l, q), q);
+    acc = wg_quad_sum(acc, sh, vl, q, nq);
     if (vl == 0) qstore(buckets + kh, q, acc);
     __syncthreads();
+  }
+}
+
+// finalize: one quad per bucket, ONE-WAVE workgroups (a workgroup that needs four wave slots on one CU at once waits for
+// milliseconds among the accumulate waves of a batch: measured 5 ms for a 0.3 ms pass).  Empty bucket -> identity; bucket
+// inside one lane's range, or already summed by msm_heavy_kernel -> untouched; otherwise tail + heads.  (Forming the sum
+// inside the reduction's bucket load instead was measured and rejected: it puts independent work into the reduction's
+// dependent chains -- 434 vs 490 proofs/s one at a time.)
+constexpr int FIN_THREADS = 64;
+template <class Fld>
+__global__ __launch_bounds__(FIN_THREADS) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes,
+                                                               uint32_t tmin,
+                                                               const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                               XYZZ<Fld>* __restrict__ buckets0, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(offsets);
+  const XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
+  const XYZZ<Fld>* __restrict__ tail = head + nlanes;
+  XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
+  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin);
+  const int q = threadIdx.x & 3;
+  // grid-stride over the buckets: the launch is capped so that it does not queue thousands of workgroups behind the
+  // accumulate waves
+  for (size_t k = (size_t)blockIdx.x * (FIN_THREADS / 4) + (threadIdx.x >> 2); k < nkeys;
+       k += (size_t)gridDim.x * (FIN_THREADS / 4)) {
+    const uint32_t o0 = offsets[k], o1 = offsets[k + 1];
+    if (o0 == o1) {
+      qstore(buckets + k, q, qidentity<Fld>(q));
+      continue;
+    }
+    const uint32_t l0 = o0 / T, l1 = (o1 - 1) / T;
+    if (l1 == l0 || l1 - l0 > FIN_SEQ) continue;
+    Fld acc = qload(tail + l0, q);
+    for (uint32_t l = l0 + 1; l <= l1; l++) acc = qadd(acc, qload(head + l, q), q);
+    qstore(buckets + k, q, acc);
   }
 }
 
@@ -738,7 +877,7 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_reduce_a_kernel(const XYZ
   const uint32_t ngroups = HI + 1 + LO;
   const XYZZ<Fld>* __restrict__ wb = buckets0 + (size_t)blockIdx.y * B;     // bucket of digit magnitude k is wb[k - 1]
   const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
-  const uint32_t g = blockIdx.x * (uint32_t)(QUAD_VL / nvl) + (uint32_t)(vl / nvl);
+  const uint32_t g = blockIdx.x * (uint32_t)((int)blockDim.x / 4 / nvl) + (uint32_t)(vl / nvl);
   const uint32_t sub = (uint32_t)(vl & (nvl - 1));
   Fld acc = qidentity<Fld>(q);
   if (g <= HI) {                                    // row hi = g: lo runs over the row
@@ -771,7 +910,7 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_reduce_b_kernel(const XYZ
   const int nslices = hb + 1 + lo_bits;
   const XYZZ<Fld>* __restrict__ rc = rc0 + (size_t)blockIdx.y * ngroups;
   const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
-  const int j = (int)blockIdx.x * (QUAD_VL / nvl) + vl / nvl;
+  const int j = (int)blockIdx.x * ((int)blockDim.x / 4 / nvl) + vl / nvl;
   const uint32_t sub = (uint32_t)(vl & (nvl - 1));
   Fld acc = qidentity<Fld>(q);
   if (j <= hb) {
@@ -833,11 +972,9 @@ struct MsmSlot {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   hipEvent_t ev = nullptr;
-  hipEvent_t ev_sort = nullptr;     // the sort of the slot's last launch is complete (consumed by MSMs that share it)
   ~MsmSlot() {
     if (pinned) (void)hipHostFree(pinned);
     if (ev) (void)hipEventDestroy(ev);
-    if (ev_sort) (void)hipEventDestroy(ev_sort);
   }
   hipError_t ensure_pinned(size_t b) {
     if (b <= pinned_bytes) return hipSuccess;
@@ -862,21 +999,11 @@ struct MsmPending {
   bool active = false;
   int kwin = 0, c = 0, wide = 0, nb = 1, lo_bits = 0;
   int batch = 1;                                 // scalar vectors of the launch (results: [base vector][batch])
+  size_t stats_off = 0, offered = 0;             // statistics: where the sorts' entry counts land in the pinned buffer;
+  int nsorts = 1;                                // (point, window) pairs offered to the sort
+  bool g2 = false;
   MsmSlot* slot = nullptr;
   std::shared_ptr<const MsmTable> tab, tab2;     // keep the tables alive while the kernels run
-  // the sort this launch produced (device pointers into the slot's workspace): another MSM over the SAME scalars with
-  // the same window layout -- Groth16's a_query / b_g1_query / b_g2_query over the witness shares -- may run its
-  // accumulate on it instead of sorting again (MsmTuning::share)
-  struct Sort {
-    const void* scalars = nullptr;
-    const void* coef = nullptr;
-    size_t npts = 0, part_len = 0, nkeys = 0, max_segs = 0;
-    int c = 0, nwin = 0, wide = 0;
-    uint32_t seg = 0, pre_stride = 0, pre_off = 0;
-    const uint32_t *sorted = nullptr, *order = nullptr;
-    const SegDesc* segs = nullptr;
-    const uint2* offsets = nullptr;
-  } sort;
 };
 
 // Ordering between the accumulate kernels of concurrent launches (the Groth16 prover runs the G2 accumulate ahead of the
@@ -894,7 +1021,6 @@ struct MsmGate {
 struct MsmTuning {
   size_t bigsort_min;
   MsmGate gate;
-  const MsmPending* share = nullptr;   // reuse this launch's sort when it matches (same scalars, layout, table geometry)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -927,21 +1053,25 @@ inline int msm_pick_c(size_t npts, bool g2 = false) {
   return best;
 }
 
-// points per accumulate lane (a bucket longer than this is cut into segments)
-inline uint32_t msm_pick_seg(size_t npts, bool g2 = false) {
-  if (g2)
-    if (const char* e = getenv("ZK_MSM_SEG_G2")) {
-      int v = atoi(e);
-      if (v >= 1 && v <= 1024) return (uint32_t)v;
-    }
-  if (const char* e = getenv("ZK_MSM_SEG")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= 1024) return (uint32_t)v;
-  }
-  // Measured on MI355X (SHA-256 circuit, 111k-point MSMs): the accumulate kernel's duration is set by its
-  // longest lane chain, so short segments win (8.9 ms/proof at 16 vs 10.9 at 64); for multi-million-point MSMs
-  // the buckets are long anyway and 64 keeps the number of partial sums down.
-  return npts >= ((size_t)1 << 21) ? 64u : (uint32_t)MSM_SEG_MAX;
+// Accumulate lanes of a launch with at most `max_entries` sorted entries (msm.hpp "balanced partition"): entries per
+// lane `t` and the lane count that covers max_entries at that length.  Measured on batches of 1 / 2 / 4 / 8 119k-point
+// MSMs alone on the chip (1.9 M .. 15 M entries; the chip holds 196 608 lanes at three waves per SIMD;
+// profiles/r03_range_sweep.txt): what matters is how many ROUNDS of waves a launch makes -- >= 1.6 rounds run at
+// 98-116 G multiplications/s, exactly one round at 79 (a grid that just fills the chip leaves the dispatcher no slack and
+// all its waves march in step), fewer than one underfills -- while every lane boundary costs one full addition (14
+// multiplications; 42 in G2) in the finalize kernel.  So: ~2.4 rounds, but never fewer than `lo` entries per lane (small
+// launches: the MSMs of ONE proof run four at a time and fill the chip together) nor more than `hi`.
+// ZK_MSM_RANGE=<entries per lane> overrides (experiments).
+struct MsmLanes {
+  uint32_t nlanes, tmin;
+};
+inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair) {
+  static const int env_t = getenv("ZK_MSM_RANGE") ? atoi(getenv("ZK_MSM_RANGE")) : 0;
+  const size_t cap = (size_t)1024 * waves * (pair ? 32 : 64);
+  const size_t lo = pair ? MSM_RANGE_MIN_G2 : MSM_RANGE_MIN, hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
+  size_t t = env_t >= 1 ? (size_t)env_t : (size_t)((double)max_entries / (2.4 * (double)cap));
+  if (env_t < 1) t = std::min(hi, std::max(lo, t));
+  return MsmLanes{(uint32_t)std::max<size_t>(1, (max_entries + t - 1) / t), (uint32_t)t};
 }
 
 template <class FrP>
@@ -951,7 +1081,10 @@ inline void msm_plan_of(size_t npts, bool g2, int* out) {
   const int nwin = (T + c_req - 1) / c_req;
   out[0] = (T + nwin - 1) / nwin;
   out[1] = nwin;
-  out[2] = (int)msm_pick_seg(npts, g2);
+  {
+    const size_t entries = npts * (size_t)nwin;
+    out[2] = (int)msm_pick_lanes(entries, g2 ? 2 : 3, g2).tmin;     // sorted entries (= mixed additions) per accumulate lane
+  }
   out[3] = g2 ? 28 : 10;
 }
 
@@ -986,6 +1119,14 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
   const int kwin = p.kwin, c = p.c, wide = p.wide, lo_bits = p.lo_bits, nslices = p.c;
   const int hb = c - 1 - lo_bits;                  // row slices 0..hb come first, then lo_bits column slices
   const XYZZ<Fld>* hall = (const XYZZ<Fld>*)p.slot->pinned;
+  {
+    // statistics (zk_msm_stats): mixed additions performed = sorted entries, per base vector
+    const uint32_t* cnt = (const uint32_t*)((const char*)p.slot->pinned + p.stats_off);
+    uint64_t adds = 0;
+    for (int v = 0; v < p.nb; v++) adds += cnt[2 * (p.nsorts == 2 ? v : 0)];
+    eng->msm_adds[p.g2 ? 1 : 0].fetch_add(adds, std::memory_order_relaxed);
+    eng->msm_offered[p.g2 ? 1 : 0].fetch_add(p.offered, std::memory_order_relaxed);
+  }
   if (nvec > p.nb) nvec = p.nb;
   // windows [w_lo, w_hi] of one vector, high to low, doublings only INSIDE the range:
   // sum_w 2^(start_w - start_w_lo) X_w with X_w = sum_j 2^(j + lo_bits) TR_j + sum_j 2^j TC_j
@@ -1118,10 +1259,10 @@ class MsmRunner {
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
                hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, MsmGate gate = MsmGate{},
-               const MsmPending* share = nullptr, const MsmBatchArg* batch = nullptr) {
+               const MsmBatchArg* batch = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate, share};
+    MsmTuning tune{bigsort_min, gate};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }

@@ -45,23 +45,11 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const size_t max_sorted = npts * batch * nwin;
   if (max_sorted >= ((size_t)1 << 32)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large (points x windows >= 2^32)");
   const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
-  uint32_t seg = msm_pick_seg(npts, G2FLD);
-  {
-    // keep the average bucket at no more than ~4 segments: with 2^26 points and 2^16 buckets per window a 64-point
-    // segment would leave 16 partial sums per bucket, i.e. every bucket on the slow heavy-bucket path
-    const size_t avg = (tab ? npts * nwin : npts) >> (c - 1);
-    uint32_t want = 1;
-    while ((size_t)want * 4 < avg && want < 1024) want <<= 1;
-    const bool overridden = getenv("ZK_MSM_SEG") || (G2FLD && getenv("ZK_MSM_SEG_G2"));
-    if (!overridden && want > seg) seg = want;
-    // a batch has lanes to spare (batch x the segments of one MSM): longer segments leave fewer partial sums to the
-    // finalize kernel.  ZK_MSM_SEG_BATCH overrides (measured in DESIGN.md "batched proving").
-    if (batch > 1) {
-      static const int seg_batch = getenv("ZK_MSM_SEG_BATCH") ? atoi(getenv("ZK_MSM_SEG_BATCH")) : 128;
-      if (seg_batch >= 1 && seg_batch <= 1024 && !overridden) seg = (uint32_t)seg_batch;
-    }
-  }
-  const size_t max_segs = nkeys + max_sorted / seg + 1;   // every bucket has < count/seg + 1 segments
+  // accumulate lanes (msm.hpp "balanced partition"): every lane adds the same number of sorted entries
+  static const bool pair_acc = !getenv("ZK_ACC_PAIR") || atoi(getenv("ZK_ACC_PAIR")) != 0;
+  const bool pair = G2FLD && pair_acc;
+  const MsmLanes ml = msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair);
+  const uint32_t nlanes = ml.nlanes, tmin = ml.tmin;
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
   const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
   const uint32_t red_groups = (B >> lo_bits) + 1 + (1u << lo_bits);
@@ -85,14 +73,16 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const bool none = tab && !tab->any_identity && (NB == 1 || (tab2 && !tab2->any_identity));
   const unsigned NS = (NB == 2 && skip_on && !one_sort && !none) ? 2u : 1u;       // sorts of this launch
   // ---- sort region (replicated NS times)
-  size_t o_counts = take(nkeys * 4), o_lenhist = take(2 * SEG_BINS * 4), o_order = take(max_segs * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 8),
-         o_bt = take(iscan_blocks * 8), o_sorted = take(max_sorted * 4), o_segs = take(max_segs * sizeof(SegDesc));
+  size_t o_counts = take(nkeys * 4), o_heavy = take(((size_t)nlanes / FIN_SEQ + 8) * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 4),
+         o_bt = take(iscan_blocks * 4), o_sorted = take(max_sorted * 4);
   // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
   const int sort_hi = msm_big_hi(nsets);
   const int sort_lo = c - 1 - sort_hi;
   const bool big = npts * batch >= tune.bigsort_min && sort_hi >= 1 && sort_lo >= 1 && sort_lo <= 12;
   const size_t kbin = nsets;                       // set components of the sort bins
   const size_t o_skip = take(((npts + 63) / 64) * 8);
+  const size_t o_k0 = take((size_t)nlanes * 4);                // first bucket of every accumulate lane
+  const size_t o_canon = take(npts * batch * sizeof(Fr));      // canonical scalars (written by the first sort pass)
   size_t o_bins = 0, o_tmp = 0;
   if (big) {
     o_bins = take((3 * (kbin << sort_hi) + 1) * 4);
@@ -102,13 +92,13 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const size_t ys = NS == 2 ? sort_region : 0;     // byte distance between the two copies
   off = sort_region * NS;
   // ---- per base vector
-  size_t o_partial = take(NB * max_segs * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
+  size_t o_edge = take(NB * 2 * (size_t)nlanes * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
          o_rc = take(NB * nsets * red_groups * sizeof(XYZZ<Fld>)),
          o_out = take(NB * nsets * nslices * sizeof(XYZZ<Fld>));
   hipError_t he = slot.ws.ensure(off);
   if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
   const size_t out_bytes = NB * nsets * nslices * sizeof(XYZZ<Fld>);
-  he = slot.ensure_pinned(out_bytes);
+  he = slot.ensure_pinned(out_bytes + 64);           // + the sorted-entry counts of the launch's sorts (msm statistics)
   if (he != hipSuccess) return eng->hip_fail(he, "msm pinned buffer");
   if (!slot.ev) {
     he = hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming);
@@ -116,16 +106,15 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   }
   char* ws = (char*)slot.ws.p;
   uint32_t* counts = (uint32_t*)(ws + o_counts);
-  uint32_t* lenhist = (uint32_t*)(ws + o_lenhist);   // [SEG_BINS] histogram, [SEG_BINS] cursors
-  uint32_t* order = (uint32_t*)(ws + o_order);
   uint32_t* cursor = (uint32_t*)(ws + o_cursor);
-  uint2* offsets = (uint2*)(ws + o_offsets);
-  uint2* bt = (uint2*)(ws + o_bt);
+  uint32_t* heavy = (uint32_t*)(ws + o_heavy);
+  uint32_t* k0 = (uint32_t*)(ws + o_k0);
+  uint32_t* offsets = (uint32_t*)(ws + o_offsets);
+  uint32_t* bt = (uint32_t*)(ws + o_bt);
   uint32_t* sorted = (uint32_t*)(ws + o_sorted);
-  SegDesc* segs = (SegDesc*)(ws + o_segs);
   using KF = typename KernelField<Fld>::type;     // same layout as Fld
   static_assert(sizeof(KF) == sizeof(Fld), "kernel field layout");
-  XYZZ<KF>* partial = (XYZZ<KF>*)(ws + o_partial);
+  XYZZ<KF>* edge = (XYZZ<KF>*)(ws + o_edge);         // per base vector: head[nlanes], tail[nlanes]
   XYZZ<KF>* buckets = (XYZZ<KF>*)(ws + o_buckets);
   XYZZ<KF>* rc = (XYZZ<KF>*)(ws + o_rc);
   XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
@@ -145,28 +134,10 @@ do {                                                                           \
     if (_e != hipSuccess) return eng->hip_fail(_e, name);                      \
   }                                                                            \
 } while (0)
-  // another launch already sorted these scalars with this layout?
-  const MsmPending::Sort* sh = nullptr;
-  // (a shared sort leaves out the identities of the launch that built it: only valid when identity skipping is off)
-  if (batch == 1 && tune.share && tune.share->active && getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0) {
-    const MsmPending::Sort& s0 = tune.share->sort;
-    if (s0.scalars == scalars && s0.coef == (const void*)coef_d && s0.npts == npts && s0.part_len == (part_len ? part_len : npts) &&
-        s0.c == c && s0.nwin == nwin && s0.wide == wide && s0.seg == seg && s0.pre_stride == pre_stride &&
-        s0.pre_off == pre_off && s0.nkeys == nkeys && s0.max_segs == max_segs && tune.share->slot->ev_sort)
-      sh = &s0;
-  }
-  if (!slot.ev_sort) {
-    he = hipEventCreateWithFlags(&slot.ev_sort, hipEventDisableTiming);
-    if (he != hipSuccess) return eng->hip_fail(he, "msm event");
-  }
-  if (sh) {
-    MSM_HIP(hipStreamWaitEvent(st, tune.share->slot->ev_sort, 0));
-    sorted = const_cast<uint32_t*>(sh->sorted);
-    segs = const_cast<SegDesc*>(sh->segs);
-    offsets = const_cast<uint2*>(sh->offsets);
-    order = const_cast<uint32_t*>(sh->order);
-  } else {
-  MSM_HIP(msm_zero(counts, o_lenhist + 2 * SEG_BINS * 4 - o_counts, st, NS, ys));   // counts and lenhist
+  {
+  // counts (the two-level sort writes every count itself) and the heavy-bucket counter that follows them
+  if (big) MSM_HIP(msm_zero(heavy, 16, st, NS, ys));
+  else MSM_HIP(msm_zero(counts, o_heavy + 16 - o_counts, st, NS, ys));
   dim3 pg((unsigned)((npts + 255) / 256), NS), pb(256);
   dim3 pgb((unsigned)((npts * batch + 255) / 256), NS);     // one thread per (scalar vector, point)
   MsmScalars<Fr> sc{};
@@ -174,6 +145,7 @@ do {                                                                           \
   sc.npts = (uint32_t)npts;
   sc.nb = (uint32_t)batch;
   sc.sets_per = (uint32_t)kwin;
+  Fr* canon = (Fr*)(ws + o_canon);
   uint32_t* skip = nullptr;
   if (skip_on && !none) {
     skip = (uint32_t*)(ws + o_skip);
@@ -197,46 +169,33 @@ do {                                                                           \
     const uint32_t wmask = tab ? 0u : ~0u;
     msm_part_hist_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), nbins * 4, st>>>(sc, coef_d, plen, c, nwin, wide,
                                                                                     sort_hi, sort_lo, ppt, wmask,
-                                                                                    bin_counts, skip, ys);
+                                                                                    bin_counts, skip, canon, ys);
     msm_bin_scan_kernel<<<dim3(1, NS), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor, ys);
     msm_part_scatter_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-        sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp, skip, ys);
+        sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp, canon, ys);
     msm_bin_sort_kernel<<<dim3(nbins, NS), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_hi, sort_lo, (uint32_t)(c - 1),
                                                                        counts, sorted, ys);
     MSM_STAGE("big sort");
   } else {
     msm_digits_kernel<FrP, 0><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, counts, nullptr,
-                                                 nullptr, skip, ys);
+                                                 nullptr, skip, canon, ys);
     MSM_STAGE("digits/count");
   }
   iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
-                                                                                       nullptr, 0, seg, ys);
+                                                                                       nullptr, nullptr, 0, ys);
   iscan_carry_kernel<<<dim3(1, NS), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks, ys);
-  iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
-                                                                                       offsets, 1, seg, ys);
+  iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(
+      counts, nkeys, nullptr, bt, offsets, big ? nullptr : cursor, 1, ys);
   MSM_STAGE("scan");
-  msm_expand_kernel<<<dim3((unsigned)((nkeys + 255) / 256), NS), dim3(256), 0, st>>>(offsets, nkeys, cursor, segs, seg,
-                                                                                     lenhist, ys);
-  msm_order_kernel<<<dim3((unsigned)((max_segs + 255) / 256), NS), dim3(256), 0, st>>>(
-      segs, offsets, nkeys, seg, lenhist, lenhist + SEG_BINS, order, ys);
-  MSM_STAGE("expand");
+  msm_lane_start_kernel<<<dim3((nlanes + 255) / 256, NS), dim3(256), 0, st>>>(offsets, (uint32_t)nkeys, nlanes, tmin, k0, ys);
   if (!big)
     msm_digits_kernel<FrP, 1><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, nullptr, cursor,
-                                                 sorted, skip, ys);
+                                                 sorted, skip, canon, ys);
   }
-  MSM_HIP(hipEventRecord(slot.ev_sort, st));
   }
   MSM_STAGE("scatter");
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB * batch);
-  size_t acc_wgs = (max_segs + 127) / 128;
-  {
-    static const int cap_g1 = getenv("ZK_ACC_WGS_G1") ? atoi(getenv("ZK_ACC_WGS_G1")) : 0;
-    static const int cap_g2 = getenv("ZK_ACC_WGS_G2") ? atoi(getenv("ZK_ACC_WGS_G2")) : 0;
-    const int cap = G2FLD ? cap_g2 : cap_g1;
-    if (cap > 0 && acc_wgs > (size_t)cap) acc_wgs = (size_t)cap;
-  }
-  static const bool pair_acc = !getenv("ZK_ACC_PAIR") || atoi(getenv("ZK_ACC_PAIR")) != 0;
   if (tune.gate.wait_ev) {
     if (tune.gate.wait_flag)
       while (!tune.gate.wait_flag->load(std::memory_order_acquire)) std::this_thread::yield();
@@ -244,17 +203,18 @@ do {                                                                           \
   }
   bool launched = false;
   if constexpr (G2FLD) {
-    if (pair_acc) {
-      // extension field: a pair of lanes per segment (two waves per SIMD instead of one; quad.hpp pair_madd)
-      msm_accumulate_pair_kernel<KF><<<dim3((unsigned)((max_segs + 63) / 64), NB), dim3(128), 0, st>>>(
-          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial,
-          ys);
+    if (pair) {
+      // extension field: a pair of lanes per range (two waves per SIMD instead of one; quad.hpp pair_madd)
+      msm_accumulate_pair_kernel<KF><<<dim3((nlanes + 63) / 64, NB), dim3(128), 0, st>>>(
+          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, buckets, edge,
+          heavy, k0, ys);
       launched = true;
     }
   }
   if (!launched)
-    msm_accumulate_kernel<KF><<<dim3((unsigned)acc_wgs, NB), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, max_segs, sorted, segs, offsets, nkeys, order, partial, ys);
+    msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), 0, st>>>(
+        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, buckets, edge,
+        heavy, k0, ys);
   if (tune.gate.signal_ev) {
     MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
     if (tune.gate.signal_flag) tune.gate.signal_flag->store(1, std::memory_order_release);
@@ -263,9 +223,18 @@ do {                                                                           \
   MSM_STAGE("accumulate");
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_REDUCE_G2 : PROF_MSM_REDUCE, st, (double)nkeys * NB);   // units: buckets
-  const size_t quad_lds = QUAD_VL * sizeof(XYZZ<Fld>);
-  msm_finalize_kernel<KF><<<dim3((unsigned)((nkeys + QUAD_VL - 1) / QUAD_VL), NB), dim3(QUAD_THREADS), quad_lds, st>>>(
-      partial, max_segs, offsets, nkeys, buckets, ys);
+  const int qt = quad_threads(batch > 1), qvl = qt / 4;
+  const size_t quad_lds = (size_t)qvl * sizeof(XYZZ<Fld>);
+  // buckets spread over many lanes (none for well-spread scalars: the workgroups read a zero count and leave)
+  msm_heavy_kernel<KF><<<dim3(64, NB), dim3((unsigned)qt), quad_lds, st>>>(edge, nlanes, tmin, offsets, (uint32_t)nkeys,
+                                                                   buckets, heavy, ys);
+  MSM_STAGE("heavy buckets");
+  {
+    // capped grid (grid-stride inside): enough one-wave workgroups to cover the chip a few times over
+    const size_t fin_wgs = std::min<size_t>((nkeys + FIN_THREADS / 4 - 1) / (FIN_THREADS / 4), 8192);
+    msm_finalize_kernel<KF><<<dim3((unsigned)fin_wgs, NB), dim3(FIN_THREADS), 0, st>>>(edge, nlanes, tmin, offsets,
+                                                                                    (uint32_t)nkeys, buckets, ys);
+  }
   MSM_STAGE("finalize");
   // quads per group: few groups (one bucket set) -> whole workgroups per group, shortest dependent chain; many groups
   // (one bucket set per window) -> 4 quads per group, waves stay full
@@ -276,7 +245,7 @@ do {                                                                           \
   const size_t tot_slices = (size_t)nslices * NB * nsets;
   const size_t cap_quads = (size_t)1024 * (G2FLD ? 2 : 3) * 16;
   auto pick_nvl = [&](size_t groups) {
-    int v = QUAD_VL;
+    int v = qvl;
     while (v > 4 && groups * (size_t)v > cap_quads) v >>= 1;
     return v;
   };
@@ -285,15 +254,21 @@ do {                                                                           \
   int nvl_a = pick_nvl(tot_groups), nvl_b = pick_nvl(tot_slices);
   if (env_a == 4 || env_a == 8 || env_a == 16 || env_a == 32 || env_a == 64) nvl_a = env_a;
   if (env_b == 4 || env_b == 8 || env_b == 16 || env_b == 32 || env_b == 64) nvl_b = env_b;
-  const unsigned gpw_a = QUAD_VL / nvl_a, gpw_b = QUAD_VL / nvl_b;
-  msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)nsets), dim3(QUAD_THREADS), quad_lds, st>>>(
+  if (nvl_a > qvl) nvl_a = qvl;
+  if (nvl_b > qvl) nvl_b = qvl;
+  const unsigned gpw_a = (unsigned)(qvl / nvl_a), gpw_b = (unsigned)(qvl / nvl_b);
+  msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)nsets), dim3((unsigned)qt), quad_lds, st>>>(
       buckets, B, lo_bits, nvl_a, rc);
-  msm_reduce_b_kernel<KF><<<dim3(((unsigned)nslices + gpw_b - 1) / gpw_b, NB * (unsigned)nsets), dim3(QUAD_THREADS), quad_lds,
+  msm_reduce_b_kernel<KF><<<dim3(((unsigned)nslices + gpw_b - 1) / gpw_b, NB * (unsigned)nsets), dim3((unsigned)qt), quad_lds,
                             st>>>(rc, B, lo_bits, nvl_b, out);
   }
   MSM_HIP(hipGetLastError());
   MSM_STAGE("reduce");
   MSM_HIP(hipMemcpyAsync(slot.pinned, out, out_bytes, hipMemcpyDeviceToHost, st));
+  // mixed additions actually performed = sorted entries (identity bases and zero digits leave none): one count per sort
+  for (unsigned y = 0; y < NS; y++)
+    MSM_HIP(hipMemcpyAsync((char*)slot.pinned + out_bytes + 8 * y, (const char*)(offsets + nkeys) + (size_t)y * ys, 4,
+                           hipMemcpyDeviceToHost, st));
   MSM_HIP(hipEventRecord(slot.ev, st));
 #undef MSM_HIP
 #undef MSM_STAGE
@@ -304,22 +279,10 @@ do {                                                                           \
   pend->nb = (int)NB;
   pend->lo_bits = lo_bits;
   pend->slot = &slot;
-  pend->sort.scalars = scalars;
-  pend->sort.coef = (const void*)coef_d;
-  pend->sort.npts = npts;
-  pend->sort.part_len = part_len ? part_len : npts;
-  pend->sort.nkeys = nkeys;
-  pend->sort.max_segs = max_segs;
-  pend->sort.c = c;
-  pend->sort.nwin = nwin;
-  pend->sort.wide = wide;
-  pend->sort.seg = seg;
-  pend->sort.pre_stride = pre_stride;
-  pend->sort.pre_off = pre_off;
-  pend->sort.sorted = sorted;
-  pend->sort.order = order;
-  pend->sort.segs = segs;
-  pend->sort.offsets = offsets;
+  pend->stats_off = out_bytes;
+  pend->nsorts = (int)NS;
+  pend->g2 = G2FLD;
+  pend->offered = npts * batch * NB * (size_t)nwin;
   pend->tab = std::move(tab);
   pend->tab2 = std::move(tab2);
   return ZK_OK;
