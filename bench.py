@@ -95,14 +95,15 @@ PMC_KERNEL = {"msm_accumulate_kernel<G1>": "msm_accumulate_kernel<Fp<", "msm_acc
               "ntt_pass_kernel": "ntt_pass_kernel", "king_fft2_kernel": "king_fft2_kernel",
               "king_degred_kernel": "king_degred_kernel", "msm_finalize+reduce<G1>": "msm_finalize_kernel<Fp<",
               "msm_finalize+reduce<G2>": "msm_finalize_kernel<Fp2"}
-PMC_FILE = "r02_c4_pmc_hbm.json"
+PMC_FILE = "r03_c4_pmc_hbm.json"
 
 
 def pmc_traffic(slot_name):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC summary of this same command
-    (profiles/r02_c4_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes; the summary tool
-    applies the guide's gfx950 correction -- FETCH_SIZE x 2 for the 16-byte-per-lane streaming kernels -- and
-    records per kernel whether it did)."""
+    (profiles/<PMC_FILE>: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, which cannot run inside this
+    process; the summary tool applies the guide's gfx950 correction -- FETCH_SIZE x 2 for the 16-byte-per-lane
+    streaming kernels -- and records per kernel whether it did).  The bench line names the file (`traffic_source`):
+    it is regenerated by tools/refresh_profiles.sh whenever the kernel changes."""
     path = os.path.join(ROOT, "profiles", PMC_FILE)
     prefix = PMC_KERNEL.get(slot_name)
     if not prefix or not os.path.exists(path):
@@ -116,7 +117,15 @@ def pmc_traffic(slot_name):
     return None
 
 
-def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None):
+def msm_stats(pp):
+    """zk_msm_stats: (G1 additions, G2 additions, G1 offered, G2 offered) since the context was created -- additions =
+    sorted (point, window) entries the accumulate kernels actually walk (identity bases and zero digits leave none)."""
+    st = (C.c_uint64 * 4)()
+    pp._check(pp.lib.zk_msm_stats(pp.h, st))
+    return [int(v) for v in st]
+
+
+def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=None):
     """The slot with the largest share of the timed region -- also when it is a latency-bound helper."""
     cands = [e for e in prof if e["launches"]]
     if not cands:
@@ -139,6 +148,11 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None):
         if table_windows:           # fixed-base tables: every MSM runs with the table's window layout
             plan["windows"], plan["window_bits"], plan["fixed_base_table"] = table_windows, -(-256 // table_windows), True
         muls = pts * plan["windows"] * plan["muls_per_add"]
+        if adds is not None:
+            # mixed additions the kernel PERFORMED per launch (zk_msm_stats), not points x windows: the sort leaves out
+            # identity bases (config.crs_identity_fraction) and zero digits
+            muls = adds["g2" if "G2" in name else "g1"] / best["launches"] * plan["muls_per_add"]
+            plan["additions_per_launch"] = int(adds["g2" if "G2" in name else "g1"] / best["launches"])
         rate = muls / (avg_ms * 1e-3) / 1e9
         alu = {"achieved": round(rate, 2), "peak": round(MAD_ISSUE_BOUND_G, 1),
                "unit": "G modmul/s (256-bit Montgomery; peak = v_mad_u64_u32 issue bound)",
@@ -146,6 +160,8 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None):
                "plan": plan}
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name),
+            "traffic_source": "profiles/" + PMC_FILE,
+            "slot_times": "HIP-event spans on the launching streams; the MSMs of a proof run on 5 streams and overlap",
             "latency_bound_helper": name in LATENCY_BOUND, "alu": alu,
             "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "launches": best["launches"],
@@ -163,26 +179,18 @@ def identity_fractions(pp, crs):
     return out
 
 
-def proof_alu(prof, pp, table_windows, steps, dt):
-    """Whole-proof multiplier utilisation: the base-field products of all accumulate launches of one proof (points x
-    windows x products per mixed addition: 10 in G1, 28 in G2 = 8 Fq2 products + 2 Fq2 squarings) over the proof's
-    WALL time.  The per-kernel figure in `roofline.alu` divides one launch's products by that launch's duration while
-    three or four other MSMs share the chip with it; this one does not depend on how the launches overlap.  It counts
-    the additions of ALL points, also of the identity bases the sort leaves out (config.crs_identity_fraction)."""
-    from zksaas_amd.api import ZK_G1, ZK_G2, msm_plan
-    muls = 0.0
-    for e in prof:
-        if not e["launches"] or not e["kernel"].startswith("msm_accumulate"):
-            continue
-        g2 = "G2" in e["kernel"]
-        plan = msm_plan(pp, ZK_G2 if g2 else ZK_G1, int(e["units"] / e["launches"]))
-        if isinstance(table_windows, dict):
-            windows = table_windows["g2" if g2 else "g1"]
-        else:
-            windows = table_windows if table_windows else plan["windows"]
-        muls += e["units"] / steps * windows * (28 if g2 else 10)
-    rate = muls / (dt / steps) / 1e9
-    return {"modmuls_per_proof": int(muls), "achieved": round(rate, 2), "unit": "G modmul/s over the proof's wall time",
+def proof_alu(adds, offered, proofs, dt):
+    """Whole-proof multiplier utilisation: the base-field products of the mixed additions the accumulate kernels of one
+    proof actually PERFORMED (zk_msm_stats: sorted entries; 10 products per addition in G1, 28 in G2 = 8 Fq2 products + 2
+    Fq2 squarings) over the proof's WALL time.  The per-kernel figure in `roofline.alu` divides one launch's products by
+    that launch's duration while other MSMs share the chip with it; this one does not depend on how the launches
+    overlap.  `identity_points_skipped` = (point, window) pairs the sort left out (identity bases of the CRS, zero
+    digits).  NTT / king / reduction multiplications (about 20 M per proof) are not counted."""
+    muls = (adds["g1"] * 10 + adds["g2"] * 28) / proofs
+    rate = muls / (dt / proofs) / 1e9
+    return {"modmuls_per_proof": int(muls), "additions_per_proof": {k: int(v / proofs) for k, v in adds.items()},
+            "identity_points_skipped": {k: int((offered[k] - adds[k]) / proofs) for k in adds},
+            "achieved": round(rate, 2), "unit": "G modmul/s over the proof's wall time",
             "frac_issue_bound": round(rate / MAD_ISSUE_BOUND_G, 3),
             "frac_of_measured_multiplier": round(rate / MUL_MEASURED_G, 3)}
 
@@ -338,19 +346,78 @@ def cpu_baseline(pp, crs, wit, r, s, seed, masks, gpu_proof):
             "runs": runs, "host_cpus": cores, "cpu_model": cpu_model(), "proof_matches_gpu": bool(ok)}
 
 
-def timed(pp, zg, crs, wit, r, s, masks, steps, warmup, torch):
+REPS = 5
+
+
+def timed(pp, zg, crs, wit, r, s, masks, steps, warmup, torch, reps=REPS):
+    """W warm-up proofs, then the K-step loop `reps` times (each bracketed by a device synchronise): returns the MEDIAN
+    loop time, the min / max, the per-kernel slot times of the median-adjacent last repetition, the MSM work counters
+    of that repetition and the last proof."""
     for i in range(warmup):
         proof = zg.prove(pp, crs, wit, r, s, masks=masks, seed=1000 + i)
     torch.cuda.synchronize()
-    pp._check(pp.lib.zk_profile_enable(pp.h, 1))
-    t0 = time.perf_counter()
-    for i in range(steps):
-        proof = zg.prove(pp, crs, wit, r, s, masks=masks, seed=2000 + i)      # fresh share randomness per proof
+    dts = []
+    prof = adds = offered = None
+    for rep_i in range(reps):
+        last = rep_i == reps - 1
+        if last:
+            pp._check(pp.lib.zk_profile_enable(pp.h, 1))
+        st0 = msm_stats(pp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            proof = zg.prove(pp, crs, wit, r, s, masks=masks, seed=2000 + i)      # fresh share randomness per proof
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+        st1 = msm_stats(pp)
+        if last:
+            prof = read_profile(pp)
+            pp._check(pp.lib.zk_profile_enable(pp.h, 0))
+            adds = {"g1": st1[0] - st0[0], "g2": st1[1] - st0[1]}
+            offered = {"g1": st1[2] - st0[2], "g2": st1[3] - st0[3]}
+    srt = sorted(dts)
+    med = srt[len(srt) // 2]
+    return {"dt": med, "dt_last": dts[-1], "min": srt[0], "max": srt[-1], "prof": prof, "adds": adds, "offered": offered,
+            "proof": proof}
+
+
+def batched(pp, zg, crs, wit, r, s, masks, nb, nbatches, torch, ref_proof, inflight=1):
+    """zk_groth16_prove_batch: nb proofs of the workload against the one CRS per call (a proving service's throughput
+    mode; each proof of a batch may have its own witness, (r, s) and masks -- here nb copies of the bench witness).
+    inflight = 2: zk_groth16_prove_batch_async, the next batch enqueued before the previous one is collected."""
+    mk = None if masks is None else [masks] * nb
+    args = (pp, crs, [wit] * nb, [r] * nb, [s] * nb)
+    out = zg.prove_batch(*args, masks=mk, seed=11)
+    same = all(same_shares(pp, o, ref_proof) for o in out)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = read_profile(pp)
-    pp._check(pp.lib.zk_profile_enable(pp.h, 0))
-    return dt, prof, proof
+    ts = []
+    for rep_i in range(3):
+        st0 = msm_stats(pp)
+        t0 = time.perf_counter()
+        if inflight == 1:
+            for i in range(nbatches):
+                out = zg.prove_batch(*args, masks=mk, seed=4000 + i)
+        else:
+            prev = zg.prove_batch_async(*args, masks=mk, seed=4000)
+            for i in range(1, nbatches):
+                cur = zg.prove_batch_async(*args, masks=mk, seed=4000 + i)
+                prev.wait()
+                prev = cur
+            out = prev.wait()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        st1 = msm_stats(pp)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    proofs = nb * nbatches
+    adds = {"g1": st1[0] - st0[0], "g2": st1[1] - st0[1]}
+    offered = {"g1": st1[2] - st0[2], "g2": st1[3] - st0[3]}
+    return {"batch": nb, "batches_in_flight": inflight, "proofs": proofs, "proofs_per_s": round(proofs / dt, 2),
+            "ms_per_proof": round(dt / proofs * 1e3, 4), "ms_per_batch": round(dt / nbatches * 1e3, 3),
+            "min_max_proofs_per_s": [round(proofs / ts[-1], 1), round(proofs / ts[0], 1)],
+            "proof_alu": proof_alu(adds, offered, proofs, dt),
+            "same_proof": bool(same and all(same_shares(pp, o, ref_proof) for o in out)),
+            "api": "zk_groth16_prove_batch" + ("_async / zk_groth16_batch_wait" if inflight > 1 else "")}
 
 
 def main():
@@ -408,7 +475,8 @@ def main():
         crs.precompute()
         table_windows = api.msm_table_info(pp, api.ZK_G1, crs.s)["windows"]
         table_windows_by_group = {"g1": table_windows, "g2": api.msm_table_info(pp, api.ZK_G2, crs.v)["windows"]}
-    dt, prof, proof = timed(pp, zg, crs, wit, r, s, masks, args.steps, args.warmup, torch)
+    tm = timed(pp, zg, crs, wit, r, s, masks, args.steps, args.warmup, torch)
+    dt, prof, proof = tm["dt"], tm["prof"], tm["proof"]
 
     proofs_per_s = args.steps / dt
     res = {
@@ -426,8 +494,14 @@ def main():
                    "fixed_base_tables": not args.no_tables,
                    "crs_identity_fraction": identity_fractions(pp, crs)},
         "constraints_per_sec": round(proofs_per_s * r1.num_constraints, 1),
-        "roofline": roofline_of(prof, ntt_passes=2, masks_on=masks is not None, pp=pp, table_windows=table_windows),
-        "proof_alu": proof_alu(prof, pp, table_windows_by_group, args.steps, dt),
+        "repetitions": {"count": REPS, "ms_per_step_median": round(dt / args.steps * 1e3, 4),
+                        "ms_per_step_min": round(tm["min"] / args.steps * 1e3, 4),
+                        "ms_per_step_max": round(tm["max"] / args.steps * 1e3, 4),
+                        "note": "the K-step loop is timed %d times after the warm-up; value and ms_per_step are the "
+                                "median repetition, roofline / kernels the last one" % REPS},
+        "roofline": roofline_of(prof, ntt_passes=2, masks_on=masks is not None, pp=pp, table_windows=table_windows,
+                                adds=tm["adds"]),
+        "proof_alu": proof_alu(tm["adds"], tm["offered"], args.steps, tm["dt_last"]),
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
     if not args.no_primitives:
@@ -436,16 +510,22 @@ def main():
             from zksaas_amd import api
             for buf in (crs.s, crs.h, crs.v, crs.w, crs.u):
                 api.msm_forget(pp, buf)
-            dt2, prof2, proof2 = timed(pp, zg, crs, wit, r, s, masks, args.steps, max(2, args.warmup // 2), torch)
+            tm2 = timed(pp, zg, crs, wit, r, s, masks, args.steps, max(2, args.warmup // 2), torch, reps=3)
+            dt2, prof2, proof2 = tm2["dt"], tm2["prof"], tm2["proof"]
             res["table_free"] = {"value": round(args.steps / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                                  "fixed_base_tables": False,
-                                 "roofline": roofline_of(prof2, 2, masks is not None, pp=pp),
-                                 "proof_alu": proof_alu(prof2, pp, None, args.steps, dt2),
+                                 "roofline": roofline_of(prof2, 2, masks is not None, pp=pp, adds=tm2["adds"]),
+                                 "proof_alu": proof_alu(tm2["adds"], tm2["offered"], args.steps, tm2["dt_last"]),
                                  "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof2 if e["launches"]],
                                  "same_proof": same_shares(pp, proof2, proof)}
             crs.precompute()
         res["pipelined"], plast = pipelined(zg, pp, crs, wit, r, s, masks, max(8, args.steps), torch)
         res["pipelined"]["same_proof"] = same_shares(pp, plast, proof)
+        # throughput mode: batches of proofs against the one CRS (outside the timed K steps; `value` stays one proof at a
+        # time).  Total proofs per measurement ~ max(64, steps).
+        nproofs = max(64, args.steps)
+        res["batched"] = [batched(pp, zg, crs, wit, r, s, masks, nb, max(2, nproofs // nb), torch, proof, inflight=fl)
+                          for nb, fl in ((4, 1), (8, 1), (8, 2), (16, 2))]
         res["primitives"] = primitives(pp, zk)
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(pp, crs, wit, r, s, 2000 + args.steps - 1, masks, proof)
