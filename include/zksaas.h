@@ -263,7 +263,8 @@ int zk_fr_from_bytes(zk_ctx* ctx, const void* bytes_d, size_t len, void* x_out_d
  * BN254 / BLS12-377: ark-ec's default flags (little-endian x, bit 7 / 6 of the last byte = y is the larger root /
  * infinity); BLS12-381: the zcash encoding ark-bls12-381 uses (big-endian, c1 || c0, flags in the first byte).
  * Decompression validates like arkworks (x below the modulus, on the curve, consistent flags) and returns
- * ZK_ERR_GENERIC naming the first bad index; it needs q = 3 mod 4 (BN254, BLS12-381). */
+ * ZK_ERR_GENERIC naming the first bad index.  Square roots: the (q + 1) / 4 power for q = 3 mod 4 (BN254, BLS12-381),
+ * Tonelli-Shanks for BLS12-377 (q - 1 = 2^46 t). */
 int zk_points_decompress(zk_ctx* ctx, int group, const void* bytes_d, size_t len, void* out_affine_d, void* stream);
 int zk_points_compress(zk_ctx* ctx, int group, const void* affine_d, size_t len, void* bytes_out_d, void* stream);
 /* libsnark_h (ext_wit.rs:14-102) for all parties on this device: fft_in / fft_out: 7 mask pointers each ([n][m/l]

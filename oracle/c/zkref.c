@@ -24,7 +24,9 @@
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
 
-#define NL 4
+#ifndef NL
+#define NL 4   /* 64-bit limbs per field element; the Makefile also builds libzkref6.so with -DNL=6 (BLS12-381 / -377 Fq) */
+#endif
 typedef struct { u64 v[NL]; } fe;
 
 typedef struct {
@@ -35,9 +37,15 @@ typedef struct {
 } field_t;
 
 /* ------------------------------------------------------------------------------------------------ field */
-static inline int fe_is_zero(const fe* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
+static inline int fe_is_zero(const fe* a) {
+  u64 o = 0;
+  for (int i = 0; i < NL; i++) o |= a->v[i];
+  return o == 0;
+}
 static inline int fe_eq(const fe* a, const fe* b) {
-  return ((a->v[0] ^ b->v[0]) | (a->v[1] ^ b->v[1]) | (a->v[2] ^ b->v[2]) | (a->v[3] ^ b->v[3])) == 0;
+  u64 o = 0;
+  for (int i = 0; i < NL; i++) o |= a->v[i] ^ b->v[i];
+  return o == 0;
 }
 static inline int ge_mod(const u64* a, const field_t* F) {
   for (int i = NL - 1; i >= 0; i--) {
@@ -84,7 +92,7 @@ static inline void fe_sub(fe* r, const fe* a, const fe* b, const field_t* F) {
   memcpy(r->v, t, sizeof t);
 }
 static inline void fe_neg(fe* r, const fe* a, const field_t* F) {
-  fe z = {{0, 0, 0, 0}};
+  fe z = {{0}};
   fe_sub(r, &z, a, F);
 }
 static inline void fe_dbl(fe* r, const fe* a, const field_t* F) { fe_add(r, a, a, F); }
@@ -140,7 +148,7 @@ static void fe_inv(fe* r, const fe* a, const field_t* F) {
 static void fe_pow_u64(fe* r, const fe* a, u64 e, const field_t* F) { fe_pow(r, a, &e, 1, F); }
 static void fe_one(fe* r, const field_t* F) { memcpy(r->v, F->r1, sizeof r->v); }
 static void fe_from_mont(fe* r, const fe* a, const field_t* F) {
-  fe one = {{1, 0, 0, 0}};
+  fe one = {{1}};
   fe_mul(r, a, &one, F);
 }
 
@@ -278,14 +286,15 @@ static inline u64 mix64(u64 z) {
 }
 static void rand_fe(fe* r, u64 seed, u64 idx, int bits, const field_t* F) { /* oracle/prng.py, Montgomery out */
   u64 state = mix64(seed ^ mix64(idx + 0x632BE59BD9B4E019ull));
-  int top = bits - 192;
+  const int nd = (bits + 63) / 64;          /* limbs drawn: ceil(bits / 64), as oracle/prng.py; higher limbs are zero */
+  const int top = bits - 64 * (nd - 1);
   for (;;) {
-    fe x;
-    for (int i = 0; i < NL; i++) {
+    fe x = {{0}};
+    for (int i = 0; i < nd; i++) {
       state += 0x9E3779B97F4A7C15ull;
       x.v[i] = mix64(state);
     }
-    if (top < 64) x.v[3] &= (((u64)1 << top) - 1);
+    if (top < 64) x.v[nd - 1] &= (((u64)1 << top) - 1);
     if (!ge_mod(x.v, F)) {
       fe r2;
       memcpy(r2.v, F->r2, sizeof r2.v);
@@ -534,7 +543,9 @@ static void make_digits(const u64* a /* canonical, NL limbs */, int w, int num_b
   } NAME##_job;                                                                                               \
   static void* NAME##_worker(void* arg) {                                                                     \
     NAME##_job* J = (NAME##_job*)arg;                                                                         \
-    size_t nb = (size_t)1 << (J->c - 1);                                                                      \
+    /* 2^c buckets: the top digit is not re-centred (make_digits adds the last carry back), so for a modulus whose  \
+     * top window is nearly full (BLS12-381 Fr with c = 15: up to 29 678) it exceeds 2^(c-1) */                      \
+    size_t nb = (size_t)1 << J->c;                                                                            \
     JT* buckets = malloc(sizeof(JT) * nb);                                                                    \
     for (int w = J->w0; w < J->w1; w++) {                                                                     \
       for (size_t b = 0; b < nb; b++) NAME##_set_identity(&buckets[b]);                                       \

@@ -178,3 +178,95 @@ class CPss:
         out = np.zeros((n, 8), dtype=np.uint64)
         lib().zkref_g1_doubling_chain(C.byref(self.fq.ct), self._p(base), C.c_size_t(n), self._p(out))
         return out
+
+
+
+# ---------------------------------------------------------------------------------------------- six-limb build
+# libzkref6.so = the same C source compiled with six 64-bit limbs per element (Makefile): G1 of BLS12-381 / BLS12-377 at
+# sizes the Python oracle cannot reach.  Scalars and coordinates are Montgomery residues to the radix 2^384 there; the
+# coordinate layout (12 x u32 little-endian) is the GPU's own.
+_SO6 = os.path.join(_HERE, "c", "libzkref6.so")
+_lib6 = None
+NL6 = 6
+
+
+def lib6():
+    global _lib6
+    if _lib6 is None:
+        if not os.path.exists(_SO6):
+            subprocess.run(["make", "-C", os.path.join(_HERE, "c")], check=True)
+        _lib6 = C.CDLL(_SO6)
+    return _lib6
+
+
+class FieldT6(C.Structure):
+    _fields_ = [("mod", C.c_uint64 * NL6), ("n0inv", C.c_uint64), ("r1", C.c_uint64 * NL6), ("r2", C.c_uint64 * NL6)]
+
+
+class Field6:
+    """six-limb Montgomery field description (radix 2^384) + codecs"""
+
+    def __init__(self, p):
+        assert p.bit_length() <= 384
+        self.p, self.bits, self.R = p, p.bit_length(), 1 << 384
+        self.Rinv = pow(self.R, -1, p)
+        lim = lambda v: (C.c_uint64 * NL6)(*[(v >> (64 * i)) & ((1 << 64) - 1) for i in range(NL6)])
+        self.ct = FieldT6(lim(p), (-pow(p, -1, 1 << 64)) % (1 << 64), lim(self.R % p), lim(self.R * self.R % p))
+
+    def enc(self, vals):
+        out = np.empty((len(vals), NL6), dtype=np.uint64)
+        mask = (1 << 64) - 1
+        for i, v in enumerate(vals):
+            m = v % self.p * self.R % self.p
+            for k in range(NL6):
+                out[i, k] = (m >> (64 * k)) & mask
+        return out
+
+    def dec(self, arr):
+        arr = np.asarray(arr, dtype=np.uint64).reshape(-1, NL6)
+        return [sum(int(row[k]) << (64 * k) for k in range(NL6)) * self.Rinv % self.p for row in arr]
+
+
+class CGroup6:
+    """G1 of a curve with a 6-limb base field through libzkref6.so: arkworks' signed-digit Pippenger (zkref.c DEF_MSM)
+    and the doubling chain the size tests build their bases with."""
+
+    def __init__(self, curve_name):
+        self.curve = CURVES[curve_name]
+        self.fr, self.fq = Field6(self.curve.r), Field6(self.curve.q)
+
+    @staticmethod
+    def _p(arr):
+        return arr.ctypes.data_as(C.c_void_p)
+
+    def scalars_from_gpu_residues(self, arr4):
+        """uint64 [n][4] Montgomery residues of the GPU's 4-limb scalar field (radix 2^256) -> the SAME field values as
+        uint64 [n][6] residues to the radix 2^384: m6 = m4 * 2^128 mod r."""
+        r = self.curve.r
+        k = (1 << 128) % r
+        a = np.asarray(arr4, dtype=np.uint64)
+        out = np.zeros((a.shape[0], NL6), dtype=np.uint64)
+        mask = (1 << 64) - 1
+        for i in range(a.shape[0]):
+            m = (int(a[i, 0]) | (int(a[i, 1]) << 64) | (int(a[i, 2]) << 128) | (int(a[i, 3]) << 192)) * k % r
+            for j in range(4):
+                out[i, j] = (m >> (64 * j)) & mask
+        return out
+
+    def msm_g1_arrays(self, bases, scalars6, n, nthreads=1):
+        """bases uint64 [n][12] affine Montgomery (the GPU layout), scalars6 uint64 [n][6]; returns uint64[18] Jacobian."""
+        out = np.zeros(18, dtype=np.uint64)
+        lib6().zkref_msm_g1(C.byref(self.fr.ct), C.byref(self.fq.ct), self.fr.bits, self._p(bases), self._p(scalars6),
+                            C.c_size_t(n), nthreads, self._p(out))
+        return out
+
+    def msm_g1(self, pts, scalars, nthreads=1):
+        b = self.fq.enc([c for p in pts for c in ((0, 0) if p is None else p)]).reshape(len(pts), 12)
+        v = self.fq.dec(self.msm_g1_arrays(b, self.fr.enc(scalars), len(pts), nthreads))
+        return (v[0], v[1], v[2])
+
+    def doubling_chain_g1(self, p, n):
+        base = self.fq.enc(list(p)).reshape(-1)
+        out = np.zeros((n, 12), dtype=np.uint64)
+        lib6().zkref_g1_doubling_chain(C.byref(self.fq.ct), self._p(base), C.c_size_t(n), self._p(out))
+        return out

@@ -124,6 +124,47 @@ def test_msm_mask_sample_matches_oracle(curve, group):
     assert G.eq(o.unpack2(got, ops)[0], G.msm(G.batch_to_affine(x_pub), y_pub))
 
 
+def test_bls12_377_points_decompress_on_the_device_with_tonelli_shanks():
+    """BLS12-377 (q = 1 mod 4: q - 1 = 2^46 t), the curve the reference's own dist-primitives tests run on
+    (dmsm/mod.rs:114-119): zk_points_decompress takes its square roots by Tonelli-Shanks.  The arkworks generator
+    (ark-bls12-377 G1_GENERATOR_X / _Y, restated as literals here) compresses to its x with the sort flag the oracle's
+    ark-serialize restatement gives and decompresses back; 60 random multiples, their negatives and the identity
+    round-trip; an x off the curve is rejected with its index."""
+    import random
+    from zksaas_amd import wire
+    from zksaas_amd.api import ZK_G1
+    from oracle import curve as ocurve, ser as oser
+    from oracle.params import CURVES
+    from gpu_util import enc_affine
+    cv = CURVES["bls12_377"]
+    gx = 0x008848DEFE740A67C8FC6225BF87FF5485951E2CAA9D41BB188282C8BD37CB5CD5481512FFCD394EEAB9B16EB21BE9EF
+    gy = 0x01914A69C5102EFF1F674F5D30AFEEC4BD7FB348CA3E52D96D182AD44FB82305C2FE3D3634A9591AFD82DE55559C8EA6
+    assert cv.g1 == (gx, gy) and (gy * gy - gx ** 3 - 1) % cv.q == 0
+    pp = ctx("bls12_377", 2)
+    G = ocurve.g1(cv)
+    rng = random.Random(6)
+    pts = [None, cv.g1] + [G.to_affine(G.mul(G.from_affine(cv.g1), rng.randrange(1, cv.r))) for _ in range(60)]
+    pts += [G.to_affine(G.neg(G.from_affine(p))) for p in pts[1:8]]
+    want = b"".join(oser.g1_compressed(p, cv.q) for p in pts)
+    dev = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts, False))
+    assert wire.points_to_bytes(pp, ZK_G1, dev, len(pts)) == want
+    back, count = wire.points_from_bytes(pp, ZK_G1, want)
+    assert count == len(pts) and np.array_equal(back.to_numpy()[: dev.nbytes // 8], dev.to_numpy())
+    size = 48
+    for k in range(1, 200):
+        bad = bytearray(want)
+        bad[5 * size + 7] ^= k
+        try:
+            wire.point_from_bytes(pp, bytes(bad[5 * size:6 * size]), False, "bls12_377")
+        except ValueError:
+            with pytest.raises(zk.ZkError) as e:
+                wire.points_from_bytes(pp, ZK_G1, bytes(bad))
+            assert e.value.code == 1 and "index 5" in e.value.msg
+            break
+    else:
+        pytest.fail("no invalid mutation found")
+
+
 @pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
 @pytest.mark.parametrize("is2", [False, True])
 def test_point_vectors_compressed_on_the_device_match_the_host_codec(curve, is2):
@@ -163,6 +204,17 @@ def test_point_vectors_compressed_on_the_device_match_the_host_codec(curve, is2)
             break
     else:
         pytest.fail("no invalid mutation found")
+    # a WHOLE mpc-net frame (ser_net.rs:24-25, 111-112): Vec<G::Affine>::serialize_compressed = u64 length prefix + items
+    frame = wire.point_vec_to_bytes(pp, grp, dev, len(pts))
+    assert frame == len(pts).to_bytes(8, "little") + want
+    back2, count2 = wire.point_vec_from_bytes(pp, grp, frame)
+    assert count2 == len(pts) and np.array_equal(back2.to_numpy()[: dev.nbytes // 8], dev.to_numpy())
+    with pytest.raises(ValueError):
+        wire.point_vec_from_bytes(pp, grp, frame[:-1])                  # truncated payload
+    with pytest.raises(ValueError):
+        wire.point_vec_from_bytes(pp, grp, (len(pts) + 1).to_bytes(8, "little") + want)     # prefix says one more
+    empty, zero = wire.point_vec_from_bytes(pp, grp, (0).to_bytes(8, "little"))
+    assert zero == 0
 
 
 def test_deg_red_over_group_elements_matches_oracle():
@@ -211,3 +263,92 @@ def test_deg_red_over_group_elements_matches_oracle():
         rec = o.unpack([want[p][j] for p in range(o.n)], ops)
         for i in range(o.l):
             assert G.eq(rec[i], G.mul(gen, a[j * o.l + i] * b[j * o.l + i] % o.p))
+
+
+
+@pytest.mark.parametrize("curve,is2", [("bn254", True), ("bls12_381", False), ("bls12_381", True)])
+def test_deg_red_over_group_elements_other_groups_match_oracle(curve, is2):
+    """deg_red.rs:80-126 with T = G2 and on BLS12-381 (round 2 covered G1 / BN254 only): output share points and the
+    sampled masks equal oracle/dist.py with group operations, 3 chunks."""
+    from zksaas_amd.api import ZK_G1, ZK_G2
+    from oracle import dist as od
+    from oracle.curve import g1, g2, GroupOps
+    from oracle.params import CURVES
+    from oracle.prng import rand_fp
+    from gpu_util import enc_affine, opp
+    cv = CURVES[curve]
+    pp, o = ctx(curve, 2), opp(curve, 2)
+    G = g2(cv) if is2 else g1(cv)
+    grp = ZK_G2 if is2 else ZK_G1
+    ops = GroupOps(G)
+    gen = G.from_affine(G.gen)
+    nch = 3
+    a = [rand_fp(190, i, o.p) for i in range(nch * o.l)]
+    b = [rand_fp(191, i, o.p) for i in range(nch * o.l)]
+    sa, sb = od.transpose(od.pack_vec(a, o, 192)), od.transpose(od.pack_vec(b, o, 193))
+    xs = [[G.mul(gen, x * y % o.p) for x, y in zip(sa[p], sb[p])] for p in range(o.n)]
+    masks = od.DegRedMask.sample(o, gen, nch, 194, ops)
+    want = od.deg_red(xs, masks, o, seed=195, ops=ops, gen=gen)
+    width = pp.fq.nbytes * (4 if is2 else 2)
+    aff = lambda rows: zk.DeviceBuffer.from_numpy(pp, np.concatenate([enc_affine(pp, G.batch_to_affine(r), is2) for r in rows]))
+    g_aff = enc_affine(pp, [G.gen], is2).reshape(-1)
+    im, om = zk.DeviceBuffer(pp, o.n * nch * width), zk.DeviceBuffer(pp, o.n * nch * width)
+    pp._check(pp.lib.zk_degred_mask_sample_points(pp.h, grp, g_aff.ctypes.data, nch, 194, im.ptr, om.ptr, None))
+    assert np.array_equal(im.to_numpy(), aff([m.in_mask for m in masks]).to_numpy())
+    assert np.array_equal(om.to_numpy(), aff([m.out_mask for m in masks]).to_numpy())
+    out = zk.DeviceBuffer(pp, o.n * nch * width)
+    xs_d = aff(xs)
+    pp._check(pp.lib.zk_deg_red_points(pp.h, grp, xs_d.ptr, im.ptr, om.ptr, nch, g_aff.ctypes.data, 195, out.ptr, None))
+    assert np.array_equal(out.to_numpy(), aff(want).to_numpy())
+
+
+@pytest.mark.parametrize("curve,is2", [("bn254", False), ("bls12_381", False), ("bn254", True)])
+def test_deg_red_over_group_elements_1024_chunks(curve, is2):
+    """The same with 1024 chunks (2048 secrets): the product sharing is dealt in the scalar field and lifted with
+    zk_base_mul; after deg_red with sampled masks zk_pss_unpack_points (degree l + t - 1 now) must give a_i * b_i * G for
+    every secret, and four chunks chosen across the vector equal the oracle's deg_red point for point."""
+    from zksaas_amd import api, groth16 as zg
+    from zksaas_amd.api import ZK_G1, ZK_G2
+    from oracle import dist as od
+    from oracle.curve import g1, g2, GroupOps
+    from oracle.params import CURVES
+    from oracle.prng import rand_vec
+    from gpu_util import enc_affine, opp
+    cv = CURVES[curve]
+    pp, o = ctx(curve, 2), opp(curve, 2)
+    G = g2(cv) if is2 else g1(cv)
+    grp = ZK_G2 if is2 else ZK_G1
+    ops = GroupOps(G)
+    gen = G.from_affine(G.gen)
+    nch = 1024
+    a, b = rand_vec(290, nch * o.l, o.p), rand_vec(291, nch * o.l, o.p)
+    sa, sb = od.transpose(od.pack_vec(a, o, 292)), od.transpose(od.pack_vec(b, o, 293))
+    prod = [x * y % o.p for p in range(o.n) for x, y in zip(sa[p], sb[p])]                     # [n][nch] flat
+    width = pp.fq.nbytes * (4 if is2 else 2)
+    xs_d = zg.base_points(pp, grp, pp.upload_fr(prod), o.n * nch)
+    g_aff = enc_affine(pp, [G.gen], is2).reshape(-1)
+    im, om = zk.DeviceBuffer(pp, o.n * nch * width), zk.DeviceBuffer(pp, o.n * nch * width)
+    pp._check(pp.lib.zk_degred_mask_sample_points(pp.h, grp, g_aff.ctypes.data, nch, 294, im.ptr, om.ptr, None))
+    out = zk.DeviceBuffer(pp, o.n * nch * width)
+    pp._check(pp.lib.zk_deg_red_points(pp.h, grp, xs_d.ptr, im.ptr, om.ptr, nch, g_aff.ctypes.data, 295, out.ptr, None))
+    rec = api.unpack_points(pp, grp, out, nch, two=False)
+    want = zg.base_points(pp, grp, pp.upload_fr([x * y % o.p for x, y in zip(a, b)]), nch * o.l)
+    assert np.array_equal(rec.to_numpy(), want.to_numpy())
+    # four chunks against the oracle (the king step is chunk-local; share randomness is indexed by the chunk)
+    words = width // 8
+    rows = lambda buf: buf.to_numpy().reshape(o.n, nch, words)
+    x_np, im_np, om_np, out_np = rows(xs_d), rows(im), rows(om), rows(out)
+
+    def dec(v):
+        c = pp.fq.decode(v.reshape(-1, pp.fq.nl))
+        if not any(c):
+            return G.identity
+        return G.from_affine(((c[0], c[1]), (c[2], c[3])) if is2 else (c[0], c[1]))
+    for j in (0, 1, 517, 1023):
+        xm = [ops.add(dec(x_np[p, j]), dec(im_np[p, j])) for p in range(o.n)]
+        sec = o.unpack2(xm, ops)
+        from oracle.prng import rand_fp
+        rnd = [G.mul(gen, rand_fp(295, j * o.t + i, o.p)) for i in range(o.t)]
+        sh = o.pack(sec, rnd, ops)
+        for p in range(o.n):
+            assert G.eq(ops.add(sh[p], dec(om_np[p, j])), dec(out_np[p, j])), (j, p)

@@ -22,9 +22,12 @@ def _rand_fr_array(count, seed, top_bits=60):
     return a
 
 
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_d_fft_2_20_shares_equal_c_oracle(inverse):
-    """Config 2: d_fft / d_ifft, m = 2^20, BN254, l = 2, n = 8: every output SHARE equals the C restatement's."""
+def test_d_fft_2_20_shares_equal_c_oracle(inverse, masked):
+    """Config 2: d_fft / d_ifft, m = 2^20, BN254, l = 2, n = 8: every output SHARE equals the C restatement's -- with
+    FftMask::zero() and with a SAMPLED mask pair (dfft/mod.rs:30-85; the masks the headline bench runs with), whose
+    in-mask is added after fft1 and whose out-mask after the king's pack."""
     pp = ctx("bn254", 2)
     cp = CPss("bn254", 2)
     log_m = 20
@@ -33,15 +36,32 @@ def test_d_fft_2_20_shares_equal_c_oracle(inverse):
     shares = _rand_fr_array(pp.n * (m // 2), 5)
     g = Domain(BN254, 2 * m).element(1) if inverse else None
     buf = zk.DeviceBuffer.from_numpy(pp, shares)
+    mask, im, om = zk.FftMask.zero(), None, None
+    if masked:
+        mask = zk.FftMask.sample(pp, inverse, g, 1 if inverse else 0, log_m, 123)
+        im = mask.in_mask.to_numpy().reshape(-1, 4).copy()
+        om = mask.out_mask.to_numpy().reshape(-1, 4).copy()
+        assert im.any() and om.any() and not np.array_equal(im, om)
     if inverse:
-        zk.d_ifft(pp, buf, zk.FftMask.zero(), True, log_m, g=g, seed=77)
+        zk.d_ifft(pp, buf, mask, True, log_m, g=g, seed=77)
     else:
-        zk.d_fft(pp, buf, zk.FftMask.zero(), False, log_m, seed=77)
+        zk.d_fft(pp, buf, mask, False, log_m, seed=77)
     got = buf.to_numpy().reshape(-1, 4)
     want = shares.copy()
     cp.d_fft_arrays(want, m // 2, dom.group_gen_inv if inverse else dom.group_gen, dom.size_inv if inverse else None, g,
-                    inverse, None, None, 77)
+                    inverse, im, om, 77)
     assert np.array_equal(got, want)
+    if masked:
+        # the masks cancel: unpack2 of the masked output is the transform of the unpacked input (spot check, first
+        # chunks) -- i.e. the SAME secrets the unmasked run reconstructs to
+        buf0 = zk.DeviceBuffer.from_numpy(pp, shares)
+        if inverse:
+            zk.d_ifft(pp, buf0, zk.FftMask.zero(), True, log_m, g=g, seed=77)
+        else:
+            zk.d_fft(pp, buf0, zk.FftMask.zero(), False, log_m, seed=77)
+        a = pp.unpack2(buf, m // 2).to_numpy().reshape(-1, 4)
+        b = pp.unpack2(buf0, m // 2).to_numpy().reshape(-1, 4)
+        assert np.array_equal(a, b)
 
 
 def test_msm_2_20_equals_c_oracle():
@@ -180,3 +200,22 @@ def test_d_pp_telescopes_bls12_381_2_18():
     prod = pp.unpack(res, m // l)
     zk.api.vec_scale(pp, prod, pp.download_fr(x, 1)[0], m)
     assert np.array_equal(prod.to_numpy()[: m * nl], x.to_numpy()[nl:(m + 1) * nl])
+
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_msm_2_20_on_12_limb_curves_equals_six_limb_c_oracle(curve):
+    """Config-3 size on the 12-limb base fields (round 2 checked these through properties only): a 2^20-point G1 MSM
+    (doubling-chain bases, random scalars) equals arkworks' Pippenger restated in C with six 64-bit limbs
+    (oracle/c libzkref6.so, pinned on the Python oracle in tests/test_oracle_c.py)."""
+    from oracle.cref import CGroup6
+    cv = CURVES[curve]
+    pp = ctx(curve, 2)
+    cg = CGroup6(curve)
+    n = 1 << 20
+    bases = cg.doubling_chain_g1(cv.g1, n)
+    scalars = _rand_fr_array(n, 16)
+    got = msm(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, bases), zk.DeviceBuffer.from_numpy(pp, scalars), n)
+    want = cg.msm_g1_arrays(bases, cg.scalars_from_gpu_residues(scalars), n, nthreads=8)
+    G = g1(cv)
+    assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))

@@ -97,3 +97,33 @@ def test_doubling_chain():
         aff = G.to_affine(P)
         assert cp.fq.dec(chain[i]) == [aff[0], aff[1]]
         P = G.double(P)
+
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bls12_377"])
+def test_six_limb_build_msm_and_doubling_chain_equal_the_python_oracle(curve):
+    """libzkref6.so (zkref.c with NL = 6): arkworks' signed-digit Pippenger over the 381 / 377-bit base fields and the
+    doubling chain, pinned on the Python big-integer oracle (edge scalars, an identity base, threads)."""
+    from oracle.cref import CGroup6
+    from oracle.curve import g1
+    from oracle.params import CURVES
+    from oracle.prng import rand_vec
+    cv = CURVES[curve]
+    G, cg = g1(cv), CGroup6(curve)
+    gen = G.from_affine(cv.g1)
+    pts = G.batch_to_affine([G.mul(gen, 3 + i * i) for i in range(70)])
+    pts[7] = None
+    sc = rand_vec(5, 70, cv.r)
+    sc[3], sc[4], sc[5] = 0, cv.r - 1, 1
+    want = G.msm(pts, sc)
+    for th in (1, 3):
+        assert G.eq(cg.msm_g1(pts, sc, nthreads=th), want)
+    chain = cg.doubling_chain_g1(cv.g1, 6)
+    for i in range(6):
+        v = cg.fq.dec(chain[i])
+        assert (v[0], v[1]) == G.to_affine(G.mul(gen, 1 << i))
+    # residues of the GPU's 4-limb scalar field carry over: m6 = m4 * 2^128
+    import numpy as np
+    vals = [0, 1, cv.r - 1, 123456789 ** 4 % cv.r]
+    m4 = np.array([[(v * (1 << 256) % cv.r >> (64 * k)) & ((1 << 64) - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+    assert cg.fr.dec(cg.scalars_from_gpu_residues(m4)) == vals

@@ -14,6 +14,24 @@ __device__ __forceinline__ F mulv(const F& a, const F& b) {
   else return F::mul_pairs(a, b);
 }
 
+// squaring chains: variant 2 = the production multiplier called with equal operands, variant 3 = sqr_fips
+template <class F, int VAR>
+__global__ void sqr_chain(F* x, const F* y, int iters) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  F a = x[i], b = y[i];
+  for (int k = 0; k < iters; k++) {
+    a = VAR == 3 ? F::sqr_fips(a) : F::mul_fips(a, a);
+    b = VAR == 3 ? F::sqr_fips(b) : F::mul_fips(b, b);
+  }
+  x[i] = a + b;
+}
+template <class F>
+__global__ void check_sqr(const F* x, int* bad, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (F::mul_ref(x[i], x[i]) != F::sqr_fips(x[i])) atomicAdd(bad, 1);
+}
+
 template <class F, int VAR>
 __global__ void chain(F* x, const F* y, int iters) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,6 +82,10 @@ void run(const char* name) {
   int bad = -1;
   hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost);
   printf("%s: mismatches new-vs-ref = %d of %zu\n", name, bad, n);
+  hipMemset(dbad, 0, 4);
+  check_sqr<F><<<n / 256, 256>>>(dx, dbad, n);
+  hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost);
+  printf("%s: mismatches sqr_fips-vs-ref = %d of %zu\n", name, bad, n);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -81,6 +103,20 @@ void run(const char* name) {
       hipEventElapsedTime(&ms, e0, e1);
       if (rep) printf("%s variant %d: %.3f ms for %.1f M mul -> %.1f G mul/s\n", name, var, ms, n * 2.0 * iters / 1e6,
                       n * 2.0 * iters / ms / 1e6);
+    }
+  }
+  for (int var = 2; var <= 3; var++) {
+    for (int rep = 0; rep < 2; rep++) {
+      hipMemcpy(dx, hx.data(), n * sizeof(F), hipMemcpyHostToDevice);
+      hipEventRecord(e0);
+      if (var == 2) sqr_chain<F, 2><<<n / 256, 256>>>(dx, dy, iters);
+      else sqr_chain<F, 3><<<n / 256, 256>>>(dx, dy, iters);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (rep) printf("%s SQUARING %s: %.3f ms for %.1f M sqr -> %.1f G sqr/s\n", name, var == 2 ? "mul_fips(a, a)" : "sqr_fips(a)",
+                      ms, n * 2.0 * iters / 1e6, n * 2.0 * iters / ms / 1e6);
     }
   }
   // single-wave latency: 64 lanes only

@@ -2248,6 +2248,38 @@ class Engine : public IEngine {
     }
   }
 
+  // Tonelli-Shanks parameters of the base field (q - 1 = 2^s t): z = c^t for the least quadratic non-residue c, e = (t-1)/2
+  TsParams<typename Cfg::FqP> ts_params() {
+    using FqP = typename Cfg::FqP;
+    static const TsParams<FqP> cached = [] {
+      TsParams<FqP> tp{};
+      constexpr int N = FqP::N;
+      uint32_t t[N];
+      for (int i = 0; i < N; i++) t[i] = FqP::MOD[i];
+      t[0] -= 1;                                        // q - 1 (q odd)
+      int sh = 0;
+      while (!(t[0] & 1u)) {                            // t = (q - 1) >> s
+        for (int i = 0; i < N - 1; i++) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+        t[N - 1] >>= 1;
+        sh++;
+      }
+      tp.s = sh;
+      uint32_t half[N];                                 // (q - 1) / 2: Euler's criterion
+      for (int i = 0; i < N; i++) half[i] = (FqP::MOD[i] >> 1) | (i + 1 < N ? FqP::MOD[i + 1] << 31 : 0u);
+      const Fq_ minus_one = Fq_::one().neg();
+      for (uint64_t c = 2;; c++) {
+        const Fq_ cv = Fq_::from_u64(c);
+        if (cv.pow(half, N) == minus_one) {
+          tp.z = cv.pow(t, N);
+          break;
+        }
+      }
+      for (int i = 0; i < N; i++) tp.e[i] = (t[i] >> 1) | (i + 1 < N ? t[i + 1] << 31 : 0u);      // (t - 1) / 2, t odd
+      return tp;
+    }();
+    return cached;
+  }
+
   // ---------------------------------------------------------------- compressed point vectors (ser_net.rs:111-120)
   template <class Fld>
   int points_codec_t(const void* in, size_t len, void* out, int decompress, const Fld& b, hipStream_t st) {
@@ -2259,8 +2291,15 @@ class Engine : public IEngine {
     }
     ZK_HIP(flag_.ensure(4));
     ZK_HIP(hipMemsetAsync(flag_.p, 0, 4, st));
-    points_decompress_kernel<Fld><<<g, blk, 0, st>>>((const uint8_t*)in, len, b, Cfg::ZCASH ? 1 : 0, (Affine<Fld>*)out,
-                                                    (uint32_t*)flag_.p);
+    if constexpr (Cfg::SQRT_3MOD4) {
+      points_decompress_kernel<Fld, NoTs><<<g, blk, 0, st>>>((const uint8_t*)in, len, b, Cfg::ZCASH ? 1 : 0, NoTs{},
+                                                            (Affine<Fld>*)out, (uint32_t*)flag_.p);
+    } else if constexpr (!IsExtField<Fld>::value) {
+      points_decompress_kernel<Fld, TsParams<typename Cfg::FqP>><<<g, blk, 0, st>>>(
+          (const uint8_t*)in, len, b, Cfg::ZCASH ? 1 : 0, ts_params(), (Affine<Fld>*)out, (uint32_t*)flag_.p);
+    } else {
+      return fail(ZK_ERR_BAD_INPUT, "device-side decompression over Fq2 needs q = 3 mod 4");
+    }
     ZK_HIP(hipGetLastError());
     uint32_t bad = 0;
     ZK_HIP(hipMemcpyAsync(&bad, flag_.p, 4, hipMemcpyDeviceToHost, st));
@@ -2271,9 +2310,6 @@ class Engine : public IEngine {
   int points_codec(int group, const void* in, size_t len, void* out, int decompress, hipStream_t st) override {
     if (!len) return ZK_OK;
     if (!in || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    if constexpr (!Cfg::SQRT_3MOD4) {
-      if (decompress) return fail(ZK_ERR_BAD_INPUT, "device-side decompression needs q = 3 mod 4 (use the host path)");
-    }
     if (group == ZK_G1) return points_codec_t<Fq_>(in, len, out, decompress, Fq_::from_u64((uint64_t)Cfg::B1), st);
     if (group == ZK_G2) {
       if constexpr (Cfg::HAS_G2) {

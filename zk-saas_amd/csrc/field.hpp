@@ -354,6 +354,67 @@ struct Fp {
 #endif
   }
 
+  // Dedicated product-scanning SQUARING, measured and NOT adopted (tools/mulbench.hip variant 3,
+  // profiles/r03_mulbench_sqr.txt): the off-diagonal products a_i a_j (i < j) of a column are accumulated once and
+  // doubled, the diagonal and the Montgomery terms follow -- 36 + 64 + 8 multiply instructions instead of 128 + 8.  The
+  // doubling of the 96-bit column accumulator and the re-insertion of the carried column cost ~9 full-rate instructions
+  // per column, about what the 28 saved quarter-rate multiplies (and their carry instructions) are worth.
+  ZK_HD static Fp sqr_fips(const Fp& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m[N], r[N];
+    uint64_t carry = 0;                // column value carried in from the column below (not to be doubled)
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+      uint64_t acc = 0, cy;
+      uint32_t acc2 = 0;
+      // off-diagonal products of this column, once
+#pragma unroll
+      for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; i++) {
+        acc = madc(a.v[i], a.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      // ... doubled
+      acc2 = (acc2 << 1) | (uint32_t)(acc >> 63);
+      acc <<= 1;
+      // + the carried column
+      {
+        const uint64_t t = acc + carry;
+        acc2 += t < acc ? 1u : 0u;
+        acc = t;
+      }
+      if (!(k & 1)) {
+        acc = madc(a.v[k / 2], a.v[k / 2], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      if (k < N) {
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+          acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+        m[k] = (uint32_t)acc * P::N0INV;
+        acc = madc_k(m[k], P::MOD[0], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      } else {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+          acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+        r[k - N] = (uint32_t)acc;
+      }
+      carry = (acc >> 32) | ((uint64_t)acc2 << 32);
+    }
+    r[N - 1] = (uint32_t)carry;
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = r[i];
+    return reduce_once(o, (uint32_t)(carry >> 32));
+#else
+    return mul_ref(a, a);
+#endif
+  }
+
   // Out-of-line multiply for cold code (G2 tower, bucket reduction, l > 2 kernels): one copy per field
   // instead of one per call site keeps code size and compile time bounded.
   static ZK_HD_NOINLINE Fp mul_ni(const Fp& a, const Fp& b) { return mul_inline(a, b); }

@@ -73,6 +73,46 @@ ZK_D bool fq_sqrt(const Fp<P>& a, Fp<P>* out) {        // a^((q+1)/4), checked
   *out = r;
   return Fp<P>::mul_ni(r, r) == a;
 }
+// ---- square roots for any odd q: Tonelli-Shanks (BLS12-377: q = 1 mod 4, q - 1 = 2^46 t).  The parameters are built
+// on the host once per context (Engine::ts_params): z = c^t for a quadratic non-residue c (a generator of the 2^s-th
+// roots of unity), e = (t - 1) / 2.
+template <class P>
+struct TsParams {
+  Fp<P> z;
+  uint32_t e[P::N];
+  int s;
+};
+template <class P>
+ZK_D bool fq_sqrt_ts(const Fp<P>& a, const TsParams<P>& ts, Fp<P>* out) {
+  using F = Fp<P>;
+  if (a.is_zero()) {
+    *out = a;
+    return true;
+  }
+  F w = a.pow(ts.e, P::N);            // a^((t-1)/2)
+  F x = F::mul_ni(a, w);              // a^((t+1)/2)
+  F b = F::mul_ni(x, w);              // a^t
+  F z = ts.z;
+  int v = ts.s;
+  while (!(b == F::one())) {
+    int k = 0;
+    F b2k = b;
+    while (!(b2k == F::one())) {      // least k with b^(2^k) = 1
+      b2k = F::mul_ni(b2k, b2k);
+      k++;
+      if (k >= v) return false;       // a is not a square
+    }
+    F wz = z;
+    for (int j = 0; j < v - k - 1; j++) wz = F::mul_ni(wz, wz);
+    z = F::mul_ni(wz, wz);
+    b = F::mul_ni(b, z);
+    x = F::mul_ni(x, wz);
+    v = k;
+  }
+  *out = x;
+  return F::mul_ni(x, x) == a;
+}
+
 template <class F2>
 ZK_D F2 f2_pow(const F2& a, const uint32_t* e, int nl) {
   F2 r = F2::one();
@@ -200,9 +240,20 @@ struct PointCodec<Fp2T<P, I>> {
 
 // bytes [len][SIZE] -> affine Montgomery points; err[0] = 1 + index of the first offending element (atomicMin-free:
 // any offender is reported)
+// square root as the decompression kernel calls it: the (q + 1) / 4 power when q = 3 mod 4, Tonelli-Shanks otherwise
+struct NoTs {};
 template <class Fld>
+ZK_D bool codec_sqrt(const Fld& a, const NoTs&, Fld* out) {
+  return fq_sqrt(a, out);
+}
+template <class P>
+ZK_D bool codec_sqrt(const Fp<P>& a, const TsParams<P>& ts, Fp<P>* out) {
+  return fq_sqrt_ts(a, ts, out);
+}
+
+template <class Fld, class Sqrt>
 __global__ __launch_bounds__(128) void points_decompress_kernel(const uint8_t* __restrict__ bytes, size_t len, Fld b,
-                                                               int zcash, Affine<Fld>* __restrict__ out,
+                                                               int zcash, Sqrt sq, Affine<Fld>* __restrict__ out,
                                                                uint32_t* __restrict__ err) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= len) return;
@@ -220,7 +271,7 @@ __global__ __launch_bounds__(128) void points_decompress_kernel(const uint8_t* _
   } else if (ok) {
     Fld y;
     Fld rhs = x.sqr() * x + b;
-    if (!fq_sqrt(rhs, &y)) ok = false;
+    if (!codec_sqrt(rhs, sq, &y)) ok = false;
     else {
       if (y_is_larger(y) != larger) y = y.neg();
       r = {x, y};

@@ -289,3 +289,23 @@ def points_to_bytes(pp, group, pts_d, count, stream=None):
     pp._check(pp.lib.zk_points_compress(pp.h, group, api._ptr(pts_d), count, out.ptr, stream))
     pp.sync(stream)
     return out.to_numpy(dtype=np.uint8)[: count * size].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ whole mpc-net frames
+def point_vec_to_bytes(pp, group, pts_d, count, stream=None):
+    """Vec<G::Affine>::serialize_compressed of a device vector as it crosses an mpc-net wire
+    (mpc-net/src/ser_net.rs:24-25, 111-112): u64 little-endian length + the compressed points."""
+    return count.to_bytes(8, "little") + points_to_bytes(pp, group, pts_d, count, stream)
+
+
+def point_vec_from_bytes(pp, group, data, stream=None):
+    """deserialize_compressed of a whole Vec<G::Affine> frame.  Returns (device vector of affine points, count); raises
+    ValueError when the length prefix and the payload disagree, ZkError (InvalidData) on an invalid point."""
+    if len(data) < 8:
+        raise ValueError("missing length prefix")
+    count = int.from_bytes(data[:8], "little")
+    size = pp.fq.nbytes * (2 if group == api.ZK_G2 else 1)
+    if len(data) != 8 + count * size:
+        raise ValueError("length prefix does not match the payload")
+    out, n = points_from_bytes(pp, group, data[8:], stream)
+    return out, count
