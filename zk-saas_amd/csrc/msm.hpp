@@ -521,7 +521,7 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint3
 #define ZK_PAIR_WAVES_12 2
 #endif
 template <class Fld>
-constexpr int ACC_WAVES = sizeof(Fld) > 48 ? 1 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8);
+constexpr int ACC_WAVES = sizeof(Fld) > 64 ? 1 : (sizeof(Fld) == 64 ? 2 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8));
 template <class Fld>
 constexpr int PAIR_WAVES = sizeof(Fld) > 64 ? ZK_PAIR_WAVES_12 : 2;
 // BALANCED PARTITION.  The sorted entry array (offsets[nkeys] entries, grouped by bucket) is cut into `nlanes`
@@ -564,9 +564,26 @@ __device__ __forceinline__ void store_elem_untracked(F* p, const F& v) {
   zk_store_chunks<0, (int)(sizeof(F) / 16)>((const void*)p, c);
 }
 
-ZK_D uint32_t msm_range_len(uint32_t entries, uint32_t nlanes, uint32_t tmin) {
+// `cap` = lanes the chip holds at once for this kernel: when the entries make one round of waves or more, the range
+// length is stretched so that the launch is a WHOLE number of rounds -- a last round that is 5 % full costs as much as a
+// full one (measured: 3.05 rounds of a G2 accumulate ran 25 % slower than 2.9)
+ZK_D uint32_t msm_range_len(uint32_t entries, uint32_t nlanes, uint32_t tmin, uint32_t cap) {
   uint32_t T = (entries + nlanes - 1) / nlanes;
-  return T > tmin ? T : tmin;
+  if (T < tmin) T = tmin;
+  const uint64_t round_entries = (uint64_t)cap * T;
+  uint32_t rounds = (uint32_t)(entries / round_entries);
+  if (rounds == 1) {
+    // exactly one round is the slow case (79 against 100+ G multiplications/s): two rounds of shorter ranges instead,
+    // unless that makes them shorter than 12 entries
+    const uint32_t T2 = (uint32_t)((entries + 2ull * cap - 1) / (2ull * cap));
+    if (T2 >= 12) return T2;
+  }
+  if (rounds >= 1) {
+    const uint64_t lanes = (uint64_t)cap * rounds;
+    const uint32_t Tr = (uint32_t)((entries + lanes - 1) / lanes);
+    if (Tr > T) T = Tr;
+  }
+  return T;
 }
 // bucket that contains entry a (offsets[k] <= a < offsets[k+1]; empty buckets are skipped by construction)
 ZK_D uint32_t msm_bucket_of(const uint32_t* __restrict__ offsets, uint32_t nkeys, uint32_t a) {
@@ -583,7 +600,7 @@ ZK_D uint32_t msm_bucket_of(const uint32_t* __restrict__ offsets, uint32_t nkeys
 // loads of the search would open every wave (measured in a batch of eight with four MSMs in flight: accumulate slots
 // 17.6 + 10.2 ms with the search inside against 14.8 + 8.2 ms for round 2's per-bucket segments)
 static __global__ __launch_bounds__(256) void msm_lane_start_kernel(const uint32_t* __restrict__ offsets, uint32_t nkeys,
-                                                                    uint32_t nlanes, uint32_t tmin,
+                                                                    uint32_t nlanes, uint32_t tmin, uint32_t cap,
                                                                     uint32_t* __restrict__ k0, size_t ys) {
   __builtin_amdgcn_s_setprio(3);
   ZK_YSHIFT(offsets);
@@ -591,7 +608,7 @@ static __global__ __launch_bounds__(256) void msm_lane_start_kernel(const uint32
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nlanes) return;
   const uint32_t total = offsets[nkeys];
-  const uint32_t T = msm_range_len(total, nlanes, tmin);
+  const uint32_t T = msm_range_len(total, nlanes, tmin, cap);
   if ((uint64_t)lane * T >= total) return;
   k0[lane] = msm_bucket_of(offsets, nkeys, lane * T);
 }
@@ -601,7 +618,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
                                                             const Affine<Fld>* __restrict__ bases1,
                                                             const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, uint32_t nkeys,
-                                                            uint32_t nlanes, uint32_t tmin,
+                                                            uint32_t nlanes, uint32_t tmin, uint32_t cap,
                                                             XYZZ<Fld>* __restrict__ buckets0,
                                                             XYZZ<Fld>* __restrict__ edge0 /* [NB][2][nlanes]: head, tail */,
                                                             uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
   XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
   XYZZ<Fld>* __restrict__ tail = head + nlanes;
   const uint32_t total = offsets[nkeys];
-  const uint32_t T = msm_range_len(total, nlanes, tmin);
+  const uint32_t T = msm_range_len(total, nlanes, tmin, cap);
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   if (lane >= nlanes || (uint64_t)lane * T >= total) return;
   const uint32_t a = lane * T, b = a + T < total ? a + T : total;
@@ -700,7 +717,7 @@ __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kern
                                                                     const Affine<Fld>* __restrict__ bases1,
                                                                     const uint32_t* __restrict__ sorted,
                                                                     const uint32_t* __restrict__ offsets, uint32_t nkeys,
-                                                                    uint32_t nlanes, uint32_t tmin,
+                                                                    uint32_t nlanes, uint32_t tmin, uint32_t cap,
                                                                     XYZZ<Fld>* __restrict__ buckets0,
                                                                     XYZZ<Fld>* __restrict__ edge0,
                                                                     uint32_t* __restrict__ heavy,
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kern
   XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
   XYZZ<Fld>* __restrict__ tail = head + nlanes;
   const uint32_t total = offsets[nkeys];
-  const uint32_t T = msm_range_len(total, nlanes, tmin);
+  const uint32_t T = msm_range_len(total, nlanes, tmin, cap);
   const bool lb = (threadIdx.x & 1) != 0;
   const uint32_t lane = blockIdx.x * (blockDim.x / 2) + (threadIdx.x >> 1);      // pair index = range index
   if (lane >= nlanes || (uint64_t)lane * T >= total) return;
@@ -800,7 +817,7 @@ inline int quad_threads(bool batched) {
 // its own list, with one shared sort both vectors use list 0.
 template <class Fld>
 __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_heavy_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes,
-                                                                uint32_t tmin,
+                                                                uint32_t tmin, uint32_t cap,
                                                                 const uint32_t* __restrict__ offsets, uint32_t nkeys,
                                                                 XYZZ<Fld>* __restrict__ buckets0,
                                                                 const uint32_t* __restrict__ heavy, size_t ys) {
@@ -814,7 +831,7 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_heavy_kernel(const XYZZ<F
   XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
-  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin);
+  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin, cap);
   const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
   for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
     const uint32_t kh = heavy[1 + h];
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_heavy_kernel(const XYZZ<F
 constexpr int FIN_THREADS = 64;
 template <class Fld>
 __global__ __launch_bounds__(FIN_THREADS) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes,
-                                                               uint32_t tmin,
+                                                               uint32_t tmin, uint32_t cap,
                                                                const uint32_t* __restrict__ offsets, uint32_t nkeys,
                                                                XYZZ<Fld>* __restrict__ buckets0, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
@@ -845,7 +862,7 @@ __global__ __launch_bounds__(FIN_THREADS) void msm_finalize_kernel(const XYZZ<Fl
   const XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
   const XYZZ<Fld>* __restrict__ tail = head + nlanes;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
-  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin);
+  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin, cap);
   const int q = threadIdx.x & 3;
   // grid-stride over the buckets: the launch is capped so that it does not queue thousands of workgroups behind the
   // accumulate waves
@@ -1063,7 +1080,7 @@ inline int msm_pick_c(size_t npts, bool g2 = false) {
 // launches: the MSMs of ONE proof run four at a time and fill the chip together) nor more than `hi`.
 // ZK_MSM_RANGE=<entries per lane> overrides (experiments).
 struct MsmLanes {
-  uint32_t nlanes, tmin;
+  uint32_t nlanes, tmin, cap;
 };
 inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair) {
   static const int env_t = getenv("ZK_MSM_RANGE") ? atoi(getenv("ZK_MSM_RANGE")) : 0;
@@ -1071,7 +1088,7 @@ inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair) {
   const size_t lo = pair ? MSM_RANGE_MIN_G2 : MSM_RANGE_MIN, hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
   size_t t = env_t >= 1 ? (size_t)env_t : (size_t)((double)max_entries / (2.4 * (double)cap));
   if (env_t < 1) t = std::min(hi, std::max(lo, t));
-  return MsmLanes{(uint32_t)std::max<size_t>(1, (max_entries + t - 1) / t), (uint32_t)t};
+  return MsmLanes{(uint32_t)std::max<size_t>(1, (max_entries + t - 1) / t), (uint32_t)t, (uint32_t)cap};
 }
 
 template <class FrP>

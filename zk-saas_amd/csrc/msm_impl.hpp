@@ -46,10 +46,17 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   if (max_sorted >= ((size_t)1 << 32)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large (points x windows >= 2^32)");
   const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
   // accumulate lanes (msm.hpp "balanced partition"): every lane adds the same number of sorted entries
-  static const bool pair_acc = !getenv("ZK_ACC_PAIR") || atoi(getenv("ZK_ACC_PAIR")) != 0;
-  const bool pair = G2FLD && pair_acc;
+  // Extension field: one lane per range for 8-limb base fields (233 registers, two waves per SIMD: 91-106 G
+  // multiplications/s alone against the pair kernel's 81-87 since the accumulate loop requests the next point behind
+  // the first two multiplications), a PAIR of lanes per range (quad.hpp pair_madd) for 12-limb ones, where the one-lane
+  // kernel needs 453 registers.  ZK_ACC_PAIR=0 / 1 forces either.
+  static const int pair_env = getenv("ZK_ACC_PAIR") ? atoi(getenv("ZK_ACC_PAIR")) : -1;
+  // (small launches -- the G2 MSM of ONE proof -- keep the pair kernel: twice the lanes for the same entries; measured
+  // 370 against 753 us for a 58k-point launch)
+  const bool small_launch = max_sorted < (size_t)4 * 1024 * 1024;
+  const bool pair = G2FLD && (pair_env >= 0 ? pair_env != 0 : (sizeof(Fld) > 64 || small_launch));
   const MsmLanes ml = msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair);
-  const uint32_t nlanes = ml.nlanes, tmin = ml.tmin;
+  const uint32_t nlanes = ml.nlanes, tmin = ml.tmin, cap = ml.cap;
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
   const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
   const uint32_t red_groups = (B >> lo_bits) + 1 + (1u << lo_bits);
@@ -187,7 +194,7 @@ do {                                                                           \
   iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(
       counts, nkeys, nullptr, bt, offsets, big ? nullptr : cursor, 1, ys);
   MSM_STAGE("scan");
-  msm_lane_start_kernel<<<dim3((nlanes + 255) / 256, NS), dim3(256), 0, st>>>(offsets, (uint32_t)nkeys, nlanes, tmin, k0, ys);
+  msm_lane_start_kernel<<<dim3((nlanes + 255) / 256, NS), dim3(256), 0, st>>>(offsets, (uint32_t)nkeys, nlanes, tmin, cap, k0, ys);
   if (!big)
     msm_digits_kernel<FrP, 1><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, nullptr, cursor,
                                                  sorted, skip, canon, ys);
@@ -206,14 +213,14 @@ do {                                                                           \
     if (pair) {
       // extension field: a pair of lanes per range (two waves per SIMD instead of one; quad.hpp pair_madd)
       msm_accumulate_pair_kernel<KF><<<dim3((nlanes + 63) / 64, NB), dim3(128), 0, st>>>(
-          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, buckets, edge,
+          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
           heavy, k0, ys);
       launched = true;
     }
   }
   if (!launched)
     msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), 0, st>>>(
-        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, buckets, edge,
+        (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
         heavy, k0, ys);
   if (tune.gate.signal_ev) {
     MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
@@ -226,13 +233,13 @@ do {                                                                           \
   const int qt = quad_threads(batch > 1), qvl = qt / 4;
   const size_t quad_lds = (size_t)qvl * sizeof(XYZZ<Fld>);
   // buckets spread over many lanes (none for well-spread scalars: the workgroups read a zero count and leave)
-  msm_heavy_kernel<KF><<<dim3(64, NB), dim3((unsigned)qt), quad_lds, st>>>(edge, nlanes, tmin, offsets, (uint32_t)nkeys,
+  msm_heavy_kernel<KF><<<dim3(64, NB), dim3((unsigned)qt), quad_lds, st>>>(edge, nlanes, tmin, cap, offsets, (uint32_t)nkeys,
                                                                    buckets, heavy, ys);
   MSM_STAGE("heavy buckets");
   {
     // capped grid (grid-stride inside): enough one-wave workgroups to cover the chip a few times over
     const size_t fin_wgs = std::min<size_t>((nkeys + FIN_THREADS / 4 - 1) / (FIN_THREADS / 4), 8192);
-    msm_finalize_kernel<KF><<<dim3((unsigned)fin_wgs, NB), dim3(FIN_THREADS), 0, st>>>(edge, nlanes, tmin, offsets,
+    msm_finalize_kernel<KF><<<dim3((unsigned)fin_wgs, NB), dim3(FIN_THREADS), 0, st>>>(edge, nlanes, tmin, cap, offsets,
                                                                                     (uint32_t)nkeys, buckets, ys);
   }
   MSM_STAGE("finalize");
