@@ -233,7 +233,9 @@ do {                                                                           \
   const int qt = quad_threads(batch > 1), qvl = qt / 4;
   const size_t quad_lds = (size_t)qvl * sizeof(XYZZ<Fld>);
   // buckets spread over many lanes (none for well-spread scalars: the workgroups read a zero count and leave)
-  msm_heavy_kernel<KF><<<dim3(64, NB), dim3((unsigned)qt), quad_lds, st>>>(edge, nlanes, tmin, cap, offsets, (uint32_t)nkeys,
+  // (always one-wave workgroups: with 256 threads this launch, which normally reads one word and leaves, waited 90-150 us
+  // for four free wave slots on one CU in a single proof's timeline)
+  msm_heavy_kernel<KF><<<dim3(256, NB), dim3(64), (size_t)16 * sizeof(XYZZ<Fld>), st>>>(edge, nlanes, tmin, cap, offsets, (uint32_t)nkeys,
                                                                    buckets, heavy, ys);
   MSM_STAGE("heavy buckets");
   {
