@@ -406,6 +406,20 @@ int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, con
                           int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
                           void* stream);
 
+/* Throughput mode of the sharded prover: nproofs (1..16) proofs per collective call -- what a service does with the
+ * reference by running several dsha256 instances over one mesh (mpc-net/src/multi.rs:317-327; groth16/examples/
+ * sha256.rs:316-360).  ONE round of the control plane admits the batch; every rank runs each of its five d_msm once
+ * over the nproofs witnesses (zk_groth16_prove_batch's batched Pippenger) beside the king rounds of the proofs'
+ * circom_h; the partial sums of the batch cross in one host message per rank.  Pointer arrays (host arrays of device
+ * pointers) hold THIS RANK's rows of every proof; r, s: nproofs Montgomery Fr each; masks: nproofs entries (this rank's
+ * rows) or NULL; pi_a / pi_c: [nproofs][k] Jacobian G1, pi_b: [nproofs][k] Jacobian G2 (host).  Results equal nproofs
+ * calls of zk_dist_groth16_prove; in replay mode proof b draws the randomness of seed + 16 b. */
+int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, int nproofs,
+                                const void* const* qap_a_d, const void* const* qap_b_d, const void* const* qap_c_d,
+                                const void* const* a_share_d, const void* const* ax_share_d, const void* r, const void* s,
+                                int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b,
+                                void* pi_c, void* stream);
+
 /* ---- per-kernel timing (measurement only) -----------------------------------------------------------------
  * When enabled, HIP events are recorded on the launching stream around the kernels of each slot; zk_profile_read
  * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the

@@ -175,6 +175,24 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
                      G2.eq(dec_jacobian(pp, got[1][p], True), dec_jacobian(pp, ref[1][first + p], True)) and
                      G1.eq(dec_jacobian(pp, got[2][p]), dec_jacobian(pp, ref[2][first + p])) for p in range(k))
             checks["prove_%s" % ("masks" if mk else "r0")] = ok
+        # ---- a BATCH of three proofs per collective call (zk_dist_groth16_prove_batch): different (r, s) and masks per
+        # proof; every local share equals the one-context batch prover's
+        nbp = 3
+        rs_b = [rand_fp(143, b, P) for b in range(nbp)]
+        ss_b = [rand_fp(144, b, P) for b in range(nbp)]
+        rs_b[1] = 0
+        mks_b = [zg.ProofMasks(pp, setup.log_m, seed=600 + 40 * b) for b in range(nbp)]
+        refs = zg.prove_batch(pp, crs, [wit] * nbp, rs_b, ss_b, masks=mks_b, seed=21)
+        lcrs = mg.LocalCrs(pp, crs, first, k)
+        qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k)
+        lm = [mg.local_masks(pp, m_, wit.log_m, first, k) for m_ in mks_b]
+        gots = znet.dist_prove_batch(pp, net, lcrs.ct, [qap] * nbp, [a_sh] * nbp, [ax_sh] * nbp, rs_b, ss_b, wit.log_m,
+                                     masks=[x[0] for x in lm], seed=21)
+        checks["prove_batch"] = all(
+            G1.eq(dec_jacobian(pp, gots[b][0][p]), dec_jacobian(pp, refs[b][0][first + p])) and
+            G2.eq(dec_jacobian(pp, gots[b][1][p], True), dec_jacobian(pp, refs[b][1][first + p], True)) and
+            G1.eq(dec_jacobian(pp, gots[b][2][p]), dec_jacobian(pp, refs[b][2][first + p]))
+            for b in range(nbp) for p in range(k))
         # circom_h alone: shares identical to the all-in-one call
         h_ref = pp.alloc_fr(n * ((1 << wit.log_m) // 2))
         import ctypes as C

@@ -504,6 +504,17 @@ int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, con
                        pi_b, pi_c, S(stream));
 }
 
+int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, int nproofs,
+                                const void* const* qap_a_d, const void* const* qap_b_d, const void* const* qap_c_d,
+                                const void* const* a_share_d, const void* const* ax_share_d, const void* r, const void* s,
+                                int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b,
+                                void* pi_c, void* stream) {
+  const int sid = 0;
+  NET_OR_FAIL();
+  return e->dist_prove_batch(&net->net, crs, nproofs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m,
+                             masks, seed, pi_a, pi_b, pi_c, S(stream));
+}
+
 // ---- profiling slots (bench.py roofline leg) ----
 static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king_fft2_kernel", "msm_accumulate_kernel<G1>",
                                                          "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",

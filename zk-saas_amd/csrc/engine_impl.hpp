@@ -1452,7 +1452,9 @@ class Engine : public IEngine {
     zk_crs_share crs{};
     int slot = 0;
     hipEvent_t ev_in = nullptr;
-    bool own_streams = false;
+    bool own_streams = false, full = true;
+    int first = 0, count = 0;
+    MsmGate gate_u;
     hipEvent_t ev_acc[4] = {nullptr, nullptr, nullptr, nullptr};      // V, S+H, W, U: recorded behind the accumulate kernel
     std::atomic<int> acc_flag[4];                                     // ... once that record has been enqueued (MsmGate)
     hipStream_t st[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1488,14 +1490,51 @@ class Engine : public IEngine {
                                 const void* const* qc, const void* const* a_share, const void* const* ax_share,
                                 const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk, uint64_t seed,
                                 hipStream_t st, int* handle) override {
+    if (!qa || !qb || !qc || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (nb >= 1 && nb <= MAX_PROOF_BATCH)
+      for (int b = 0; b < nb; b++)
+        if (!qa[b] || !qb[b] || !qc[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int slot = -1;
+    int rc = batch_begin(crs_in, nb, a_share, ax_share, r_, s_, log_m, mk, true, 0, n, st, &slot);
+    if (rc) return rc;
+    BatchJobX& B = bjobs_[slot];
+    // ---- circom_h of the whole batch and the U-MSM behind it
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
+    rc = circom_h_batch(nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, B.hwork, B.st[5]);
+    if (!rc) rc = batch_launch_u(B, (const Fr*)B.hshare.p, per, B.st[5]);
+    if (rc) {
+      Status keep = last;
+      abort_batch(B);
+      last = keep;
+      return rc;
+    }
+    *handle = slot;
+    return ZK_OK;
+  }
+  // the U-MSM of a batch: h_all = [nb][count * m/l] (proof b at h_all + b * stride)
+  int batch_launch_u(BatchJobX& B, const Fr* h_all, size_t stride, hipStream_t st) {
+    MsmBatchArg ba_h;
+    ba_h.nb = B.nb;
+    for (int b = 0; b < B.nb; b++) ba_h.p[b] = h_all + (size_t)b * stride;
+    int rc = msm_.template launch_t<Fq_>(this, B.crs.u_d, nullptr, (size_t)B.count * B.crs.len_u, msm_.coef_d_ + B.first,
+                                        B.crs.len_u, st, 12 + 6 * B.slot + 0, &B.pU, nullptr, B.gate_u, &ba_h);
+    B.acc_flag[3].store(1, std::memory_order_release);
+    return rc;
+  }
+  // Starts a batch: the four witness MSMs of parties [first, first + count) for nb proofs (one launch chain each) and
+  // the proofs' host terms.  full: all n parties, assembly included; otherwise the partial sums of one rank (the in-mask
+  // terms only).  The caller enqueues circom_h and batch_launch_u, then batch_join.
+  int batch_begin(const zk_crs_share* crs_in, int nb, const void* const* a_share, const void* const* ax_share,
+                  const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk, bool full, int first, int count,
+                  hipStream_t st, int* slot_out) {
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     int rc = check_prove_args(crs_in, r_, s_, log_m);
     if (rc) return rc;
     if (nb < 1 || nb > MAX_PROOF_BATCH || 3 * nb > KING_BATCH || nb > DEGRED_BATCH)
       return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MAX_PROOF_BATCH));
-    if (!qa || !qb || !qc || !a_share || !ax_share || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (!a_share || !ax_share) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     for (int b = 0; b < nb; b++)
-      if (!qa[b] || !qb[b] || !qc[b] || !a_share[b] || !ax_share[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+      if (!a_share[b] || !ax_share[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     int slot = -1;
     for (int i = 0; i < NBATCH; i++)
       if (!bjobs_[i].active) {
@@ -1535,14 +1574,18 @@ class Engine : public IEngine {
     const zk_crs_share* crs = &B.crs;
     hipStream_t* const streams_ = B.st;              // this batch's stream set
     hipEvent_t const ev_batch_in_ = B.ev_in;
-    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)count * Lc;
     ZK_HIP(B.hshare.ensure(per * nb * sizeof(Fr)));
     B.nb = nb;
+    B.first = first;
+    B.count = count;
+    B.full = full;
+    const int n = count;                                 // parties of this launch (shadows the context's n below)
     while ((int)B.pj.size() < nb) B.pj.emplace_back(new ProveJob());
     bool all_r_zero = true;
     for (int b = 0; b < nb; b++) {
       Fr r = Fr::from_limbs((const uint32_t*)r_ + (size_t)b * FrP::N), s = Fr::from_limbs((const uint32_t*)s_ + (size_t)b * FrP::N);
-      init_job(*B.pj[b], crs, mk ? &mk[b] : nullptr, r, s, true, 0, n);
+      init_job(*B.pj[b], crs, mk ? &mk[b] : nullptr, r, s, full, first, count);
       all_r_zero = all_r_zero && r.is_zero();
     }
     for (int i = 0; i < 4; i++) B.rc[i] = 0;
@@ -1552,7 +1595,7 @@ class Engine : public IEngine {
     BatchJob* BJ = &B;
     const int dev = device;
     const int ws0 = 12 + 6 * slot;                      // the batch's own MSM workspaces (msm.hpp MSM_WS)
-    const Fr* cf = msm_.coef_d_;
+    const Fr* cf = msm_.coef_d_ + first;
     MsmBatchArg ba_a, ba_x;
     ba_a.nb = ba_x.nb = nb;
     for (int b = 0; b < nb; b++) {
@@ -1636,55 +1679,59 @@ class Engine : public IEngine {
         for (int b = 0; b < nb; b++) BJ->pj[b]->W = res[b];
     }));
     // ---- host terms of every proof
-    for (int b = 0; b < nb; b++) submit_host_terms(B.pj[b].get(), B.fut, true, 0, n);
-    // ---- circom_h of the whole batch and the U-MSM behind it
-    auto bail = [&](int code) {
-      Status keep = last;
-      abort_batch(B);
-      last = keep;
-      return code;
-    };
-    hipStream_t hs = streams_[5];
-    rc = circom_h_batch(nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, B.hwork, hs);
-    if (rc) return bail(rc);
-    MsmBatchArg ba_h;
-    ba_h.nb = nb;
-    for (int b = 0; b < nb; b++) ba_h.p[b] = (const Fr*)B.hshare.p + (size_t)b * per;
-    rc = msm_.template launch_t<Fq_>(this, crs->u_d, nullptr, (size_t)n * crs->len_u, cf, crs->len_u, hs, ws0 + 0, &B.pU,
-                                    nullptr, gate_u, &ba_h);
-    aflag[3].store(1, std::memory_order_release);
-    if (rc) return bail(rc);
-    *handle = slot;
+    for (int b = 0; b < nb; b++) submit_host_terms(B.pj[b].get(), B.fut, full, first, count);
+    B.gate_u = gate_u;
+    *slot_out = slot;
     return ZK_OK;
   }
-  int groth16_batch_wait(int handle, void* pi_a, void* pi_b, void* pi_c) override {
-    if (handle < 0 || handle >= NBATCH || !bjobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no batch in flight on this handle");
-    BatchJobX& B = bjobs_[handle];
-    auto bail = [&](int code) {
-      Status keep = last;
-      abort_batch(B);
-      last = keep;
-      return code;
-    };
-    if (!pi_a || !pi_b || !pi_c) return bail(fail(ZK_ERR_BAD_INPUT, "null pointer"));
+  // the five MSM totals of every proof of the batch, in-mask terms included (sums[b] = S, H, V, W, U)
+  struct BatchSums {
+    P1 S, H, W, U;
+    P2 V;
+  };
+  int batch_join(BatchJobX& B, std::vector<BatchSums>& sums) {
     const int nb = B.nb;
     std::vector<P1> ures((size_t)nb);
     int rc = msm_fold_batch<Fq_>(this, B.pU, ures.data(), 1);
-    if (rc) return bail(rc);
+    if (rc) {
+      Status keep = last;
+      abort_batch(B);
+      last = keep;
+      return rc;
+    }
     for (auto& f : B.fut)
       if (f.valid()) f.wait();
     B.fut.clear();
     B.active = false;
     for (int i = 0; i < 4; i++)
       if (B.rc[i]) return B.rc[i];
+    sums.resize((size_t)nb);
     for (int b = 0; b < nb; b++) {
       ProveJob& j = *B.pj[b];
       if (j.err.code) return fail(j.err.code, j.err.msg);
-      const P1 S = xyzz_add_ni(j.S, j.in1[0]);
-      const P1 H = j.r_zero ? P1::identity() : xyzz_add_ni(j.H, j.in1[1]);
-      const P2 V = xyzz_add_ni(j.V0, j.in2);
-      const P1 W = xyzz_add_ni(j.W, j.in1[3]);
-      const P1 U = xyzz_add_ni(ures[b], j.in1[4]);
+      sums[b].S = xyzz_add_ni(j.S, j.in1[0]);
+      sums[b].H = j.r_zero ? P1::identity() : xyzz_add_ni(j.H, j.in1[1]);
+      sums[b].V = xyzz_add_ni(j.V0, j.in2);
+      sums[b].W = xyzz_add_ni(j.W, j.in1[3]);
+      sums[b].U = xyzz_add_ni(ures[b], j.in1[4]);
+    }
+    return ZK_OK;
+  }
+  int groth16_batch_wait(int handle, void* pi_a, void* pi_b, void* pi_c) override {
+    if (handle < 0 || handle >= NBATCH || !bjobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no batch in flight on this handle");
+    BatchJobX& B = bjobs_[handle];
+    if (!pi_a || !pi_b || !pi_c) {
+      abort_batch(B);
+      return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    }
+    const int nb = B.nb;
+    std::vector<BatchSums> sums;
+    int rc = batch_join(B, sums);
+    if (rc) return rc;
+    for (int b = 0; b < nb; b++) {
+      ProveJob& j = *B.pj[b];
+      const P1 &S = sums[b].S, &H = sums[b].H, &W = sums[b].W, &U = sums[b].U;
+      const P2& V = sums[b].V;
       rc = assemble_job(j, S, H, V, W, U, (char*)pi_a + (size_t)b * n * sizeof(Jacobian<Fq_>),
                         (char*)pi_b + (size_t)b * n * sizeof(Jacobian<Fq2_>), (char*)pi_c + (size_t)b * n * sizeof(Jacobian<Fq_>));
       if (rc) return rc;
@@ -2831,6 +2878,90 @@ class Engine : public IEngine {
     rc = net_err(net, net->bcast_host(3, cmask[3], &total, sizeof(total)));
     if (rc) return rc;
     return assemble_points(crs, r, s, total.S, total.H, total.V, total.W, total.U, mk, k, pi_a, pi_b, pi_c);
+  }
+
+  // A batch of proofs per rank (zk_dist_groth16_prove_batch): the throughput mode of the sharded prover.  One round of
+  // the control plane admits the whole batch; every rank runs each of its five MSMs ONCE over the nb witnesses (the
+  // batched Pippenger of msm.hpp) while the king rounds of the proofs' circom_h go over the channels one proof after the
+  // other; the partial sums of the whole batch cross in ONE host message per rank and one answer.  Shares and masks: this
+  // rank's k parties' rows of every proof; pi_*: [nb][k] Jacobian points.  Proof b draws the share randomness
+  // zk_dist_groth16_prove draws with seed + 16 b.
+  int dist_prove_batch(Net* net, const zk_crs_share* crs, int nb, const void* const* qa, const void* const* qb,
+                       const void* const* qc, const void* const* a_share, const void* const* ax_share, const void* r_,
+                       const void* s_, int log_m, const zk_groth16_masks* mk, uint64_t seed, void* pi_a, void* pi_b,
+                       void* pi_c, hipStream_t st) override {
+    if (!qa || !qb || !qc || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (nb < 1 || nb > MAX_PROOF_BATCH) return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MAX_PROOF_BATCH));
+    for (int b = 0; b < nb; b++)
+      if (!qa[b] || !qb[b] || !qc[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const int k = net->parties_per_rank(), first = net->first_party(net->rank);
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
+    uint32_t cmask[NET_NSID];
+    int rc;
+    for (int j = 0; j < NET_NSID; j++) {
+      rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    for (int j = 0; j < NET_NSID; j++)
+      if (cmask[j] != net->full_mask())
+        return fail(ZK_ERR_PROTOCOL, "a party did not show up for the batch (timed out)", -1);
+    int slot = -1;
+    rc = batch_begin(crs, nb, a_share, ax_share, r_, s_, log_m, mk, false, first, k, st, &slot);
+    if (rc) return rc;
+    BatchJobX& B = bjobs_[slot];
+    auto bail = [&](int code) {
+      Status keep = last;
+      abort_batch(B);
+      last = keep;
+      return code;
+    };
+    // circom_h of every proof through the star (the channels carry one proof's rounds at a time; the MSMs of the whole
+    // batch run beside them)
+    for (int b = 0; b < nb; b++) {
+      rc = dist_circom_h_on(net, cmask, qa[b], qb[b], qc[b], log_m, mk ? &mk[b] : nullptr,
+                            seed + (uint64_t)PROOF_SEED_STEP * b, (Fr*)B.hshare.p + (size_t)b * per, st);
+      if (rc) return bail(rc);
+    }
+    // the U-MSM runs on its own stream of the batch's set, behind everything queued on the caller's stream
+    ZK_HIP(hipEventRecord(B.ev_in, st));
+    ZK_HIP(hipStreamWaitEvent(B.st[5], B.ev_in, 0));
+    rc = batch_launch_u(B, (const Fr*)B.hshare.p, per, B.st[5]);
+    if (rc) return bail(rc);
+    std::vector<BatchSums> mine;
+    rc = batch_join(B, mine);
+    if (rc) return rc;
+    // d_msm's king step for the 5 nb products (dmsm/mod.rs:76-92): host messages of as many proofs as fit the payload
+    std::vector<BatchSums> total = mine;
+    const int per_msg = (int)(NET_PAYLOAD / sizeof(BatchSums));
+    static_assert(sizeof(BatchSums) <= NET_PAYLOAD, "payload");
+    std::vector<BatchSums> all((size_t)net->world * per_msg);
+    for (int b0 = 0; b0 < nb; b0 += per_msg) {
+      const int cnt = nb - b0 < per_msg ? nb - b0 : per_msg;
+      const size_t bytes = (size_t)cnt * sizeof(BatchSums);
+      rc = net_err(net, net->gather_host(3, cmask[3], mine.data() + b0, bytes, all.data()));
+      if (rc) return rc;
+      if (net->rank == 0)
+        for (int rr = 1; rr < net->world; rr++)
+          for (int i = 0; i < cnt; i++) {
+            const BatchSums& o = *(const BatchSums*)((const char*)all.data() + (size_t)rr * bytes + (size_t)i * sizeof(BatchSums));
+            BatchSums& t_ = total[b0 + i];
+            t_.S = xyzz_add_ni(t_.S, o.S);
+            t_.H = xyzz_add_ni(t_.H, o.H);
+            t_.V = xyzz_add_ni(t_.V, o.V);
+            t_.W = xyzz_add_ni(t_.W, o.W);
+            t_.U = xyzz_add_ni(t_.U, o.U);
+          }
+      rc = net_err(net, net->bcast_host(3, cmask[3], total.data() + b0, bytes));
+      if (rc) return rc;
+    }
+    for (int b = 0; b < nb; b++) {
+      const ProveJob& j = *B.pj[b];
+      rc = assemble_points(crs, j.r, j.s, total[b].S, total[b].H, total[b].V, total[b].W, total[b].U, mk ? &mk[b] : nullptr, k,
+                           (char*)pi_a + (size_t)b * k * sizeof(Jacobian<Fq_>), (char*)pi_b + (size_t)b * k * sizeof(Jacobian<Fq2_>),
+                           (char*)pi_c + (size_t)b * k * sizeof(Jacobian<Fq_>));
+      if (rc) return rc;
+    }
+    return ZK_OK;
   }
 
   int ensure_streams() {

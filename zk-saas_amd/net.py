@@ -168,3 +168,28 @@ def dist_prove(pp, net, crs_ct, qap_local, a_share_local, ax_share_local, r, s, 
                                            None if masks is None else C.byref(masks), seed, pa.ctypes.data,
                                            pb.ctypes.data, pc.ctypes.data, stream))
     return pa, pb, pc
+
+
+def dist_prove_batch(pp, net, crs_ct, qaps_local, a_shares_local, ax_shares_local, rs, ss, log2_m, masks=None, seed=0,
+                     stream=None):
+    """zk_dist_groth16_prove_batch: len(rs) proofs per collective call for this rank's k parties.  qaps_local: per proof
+    the three local QAP buffers; a_shares_local / ax_shares_local: per proof the local witness shares; masks: per proof a
+    groth16.Masks over the LOCAL rows (or None).  Returns a list of (pi_a [k][3nl], pi_b [k][6nl], pi_c [k][3nl])."""
+    from .groth16 import Masks
+    nb, nl = len(rs), pp.fq.nl
+    pa = np.zeros((nb, net.k, 3 * nl), dtype=np.uint64)
+    pb = np.zeros((nb, net.k, 6 * nl), dtype=np.uint64)
+    pc = np.zeros((nb, net.k, 3 * nl), dtype=np.uint64)
+    rr = np.ascontiguousarray(np.stack([pp.fr.encode_one(v) for v in rs]))
+    sv = np.ascontiguousarray(np.stack([pp.fr.encode_one(v) for v in ss]))
+    arr = lambda vals: (C.c_void_p * nb)(*[_ptr(v) for v in vals])
+    mk = None
+    if masks is not None:
+        mk = (Masks * nb)()
+        for b, m in enumerate(masks):
+            C.memmove(C.byref(mk, b * C.sizeof(Masks)), C.byref(m), C.sizeof(Masks))
+    pp._check(pp.lib.zk_dist_groth16_prove_batch(
+        pp.h, net.h, C.byref(crs_ct), nb, arr([q[0] for q in qaps_local]), arr([q[1] for q in qaps_local]),
+        arr([q[2] for q in qaps_local]), arr(a_shares_local), arr(ax_shares_local), rr.ctypes.data, sv.ctypes.data, log2_m,
+        None if mk is None else C.cast(mk, C.c_void_p), seed, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data, stream))
+    return [(pa[b], pb[b], pc[b]) for b in range(nb)]
