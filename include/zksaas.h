@@ -307,8 +307,9 @@ int zk_groth16_prove_batch(zk_ctx* ctx, const zk_crs_share* crs, int nproofs, co
                            const void* const* ax_share_d, const void* r, const void* s, int log2_m,
                            const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c, void* stream);
 /* Asynchronous form: _async enqueues the batch (device pipelines on the batch's own stream set, host terms on the worker
- * pool) and returns a handle; zk_groth16_batch_wait joins it and writes the shares.  Up to TWO batches may be in flight
- * per context, each with its own scratch: the sorts of one run under the accumulate kernels of the other.  Inputs must
+ * pool) and returns a handle; zk_groth16_batch_wait joins it and writes the shares.  Up to THREE batches may be in flight
+ * per context, each with its own scratch: the sorts of one run under the accumulate kernels of the other (two already
+ * saturate the chip: 814 / 813 proofs/s with two / three batches of 8 in flight).  Inputs must
  * stay valid and unmodified until _wait returns (the pointer ARRAYS are copied and may be reused at once). */
 int zk_groth16_prove_batch_async(zk_ctx* ctx, const zk_crs_share* crs, int nproofs, const void* const* qap_a_d,
                                  const void* const* qap_b_d, const void* const* qap_c_d, const void* const* a_share_d,

@@ -17,6 +17,7 @@
  *
  * All field elements cross this API as 4 little-endian u64 limbs in Montgomery form (arkworks layout).
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -274,6 +275,84 @@ static void pss_unpack2(const pss_t* P, const fe* shares, fe* secrets) {
   dom_fft(&P->secret2, buf, &P->F);
   for (int i = 0; i < P->l; i++) secrets[i] = buf[2 * i];
 }
+/* ---- the TUNED king (cpu_baseline only; off by default): pack and unpack2 are fixed linear maps, so a CPU prover that
+ * cared would apply them as precomputed matrices (n x (l+t) and l x n: 48 multiplications per chunk at l = 2 instead of
+ * two size-8 and two size-4/16 FFTs with their bit reversals and scalings) and split the chunks over threads.  The
+ * reference does neither (its king is the serial FFT form above: dfft/mod.rs:264-304); bench.py reports both. */
+static int g_fast_king = 0, g_king_threads = 1;
+void zkref_set_fast_king(int on, int threads) {
+  g_fast_king = on;
+  g_king_threads = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+}
+typedef struct {
+  fe pack[MAXN][MAXN];     /* shares[p] = sum_j pack[p][j] * v[j], j < l + t */
+  fe unpack2[MAXN][MAXN];  /* secrets[i] = sum_p unpack2[i][p] * shares[p] */
+} king_mats;
+static void king_mats_build(const pss_t* P, king_mats* M) {
+  fe unit[MAXN], col[MAXN];
+  for (int j = 0; j < P->l + P->t; j++) {
+    memset(unit, 0, sizeof unit);
+    fe_one(&unit[j], &P->F);
+    pss_pack(P, unit, unit + P->l, col);
+    for (int p = 0; p < P->n; p++) M->pack[p][j] = col[p];
+  }
+  for (int p = 0; p < P->n; p++) {
+    memset(unit, 0, sizeof unit);
+    fe_one(&unit[p], &P->F);
+    pss_unpack2(P, unit, col);
+    for (int i = 0; i < P->l; i++) M->unpack2[i][p] = col[i];
+  }
+}
+static inline void mat_unpack2(const pss_t* P, const king_mats* M, const fe* sh, fe* sec) {
+  for (int i = 0; i < P->l; i++) {
+    fe acc = {{0}}, t;
+    for (int p = 0; p < P->n; p++) {
+      fe_mul(&t, &M->unpack2[i][p], &sh[p], &P->F);
+      fe_add(&acc, &acc, &t, &P->F);
+    }
+    sec[i] = acc;
+  }
+}
+static inline void mat_pack(const pss_t* P, const king_mats* M, const fe* sec, const fe* rnd, fe* sh) {
+  for (int p = 0; p < P->n; p++) {
+    fe acc = {{0}}, t;
+    for (int j = 0; j < P->l; j++) {
+      fe_mul(&t, &M->pack[p][j], &sec[j], &P->F);
+      fe_add(&acc, &acc, &t, &P->F);
+    }
+    for (int j = 0; j < P->t; j++) {
+      fe_mul(&t, &M->pack[p][P->l + j], &rnd[j], &P->F);
+      fe_add(&acc, &acc, &t, &P->F);
+    }
+    sh[p] = acc;
+  }
+}
+/* run fn(arg, lo, hi) over [0, count) on g_king_threads threads */
+typedef struct {
+  void (*fn)(void*, size_t, size_t);
+  void* arg;
+  size_t lo, hi;
+} king_span;
+static void* king_span_run(void* a) {
+  king_span* s = (king_span*)a;
+  s->fn(s->arg, s->lo, s->hi);
+  return NULL;
+}
+static void king_parallel(void (*fn)(void*, size_t, size_t), void* arg, size_t count) {
+  int nt = g_king_threads;
+  if (nt <= 1 || count < 1024) {
+    fn(arg, 0, count);
+    return;
+  }
+  pthread_t th[64];
+  king_span sp[64];
+  for (int t = 0; t < nt; t++) {
+    sp[t] = (king_span){fn, arg, count * t / nt, count * (t + 1) / nt};
+    pthread_create(&th[t], NULL, king_span_run, &sp[t]);
+  }
+  for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+}
+
 void zkref_pack(const pss_t* P, const fe* secrets, const fe* rnd, fe* shares) { pss_pack(P, secrets, rnd, shares); }
 void zkref_unpack(const pss_t* P, const fe* shares, fe* secrets) { pss_unpack(P, shares, secrets); }
 void zkref_unpack2(const pss_t* P, const fe* shares, fe* secrets) { pss_unpack2(P, shares, secrets); }
@@ -360,6 +439,39 @@ static void fft2(const pss_t* P, fe** s1p, fe** s2p, size_t dom_size, const fe* 
   *s2p = s2;
 }
 
+/* chunk loops of the tuned king (g_fast_king) */
+typedef struct {
+  const pss_t* P;
+  const king_mats* M;
+  const fe* in;
+  fe* s1;
+  fe* out;
+  size_t mbyl;
+  int rearrange;
+  u64 seed;
+  int fr_bits;
+} kf_ctx;
+static void kf_unpack(void* a, size_t lo, size_t hi) {
+  kf_ctx* c = (kf_ctx*)a;
+  fe sh[MAXN], sec[MAXN];
+  for (size_t i = lo; i < hi; i++) {
+    for (int p = 0; p < c->P->n; p++) sh[p] = c->in[(size_t)p * c->mbyl + i];
+    mat_unpack2(c->P, c->M, sh, sec);
+    for (int j = 0; j < c->P->l; j++) c->s1[i * c->P->l + j] = sec[j];
+  }
+}
+static void kf_pack(void* a, size_t lo, size_t hi) {
+  kf_ctx* c = (kf_ctx*)a;
+  const int l = c->P->l, t = c->P->t;
+  fe sh[MAXN], sec[MAXN], rnd[MAXN];
+  for (size_t j = lo; j < hi; j++) {
+    for (int i = 0; i < l; i++) sec[i] = c->rearrange ? c->s1[j + (size_t)i * c->mbyl] : c->s1[j * l + i];
+    for (int i = 0; i < t; i++) rand_fe(&rnd[i], c->seed, (u64)j * t + i, c->fr_bits, &c->P->F);
+    mat_pack(c->P, c->M, sec, rnd, sh);
+    for (int p = 0; p < c->P->n; p++) c->out[(size_t)p * c->mbyl + j] = sh[p];
+  }
+}
+
 /* King closure of fft2_with_rearrange (dfft/mod.rs:264-304), all n parties present.
  * in: [n][mbyl] (already masked); out: [n][mbyl]; g == NULL means 1; fr_bits for the PRNG. */
 void zkref_king_fft2(const pss_t* P, const fe* in, size_t mbyl, const fe* gen, const fe* g, int rearrange, u64 seed,
@@ -370,6 +482,14 @@ void zkref_king_fft2(const pss_t* P, const fe* in, size_t mbyl, const fe* gen, c
   fe* s1 = malloc(sizeof(fe) * m);
   fe* s2 = malloc(sizeof(fe) * m);
   fe sh[MAXN], sec[MAXN], rnd[MAXN];
+  king_mats* KM = NULL;
+  kf_ctx kc;
+  if (g_fast_king) {
+    KM = malloc(sizeof(king_mats));
+    king_mats_build(P, KM);
+    kc = (kf_ctx){P, KM, in, s1, out, mbyl, rearrange, seed, fr_bits};
+    king_parallel(kf_unpack, &kc, mbyl);
+  } else
   for (size_t i = 0; i < mbyl; i++) {          /* transpose + unpack per chunk */
     for (int p = 0; p < n; p++) sh[p] = in[(size_t)p * mbyl + i];
     pss_unpack2(P, sh, sec);
@@ -380,6 +500,11 @@ void zkref_king_fft2(const pss_t* P, const fe* in, size_t mbyl, const fe* gen, c
   fe_one(&one, F);
   if (g && !fe_eq(g, &one)) distribute_powers(s1, m, g, &one, F);
   if (rearrange) bitrev_inplace(s1, m);
+  if (g_fast_king) {
+    kc.s1 = s1;                                 /* fft2 may have swapped its two buffers */
+    king_parallel(kf_pack, &kc, mbyl);
+    free(KM);
+  } else
   for (size_t j = 0; j < mbyl; j++) {
     for (int i = 0; i < l; i++) sec[i] = rearrange ? s1[j + (size_t)i * mbyl] : s1[j * l + i];
     for (int i = 0; i < t; i++) rand_fe(&rnd[i], seed, (u64)j * t + i, fr_bits, F);
@@ -681,10 +806,46 @@ void zkref_mul_sub(const field_t* F, const fe* a, const fe* b, const fe* c, size
   }
 }
 /* deg_red king + masks for all parties (deg_red.rs:80-126); x [n][len] in place */
+typedef struct {
+  const pss_t* P;
+  const king_mats* M;
+  fe* x;
+  size_t len;
+  const fe *in_mask, *out_mask;
+  u64 seed;
+  int fr_bits;
+} dr_ctx;
+static void dr_span(void* a, size_t lo, size_t hi) {
+  dr_ctx* c = (dr_ctx*)a;
+  const field_t* F = &c->P->F;
+  const int n = c->P->n;
+  fe sh[MAXN], sec[MAXN], rnd[MAXN];
+  for (size_t j = lo; j < hi; j++) {
+    for (int p = 0; p < n; p++) {
+      sh[p] = c->x[(size_t)p * c->len + j];
+      if (c->in_mask) fe_add(&sh[p], &sh[p], &c->in_mask[(size_t)p * c->len + j], F);
+    }
+    mat_unpack2(c->P, c->M, sh, sec);
+    for (int i = 0; i < c->P->t; i++) rand_fe(&rnd[i], c->seed, (u64)j * c->P->t + i, c->fr_bits, F);
+    mat_pack(c->P, c->M, sec, rnd, sh);
+    for (int p = 0; p < n; p++) {
+      if (c->out_mask) fe_add(&sh[p], &sh[p], &c->out_mask[(size_t)p * c->len + j], F);
+      c->x[(size_t)p * c->len + j] = sh[p];
+    }
+  }
+}
 void zkref_deg_red(const pss_t* P, fe* x, size_t len, const fe* in_mask, const fe* out_mask, u64 seed, int fr_bits) {
   const field_t* F = &P->F;
   int n = P->n;
   fe sh[MAXN], sec[MAXN], rnd[MAXN];
+  if (g_fast_king) {
+    king_mats* KM = malloc(sizeof(king_mats));
+    king_mats_build(P, KM);
+    dr_ctx c = {P, KM, x, len, in_mask, out_mask, seed, fr_bits};
+    king_parallel(dr_span, &c, len);
+    free(KM);
+    return;
+  }
   for (size_t j = 0; j < len; j++) {
     for (int p = 0; p < n; p++) {
       sh[p] = x[(size_t)p * len + j];

@@ -86,13 +86,20 @@ class CpuProver:
         cp.deg_red_arrays(h, Lc, dm[0], dm[1], seed + 6)
         return h
 
-    def prove(self, inp, threads=8, msm_threads=1):
+    def prove(self, inp, threads=8, msm_threads=1, tuned_king=0):
         """inp: dict of numpy arrays (see bench.py); returns (A, B, C) Jacobian uint64 arrays and timing.
-        threads: parties proved concurrently; msm_threads: window-parallel threads inside each G::msm."""
+        threads: parties proved concurrently; msm_threads: window-parallel threads inside each G::msm; tuned_king = T > 0:
+        the king's pack / unpack2 as precomputed matrices over T threads (zkref.c zkref_set_fast_king) instead of the
+        reference's serial FFT-form king (same shares)."""
+        from .cref import lib
         cp = self.cp
         n = cp.n
+        lib().zkref_set_fast_king(1 if tuned_king else 0, max(1, tuned_king))
         t0 = time.perf_counter()
-        h = self.circom_h(inp["qap"], inp["log_m"], inp["seed"], inp.get("fft_masks"), inp.get("degred_mask"))
+        try:
+            h = self.circom_h(inp["qap"], inp["log_m"], inp["seed"], inp.get("fft_masks"), inp.get("degred_mask"))
+        finally:
+            lib().zkref_set_fast_king(0, 1)
         t1 = time.perf_counter()
         Lc = h.shape[0] // n
 

@@ -127,3 +127,40 @@ def test_six_limb_build_msm_and_doubling_chain_equal_the_python_oracle(curve):
     vals = [0, 1, cv.r - 1, 123456789 ** 4 % cv.r]
     m4 = np.array([[(v * (1 << 256) % cv.r >> (64 * k)) & ((1 << 64) - 1) for k in range(4)] for v in vals], dtype=np.uint64)
     assert cg.fr.dec(cg.scalars_from_gpu_residues(m4)) == vals
+
+
+
+def test_tuned_king_gives_the_reference_kings_shares():
+    """cpu_baseline's `all_cores_tuned_king` leg (zkref_set_fast_king: pack / unpack2 as precomputed matrices over threads)
+    must produce exactly the shares of the serial FFT-form king it stands in for: d_fft, d_ifft (rearranged, coset), masked,
+    and deg_red."""
+    import numpy as np
+    from oracle.cref import CPss, lib
+    from oracle.field import Domain
+    from oracle.params import BN254
+    cp = CPss("bn254", 2)
+    m = 1 << 12
+    dom = Domain(BN254, m)
+    rng = np.random.default_rng(1)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    a, im, om = rand(8 * (m // 2)), rand(8 * (m // 2)), rand(8 * (m // 2))
+    res = []
+    try:
+        for fast in (0, 1):
+            lib().zkref_set_fast_king(fast, 4)
+            for rearr, inv in ((False, False), (True, True)):
+                w = a.copy()
+                g = Domain(BN254, 2 * m).element(1) if inv else None
+                cp.d_fft_arrays(w, m // 2, dom.group_gen_inv if inv else dom.group_gen, dom.size_inv if inv else None, g,
+                                rearr, im, om, 7)
+                res.append(w)
+            x = a.copy()
+            cp.deg_red_arrays(x, m // 2, im, om, 9)
+            res.append(x)
+    finally:
+        lib().zkref_set_fast_king(0, 1)
+    assert all(np.array_equal(res[i], res[i + 3]) for i in range(3))

@@ -47,14 +47,16 @@ def main():
         if inflight > 1:
             # two batches in flight: start batch i + 1 before waiting for batch i; time = whole run / batches
             for rep in range(3):
-                nbat = max(reps, 4)
+                nbat = max(reps, 6)
                 t0 = time.perf_counter()
-                prev = zg.prove_batch_async(pp, crs, [wit] * nb, [r] * nb, [s] * nb, masks=mk, seed=100)
-                for i in range(1, nbat):
-                    cur = zg.prove_batch_async(pp, crs, [wit] * nb, [r] * nb, [s] * nb, masks=mk, seed=100 + i)
-                    prev.wait()
-                    prev = cur
-                last = prev.wait()
+                from collections import deque
+                q = deque()
+                for i in range(nbat):
+                    q.append(zg.prove_batch_async(pp, crs, [wit] * nb, [r] * nb, [s] * nb, masks=mk, seed=100 + i))
+                    if len(q) >= inflight:
+                        last = q.popleft().wait()
+                while q:
+                    last = q.popleft().wait()
                 ts.append((time.perf_counter() - t0) / nbat)
             same = same and all(bench.same_shares(pp, o, ref) for o in last)
         else:

@@ -1447,7 +1447,7 @@ class Engine : public IEngine {
   // Two batches may be in flight (zk_groth16_prove_batch_async): each has its own MSM workspaces, scratch and stream
   // set, so that the sort phase of one batch runs under the accumulate kernels of the other and the reduction tails of one
   // under the other's accumulates -- one batch alone leaves the chip partly idle for ~1 ms at either end.
-  static constexpr int NBATCH = 2;
+  static constexpr int NBATCH = 3;
   struct BatchJobX : BatchJob {
     zk_crs_share crs{};
     int slot = 0;

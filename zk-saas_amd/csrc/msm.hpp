@@ -39,7 +39,7 @@ namespace zk {
 constexpr size_t MSM_RANGE_MIN = 20, MSM_RANGE = 32;        // entries per accumulate lane: fewest (small MSMs), most
 constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 20;  // ... per lane pair of the extension-field kernel
 constexpr uint32_t FIN_SEQ = 16;      // a bucket spread over more accumulate lanes than this is summed by a workgroup
-constexpr int MSM_WS = 24;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
+constexpr int MSM_WS = 30;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
                                       // streams) + 6 per batch of proofs in flight (zk_groth16_prove_batch)
 
 // Sort-stage arrays of a launch over TWO base vectors with per-vector sorts (their identity bases differ) live in two
