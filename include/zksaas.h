@@ -421,6 +421,19 @@ int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* cr
                                 int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b,
                                 void* pi_c, void* stream);
 
+/* ---- host-pointer forms of the primitives (the reference's own signatures take and return host vectors: dfft/mod.rs:99,
+ * dmsm/mod.rs:59): the call stages its operands through device scratch (H2D, compute, D2H) and returns when the result is
+ * in host memory.  zk_d_fft_host: shares [n][m/l] in place, masks host [n][m/l] or NULL, inverse != 0 = d_ifft with the
+ * coset element g (Montgomery Fr, host, or NULL).  zk_msm_host / zk_d_msm_host: affine bases and scalars in host memory,
+ * results as zk_msm / zk_d_msm.  The device-pointer forms stay the fast path: a 2^20 d_fft moves 2 x 128 MiB over PCIe
+ * (~4.3 ms at 63 GB/s) around 0.87 ms of compute. */
+int zk_d_fft_host(zk_ctx* ctx, void* shares, const void* in_mask, const void* out_mask, int rearrange, int log2_m,
+                  int inverse, const void* g, uint64_t seed, void* stream);
+int zk_msm_host(zk_ctx* ctx, int group, const void* bases, size_t len_bases, const void* scalars, size_t len_scalars,
+                void* out, void* stream);
+int zk_d_msm_host(zk_ctx* ctx, int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                  const void* out_mask, void* out, void* stream);
+
 /* ---- per-kernel timing (measurement only) -----------------------------------------------------------------
  * When enabled, HIP events are recorded on the launching stream around the kernels of each slot; zk_profile_read
  * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the

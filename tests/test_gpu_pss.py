@@ -149,3 +149,53 @@ def test_field_arithmetic_edge_values(curve):
         xs = up(pp, a)
         zk.api.vec_scale(pp, xs, k, n)
         assert pp.download_fr(xs) == [x * k % p for x in a]
+
+
+
+def test_host_pointer_forms_equal_the_device_forms():
+    """zk_d_fft_host / zk_msm_host / zk_d_msm_host (operands and results in HOST memory, as the reference's own signatures)
+    give exactly what the device-pointer entry points give."""
+    import zksaas_amd as zk
+    from zksaas_amd.api import ZK_G1, msm
+    from zksaas_amd import groth16 as zg, wire
+    pp = ctx("bn254", 2)
+    log_m = 12
+    m = 1 << log_m
+    rng = np.random.default_rng(9)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    sh = rand(pp.n * (m // 2))
+    mask = zk.FftMask.sample(pp, False, None, 0, log_m, 31)
+    dev = zk.DeviceBuffer.from_numpy(pp, sh)
+    zk.d_fft(pp, dev, mask, False, log_m, seed=4)
+    host = sh.copy()
+    im, om = mask.in_mask.to_numpy().copy(), mask.out_mask.to_numpy().copy()
+    pp._check(pp.lib.zk_d_fft_host(pp.h, host.ctypes.data, im.ctypes.data, om.ctypes.data, 0, log_m, 0, None, 4, None))
+    assert np.array_equal(host.reshape(-1), dev.to_numpy().reshape(-1))
+    # d_ifft with the coset element, zero masks
+    g = zg._root_of_unity("bn254", log_m + 1)
+    dev = zk.DeviceBuffer.from_numpy(pp, sh)
+    zk.d_ifft(pp, dev, zk.FftMask.zero(), True, log_m, g=g, seed=5)
+    host = sh.copy()
+    garr = pp.fr.encode_one(g)
+    pp._check(pp.lib.zk_d_fft_host(pp.h, host.ctypes.data, None, None, 1, log_m, 1, garr.ctypes.data, 5, None))
+    assert np.array_equal(host.reshape(-1), dev.to_numpy().reshape(-1))
+    # msm / d_msm
+    ln = 300
+    bases_d = zg.base_points(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, rand(pp.n * ln)), pp.n * ln)
+    sc = rand(pp.n * ln)
+    bases_h = bases_d.to_numpy().copy()
+    want = msm(pp, ZK_G1, bases_d, zk.DeviceBuffer.from_numpy(pp, sc), pp.n * ln)
+    got = np.zeros_like(want)
+    pp._check(pp.lib.zk_msm_host(pp.h, ZK_G1, bases_h.ctypes.data, pp.n * ln, sc.ctypes.data, pp.n * ln, got.ctypes.data, None))
+    # the same group element; its Jacobian coordinates depend on the order buckets were summed in
+    assert wire.jacobian_to_affine(pp, got, False) == wire.jacobian_to_affine(pp, want, False)
+    want = zk.d_msm(pp, ZK_G1, bases_d, zk.DeviceBuffer.from_numpy(pp, sc), ln)
+    got = np.zeros_like(want)
+    pp._check(pp.lib.zk_d_msm_host(pp.h, ZK_G1, bases_h.ctypes.data, sc.ctypes.data, ln, None, None, got.ctypes.data, None))
+    got, want = got.reshape(pp.n, -1), np.asarray(want).reshape(pp.n, -1)
+    for i in range(pp.n):
+        assert wire.jacobian_to_affine(pp, got[i], False) == wire.jacobian_to_affine(pp, want[i], False)

@@ -222,6 +222,69 @@ int zk_d_msm(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d,
   return e->d_msm(group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
 }
 
+// ---- host-pointer forms: the reference's functions take and return host vectors (Vec<F>, Vec<G::Affine>); these
+// stage them through device scratch owned by the call (H2D, compute, D2H) so that a shim can be written without managing
+// device buffers.  The device-pointer forms above are the fast path (shares resident in HBM across calls).
+namespace {
+struct HostStage {
+  std::vector<void*> bufs;
+  ~HostStage() {
+    for (void* p : bufs) (void)hipFree(p);
+  }
+  void* up(IEngine* e, const void* h, size_t bytes, hipStream_t st, int* rc) {
+    void* d = nullptr;
+    if (*rc) return nullptr;
+    hipError_t he = hipMalloc(&d, bytes ? bytes : 1);
+    if (he == hipSuccess) bufs.push_back(d);
+    if (he == hipSuccess && h && bytes) he = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+    if (he != hipSuccess) *rc = e->hip_fail(he, "host staging");
+    return d;
+  }
+};
+}  // namespace
+int zk_d_fft_host(zk_ctx* ctx, void* shares /* host [n][m/l], in place */, const void* in_mask, const void* out_mask,
+                  int rearrange, int log2_m, int inverse, const void* g, uint64_t seed, void* stream) {
+  CTX_OR_FAIL();
+  if (!shares || log2_m < 0 || log2_m > 40) return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  const size_t bytes = (size_t)e->n * (((size_t)1 << log2_m) / (size_t)e->l) * e->fr_bytes();
+  HostStage hs;
+  int rc = ZK_OK;
+  void* sd = hs.up(e, shares, bytes, S(stream), &rc);
+  void* od = hs.up(e, nullptr, bytes, S(stream), &rc);
+  void* im = in_mask ? hs.up(e, in_mask, bytes, S(stream), &rc) : nullptr;
+  void* om = out_mask ? hs.up(e, out_mask, bytes, S(stream), &rc) : nullptr;
+  if (rc) return rc;
+  rc = e->d_fft(sd, im, om, rearrange, log2_m, inverse, g, seed, od, S(stream));
+  if (rc) return rc;
+  hipError_t he = hipMemcpyAsync(shares, od, bytes, hipMemcpyDeviceToHost, S(stream));
+  if (he == hipSuccess) he = hipStreamSynchronize(S(stream));
+  return he == hipSuccess ? ZK_OK : e->hip_fail(he, "host staging");
+}
+int zk_msm_host(zk_ctx* ctx, int group, const void* bases /* host affine [len] */, size_t len_bases, const void* scalars,
+                size_t len_scalars, void* out, void* stream) {
+  CTX_OR_FAIL();
+  if (group != ZK_G1 && group != ZK_G2) return e->fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
+  const size_t pb = 2 * e->fq_bytes() * (group == ZK_G2 ? 2 : 1);
+  HostStage hs;
+  int rc = ZK_OK;
+  void* bd = hs.up(e, bases, len_bases * pb, S(stream), &rc);
+  void* sd = hs.up(e, scalars, len_scalars * e->fr_bytes(), S(stream), &rc);
+  if (rc) return rc;
+  return e->msm(group, bd, len_bases, sd, len_scalars, out, S(stream));
+}
+int zk_d_msm_host(zk_ctx* ctx, int group, const void* bases /* host affine [n][len] */, const void* scalars /* [n][len] */,
+                  size_t len, const void* in_mask, const void* out_mask, void* out, void* stream) {
+  CTX_OR_FAIL();
+  if (group != ZK_G1 && group != ZK_G2) return e->fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
+  const size_t pb = 2 * e->fq_bytes() * (group == ZK_G2 ? 2 : 1);
+  HostStage hs;
+  int rc = ZK_OK;
+  void* bd = hs.up(e, bases, (size_t)e->n * len * pb, S(stream), &rc);
+  void* sd = hs.up(e, scalars, (size_t)e->n * len * e->fr_bytes(), S(stream), &rc);
+  if (rc) return rc;
+  return e->d_msm(group, bd, sd, len, in_mask, out_mask, out, S(stream));
+}
+
 int zk_d_msm_local(zk_ctx* ctx, int group, const void* bases_d, const void* scalars_d, size_t len, int first_party,
                    int nparties, const void* in_mask, void* out, void* stream) {
   CTX_OR_FAIL();
