@@ -335,8 +335,11 @@ int zk_groth16_reconstruct(zk_ctx* ctx, const void* pi_a, const void* pi_b, cons
                            int nparties, void* proof_affine, void* proof_bytes, void* stream);
 
 /* ---- the star network on one multi-GPU node (mpc-net/src/lib.rs:43-53, 89-176 `MpcNet`; ser_net.rs:16-120) -------
- * One process per GPU; rank rho drives the k = n / world parties [rho*k, (rho+1)*k) (party p -> rank p / k is the only
- * party -> device map supported; pass it as party_to_rank or NULL); the king (party 0) lives on rank 0.
+ * One process per GPU; rank rho drives k = n / world parties: with party_to_rank == NULL the block [rho*k, (rho+1)*k),
+ * otherwise the parties p with party_to_rank[p] == rho (MpcNet ids are arbitrary, lib.rs:43-53; any map that gives every
+ * rank k parties is accepted; a rank's rows are in ascending party order, zk_net_parties lists them).  The king's work is
+ * done by rank 0.  The king kernels always see the present parties' rows in ascending party order: with a
+ * non-contiguous map gather / scatter move party rows one by one, and the all-to-all king falls back to the star.
  * `sid` = MultiplexedStreamID: channels 0..2 may be in flight at once (ext_wit.rs:158-170), calls on one channel are
  * ordered (multi.rs:418-445); channel 3 is used internally by zk_dist_groth16_prove.
  * Transports: ZK_NET_RCCL (ncclSend / ncclRecv over xGMI on device buffers), ZK_NET_SHM (staged through POSIX shared
@@ -357,6 +360,7 @@ void zk_net_destroy(zk_net* net);
 const char* zk_net_last_error(zk_net* net, int* party);
 int zk_net_set_timeout_ms(zk_net* net, uint64_t ms);
 int zk_net_info(const zk_net* net, int info[4]);          /* rank, world, first party, parties per rank */
+int zk_net_parties(const zk_net* net, int rank, int* parties /* k ids, ascending */);
 int zk_net_stats(const zk_net* net, uint64_t stats[4]);   /* since creation: gathers, scatters, all-to-alls, bytes this rank sent */
 /* raw verbs (what the primitives below are made of; exposed for hosts that compose their own rounds).
  * zk_net_enter: join the next round on `sid`; *mask = ranks taking part.  gather = client_send_or_king_receive
@@ -406,6 +410,20 @@ int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, con
                           const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r, const void* s,
                           int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
                           void* stream);
+
+/* The sharded prover in two halves (the reference's parties are concurrent tasks, mpc-net/src/multi.rs:317-327, and
+ * prove.rs:209-227 joins the W and U d_msm): zk_dist_groth16_prove_async admits the proof, starts this rank's four witness
+ * MSMs, runs circom_h's king rounds on channels 0..2 and queues the U-MSM behind them -- it returns with that work
+ * enqueued; zk_dist_groth16_wait joins it, exchanges the five partial sums with the king on channel 3 and writes the k
+ * proof shares.  Up to TWO proofs may be in flight per rank; every rank must issue the same sequence of calls (the
+ * channels are ordered): async(A), async(B), wait(A), async(C), wait(B) ... overlaps a proof's king rounds with the
+ * previous proof's MSMs.  zk_dist_groth16_prove = async + wait.  Shares stay valid until the wait; masks are read at
+ * async time (the struct is copied, the rows it points to must stay valid until the wait). */
+int zk_dist_groth16_prove_async(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                                const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r,
+                                const void* s, int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* stream,
+                                int* handle);
+int zk_dist_groth16_wait(zk_ctx* ctx, zk_net* net, int handle, void* pi_a, void* pi_b, void* pi_c);
 
 /* Throughput mode of the sharded prover: nproofs (1..16) proofs per collective call -- what a service does with the
  * reference by running several dsha256 instances over one mesh (mpc-net/src/multi.rs:317-327; groth16/examples/

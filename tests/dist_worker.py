@@ -38,8 +38,16 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         pp.set_option("msm_bigsort_min", 0 if rank % 2 else 1 << 30)      # both sort paths across the ranks
         if a2a:
             pp.set_option("king_alltoall", 1)
-        net = znet.StarNet(pp, rank, world, net_id, transport, timeout_ms=1500 if scenario == "late" else 60000)
+        # "map": an arbitrary party -> rank map (MpcNet ids are arbitrary, mpc-net/src/lib.rs:43-53) instead of the blocks
+        pmap = None
+        if scenario == "map":
+            pmap = {2: [1, 0, 0, 1, 1, 0, 1, 0], 4: [3, 1, 0, 2, 2, 0, 1, 3]}[world]
+        net = znet.StarNet(pp, rank, world, net_id, transport, timeout_ms=1500 if scenario == "late" else 60000,
+                           party_to_rank=pmap)
         first, k, n = net.first, net.k, pp.n
+        sel = list(net.parties)          # this rank's parties = the rows of its buffers, in this order
+        if pmap is not None:
+            assert sel == [p for p in range(n) if pmap[p] == rank], sel
         eb = pp.fr.nbytes
         P = BN254.r
         G1, G2 = g1(BN254), g2(BN254)
@@ -51,13 +59,13 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
             return a
 
         def loc(arr, ln):            # this rank's rows of a full [n][ln] limb array, as a device buffer
-            return DeviceBuffer.from_numpy(pp, arr.reshape(n, ln, 4)[first:first + k])
+            return DeviceBuffer.from_numpy(pp, np.ascontiguousarray(arr.reshape(n, ln, 4)[sel]))
 
         def lmask(m, ln, cls):
-            return cls(mg.rows(m.in_mask, first, k, ln * eb), mg.rows(m.out_mask, first, k, ln * eb))
+            return cls(mg.rows_of(pp, m.in_mask, sel, ln * eb), mg.rows_of(pp, m.out_mask, sel, ln * eb))
 
         def same_rows(dev_local, dev_full, ln):
-            return np.array_equal(dev_local.to_numpy().reshape(k, ln, 4), dev_full.to_numpy().reshape(n, ln, 4)[first:first + k])
+            return np.array_equal(dev_local.to_numpy().reshape(k, ln, 4), dev_full.to_numpy().reshape(n, ln, 4)[sel])
 
         checks = {}
         if scenario == "late":
@@ -137,7 +145,7 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         num, den = rand_fr(2 * ln), rand_fr(2 * ln)
         ns, ds = pp.pack(DeviceBuffer.from_numpy(pp, num), ln, 60), pp.pack(DeviceBuffer.from_numpy(pp, den), ln, 61)
         ref = zk.d_pp(pp, ns, ds, dm, ln, seed=9)
-        got = znet.dist_d_pp(pp, net, 2, mg.rows(ns, first, k, ln * eb), mg.rows(ds, first, k, ln * eb),
+        got = znet.dist_d_pp(pp, net, 2, mg.rows_of(pp, ns, sel, ln * eb), mg.rows_of(pp, ds, sel, ln * eb),
                              lmask(dm, ln, DegRedMask), ln, seed=9)
         pp.sync()
         checks["d_pp"] = same_rows(got, ref, ln)
@@ -153,10 +161,10 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
             mm = MsmMask.sample(pp, grp, gen, 70 + int(is2))
             ref = zk.d_msm(pp, grp, bases, scal, ln, mm)
             w = gen.size * 8
-            got = znet.dist_d_msm(pp, net, 0, grp, mg.rows(bases, first, k, ln * w), mg.rows(scal, first, k, ln * eb), ln,
-                                  MsmMask(mm.in_mask[first:first + k], mm.out_mask[first:first + k]))
+            got = znet.dist_d_msm(pp, net, 0, grp, mg.rows_of(pp, bases, sel, ln * w), mg.rows_of(pp, scal, sel, ln * eb), ln,
+                                  MsmMask(mm.in_mask[sel], mm.out_mask[sel]))
             checks["d_msm_g%d" % (2 if is2 else 1)] = all(
-                Gp.eq(dec_jacobian(pp, got[p], is2), dec_jacobian(pp, ref[first + p], is2)) for p in range(k))
+                Gp.eq(dec_jacobian(pp, got[p], is2), dec_jacobian(pp, ref[sel[p]], is2)) for p in range(k))
         # ---- the prover, all twelve masks, small circuit
         r1, wv = small_r1cs()
         td = [rand_fp(42, i, P) for i in range(5)]
@@ -167,13 +175,13 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         r, s = rand_fp(43, 0, P), rand_fp(43, 1, P)
         for rr, mk in ((r, masks), (0, None)):
             ref = zg.prove(pp, crs, wit, rr, s, masks=mk, seed=9)
-            lcrs = mg.LocalCrs(pp, crs, first, k)
-            qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k)
-            mct, keep = mg.local_masks(pp, mk, wit.log_m, first, k)
+            lcrs = mg.LocalCrs(pp, crs, first, k, sel)
+            qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k, sel)
+            mct, keep = mg.local_masks(pp, mk, wit.log_m, first, k, sel)
             got = znet.dist_prove(pp, net, lcrs.ct, qap, a_sh, ax_sh, rr, s, wit.log_m, masks=mct, seed=9)
-            ok = all(G1.eq(dec_jacobian(pp, got[0][p]), dec_jacobian(pp, ref[0][first + p])) and
-                     G2.eq(dec_jacobian(pp, got[1][p], True), dec_jacobian(pp, ref[1][first + p], True)) and
-                     G1.eq(dec_jacobian(pp, got[2][p]), dec_jacobian(pp, ref[2][first + p])) for p in range(k))
+            ok = all(G1.eq(dec_jacobian(pp, got[0][p]), dec_jacobian(pp, ref[0][sel[p]])) and
+                     G2.eq(dec_jacobian(pp, got[1][p], True), dec_jacobian(pp, ref[1][sel[p]], True)) and
+                     G1.eq(dec_jacobian(pp, got[2][p]), dec_jacobian(pp, ref[2][sel[p]])) for p in range(k))
             checks["prove_%s" % ("masks" if mk else "r0")] = ok
         # ---- a BATCH of three proofs per collective call (zk_dist_groth16_prove_batch): different (r, s) and masks per
         # proof; every local share equals the one-context batch prover's
@@ -183,23 +191,37 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         rs_b[1] = 0
         mks_b = [zg.ProofMasks(pp, setup.log_m, seed=600 + 40 * b) for b in range(nbp)]
         refs = zg.prove_batch(pp, crs, [wit] * nbp, rs_b, ss_b, masks=mks_b, seed=21)
-        lcrs = mg.LocalCrs(pp, crs, first, k)
-        qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k)
-        lm = [mg.local_masks(pp, m_, wit.log_m, first, k) for m_ in mks_b]
+        lcrs = mg.LocalCrs(pp, crs, first, k, sel)
+        qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k, sel)
+        lm = [mg.local_masks(pp, m_, wit.log_m, first, k, sel) for m_ in mks_b]
         gots = znet.dist_prove_batch(pp, net, lcrs.ct, [qap] * nbp, [a_sh] * nbp, [ax_sh] * nbp, rs_b, ss_b, wit.log_m,
                                      masks=[x[0] for x in lm], seed=21)
         checks["prove_batch"] = all(
-            G1.eq(dec_jacobian(pp, gots[b][0][p]), dec_jacobian(pp, refs[b][0][first + p])) and
-            G2.eq(dec_jacobian(pp, gots[b][1][p], True), dec_jacobian(pp, refs[b][1][first + p], True)) and
-            G1.eq(dec_jacobian(pp, gots[b][2][p]), dec_jacobian(pp, refs[b][2][first + p]))
+            G1.eq(dec_jacobian(pp, gots[b][0][p]), dec_jacobian(pp, refs[b][0][sel[p]])) and
+            G2.eq(dec_jacobian(pp, gots[b][1][p], True), dec_jacobian(pp, refs[b][1][sel[p]], True)) and
+            G1.eq(dec_jacobian(pp, gots[b][2][p]), dec_jacobian(pp, refs[b][2][sel[p]]))
+            for b in range(nbp) for p in range(k))
+        # ---- two proofs in flight per rank (zk_dist_groth16_prove_async / _wait) equal the sequential ones
+        def fly(b):
+            return znet.dist_prove_async(pp, net, lcrs.ct, qap, a_sh, ax_sh, rs_b[b], ss_b[b], wit.log_m, masks=lm[b][0],
+                                         seed=21 + 16 * b)
+        # rolling window: A, B issued; A joined; C issued while B is in flight; B, C joined
+        fa, fb = fly(0), fly(1)
+        flown = [fa.wait()]
+        fc = fly(2)
+        flown += [fb.wait(), fc.wait()]
+        checks["prove_in_flight"] = all(
+            G1.eq(dec_jacobian(pp, flown[b][0][p]), dec_jacobian(pp, refs[b][0][sel[p]])) and
+            G2.eq(dec_jacobian(pp, flown[b][1][p], True), dec_jacobian(pp, refs[b][1][sel[p]], True)) and
+            G1.eq(dec_jacobian(pp, flown[b][2][p]), dec_jacobian(pp, refs[b][2][sel[p]]))
             for b in range(nbp) for p in range(k))
         # circom_h alone: shares identical to the all-in-one call
         h_ref = pp.alloc_fr(n * ((1 << wit.log_m) // 2))
         import ctypes as C
         pp._check(pp.lib.zk_circom_h(pp.h, wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr, wit.log_m, C.byref(masks.ct), 4,
                                      h_ref.ptr, None))
-        qap, _, _ = mg.local_witness(pp, wit, first, k)
-        mct, keep = mg.local_masks(pp, masks, wit.log_m, first, k)
+        qap, _, _ = mg.local_witness(pp, wit, first, k, sel)
+        mct, keep = mg.local_masks(pp, masks, wit.log_m, first, k, sel)
         h = znet.dist_circom_h(pp, net, qap, wit.log_m, masks=mct, seed=4)
         pp.sync()
         checks["circom_h"] = same_rows(h, h_ref, (1 << wit.log_m) // 2)

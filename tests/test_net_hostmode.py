@@ -30,7 +30,7 @@ def _dec(arr):
     return [sum(int(row[k]) << (64 * k) for k in range(4)) for row in np.asarray(arr).reshape(-1, 4)]
 
 
-def _d_fft_round(net, o, dom, sid, mask, mine_rows, rearrange, seed):
+def _d_fft_round(net, o, dom, sid, mask, mine_rows, rearrange, seed, present=None):
     """One king round of d_fft as zk_dist_d_fft performs it, oracle compute on host arrays."""
     from oracle import dist as od
     k, Lc = net.k, len(mine_rows[0])
@@ -39,7 +39,7 @@ def _d_fft_round(net, o, dom, sid, mask, mine_rows, rearrange, seed):
     net.gather(sid, mask, local, k * Lc * 32, full)
     out = np.zeros((o.n * Lc, 4), dtype=np.uint64) if net.rank == 0 else None
     if net.rank == 0:
-        parties = [r * k + p for r in range(net.world) if mask >> r & 1 for p in range(k)]
+        parties = present or [r * k + p for r in range(net.world) if mask >> r & 1 for p in range(k)]
         flat = _dec(full[: len(parties) * Lc])
         shares = [flat[i * Lc:(i + 1) * Lc] for i in range(len(parties))]
         res = od.king_fft2(shares, parties, rearrange, 1, o, dom.group_gen, seed)
@@ -67,11 +67,24 @@ def _worker(rank, world, net_id, scenario, q):
         y = list(x)
         bitrev_permute(y)
         shares = od.transpose(od.stride_pack(y, o, 2))          # all parties' inputs (every rank deals the same)
-        net = StarNet(None, rank, world, net_id, "shm", n_parties=o.n, shm_bytes=world * 1024,    # 1 KiB slots: chunked
-                      timeout_ms=400 if scenario != "flow" else 20000)
+        pmap = {2: [1, 0, 0, 1, 1, 0, 1, 0], 4: [3, 1, 0, 2, 2, 0, 1, 3]}[world] if scenario == "map" else None
+        net = StarNet(None, rank, world, net_id, "shm", n_parties=o.n,
+                      shm_bytes=world * (768 if pmap else 1024),       # 1 KiB (768 B: not a whole party row) slots: chunked
+                      timeout_ms=400 if scenario not in ("flow", "map") else 20000, party_to_rank=pmap)
         k, first = net.k, net.first
         ok = True
-        if scenario == "flow":
+        if scenario == "map":
+            # MpcNet ids are arbitrary (lib.rs:43-53): the king sees the rows in ascending party order, every rank gets
+            # the rows of ITS parties back, whatever the map
+            sel = net.parties
+            ok = sel == [p for p in range(o.n) if pmap[p] == rank] and first == sel[0]
+            mask = net.enter(0)
+            want = od.d_fft(shares, [od.FftMask.zero(Lc)] * o.n, False, dom, o, seed=3)
+            for rnd in range(2):
+                got = _d_fft_round(net, o, dom, 0, mask, [shares[p] for p in sel], False, 3, present=list(range(o.n)))
+                ok = ok and got == [want[p] for p in sel]
+            q.put((rank, bool(ok), ""))
+        elif scenario == "flow":
             # three channels entered together, their rounds interleaved as zk_dist_circom_h does
             masks = [net.enter(sid) for sid in range(3)]
             assert masks == [(1 << world) - 1] * 3
@@ -165,6 +178,11 @@ def test_star_rounds_over_shared_memory(world):
     _run(world, "flow")
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_arbitrary_party_to_rank_map(world):
+    _run(world, "map")
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_alltoall_over_shared_memory(world):
     _run(world, "a2a")
@@ -184,6 +202,8 @@ def test_net_create_rejects_bad_layouts():
         StarNet(None, 0, 3, StarNet.unique_id(), "shm", n_parties=8)      # 3 does not divide 8
     with pytest.raises(ZkError):
         StarNet(None, 0, 2, StarNet.unique_id(), "rccl", n_parties=8)     # RCCL needs a GPU context
+    with pytest.raises(ZkError):
+        StarNet(None, 0, 2, StarNet.unique_id(), "shm", n_parties=8, party_to_rank=[0, 0, 0, 0, 0, 1, 1, 1])   # 5 + 3
     net = StarNet(None, 0, 1, None, "local", n_parties=8)                 # world 1: local transport, no id needed
     assert (net.rank, net.world, net.first, net.k) == (0, 1, 0, 8)
     assert net.enter(0) == 1

@@ -458,14 +458,11 @@ int zk_net_create(zk_ctx* ctx, int transport, int rank, int world, int n_parties
   *out = nullptr;
   const int n = ctx ? ctx->eng->n : n_parties;
   if (n <= 0 || world <= 0 || n % world) return ZK_ERR_BAD_INPUT;
-  if (party_to_rank)       // only the contiguous map is supported: party p lives on rank p / (n / world)
-    for (int p = 0; p < n; p++)
-      if (party_to_rank[p] != p / (n / world)) return ZK_ERR_BAD_INPUT;
   if (ctx) (void)hipSetDevice(ctx->eng->device);
   zk_net* z = new (std::nothrow) zk_net();
   if (!z) return ZK_ERR_GENERIC;
   int rc = z->net.open(transport, rank, world, n, ctx ? ctx->eng->device : -1, ctx == nullptr, (const unsigned char*)id,
-                       shm_bytes);
+                       shm_bytes, party_to_rank);
   *out = z;               // kept on failure so that zk_net_last_error can be read; the caller destroys it
   return rc;
 }
@@ -486,6 +483,11 @@ int zk_net_info(const zk_net* net, int info[4]) {
   info[1] = net->net.world;
   info[2] = net->net.first_party(net->net.rank);
   info[3] = net->net.parties_per_rank();
+  return ZK_OK;
+}
+int zk_net_parties(const zk_net* net, int rank, int* parties) {
+  if (!net || !parties || rank < 0 || rank >= net->net.world) return ZK_ERR_BAD_INPUT;
+  for (int i = 0; i < net->net.parties_per_rank(); i++) parties[i] = net->net.party(rank, i);
   return ZK_OK;
 }
 int zk_net_enter(zk_net* net, int sid, uint32_t* mask) {
@@ -565,6 +567,21 @@ int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, con
   NET_OR_FAIL();
   return e->dist_prove(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed, pi_a,
                        pi_b, pi_c, S(stream));
+}
+
+int zk_dist_groth16_prove_async(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
+                                const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r,
+                                const void* s, int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* stream,
+                                int* handle) {
+  const int sid = 0;
+  NET_OR_FAIL();
+  return e->dist_prove_async(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
+                             S(stream), handle);
+}
+int zk_dist_groth16_wait(zk_ctx* ctx, zk_net* net, int handle, void* pi_a, void* pi_b, void* pi_c) {
+  const int sid = 0;
+  NET_OR_FAIL();
+  return e->dist_prove_wait(&net->net, handle, pi_a, pi_b, pi_c);
 }
 
 int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, int nproofs,

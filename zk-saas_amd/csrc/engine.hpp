@@ -283,6 +283,10 @@ class IEngine {
                          const void* a_share, const void* ax_share, const void* r, const void* s, int log_m,
                          const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c,
                          hipStream_t st) = 0;
+  virtual int dist_prove_async(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                               const void* a_share, const void* ax_share, const void* r, const void* s, int log_m,
+                               const zk_groth16_masks* masks, uint64_t seed, hipStream_t st, int* handle) = 0;
+  virtual int dist_prove_wait(Net* net, int handle, void* pi_a, void* pi_b, void* pi_c) = 0;
   virtual int dist_prove_batch(Net* net, const zk_crs_share* crs, int nb, const void* const* qa, const void* const* qb,
                                const void* const* qc, const void* const* a_share, const void* const* ax_share,
                                const void* r, const void* s, int log_m, const zk_groth16_masks* masks, uint64_t seed,

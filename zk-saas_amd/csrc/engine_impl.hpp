@@ -1,5 +1,6 @@
 // Engine<Cfg>: per-curve implementation of IEngine (included by exactly one .hip file per curve).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -269,7 +270,7 @@ class Engine : public IEngine {
     points(x, y, z);
     coef.assign(np, Fr::zero());
     if (np == n) {
-      coef = msm_.coef_h_;
+      coef.assign(msm_.coef_h_.begin(), msm_.coef_h_.begin() + n);
       return ZK_OK;
     }
     for (int kk = 0; kk < l; kk++)
@@ -2414,14 +2415,33 @@ class Engine : public IEngine {
     if (rc == ZK_OK) return rc;
     return fail(rc, "net: " + net->err, net->err_party);
   }
-  // parties of the ranks in `mask`, ascending
+  // parties of the ranks in `mask`, ascending (the row order the king sees, net.hpp)
   std::vector<uint32_t> parties_of(const Net* net, uint32_t mask) const {
     std::vector<uint32_t> ps;
     const int k = net->parties_per_rank();
     for (int r = 0; r < net->world; r++)
       if (mask & (1u << r))
-        for (int p = 0; p < k; p++) ps.push_back((uint32_t)(r * k + p));
+        for (int p = 0; p < k; p++) ps.push_back((uint32_t)net->party(r, p));
+    std::sort(ps.begin(), ps.end());
     return ps;
+  }
+  // Index of this rank's first party in the d_msm coefficient table.  The parties of a contiguous map are a range of
+  // the table; those of a general party_to_rank map are copied to the window behind its n entries (msm.hpp set_window),
+  // so that everything taking (first, count) works on either.
+  int local_window(Net* net, int* first) {
+    if (net->contiguous()) {
+      *first = net->first_party(net->rank);
+      return ZK_OK;
+    }
+    const int k = net->parties_per_rank();
+    std::vector<int> mine((size_t)k);
+    for (int i = 0; i < k; i++) mine[i] = net->party(net->rank, i);
+    for (int i = 0; i < NJOBS; i++)
+      if (jobs_[i].active && mine != msm_.window_) return fail(ZK_ERR_BAD_INPUT, "a proof over another party map is in flight");
+    int rc = msm_.set_window(this, mine);
+    if (rc) return rc;
+    *first = n;
+    return ZK_OK;
   }
   hipStream_t net_stream(Net* net, int sid, hipStream_t st) { return net->stream(sid) ? net->stream(sid) : st; }
 
@@ -2558,7 +2578,7 @@ class Engine : public IEngine {
     }
     const int scale = (inverse && !in_mask) ? 1 : 0;
     rc = A2A_NOT_APPLICABLE;
-    if (king_a2a_ && net->transport != ZK_NET_LOCAL) {
+    if (king_a2a_ && net->contiguous() && net->transport != ZK_NET_LOCAL) {
       const size_t kbk = (size_t)king_block(Lc);
       const size_t Wc = Lc < kbk ? Lc : kbk;
       const int log_lc = log_m - ilog2(l);
@@ -2615,7 +2635,7 @@ class Engine : public IEngine {
       if (rc) return rc;
     }
     rc = A2A_NOT_APPLICABLE;
-    if (king_a2a_ && net->transport != ZK_NET_LOCAL)
+    if (king_a2a_ && net->contiguous() && net->transport != ZK_NET_LOCAL)
       rc = king_round_a2a(
           net, sid, mask, x, len, 1, 0u,
           [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const A2aPlan& pl, hipStream_t ks) {
@@ -2693,9 +2713,12 @@ class Engine : public IEngine {
   template <class Fld>
   int dist_d_msm_t(Net* net, int sid, const void* bases, const void* scalars, size_t len, const void* in_mask,
                    const void* out_mask, void* out, hipStream_t st) {
-    const int k = net->parties_per_rank(), first = net->first_party(net->rank);
+    const int k = net->parties_per_rank();
+    int first = 0;
     uint32_t mask = 0;
     int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = local_window(net, &first);
     if (rc) return rc;
     // coefficients of my parties in the king's linear form; they depend on who takes part (pss.rs:170-221)
     const Fr* cd = msm_.coef_d_ + first;
@@ -2705,9 +2728,12 @@ class Engine : public IEngine {
       std::vector<Fr> coef;
       rc = coefs_for(ps.data(), (int)ps.size(), coef);
       if (rc) return rc;
-      size_t pos = 0;
-      while (pos < ps.size() && ps[pos] != (uint32_t)first) pos++;
-      csub.assign(coef.begin() + pos, coef.begin() + pos + k);
+      csub.resize((size_t)k);
+      for (int i = 0; i < k; i++) {
+        size_t pos = 0;
+        while (pos < ps.size() && ps[pos] != (uint32_t)net->party(net->rank, i)) pos++;
+        csub[i] = coef[pos];
+      }
       ZK_HIP(dist_coef_[sid].ensure(k * sizeof(Fr)));
       ZK_HIP(hipMemcpy(dist_coef_[sid].p, csub.data(), k * sizeof(Fr), hipMemcpyHostToDevice));
       cd = (const Fr*)dist_coef_[sid].p;
@@ -2755,11 +2781,12 @@ class Engine : public IEngine {
   // circom_h (ext_wit.rs:104-181): the three d_ifft, then the three d_fft, each triple in flight together on channels
   // 0..2 (ext_wit.rs:158-170 joins them); then a*b - c and deg_red on channel 0.  masks: LOCAL rows.
   int dist_circom_h_on(Net* net, const uint32_t* cmask, const void* qa, const void* qb, const void* qc, int log_m,
-                       const zk_groth16_masks* mk, uint64_t seed, void* h, hipStream_t st) {
+                       const zk_groth16_masks* mk, uint64_t seed, void* h, hipStream_t st, DevBuf* wb = nullptr) {
     const int k = net->parties_per_rank();
     const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
-    ZK_HIP(dist_w0_.ensure(3 * per * sizeof(Fr)));
-    Fr* W = (Fr*)dist_w0_.p;
+    if (!wb) wb = &dist_w0_;
+    ZK_HIP(wb->ensure(3 * per * sizeof(Fr)));
+    Fr* W = (Fr*)wb->p;
     const void* q[3] = {qa, qb, qc};
     for (int j = 0; j < 3; j++) ZK_HIP(hipMemcpyAsync(W + j * per, q[j], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     Fr w2m = root_of_unity(log_m + 1);
@@ -2817,14 +2844,40 @@ class Engine : public IEngine {
     return dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, h, st);
   }
 
-  // dsha256 per rank (sha256.rs:32-129): all shares and masks are this rank's k parties' rows; pi_*: k Jacobian points
-  int dist_prove(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
-                 const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
-                 uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
+  // dsha256 per rank (sha256.rs:32-129): all shares and masks are this rank's k parties' rows; pi_*: k Jacobian points.
+  // Two halves, so that a rank can keep NJOBS proofs in flight (the reference's parties are concurrent tasks,
+  // mpc-net/src/multi.rs:317-327; prove.rs:209-227 joins the W and U d_msm):
+  //   dist_prove_async  admits the proof on the control plane, starts the four witness MSMs on the job's streams, runs
+  //                     circom_h's king rounds over channels 0..2 and queues the U-MSM behind them; returns with all of
+  //                     that ENQUEUED (the host only waited for the peers' staging ticks);
+  //   dist_prove_wait   joins the MSMs, sends this rank's five partial sums to the king on channel 3 (d_msm's king step
+  //                     for all five products in one message, dmsm/mod.rs:76-92) and assembles the k proof shares.
+  // Every rank issues the same sequence of calls (channels are ordered, multi.rs:418-445): async(A), async(B), wait(A),
+  // wait(B) overlaps B's king rounds with A's MSMs.
+  struct DistJob {
+    bool active = false;
+    int k = 0;
+    uint32_t cmask3 = 0;
+  };
+  DistJob djobs_[NJOBS];
+  DevBuf dist_wj_[NJOBS], dist_hj_[NJOBS];
+  int dist_prove_async(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                       const void* a_share, const void* ax_share, const void* r_, const void* s_, int log_m,
+                       const zk_groth16_masks* mk, uint64_t seed, hipStream_t st, int* handle) override {
     int rc = check_prove_args(crs, r_, s_, log_m);
     if (rc) return rc;
-    if (!qa || !qb || !qc || !a_share || !ax_share || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    const int k = net->parties_per_rank(), first = net->first_party(net->rank);
+    if (!qa || !qb || !qc || !a_share || !ax_share || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int slot = -1;
+    for (int i = 0; i < NJOBS; i++)
+      if (!jobs_[i].active && !djobs_[i].active) {
+        slot = i;
+        break;
+      }
+    if (slot < 0) return fail(ZK_ERR_BAD_INPUT, "too many proofs in flight (zk_dist_groth16_wait one first)");
+    const int k = net->parties_per_rank();
+    int first = 0;
+    rc = local_window(net, &first);
+    if (rc) return rc;
     const size_t Lc = ((size_t)1 << log_m) / l;
     uint32_t cmask[NET_NSID];
     for (int j = 0; j < NET_NSID; j++) {
@@ -2835,9 +2888,8 @@ class Engine : public IEngine {
       if (cmask[j] != net->full_mask())
         return fail(ZK_ERR_PROTOCOL, "a party did not show up for the proof (timed out)", -1);
     Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
-    ProveJob& j = jobs_[0];
-    if (j.active) return fail(ZK_ERR_BAD_INPUT, "a proof is already in flight");
-    j.slot = 0;
+    ProveJob& j = jobs_[slot];
+    j.slot = slot;
     // the four MSMs over the witness shares start now and overlap the king rounds of circom_h (prove.rs try_join!)
     rc = prove_begin(j, crs, nullptr, nullptr, nullptr, a_share, ax_share, r, s, log_m, mk, seed, false, first, k, st);
     auto bail = [&](int code) {
@@ -2848,23 +2900,34 @@ class Engine : public IEngine {
     };
     if (rc) return bail(rc);
     {
-      hipError_t he = dist_h_.ensure((size_t)k * Lc * sizeof(Fr));
+      hipError_t he = dist_hj_[slot].ensure((size_t)k * Lc * sizeof(Fr));
       if (he != hipSuccess) return bail(hip_fail(he, "h share buffer"));
     }
-    rc = dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, dist_h_.p, st);
+    rc = dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, dist_hj_[slot].p, st, &dist_wj_[slot]);
     if (rc) return bail(rc);
-    rc = prove_launch_u(j, dist_h_.p, st);
+    rc = prove_launch_u(j, dist_hj_[slot].p, st);
     if (rc) return bail(rc);
+    djobs_[slot].active = true;
+    djobs_[slot].k = k;
+    djobs_[slot].cmask3 = cmask[3];
+    *handle = slot;
+    return ZK_OK;
+  }
+  int dist_prove_wait(Net* net, int handle, void* pi_a, void* pi_b, void* pi_c) override {
+    if (handle < 0 || handle >= NJOBS || !djobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no sharded proof in flight on this handle");
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    ProveJob& j = jobs_[handle];
+    DistJob& d = djobs_[handle];
+    d.active = false;
     struct Sums {
       P1 S, H, W, U;
       P2 V;
     } mine, total;
-    rc = prove_join(j, &mine.S, &mine.H, &mine.V, &mine.W, &mine.U);
+    int rc = prove_join(j, &mine.S, &mine.H, &mine.V, &mine.W, &mine.U);
     if (rc) return rc;
-    // d_msm's king step for the five products at once: one small message per rank (dmsm/mod.rs:76-92)
     static_assert(sizeof(Sums) <= NET_PAYLOAD, "payload");
     std::vector<Sums> all((size_t)net->world);
-    rc = net_err(net, net->gather_host(3, cmask[3], &mine, sizeof(mine), all.data()));
+    rc = net_err(net, net->gather_host(3, d.cmask3, &mine, sizeof(mine), all.data()));
     if (rc) return rc;
     total = mine;
     if (net->rank == 0)
@@ -2875,9 +2938,19 @@ class Engine : public IEngine {
         total.W = xyzz_add_ni(total.W, all[rr].W);
         total.U = xyzz_add_ni(total.U, all[rr].U);
       }
-    rc = net_err(net, net->bcast_host(3, cmask[3], &total, sizeof(total)));
+    rc = net_err(net, net->bcast_host(3, d.cmask3, &total, sizeof(total)));
     if (rc) return rc;
-    return assemble_points(crs, r, s, total.S, total.H, total.V, total.W, total.U, mk, k, pi_a, pi_b, pi_c);
+    return assemble_points(&j.crs, j.r, j.s, total.S, total.H, total.V, total.W, total.U, j.has_mk ? &j.mk : nullptr, d.k, pi_a,
+                           pi_b, pi_c);
+  }
+  int dist_prove(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
+                 const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
+                 uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int h = -1;
+    int rc = dist_prove_async(net, crs, qa, qb, qc, a_share, ax_share, r_, s_, log_m, mk, seed, st, &h);
+    if (rc) return rc;
+    return dist_prove_wait(net, h, pi_a, pi_b, pi_c);
   }
 
   // A batch of proofs per rank (zk_dist_groth16_prove_batch): the throughput mode of the sharded prover.  One round of
@@ -2894,10 +2967,12 @@ class Engine : public IEngine {
     if (nb < 1 || nb > MAX_PROOF_BATCH) return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MAX_PROOF_BATCH));
     for (int b = 0; b < nb; b++)
       if (!qa[b] || !qb[b] || !qc[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    const int k = net->parties_per_rank(), first = net->first_party(net->rank);
+    const int k = net->parties_per_rank();
+    int first = 0;
     const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
     uint32_t cmask[NET_NSID];
-    int rc;
+    int rc = local_window(net, &first);
+    if (rc) return rc;
     for (int j = 0; j < NET_NSID; j++) {
       rc = net_err(net, net->enter(j, &cmask[j]));
       if (rc) return rc;

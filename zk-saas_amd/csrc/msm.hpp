@@ -1421,13 +1421,32 @@ class MsmRunner {
   }
 
   // coef_p = sum_k U2[k][p]  (set by the engine once the PSS matrices exist)
+  // The table has 2 n entries: [0, n) by party id, [n, 2 n) the window of set_window.
   int set_coefs(IEngine* eng, const std::vector<Fr>& coef) {
     coef_h_ = coef;
+    coef_h_.resize(2 * coef.size(), Fr::zero());
+    window_.clear();
     if (coef_d_) (void)hipFree(coef_d_);
-    hipError_t e = hipMalloc((void**)&coef_d_, coef.size() * sizeof(Fr));
+    hipError_t e = hipMalloc((void**)&coef_d_, coef_h_.size() * sizeof(Fr));
     if (e != hipSuccess) return eng->hip_fail(e, "hipMalloc coef");
-    e = hipMemcpy(coef_d_, coef.data(), coef.size() * sizeof(Fr), hipMemcpyHostToDevice);
+    e = hipMemcpy(coef_d_, coef_h_.data(), coef_h_.size() * sizeof(Fr), hipMemcpyHostToDevice);
     if (e != hipSuccess) return eng->hip_fail(e, "hipMemcpy coef");
+    return ZK_OK;
+  }
+  // window [n, n + parties.size()) = the coefficients of an arbitrary party list (a rank's parties under a general
+  // party -> rank map): callers then address them as the range (first = n, count)
+  std::vector<int> window_;
+  int set_window(IEngine* eng, const std::vector<int>& parties) {
+    if (parties == window_) return ZK_OK;
+    const size_t nn = coef_h_.size() / 2;
+    if (!coef_d_ || parties.size() > nn) return eng->fail(ZK_ERR_BAD_INPUT, "bad party window");
+    for (size_t i = 0; i < parties.size(); i++) {
+      if (parties[i] < 0 || (size_t)parties[i] >= nn) return eng->fail(ZK_ERR_BAD_INPUT, "bad party id");
+      coef_h_[nn + i] = coef_h_[(size_t)parties[i]];
+    }
+    hipError_t e = hipMemcpy(coef_d_ + nn, coef_h_.data() + nn, parties.size() * sizeof(Fr), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return eng->hip_fail(e, "hipMemcpy coef window");
+    window_ = parties;
     return ZK_OK;
   }
   ~MsmRunner() {

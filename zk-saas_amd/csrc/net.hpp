@@ -5,7 +5,10 @@
 // otherwise reports the peer as timed out), :137-176 `client_receive_or_king_send` (the king sends each party ITS
 // OWN answer, equal lengths enforced), and mpc-net/src/ser_net.rs:16-120 (the serialising wrappers; `Partial`
 // results when some parties are missing, ser_net.rs:57-94).  One process drives one GPU and the k = n / world
-// parties mapped to it (contiguous blocks; the king = party 0 lives on rank 0).
+// parties mapped to it: by default the contiguous blocks (party p on rank p / k), or any balanced `party_to_rank` map
+// (MpcNet ids are arbitrary, lib.rs:43-53).  The king's work is done by rank 0, whichever parties it holds.  The king
+// always sees the rows of the parties present in ASCENDING PARTY ORDER and answers with one row per party id, so the
+// king kernels do not know the map: with a non-contiguous map gather / scatter move party rows one by one.
 //
 // Two planes:
 //   control  a small POSIX shared-memory block (all ranks are on one node): per channel an arrival word per rank, the
@@ -138,12 +141,15 @@ class Net {
   ~Net() { close(); }
 
   int parties_per_rank() const { return n / world; }
-  int first_party(int r) const { return r * parties_per_rank(); }
+  // party held in row i of rank r's buffers (rows of a rank are in ascending party order)
+  int party(int r, int i) const { return contig_ ? r * parties_per_rank() + i : slot_party_[(size_t)r * parties_per_rank() + i]; }
+  int first_party(int r) const { return party(r, 0); }
+  bool contiguous() const { return contig_; }
 
   // id: NET_NSID RCCL unique ids (RCCL transport) or any 128-byte tag shared by the ranks (first 16 bytes name the
   // shared-memory block)
   int open(int transport_, int rank_, int world_, int n_, int device_, bool host_mode_, const unsigned char* id,
-           size_t shm_bytes_per_chan) {
+           size_t shm_bytes_per_chan, const int* party_to_rank = nullptr) {
     transport = transport_;
     rank = rank_;
     world = world_;
@@ -151,6 +157,20 @@ class Net {
     device = device_;
     host_mode = host_mode_;
     if (world < 1 || world > NET_MAXR || rank < 0 || rank >= world || n % world) return fail("bad rank / world size (world must divide n)");
+    if (party_to_rank) {
+      const int k = n / world;
+      if (n > NET_MAXR * 64) return fail("too many parties for a party_to_rank map", ZK_ERR_BAD_INPUT);
+      std::vector<int> cnt((size_t)world, 0);
+      slot_party_.assign((size_t)n, -1);
+      contig_ = true;
+      for (int p = 0; p < n; p++) {
+        const int r = party_to_rank[p];
+        if (r < 0 || r >= world || cnt[r] >= k) return fail("party_to_rank must map n / world parties to every rank", ZK_ERR_BAD_INPUT);
+        slot_party_[(size_t)r * k + cnt[r]++] = p;
+        if (r != p / k) contig_ = false;
+      }
+      if (contig_) slot_party_.clear();
+    }
     if (world == 1 && transport != ZK_NET_RCCL) transport = ZK_NET_LOCAL;
     if (transport == ZK_NET_LOCAL) {
       if (world != 1) return fail("the local transport needs world = 1");
@@ -291,6 +311,16 @@ class Net {
     return ZK_OK;
   }
   uint32_t full_mask() const { return world >= 32 ? 0xffffffffu : ((1u << world) - 1); }
+  // pos[p] = index of party p among the parties of the ranks in `mask`, ascending by party id
+  void row_positions(uint32_t mask, int* pos) const {
+    const int k = parties_per_rank();
+    bool here[NET_MAXR * 64] = {};
+    for (int r = 0; r < world; r++)
+      if (mask & (1u << r))
+        for (int i = 0; i < k; i++) here[party(r, i)] = true;
+    int c = 0;
+    for (int p = 0; p < n; p++) pos[p] = here[p] ? c++ : -1;
+  }
 
   // ---- data plane.  bytes = bytes PER RANK (k parties' rows); the king's `full` holds the present ranks' blocks
   // compacted in rank order (so that a dropout leaves the [np][len] layout the king kernels take).
@@ -302,6 +332,33 @@ class Net {
     stats[0]++;
     if (rank != 0) stats[3] += bytes;
     if (transport == ZK_NET_LOCAL) return copy_dd(full, local, bytes, sid);
+    const int k = parties_per_rank();
+    const size_t rb = bytes / (size_t)k;                 // bytes of one party row (general maps move rows)
+    int pos[NET_MAXR * 64];
+    if (!contig_) {
+      if (bytes % (size_t)k) return fail("with a party_to_rank map the block must be k equal party rows", ZK_ERR_BAD_INPUT);
+      row_positions(mask, pos);
+    }
+    if (transport == ZK_NET_RCCL && !contig_) {
+      Rccl& R = Rccl::inst();
+      int rc = R.GroupStart();
+      for (int r = 0; r < world && !rc; r++) {
+        if (!(mask & (1u << r)) || (rank != 0 && r != rank)) continue;
+        for (int i = 0; i < k && !rc; i++) {
+          const char* src = (const char*)local + (size_t)i * rb;
+          if (rank != 0) {
+            rc = R.Send(src, rb, 1, 0, comm_[sid], stream_[sid]);
+            continue;
+          }
+          char* dst = (char*)full + (size_t)pos[party(r, i)] * rb;
+          if (r == 0) rc = hipMemcpyAsync(dst, src, rb, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          else rc = R.Recv(dst, rb, 1, r, comm_[sid], stream_[sid]);
+        }
+      }
+      int rc2 = R.GroupEnd();
+      if (rc || rc2) return rccl_fail(rc ? rc : rc2, "gather");
+      return ZK_OK;
+    }
     if (transport == ZK_NET_RCCL) {
       Rccl& R = Rccl::inst();
       int rc = R.GroupStart();
@@ -336,7 +393,16 @@ class Net {
         for (int r = 0; r < world; r++) {
           if (!(mask & (1u << r))) continue;
           if (!wait_ge(c.rank_tick[r], t, "peer (gather)")) return ZK_ERR_NOT_CONNECTED;
-          if (int rc = copy_in((char*)full + (size_t)slot * bytes + off, data_[sid] + (size_t)r * cap_, len, sid)) return rc;
+          if (contig_) {
+            if (int rc = copy_in((char*)full + (size_t)slot * bytes + off, data_[sid] + (size_t)r * cap_, len, sid)) return rc;
+          } else {
+            for (size_t o = off; o < off + len;) {        // the chunk, cut at party-row boundaries
+              const size_t row = o / rb, in = o % rb, pl = rb - in < off + len - o ? rb - in : off + len - o;
+              if (int rc = copy_in((char*)full + (size_t)pos[party(r, (int)row)] * rb + in, data_[sid] + (size_t)r * cap_ + (o - off), pl, sid))
+                return rc;
+              o += pl;
+            }
+          }
           slot++;
         }
         if (int rc = sync(sid)) return rc;
@@ -352,6 +418,29 @@ class Net {
     stats[1]++;
     if (rank == 0) stats[3] += bytes * (size_t)(__builtin_popcount(mask) - 1);
     if (transport == ZK_NET_LOCAL) return copy_dd(local, full, bytes, sid);
+    const int k = parties_per_rank();
+    const size_t rb = bytes / (size_t)k;
+    if (!contig_ && bytes % (size_t)k) return fail("with a party_to_rank map the block must be k equal party rows", ZK_ERR_BAD_INPUT);
+    if (transport == ZK_NET_RCCL && !contig_) {
+      Rccl& R = Rccl::inst();
+      int rc = R.GroupStart();
+      for (int r = 0; r < world && !rc; r++) {
+        if (!(mask & (1u << r)) || (rank != 0 && r != rank)) continue;
+        for (int i = 0; i < k && !rc; i++) {
+          char* dst = (char*)local + (size_t)i * rb;
+          if (rank != 0) {
+            rc = R.Recv(dst, rb, 1, 0, comm_[sid], stream_[sid]);
+            continue;
+          }
+          const char* src = (const char*)full + (size_t)party(r, i) * rb;     // the king's output is [n][len] by party id
+          if (r == 0) rc = hipMemcpyAsync(dst, src, rb, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          else rc = R.Send(src, rb, 1, r, comm_[sid], stream_[sid]);
+        }
+      }
+      int rc2 = R.GroupEnd();
+      if (rc || rc2) return rccl_fail(rc ? rc : rc2, "scatter");
+      return ZK_OK;
+    }
     if (transport == ZK_NET_RCCL) {
       Rccl& R = Rccl::inst();
       int rc = R.GroupStart();
@@ -380,7 +469,16 @@ class Net {
         }
         for (int r = 0; r < world; r++) {
           if (!(mask & (1u << r))) continue;
-          if (int rc = copy_out(data_[sid] + (size_t)r * cap_, (const char*)full + (size_t)r * bytes + off, len, sid)) return rc;
+          if (contig_) {
+            if (int rc = copy_out(data_[sid] + (size_t)r * cap_, (const char*)full + (size_t)r * bytes + off, len, sid)) return rc;
+          } else {
+            for (size_t o = off; o < off + len;) {
+              const size_t row = o / rb, in = o % rb, pl = rb - in < off + len - o ? rb - in : off + len - o;
+              if (int rc = copy_out_async(data_[sid] + (size_t)r * cap_ + (o - off), (const char*)full + (size_t)party(r, (int)row) * rb + in, pl, sid))
+                return rc;
+              o += pl;
+            }
+          }
           last_s_[sid][r] = t;
         }
         if (int rc = sync(sid)) return rc;
@@ -655,6 +753,8 @@ class Net {
   }
 
   std::string name_;
+  std::vector<int> slot_party_;           // [world][k] party ids of a non-contiguous map
+  bool contig_ = true;
   NetCtl* ctl_ = nullptr;
   char* data_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};
   char* adata_[NET_NSID] = {nullptr, nullptr, nullptr, nullptr};     // all-to-all staging (own segment: no slot is shared

@@ -30,16 +30,27 @@ def rows(buf, first, k, row_bytes):
     return buf.view(first * row_bytes, k * row_bytes)
 
 
+def rows_of(pp, buf, parties, row_bytes):
+    """the rows of the listed parties of a party-major device buffer [n][row]: a view when they are a contiguous range,
+    otherwise a new buffer (setup-time copy through the host; a rank's parties under a general party_to_rank map)"""
+    parties = [int(p) for p in parties]
+    if parties == list(range(parties[0], parties[0] + len(parties))):
+        return rows(buf, parties[0], len(parties), row_bytes)
+    full = buf.to_numpy(np.uint8).reshape(-1, row_bytes)
+    return DeviceBuffer.from_numpy(pp, np.ascontiguousarray(full[parties]))
+
+
 class LocalCrs:
     """zk_crs_share over this rank's rows of a full PackedProvingKeyShare dealing (views, no copies)."""
 
-    def __init__(self, pp, crs, first, k):
+    def __init__(self, pp, crs, first, k, parties=None):
         e1, e2 = 2 * pp.fq.nbytes, 4 * pp.fq.nbytes
-        self.s = rows(crs.s, first, k, crs.len_a * e1)
-        self.h = rows(crs.h, first, k, crs.len_a * e1)
-        self.v = rows(crs.v, first, k, crs.len_a * e2)
-        self.w = rows(crs.w, first, k, crs.len_w * e1)
-        self.u = rows(crs.u, first, k, crs.len_u * e1)
+        ps = list(range(first, first + k)) if parties is None else parties
+        self.s = rows_of(pp, crs.s, ps, crs.len_a * e1)
+        self.h = rows_of(pp, crs.h, ps, crs.len_a * e1)
+        self.v = rows_of(pp, crs.v, ps, crs.len_a * e2)
+        self.w = rows_of(pp, crs.w, ps, crs.len_w * e1)
+        self.u = rows_of(pp, crs.u, ps, crs.len_u * e1)
         self.len_a, self.len_w, self.len_u, self.k = crs.len_a, crs.len_w, crs.len_u, k
         s1, s2 = crs.s1, crs.s2
         self._keep = (crs, s1, s2)
@@ -54,31 +65,33 @@ class LocalCrs:
             api.msm_precompute(pp, grp, buf, self.k * ln)
 
 
-def local_witness(pp, wit, first, k):
+def local_witness(pp, wit, first, k, parties=None):
     eb = pp.fr.nbytes
     Lc = (1 << wit.log_m) // pp.l
-    qap = [rows(q, first, k, Lc * eb) for q in wit.qap]
-    return qap, rows(wit.a_share, first, k, wit.len_a * eb), rows(wit.ax_share, first, k, wit.len_w * eb)
+    ps = list(range(first, first + k)) if parties is None else parties
+    qap = [rows_of(pp, q, ps, Lc * eb) for q in wit.qap]
+    return qap, rows_of(pp, wit.a_share, ps, wit.len_a * eb), rows_of(pp, wit.ax_share, ps, wit.len_w * eb)
 
 
-def local_masks(pp, masks, log_m, first, k):
+def local_masks(pp, masks, log_m, first, k, parties=None):
     """zk_groth16_masks over this rank's rows of a ProofMasks dealing; returns (struct, keep-alive list)"""
     if masks is None:
         return None, None
     eb = pp.fr.nbytes
     Lc = (1 << log_m) // pp.l
+    ps = list(range(first, first + k)) if parties is None else [int(p) for p in parties]
     keep = []
     ct = zg.Masks()
     for i in range(6):
-        a, b = rows(masks.fft[i].in_mask, first, k, Lc * eb), rows(masks.fft[i].out_mask, first, k, Lc * eb)
+        a, b = rows_of(pp, masks.fft[i].in_mask, ps, Lc * eb), rows_of(pp, masks.fft[i].out_mask, ps, Lc * eb)
         keep += [a, b]
         ct.fft_in[i], ct.fft_out[i] = a.ptr, b.ptr
-    a, b = rows(masks.degred.in_mask, first, k, Lc * eb), rows(masks.degred.out_mask, first, k, Lc * eb)
+    a, b = rows_of(pp, masks.degred.in_mask, ps, Lc * eb), rows_of(pp, masks.degred.out_mask, ps, Lc * eb)
     keep += [a, b]
     ct.degred_in, ct.degred_out = a.ptr, b.ptr
     for i in range(5):
-        a = np.ascontiguousarray(masks.msm[i].in_mask[first:first + k])
-        b = np.ascontiguousarray(masks.msm[i].out_mask[first:first + k])
+        a = np.ascontiguousarray(masks.msm[i].in_mask[ps])
+        b = np.ascontiguousarray(masks.msm[i].out_mask[ps])
         keep += [a, b]
         ct.msm_in[i], ct.msm_out[i] = a.ctypes.data, b.ctypes.data
     return ct, keep
@@ -334,9 +347,45 @@ def bench(args, rank, local_rank, world):
             batched = {"batch": nbp, "batches": nbat, "proofs_per_s": round(nbp * nbat / bdt, 2),
                        "ms_per_proof": round(bdt / (nbp * nbat) * 1e3, 4), "same_proof": bool(int(flag.item())),
                        "api": "zk_dist_groth16_prove_batch"}
+        # two proofs in flight per rank (zk_dist_groth16_prove_async / _wait): a proof's king rounds overlap the
+        # previous proof's MSMs.  Rolling window over 2 * steps proofs, every rank in the same order.
+        in_flight = None
+        if not os.environ.get("ZK_BENCH_NO_BATCH"):
+            nfl = max(4, 2 * args.steps)
+
+            def fly(i):
+                return znet.dist_prove_async(pp, net, lcrs.ct, qap, a_sh, ax_sh, r, s, wit.log_m, masks=mct, seed=7000 + i)
+            fly(0).wait()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            prev, last = fly(0), None
+            for i in range(1, nfl):
+                cur = fly(i)
+                last = prev.wait()
+                prev = cur
+            last = prev.wait()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            fdt = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([fdt], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                fdt = float(tt.item())
+            from . import wire
+            eq = all(wire.jacobian_to_affine(pp, last[kk][q_], g2) == wire.jacobian_to_affine(pp, out["proof"][kk][q_], g2)
+                     for kk, g2 in ((0, False), (1, True), (2, False)) for q_ in range(k))
+            flag = torch.tensor([1 if eq else 0], dtype=torch.int32)
+            if dist is not None:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            in_flight = {"proofs_in_flight_per_rank": 2, "proofs": nfl, "proofs_per_s": round(nfl / fdt, 2),
+                         "ms_per_proof": round(fdt / nfl * 1e3, 4), "same_proof": bool(int(flag.item())),
+                         "api": "zk_dist_groth16_prove_async / zk_dist_groth16_wait"}
         proofs_per_s = args.steps / dt
         res = dict(base, metric="Groth16 proofs/sec (SHA-256 circuit)", value=round(proofs_per_s, 3), unit="proofs/s",
-                   batched=batched,
+                   batched=batched, in_flight=in_flight,
                    ms_per_step=round(per(dt) * 1e3, 4), scaling="strong",
                    data="synthetic: SHA-256(a=1,b=2) circuit rebuilt from its semantics and padded to the reference "
                         "fixture's 29 823 wires, seeded trapdoor CRS, seeded shares and masks",

@@ -1,5 +1,6 @@
 """Host-side mirror of the reference's `MpcNet` star (mpc-net/src/lib.rs:43-53, 89-176; ser_net.rs) over the C ABI
-(include/zksaas.h "the star network"): one process per GPU, rank rho drives parties [rho*k, (rho+1)*k), king = rank 0.
+(include/zksaas.h "the star network"): one process per GPU, rank rho drives k = n / world parties -- the block
+[rho*k, (rho+1)*k) or, with `party_to_rank`, the parties mapped to it (`net.parties`, ascending); king = rank 0.
 
     net = StarNet(pp, rank, world, net_id, transport="rccl")     # collective: every rank constructs it
     dist_d_fft(pp, net, sid, shares_local, FftMask.zero(), rearrange, log_m)   # == d_fft(.., &net, sid)
@@ -19,14 +20,17 @@ ID_BYTES = 512
 
 
 class StarNet:
-    def __init__(self, pp, rank, world, net_id=None, transport="rccl", n_parties=None, shm_bytes=0, timeout_ms=None):
-        """pp = None: host-memory mode (the raw verbs move host buffers; used to test the protocol flow without a GPU)."""
+    def __init__(self, pp, rank, world, net_id=None, transport="rccl", n_parties=None, shm_bytes=0, timeout_ms=None,
+                 party_to_rank=None):
+        """pp = None: host-memory mode (the raw verbs move host buffers; used to test the protocol flow without a GPU).
+        party_to_rank: rank of every party (any map giving each rank n / world parties), None = contiguous blocks."""
         self.lib = load()
         self.pp = pp
         self.h = C.c_void_p()
         idbuf = None if net_id is None else (C.c_ubyte * ID_BYTES).from_buffer_copy(bytes(net_id))
+        pmap = None if party_to_rank is None else (C.c_int * len(party_to_rank))(*[int(v) for v in party_to_rank])
         rc = self.lib.zk_net_create(None if pp is None else pp.h, TRANSPORTS[transport], rank, world,
-                                    0 if n_parties is None else n_parties, None, idbuf, shm_bytes, C.byref(self.h))
+                                    0 if n_parties is None else n_parties, pmap, idbuf, shm_bytes, C.byref(self.h))
         if rc != 0:
             msg = self.lib.zk_net_last_error(self.h, None).decode() if self.h else "zk_net_create failed"
             if self.h:
@@ -36,6 +40,9 @@ class StarNet:
         info = (C.c_int * 4)()
         self.lib.zk_net_info(self.h, info)
         self.rank, self.world, self.first, self.k = info[0], info[1], info[2], info[3]
+        ids = (C.c_int * self.k)()
+        self.lib.zk_net_parties(self.h, self.rank, ids)
+        self.parties = list(ids)              # this rank's rows, in this order
         if timeout_ms is not None:
             self.lib.zk_net_set_timeout_ms(self.h, int(timeout_ms))
 
@@ -168,6 +175,35 @@ def dist_prove(pp, net, crs_ct, qap_local, a_share_local, ax_share_local, r, s, 
                                            None if masks is None else C.byref(masks), seed, pa.ctypes.data,
                                            pb.ctypes.data, pc.ctypes.data, stream))
     return pa, pb, pc
+
+
+class DistProofInFlight:
+    """Handle of zk_dist_groth16_prove_async; wait() is collective like the call that made it."""
+
+    def __init__(self, pp, net, handle, keep):
+        self.pp, self.net, self.handle, self._keep = pp, net, handle, keep
+
+    def wait(self):
+        pp, nl, k = self.pp, self.pp.fq.nl, self.net.k
+        pa = np.zeros((k, 3 * nl), dtype=np.uint64)
+        pb = np.zeros((k, 6 * nl), dtype=np.uint64)
+        pc = np.zeros((k, 3 * nl), dtype=np.uint64)
+        pp._check(pp.lib.zk_dist_groth16_wait(pp.h, self.net.h, self.handle, pa.ctypes.data, pb.ctypes.data, pc.ctypes.data))
+        self._keep = None
+        return pa, pb, pc
+
+
+def dist_prove_async(pp, net, crs_ct, qap_local, a_share_local, ax_share_local, r, s, log2_m, masks=None, seed=0,
+                     stream=None):
+    """First half of dist_prove: the proof is admitted and its device work enqueued; up to two may be in flight per rank,
+    issued and waited for in the same order on every rank."""
+    rr, ss = pp.fr.encode_one(r), pp.fr.encode_one(s)
+    h = C.c_int(-1)
+    pp._check(pp.lib.zk_dist_groth16_prove_async(pp.h, net.h, C.byref(crs_ct), _ptr(qap_local[0]), _ptr(qap_local[1]),
+                                                 _ptr(qap_local[2]), _ptr(a_share_local), _ptr(ax_share_local),
+                                                 rr.ctypes.data, ss.ctypes.data, log2_m,
+                                                 None if masks is None else C.byref(masks), seed, stream, C.byref(h)))
+    return DistProofInFlight(pp, net, h.value, (crs_ct, qap_local, a_share_local, ax_share_local, masks))
 
 
 def dist_prove_batch(pp, net, crs_ct, qaps_local, a_shares_local, ax_shares_local, rs, ss, log2_m, masks=None, seed=0,
