@@ -136,10 +136,19 @@ def _worker(rank, world, net_id, scenario, q):
                     net.enter(0)
                     q.put((rank, False, "late rank was admitted"))
                 except ZkError as e:
-                    q.put((rank, e.code == 2 and e.party == first, "code %d party %d" % (e.code, e.party)))
+                    ok = e.code == 2 and e.party == first
+                    try:                                        # and it stays out: no later round admits it
+                        net.enter(1)
+                        ok = False
+                    except ZkError as e2:
+                        ok = ok and e2.code == 2
+                    q.put((rank, ok, "code %d party %d" % (e.code, e.party)))
             else:
                 mask = net.enter(0)
                 assert mask == (1 << (world - 1)) - 1, mask
+                t0 = time.time()
+                assert net.enter(1) == mask                     # the king no longer waits for the rank it left out
+                assert time.time() - t0 < 0.35, time.time() - t0
                 got = _d_fft_round(net, o, dom, 0, mask, shares[first:first + k], False, 3)
                 parties = list(range((world - 1) * k))
                 want = od.d_fft(shares, [od.FftMask.zero(Lc)] * o.n, False, dom, o, seed=3, parties=parties)

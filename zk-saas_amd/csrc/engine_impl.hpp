@@ -102,7 +102,16 @@ class Engine : public IEngine {
     ZK_HIP(hipMalloc((void**)&rng_key_d_, sizeof(rng_key_h_)));
     ZK_HIP(hipMemcpy(rng_key_d_, rng_key_h_, sizeof(rng_key_h_), hipMemcpyHostToDevice));
     rng_replay_ = getenv("ZK_RNG_REPLAY") && atoi(getenv("ZK_RNG_REPLAY")) != 0;
+    if (rng_replay_) warn_replay();
     return ZK_OK;
+  }
+  // Replay mode trades the hiding property for reproducible shares (two packs with the same seed reuse their random
+  // points): it is a test / parity setting, so say so once per process wherever it gets switched on.
+  static void warn_replay() {
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true))
+      fprintf(stderr, "zksaas: share randomness is in REPLAY mode (ZK_RNG_REPLAY / option rng_replay): shares are "
+                      "reproducible from the caller's seeds and NOT hiding -- tests and parity runs only\n");
   }
   // the randomness of one launch: `span` consecutive stream ids (batch items).  Replay mode: the caller's seed;
   // otherwise the seed is IGNORED and the launch gets fresh nonces of this context's ChaCha20 stream.
@@ -1909,6 +1918,7 @@ class Engine : public IEngine {
     }
     if (!strcmp(name, "rng_replay")) {
       rng_replay_ = value != 0;
+      if (rng_replay_) warn_replay();
       return ZK_OK;
     }
     if (!strcmp(name, "king_alltoall")) {         // every rank of a net must choose alike

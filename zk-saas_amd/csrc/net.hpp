@@ -271,8 +271,11 @@ class Net {
 
   // ---- control plane: enter a collective round on channel `sid`; returns the mask of participating ranks.
   // A rank that is not in the verdict gets ZK_ERR_PROTOCOL (it arrived after the king's timeout).
+  // A rank the king once left out stays out: the king stops waiting for it (alive_), and the rank itself fails every
+  // later round at once (dead_) instead of running one round behind the others on the channels it never entered.
   int enter(int sid, uint32_t* mask) {
     if (sid < 0 || sid >= NET_NSID) return fail("bad channel id", ZK_ERR_BAD_INPUT);
+    if (dead_) return fail_party("this rank was left out of an earlier round (timed out): open a new net", first_party(rank));
     seq_[sid]++;
     op_[sid] = 0;
     if (transport == ZK_NET_LOCAL) {
@@ -286,13 +289,18 @@ class Net {
     if (rank == 0) {
       uint64_t dl = net_now_ms() + timeout_ms;
       uint32_t m = 1;
+      if (!alive_init_) {
+        alive_ = full_mask();
+        alive_init_ = true;
+      }
       for (;;) {
         m = 0;
         for (int r = 0; r < world; r++)
-          if (c.arrive[r].load(std::memory_order_acquire) >= s) m |= 1u << r;
-        if (m == full_mask() || net_now_ms() > dl) break;
+          if ((alive_ & (1u << r)) && c.arrive[r].load(std::memory_order_acquire) >= s) m |= 1u << r;
+        if (m == alive_ || net_now_ms() > dl) break;
         relax();
       }
+      alive_ = m;
       c.verdict_mask.store(m, std::memory_order_relaxed);
       c.verdict_seq.store(s, std::memory_order_release);
       *mask = m;
@@ -303,11 +311,16 @@ class Net {
       if (net_now_ms() > dl) return fail("the king did not answer (timed out)", ZK_ERR_NOT_CONNECTED);
       relax();
     }
-    if (c.verdict_seq.load(std::memory_order_acquire) != s)
+    if (c.verdict_seq.load(std::memory_order_acquire) != s) {
+      dead_ = true;
       return fail_party("this rank entered the round after the king's timeout", first_party(rank));
+    }
     uint32_t m = c.verdict_mask.load(std::memory_order_relaxed);
     *mask = m;
-    if (!(m & (1u << rank))) return fail_party("this rank entered the round after the king's timeout", first_party(rank));
+    if (!(m & (1u << rank))) {
+      dead_ = true;
+      return fail_party("this rank entered the round after the king's timeout", first_party(rank));
+    }
     return ZK_OK;
   }
   uint32_t full_mask() const { return world >= 32 ? 0xffffffffu : ((1u << world) - 1); }
@@ -770,6 +783,9 @@ class Net {
   uint64_t last_s_[NET_NSID][NET_MAXR] = {};
   int op_[NET_NSID] = {0, 0, 0, 0};
   bool aborted_ = false;
+  bool dead_ = false;                 // this rank was left out of a round
+  uint32_t alive_ = 0;                // king: ranks still taking part
+  bool alive_init_ = false;
 };
 
 }  // namespace zk
