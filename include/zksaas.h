@@ -97,10 +97,10 @@ int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, c
  *          fft2_in_place (:210-237) -> distribute_powers(g) (:278-280) -> (bit-reverse + stride) pack.
  *          in_d is [nparties][m/l], out_d is [n][m/l] and must not alias in_d.  g (Montgomery Fr, host pointer) may be NULL for 1.
  *          scale_size_inv != 0 additionally multiplies by 1/m (d_ifft's :159 folded in).
- * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l] (clobbered: it
- *          holds the fft1 output afterwards), masks [n][m/l] each or NULL for FftMask::zero.  The result is
- *          written to out_d [n][m/l]; out_d == NULL or == shares_d returns it in shares_d (one extra device copy,
- *          because the king step exchanges chunks between workgroups and cannot run in place). */
+ * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l], masks [n][m/l] each or
+ *          NULL for FftMask::zero.  The result is written to out_d [n][m/l] (shares_d is then left as it was);
+ *          out_d == NULL or == shares_d returns it in shares_d.  The local stages run out of place into a
+ *          context-owned vector and the king step writes the destination, so neither form costs a copy. */
 int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream);
 int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int nparties, int log2_m, int inverse,
                  const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out_d,

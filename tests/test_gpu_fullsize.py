@@ -219,3 +219,44 @@ def test_msm_2_20_on_12_limb_curves_equals_six_limb_c_oracle(curve):
     want = cg.msm_g1_arrays(bases, cg.scalars_from_gpu_residues(scalars), n, nthreads=8)
     G = g1(cv)
     assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_msm_at_every_lane_shape_equals_the_sum_of_small_msms(curve):
+    """Sizes across the accumulate kernel's lane shapes (fewer than one round of waves, between one and two -- the
+    case that once left entries uncovered: 2^18 .. 2^19 points at 15-bit windows --, several rounds), both kernels
+    (one lane / lane pair per range).  Reference: the sum of 8192-point MSMs of the same vectors (a size the oracle
+    comparisons of test_gpu_msm.py cover), added with the oracle's group law.  G::msm is linear (dmsm/mod.rs:73)."""
+    from zksaas_amd import groth16 as zg, wire
+    from zksaas_amd.api import ZK_G1
+    from oracle.curve import g1
+    from oracle.params import CURVES
+    pp = ctx(curve, 2)
+    G = g1(CURVES[curve])
+    nl = pp.fr.nl
+    rng = np.random.default_rng(5)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, nl), dtype=np.uint64)
+        a[:, nl - 1] &= np.uint64((1 << 58) - 1)
+        return a
+    sizes = [150000, 262144, 300000, 400000, 524288, 700000]
+    mx = max(sizes)
+    eb, w = pp.fr.nbytes, 2 * pp.fq.nbytes
+    pts = zg.base_points(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, rand(mx)), mx)
+    sc = zk.DeviceBuffer.from_numpy(pp, rand(mx))
+    pt = lambda j: G.from_affine(wire.jacobian_to_affine(pp, j, False))
+    ch = 8192
+    prefix = {0: G.identity}
+    acc = G.identity
+    for c0 in range(0, mx, ch):
+        n_ = min(ch, mx - c0)
+        acc = G.add(acc, pt(msm(pp, ZK_G1, pts.view(c0 * w, n_ * w), sc.view(c0 * eb, n_ * eb), n_)))
+        prefix[c0 + n_] = acc
+    for n_ in sizes:
+        full = (n_ // ch) * ch
+        want = prefix[full]
+        if n_ > full:
+            want = G.add(want, pt(msm(pp, ZK_G1, pts.view(full * w, (n_ - full) * w), sc.view(full * eb, (n_ - full) * eb),
+                                      n_ - full)))
+        assert G.eq(pt(msm(pp, ZK_G1, pts.view(0, n_ * w), sc.view(0, n_ * eb), n_)), want), n_

@@ -599,8 +599,7 @@ class Engine : public IEngine {
   }
 
   // d_fft / d_ifft for all n parties on this device (dfft/mod.rs:99-175).  The king kernel exchanges chunks
-  // between workgroups, so it never runs in place: with out == nullptr the result goes through a context-owned
-  // buffer and is copied back into `shares`.
+  // between workgroups, so it never runs in place.
   int d_fft(void* shares, const void* in_mask, const void* out_mask, int rearrange, int log_m, int inverse,
             const void* g, uint64_t seed, void* out, hipStream_t st) override {
     if (!shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
@@ -608,17 +607,16 @@ class Engine : public IEngine {
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     size_t bytes = (size_t)n * (((size_t)1 << log_m) / l) * sizeof(Fr);
-    int rc = fft1(shares, log_m, inverse, (size_t)n, nullptr, st);
+    // the local stages go out of place into a context-owned vector (the first pass reads `shares`), the king reads
+    // that and writes the destination: no copy back, and `shares` is left untouched when `out` is given
+    ZK_HIP(king_tmp_.ensure(bytes));
+    NttSrc<Fr> src{};
+    src.p[0] = (const Fr*)shares;
+    src.per = (uint32_t)n;
+    int rc = fft1_src(king_tmp_.p, log_m, inverse, (size_t)n, nullptr, st, src);
     if (rc) return rc;
-    void* dst = out;
-    if (!dst) {
-      ZK_HIP(king_tmp_.ensure(bytes));
-      dst = king_tmp_.p;
-    }
-    rc = fft2_king(shares, in_mask, nullptr, n, log_m, inverse, g, inverse ? 1 : 0, rearrange, seed, dst, out_mask, st);
-    if (rc) return rc;
-    if (!out) ZK_HIP(hipMemcpyAsync(shares, dst, bytes, hipMemcpyDeviceToDevice, st));
-    return ZK_OK;
+    return fft2_king(king_tmp_.p, in_mask, nullptr, n, log_m, inverse, g, inverse ? 1 : 0, rearrange, seed,
+                     out ? out : shares, out_mask, st);
   }
 
   // FftMask::sample (dfft/mod.rs:30-85).  Streams: values = seed, in-mask randomness = seed ^ 0x1111,
@@ -2461,15 +2459,20 @@ class Engine : public IEngine {
   // parties) the king reads the caller's rows directly and the result comes back through ONE pass that adds the mask,
   // instead of a gather copy, a scatter copy and an addition (d_fft 2^20 on one GPU: 0.96 -> 0.87 ms).
   template <class KingFn>
-  int king_round(Net* net, int sid, uint32_t mask, Fr* local, size_t len, KingFn king, const Fr* out_mask = nullptr) {
+  int king_round(Net* net, int sid, uint32_t mask, Fr* local, size_t len, KingFn king, const Fr* out_mask = nullptr,
+                 const Fr* king_in = nullptr, bool in_place_ok = false) {
     const int k = net->parties_per_rank();
     const size_t bytes = (size_t)k * len * sizeof(Fr);
     hipStream_t ks = net_stream(net, sid, nullptr);
     if (net->transport == ZK_NET_LOCAL) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      // one rank holds all parties: no gather / scatter.  The king writes the caller's rows directly (out-mask added in
+      // its store) when its input lives elsewhere (king_in: d_fft's local stages went out of place) or when it only
+      // touches its own column (in_place_ok: deg_red); otherwise through a scratch vector and one pass back.
+      if (king_in || in_place_ok) return king(king_in ? king_in : local, ps.data(), (int)ps.size(), local, out_mask, ks);
       ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(Fr)));
       Fr* fout = (Fr*)dist_out_[sid].p;
-      std::vector<uint32_t> ps = parties_of(net, mask);
-      int rc = king(local, ps.data(), (int)ps.size(), fout, ks);
+      int rc = king(local, ps.data(), (int)ps.size(), fout, nullptr, ks);
       if (rc) return rc;
       const size_t cnt = (size_t)k * len;
       if (out_mask) {
@@ -2491,7 +2494,7 @@ class Engine : public IEngine {
     if (rc) return rc;
     if (net->rank == 0) {
       std::vector<uint32_t> ps = parties_of(net, mask);
-      rc = king(fin, ps.data(), (int)ps.size(), fout, ks);
+      rc = king(fin, ps.data(), (int)ps.size(), fout, nullptr, ks);
       if (rc) return rc;
     }
     rc = net_err(net, net->scatter(sid, mask, fout, bytes, local));
@@ -2572,6 +2575,7 @@ class Engine : public IEngine {
     const size_t Lc = ((size_t)1 << log_m) / l;
     hipStream_t s = net_stream(net, sid, nullptr);
     int rc;
+    const Fr* king_in = nullptr;
     if (do_fft1) {
       // d_ifft scales by 1/m before anything else (dfft/mod.rs:159); without an in-mask the king folds the factor
       // into its g^i table (same field values), with one it has to come before the mask is added (:254-258)
@@ -2580,7 +2584,18 @@ class Engine : public IEngine {
         rc = vec_scale(shares, &c, (size_t)k * Lc, s);
         if (rc) return rc;
       }
-      rc = fft1(shares, log_m, inverse, (size_t)k, in_mask, s);
+      if (net->transport == ZK_NET_LOCAL) {
+        // one rank: the first NTT pass reads the caller's rows and writes a work vector, the king reads that and writes
+        // the caller's rows -- no copy back (d_fft 2^20: one 60 us pass less)
+        ZK_HIP(dist_in_[sid].ensure((size_t)k * Lc * sizeof(Fr)));
+        NttSrc<Fr> src{};
+        src.p[0] = shares;
+        src.per = (uint32_t)k;
+        rc = fft1_src(dist_in_[sid].p, log_m, inverse, (size_t)k, in_mask, s, src);
+        king_in = (const Fr*)dist_in_[sid].p;
+      } else {
+        rc = fft1(shares, log_m, inverse, (size_t)k, in_mask, s);
+      }
       if (rc) return rc;
     } else if (in_mask) {
       rc = vec_add(shares, in_mask, (size_t)k * Lc, s);
@@ -2611,12 +2626,12 @@ class Engine : public IEngine {
             });
     }
     if (rc == A2A_NOT_APPLICABLE)
-    rc = king_round(net, sid, mask, shares, Lc, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
+    rc = king_round(net, sid, mask, shares, Lc, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr* om, hipStream_t ks) {
       const Fr* U = nullptr;
       int r2 = umat_for(ps, np, &U);
       if (r2) return r2;
-      return king_dispatch(in, nullptr, np, log_m, inverse, U, g, scale, rearrange, seed, out, nullptr, false, ks);
-    }, out_mask);
+      return king_dispatch(in, nullptr, np, log_m, inverse, U, g, scale, rearrange, seed, out, om, false, ks);
+    }, out_mask, king_in);
     else if (!rc && out_mask) rc = vec_add(shares, out_mask, (size_t)k * Lc, s);       // after the all-to-all king
     return rc;
   }
@@ -2659,9 +2674,9 @@ class Engine : public IEngine {
             return (int)ZK_OK;
           });
     if (rc == A2A_NOT_APPLICABLE)
-      return king_round(net, sid, mask, x, len, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, hipStream_t ks) {
-        return deg_red_np(in, nullptr, ps, np, len, seed, out, nullptr, ks);
-      }, out_mask);
+      return king_round(net, sid, mask, x, len, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr* om, hipStream_t ks) {
+        return deg_red_np(in, nullptr, ps, np, len, seed, out, om, ks);
+      }, out_mask, nullptr, true);
     if (rc) return rc;
     if (out_mask) return vec_add(x, out_mask, (size_t)k * len, s);        // after the all-to-all king
     return ZK_OK;

@@ -575,8 +575,10 @@ ZK_D uint32_t msm_range_len(uint32_t entries, uint32_t nlanes, uint32_t tmin, ui
   if (rounds == 1) {
     // exactly one round is the slow case (79 against 100+ G multiplications/s): two rounds of shorter ranges instead,
     // unless that makes them shorter than 12 entries
+    // (only when the launch has the lanes for it: ranges shorter than entries / nlanes would leave entries uncovered --
+    // msm_pick_lanes sizes such launches at 2 cap lanes)
     const uint32_t T2 = (uint32_t)((entries + 2ull * cap - 1) / (2ull * cap));
-    if (T2 >= 12) return T2;
+    if (T2 >= 12 && (uint64_t)T2 * nlanes >= entries) return T2;
   }
   if (rounds >= 1) {
     const uint64_t lanes = (uint64_t)cap * rounds;
@@ -1088,7 +1090,13 @@ inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair) {
   const size_t lo = pair ? MSM_RANGE_MIN_G2 : MSM_RANGE_MIN, hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
   size_t t = env_t >= 1 ? (size_t)env_t : (size_t)((double)max_entries / (2.4 * (double)cap));
   if (env_t < 1) t = std::min(hi, std::max(lo, t));
-  return MsmLanes{(uint32_t)std::max<size_t>(1, (max_entries + t - 1) / t), (uint32_t)t, (uint32_t)cap};
+  size_t nl = std::max<size_t>(1, (max_entries + t - 1) / t);
+  // between one and two rounds at this length msm_range_len splits the entries over TWO rounds of shorter ranges: the
+  // launch needs the lanes of two rounds then (found by the 2^18-point BLS12-381 prover test: 4.4 M entries at 20 per
+  // lane made 222 823 lanes, the two-round length of 12 covered 2.7 M entries and the rest was never added)
+  if (max_entries >= cap * t && max_entries < 2 * cap * t && (max_entries + 2 * cap - 1) / (2 * cap) >= 12)
+    nl = std::max(nl, 2 * cap);
+  return MsmLanes{(uint32_t)nl, (uint32_t)t, (uint32_t)cap};
 }
 
 template <class FrP>

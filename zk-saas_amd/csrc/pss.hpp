@@ -89,6 +89,47 @@ ZK_D void pack_chunk(const Fp<P>* v, const Fp<P>* __restrict__ Pm, const PackL2<
   }
 }
 
+// sec[i] += sum_s U[i][s] * row(s) over the np party rows of one chunk (unpack / unpack2 / lagrange_unpack as a matrix,
+// pss.rs:125-221).  The rows are fetched in groups of up to 8 whose loads are all in flight before the first
+// multiplication (one load -> multiply -> next load chain per party made the king kernels latency-bound: d_fft 2^20
+// king 270 us for 30 multiplications per chunk); party counts that are not a multiple of the group (dropouts) take the
+// row-at-a-time loop.
+template <class F, int L>
+ZK_D void unpack_term(F* sec, const F* __restrict__ U, int np, int s, const F& x) {
+#pragma unroll
+  for (int i = 0; i < L; i++) sec[i] = sec[i] + mulsel<L>(U[i * np + s], x);
+}
+template <class F, int L, class RowFn>
+ZK_D void unpack_accumulate(F* sec, const F* __restrict__ U, int np, RowFn row) {
+  constexpr int N = 4 * L, G = N < 8 ? N : 8;
+  if (np % G == 0) {
+#pragma unroll 1
+    for (int s0 = 0; s0 < np; s0 += G) {
+      // named values, not an array: an array of loaded elements indexed in an unrolled loop ended up in scratch memory
+      const F x0 = row(s0), x1 = row(s0 + 1), x2 = row(s0 + 2), x3 = row(s0 + 3);
+      if constexpr (G == 8) {
+        const F x4 = row(s0 + 4), x5 = row(s0 + 5), x6 = row(s0 + 6), x7 = row(s0 + 7);
+        unpack_term<F, L>(sec, U, np, s0, x0);
+        unpack_term<F, L>(sec, U, np, s0 + 1, x1);
+        unpack_term<F, L>(sec, U, np, s0 + 2, x2);
+        unpack_term<F, L>(sec, U, np, s0 + 3, x3);
+        unpack_term<F, L>(sec, U, np, s0 + 4, x4);
+        unpack_term<F, L>(sec, U, np, s0 + 5, x5);
+        unpack_term<F, L>(sec, U, np, s0 + 6, x6);
+        unpack_term<F, L>(sec, U, np, s0 + 7, x7);
+      } else {
+        unpack_term<F, L>(sec, U, np, s0, x0);
+        unpack_term<F, L>(sec, U, np, s0 + 1, x1);
+        unpack_term<F, L>(sec, U, np, s0 + 2, x2);
+        unpack_term<F, L>(sec, U, np, s0 + 3, x3);
+      }
+    }
+    return;
+  }
+#pragma unroll 1
+  for (int s = 0; s < np; s++) unpack_term<F, L>(sec, U, np, s, row(s));
+}
+
 // shares[p][j] for p < n from l secrets + t randoms.  One thread per chunk.
 //   order 0: secrets[j*l + i];  order 1: secrets[j + i*nchunks].
 template <class P, int L, bool DET>
@@ -204,15 +245,22 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     F v[L];
 #pragma unroll
     for (int i = 0; i < L; i++) v[i] = F::zero();
-#pragma unroll 1
-    for (int s = 0; s < np; s++) {
-      F x = seg ? load_elem(in + (size_t)s * seg + (blockIdx.x * Wc + tid)) : load_elem(in + ((size_t)s << log_lc) + k);
-      // d_ifft scales the share by 1/m BEFORE the mask is added (dfft/mod.rs:159 then :254-258); without a
-      // mask the factor is folded into gtab instead.
-      if (in_scale) x = mulsel<L>(x, load_elem(in_scale));
-      if (in_mask) x = x + load_elem(in_mask + ((size_t)s << log_lc) + k);
-#pragma unroll
-      for (int i = 0; i < L; i++) v[i] = v[i] + mulsel<L>(U[i * np + s], x);
+    // d_ifft scales the share by 1/m BEFORE the mask is added (dfft/mod.rs:159 then :254-258); without a mask the
+    // factor is folded into gtab instead.  One branch-free row function per case: a uniform branch between the loads
+    // of a row keeps the compiler from putting the loads of the whole group in flight together.
+    const F* __restrict__ col = seg ? in + (blockIdx.x * Wc + tid) : in + k;
+    const size_t pitch = seg ? (size_t)seg : (size_t)1 << log_lc;
+    if (!in_mask) {
+      unpack_accumulate<F, L>(v, U, np, [&](int s) { return load_elem(col + (size_t)s * pitch); });
+    } else if (!in_scale) {
+      unpack_accumulate<F, L>(v, U, np, [&](int s) {
+        return load_elem(col + (size_t)s * pitch) + load_elem(in_mask + ((size_t)s << log_lc) + k);
+      });
+    } else {
+      const F sc = load_elem(in_scale);
+      unpack_accumulate<F, L>(v, U, np, [&](int s) {
+        return mulsel<L>(load_elem(col + (size_t)s * pitch), sc) + load_elem(in_mask + ((size_t)s << log_lc) + k);
+      });
     }
     // fft2 inside the chunk.  tk[s'] = gen^((l >> (s'+1)) * (k+1)); last stage uses gen^(k+1).
     if (L > 1) {
@@ -360,9 +408,9 @@ struct DegredBatch {
 };
 template <class P, int L>
 __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
-    const Fp<P>* __restrict__ in, DegredBatch<Fp<P>> db, int np, size_t len,
-    const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
-    Fp<P>* __restrict__ out, size_t stride, size_t j0,
+    const Fp<P>* in /* may alias out: a thread reads and writes only its own column */, DegredBatch<Fp<P>> db, int np,
+    size_t len, const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2,
+    RngSeed seed, Fp<P>* out, size_t stride, size_t j0,
     const Fp<P>* __restrict__ mul_b, const Fp<P>* __restrict__ sub_c) {
   const Fp<P>* __restrict__ in_mask = db.in_mask[blockIdx.y];
   const Fp<P>* __restrict__ out_mask = db.out_mask[blockIdx.y];
@@ -385,13 +433,23 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
   F sec[L + T];
 #pragma unroll
   for (int i = 0; i < L; i++) sec[i] = F::zero();
-#pragma unroll 1
-  for (int s = 0; s < np; s++) {
-    F x = load_elem(in + (size_t)s * stride + j);
-    if (mul_b) x = x * load_elem(mul_b + (size_t)s * stride + j) - load_elem(sub_c + (size_t)s * stride + j);
-    if (in_mask) x = x + load_elem(in_mask + (size_t)s * stride + j);
-#pragma unroll
-    for (int i = 0; i < L; i++) sec[i] = sec[i] + mulsel<L>(U[i * np + s], x);
+  // one branch-free row function per case (see king_fft2_kernel)
+  if (!mul_b && !in_mask) {
+    unpack_accumulate<F, L>(sec, U, np, [&](int s) { return load_elem(in + (size_t)s * stride + j); });
+  } else if (!mul_b) {
+    unpack_accumulate<F, L>(sec, U, np, [&](int s) {
+      return load_elem(in + (size_t)s * stride + j) + load_elem(in_mask + (size_t)s * stride + j);
+    });
+  } else if (!in_mask) {
+    unpack_accumulate<F, L>(sec, U, np, [&](int s) {
+      return load_elem(in + (size_t)s * stride + j) * load_elem(mul_b + (size_t)s * stride + j) -
+             load_elem(sub_c + (size_t)s * stride + j);
+    });
+  } else {
+    unpack_accumulate<F, L>(sec, U, np, [&](int s) {
+      return load_elem(in + (size_t)s * stride + j) * load_elem(mul_b + (size_t)s * stride + j) -
+             load_elem(sub_c + (size_t)s * stride + j) + load_elem(in_mask + (size_t)s * stride + j);
+    });
   }
 #pragma unroll
   for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)(j0 + j) * T + i);
