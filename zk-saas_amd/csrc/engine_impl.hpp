@@ -497,7 +497,10 @@ class Engine : public IEngine {
     for (int p = 0; p < plan.npass; p++) {
       const NttPass& ps = plan.pass[p];
       int rbits = ps.s1 - ps.s0;
-      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (TILE + ((size_t)1 << rbits) / 2 + 1);
+      // large tile: every fourth stage twiddle in LDS (72 KB: two workgroups per CU), see ntt_pass_kernel
+      static const int tws_env = getenv("ZK_NTT_TWS") ? atoi(getenv("ZK_NTT_TWS")) : -1;
+      const int tws = tws_env >= 0 ? (tws_env <= 2 ? tws_env : 2) : ((TB >= 10 && rbits >= 4) ? 2 : 0);
+      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (TILE + ((((size_t)1 << rbits) / 2) >> tws) + 1);
       bool& attr_set = ntt_attr_set_[TB == NTT_TILE_BITS_SMALL ? 0 : 1];     // per engine, i.e. per device
       if (!attr_set) {
         ZK_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<Fr, TB>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -508,7 +511,7 @@ class Engine : public IEngine {
       ProfScope ps_(prof, PROF_NTT_PASS, st, (double)nvec * batch);
       ntt_pass_kernel<Fr, TB><<<grid, dim3((unsigned)(TILE / 4)), lds, st>>>(
           data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l, p == plan.npass - 1 ? add : nullptr,
-          p == 0 ? src : NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1});
+          p == 0 ? src : NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1}, rbits >= 4 ? tws : 0);
       ZK_HIP(hipGetLastError());
     }
     return ZK_OK;

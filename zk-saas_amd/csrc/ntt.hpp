@@ -131,7 +131,13 @@ template <class F, int TB>
 __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_kernel(F* __restrict__ data, int log_n, int s0,
                                                                                int s1, int cbits,
                                                                                const F* __restrict__ tw_full, int log_l,
-                                                                               const F* __restrict__ add, NttSrc<F> src) {
+                                                                               const F* __restrict__ add, NttSrc<F> src,
+                                                                               int tws) {
+  // tws: log2 stride of the stage-twiddle table kept in LDS.  0 = all R/2 + 1 twiddles of the pass (small tiles).  2 = every
+  // fourth one: what every stage but the last two of a pass needs; the last round trip reads its three twiddles per thread
+  // from the full table in HBM / L2 instead.  For the 2^11-element tile that makes the workgroup 72 KB of LDS instead of
+  // 96 KB, i.e. TWO workgroups per CU instead of one -- the load / pre-twiddle / store phases of one overlap the
+  // butterflies of the other (d_fft 2^20: see DESIGN.md "d_fft on one GPU").
   constexpr int NTT_TILE_BITS = TB;                  // shadow the namespace-level (large tile) constants
   constexpr int NTT_TILE = 1 << TB;
   constexpr int NTT_THREADS = NTT_TILE / 4;
@@ -143,7 +149,13 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
   const int C = 1 << cbits;
   const int hbbits = NTT_TILE_BITS - rbits - cbits;
   LdsVec<F> tile{smem, NTT_TILE};
-  LdsVec<F> twl{smem + H * NTT_TILE, R / 2 + 1};
+  LdsVec<F> twl{smem + H * NTT_TILE, ((R / 2) >> tws) + 1};
+  const int tw_sh = log_n + log_l - rbits;           // w_{2^rbits}^j = tw_full[j << tw_sh]
+  // stage twiddle with exponent idx = j << sft (sft = the stage's shift): from LDS when the table holds it
+  auto stage_tw = [&](uint32_t j, int sft) -> F {
+    if (sft >= tws) return twl.get((j << sft) >> tws);
+    return load_elem(tw_full + ((size_t)(j << sft) << tw_sh));
+  };
   const int tid = threadIdx.x;
   const size_t n = (size_t)1 << log_n;
   F* vec = data + (size_t)blockIdx.y * n;
@@ -164,8 +176,8 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
   const bool shifted = (s0 == 0);
 
   // stage twiddles into LDS
-  for (int j = tid; j <= R / 2; j += NTT_THREADS)
-    twl.put(j, load_elem(tw_full + ((size_t)j << (log_n + log_l - rbits))));
+  for (int j = tid; j <= ((R / 2) >> tws); j += NTT_THREADS)
+    twl.put(j, load_elem(tw_full + ((size_t)(j << tws) << tw_sh)));
 
   // load 4 elements per thread (coalesced along c), pre-twiddle for later passes
 #pragma unroll
@@ -226,7 +238,7 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
     F v0 = tile.get(ib), v1 = tile.get(ib + step), v2 = tile.get(ib + 2 * step), v3 = tile.get(ib + 3 * step);
     // stage sigma0+1: pairs (v0,v1), (v2,v3); twiddle exponent (rl + sh) in units of w_{2^(sigma0+1)}
     {
-      F w = twl.get((rl + sh) << (rbits - sigma0 - 1));
+      F w = stage_tw(rl + sh, rbits - sigma0 - 1);
       F t1 = v1 * w, t3 = v3 * w;
       v1 = v0 - t1;
       v0 = v0 + t1;
@@ -235,8 +247,8 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
     }
     // stage sigma0+2: pairs (v0,v2) with q = rl, (v1,v3) with q = rl + 2^sigma0
     {
-      F wa = twl.get((rl + sh) << (rbits - sigma0 - 2));
-      F wb = twl.get((rl + (1u << sigma0) + sh) << (rbits - sigma0 - 2));
+      F wa = stage_tw(rl + sh, rbits - sigma0 - 2);
+      F wb = stage_tw(rl + (1u << sigma0) + sh, rbits - sigma0 - 2);
       F t2 = v2 * wa, t3 = v3 * wb;
       v2 = v0 - t2;
       v0 = v0 + t2;
