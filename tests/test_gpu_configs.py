@@ -184,6 +184,33 @@ def test_c5_bls12_381_composed_proof_equals_oracle_and_verifies(masked):
     assert not op.verify_proof(c, vk, (A, B, Cc), [(w[1] + 1) % P], G1)
 
 
+def test_c5_bls12_381_composed_proof_at_2_12_is_exact():
+    """The composed prover on BLS12-381 at a domain of 2^12 (4094 constraints + 2 inputs), all twelve masks on: the proof
+    reconstructed from the n parties' shares equals the trapdoor closed form (og.prove_scalars: the discrete logs of A, B,
+    C from the QAP evaluated at tau -- exact, not a property) point for point and verifies by pairing; the setup scalars of
+    the host mirror equal the oracle's."""
+    c = BLS12_381
+    P = c.r
+    r1, w = _small_r1cs_mod(P, nc=4094)
+    pp, o = ctx("bls12_381", 2), opp("bls12_381", 2)
+    td = [rand_fp(152, i, P) for i in range(5)]
+    setup = zg.SetupScalars("bls12_381", r1, *td)
+    assert setup.log_m == 12
+    okey = og.setup_scalars(c, r1, og.Trapdoor(*td))
+    assert setup.a_query == okey.a_query and setup.h_query == okey.h_query and setup.l_query == okey.l_query
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bls12_381", r1, w, seed=15)
+    r, s = rand_fp(153, 0, P), rand_fp(153, 1, P)
+    masks = zg.ProofMasks(pp, setup.log_m, seed=1700)
+    A, B, Cc = _reconstructed(pp, o, "bls12_381", zg.prove(pp, crs, wit, r, s, masks=masks, seed=19))
+    G1, G2 = g1(c), g2(c)
+    sa, sb, sc_ = og.prove_scalars(c, r1, okey, w, r, s)
+    assert A == G1.to_affine(G1.mul(G1.from_affine(c.g1), sa)) and B == G2.to_affine(G2.mul(G2.from_affine(c.g2), sb))
+    assert Cc == G1.to_affine(G1.mul(G1.from_affine(c.g1), sc_))
+    vk = _oracle_vk(zg.verifying_key(pp, setup))
+    assert op.verify_proof(c, vk, (A, B, Cc), [w[1]], G1)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_c5_bls12_381_d_fft_2_20_shares_equal_c_oracle(inverse):
     """d_fft / d_ifft on the config-5 scalar field at m = 2^20 (16 M-element share matrix): every output share
