@@ -221,18 +221,19 @@ def test_msm_2_20_on_12_limb_curves_equals_six_limb_c_oracle(curve):
     assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
 
 
-@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
-def test_msm_at_every_lane_shape_equals_the_sum_of_small_msms(curve):
+@pytest.mark.parametrize("curve,g2", [("bn254", False), ("bls12_381", False), ("bn254", True)])
+def test_msm_at_every_lane_shape_equals_the_sum_of_small_msms(curve, g2):
     """Sizes across the accumulate kernel's lane shapes (fewer than one round of waves, between one and two -- the
     case that once left entries uncovered: 2^18 .. 2^19 points at 15-bit windows --, several rounds), both kernels
     (one lane / lane pair per range).  Reference: the sum of 8192-point MSMs of the same vectors (a size the oracle
     comparisons of test_gpu_msm.py cover), added with the oracle's group law.  G::msm is linear (dmsm/mod.rs:73)."""
     from zksaas_amd import groth16 as zg, wire
-    from zksaas_amd.api import ZK_G1
-    from oracle.curve import g1
+    from zksaas_amd.api import ZK_G1, ZK_G2
+    from oracle.curve import g1, g2 as g2f
     from oracle.params import CURVES
     pp = ctx(curve, 2)
-    G = g1(CURVES[curve])
+    G = g2f(CURVES[curve]) if g2 else g1(CURVES[curve])
+    grp = ZK_G2 if g2 else ZK_G1
     nl = pp.fr.nl
     rng = np.random.default_rng(5)
 
@@ -240,23 +241,49 @@ def test_msm_at_every_lane_shape_equals_the_sum_of_small_msms(curve):
         a = rng.integers(0, 1 << 62, size=(count, nl), dtype=np.uint64)
         a[:, nl - 1] &= np.uint64((1 << 58) - 1)
         return a
-    sizes = [150000, 262144, 300000, 400000, 524288, 700000]
+    sizes = [60000, 100000, 150000, 200000, 300000] if g2 else [150000, 262144, 300000, 400000, 524288, 700000]
     mx = max(sizes)
-    eb, w = pp.fr.nbytes, 2 * pp.fq.nbytes
-    pts = zg.base_points(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, rand(mx)), mx)
+    eb, w = pp.fr.nbytes, (4 if g2 else 2) * pp.fq.nbytes
+    pts = zg.base_points(pp, grp, zk.DeviceBuffer.from_numpy(pp, rand(mx)), mx)
     sc = zk.DeviceBuffer.from_numpy(pp, rand(mx))
-    pt = lambda j: G.from_affine(wire.jacobian_to_affine(pp, j, False))
+    pt = lambda j: G.from_affine(wire.jacobian_to_affine(pp, j, g2))
     ch = 8192
     prefix = {0: G.identity}
     acc = G.identity
     for c0 in range(0, mx, ch):
         n_ = min(ch, mx - c0)
-        acc = G.add(acc, pt(msm(pp, ZK_G1, pts.view(c0 * w, n_ * w), sc.view(c0 * eb, n_ * eb), n_)))
+        acc = G.add(acc, pt(msm(pp, grp, pts.view(c0 * w, n_ * w), sc.view(c0 * eb, n_ * eb), n_)))
         prefix[c0 + n_] = acc
     for n_ in sizes:
         full = (n_ // ch) * ch
         want = prefix[full]
         if n_ > full:
-            want = G.add(want, pt(msm(pp, ZK_G1, pts.view(full * w, (n_ - full) * w), sc.view(full * eb, (n_ - full) * eb),
+            want = G.add(want, pt(msm(pp, grp, pts.view(full * w, (n_ - full) * w), sc.view(full * eb, (n_ - full) * eb),
                                       n_ - full)))
-        assert G.eq(pt(msm(pp, ZK_G1, pts.view(0, n_ * w), sc.view(0, n_ * eb), n_)), want), n_
+        assert G.eq(pt(msm(pp, grp, pts.view(0, n_ * w), sc.view(0, n_ * eb), n_)), want), n_
+
+
+@pytest.mark.parametrize("table", [False, True])
+def test_msm_batch_at_every_lane_shape_equals_single_msms(table):
+    """zk_msm_batch of 1..6 scalar vectors over the SHA-256 circuit's 119 296-point base vector (and G2 at half of it):
+    the batch multiplies the sorted entries, so these sizes walk through every lane shape of the accumulate kernels --
+    B = 3 (5.7 M entries) sat in the gap between one and two rounds of waves that once left entries uncovered.
+    Every result equals the same vector's single zk_msm as a group element."""
+    from zksaas_amd import groth16 as zg, wire, api
+    from zksaas_amd.api import ZK_G1, ZK_G2
+    pp = ctx("bn254", 2)
+    rng = np.random.default_rng(15)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 58) - 1)
+        return a
+    for group, npts, g2 in ((ZK_G1, 119296, False), (ZK_G2, 59648, True)):
+        bases = zg.base_points(pp, group, zk.DeviceBuffer.from_numpy(pp, rand(npts)), npts)
+        if table:
+            api.msm_precompute(pp, group, bases, npts)
+        vecs = [zk.DeviceBuffer.from_numpy(pp, rand(npts)) for _ in range(6)]
+        single = [wire.jacobian_to_affine(pp, msm(pp, group, bases, v, npts), g2) for v in vecs]
+        for nb in (2, 3, 5, 6):
+            got = api.msm_batch(pp, group, bases, vecs[:nb], npts)
+            assert [wire.jacobian_to_affine(pp, got[b], g2) for b in range(nb)] == single[:nb], (group, nb)
