@@ -307,82 +307,83 @@ def bench(args, rank, local_rank, world):
             full = tuple(np.concatenate(c) for c in cols)
             ref = zg.prove(pp, crs, wit, r, s, masks=masks, seed=1)
             ok = bool(same_shares(pp, full, ref))
-        # throughput mode (outside the timed K steps; `value` stays one proof at a time): batches of 8 proofs per
-        # collective call (zk_dist_groth16_prove_batch) -- every rank runs each of its MSMs once per batch
-        batched = None
+        # ---- throughput modes, outside the timed K steps (`value` stays one proof at a time).  A leg must never cost the
+        # headline: it runs without launcher collectives inside (a rank that fails would leave the others in a mismatched
+        # one), waits for the channels with the net's deadline before synchronising the device (a hung collective then
+        # raises instead of hanging), and the ranks agree on the outcome afterwards; a failure is reported in the leg's place.
+        from . import wire
+
+        def same_as_headline(p_):
+            return all(wire.jacobian_to_affine(pp, p_[kk][q_], g2) == wire.jacobian_to_affine(pp, out["proof"][kk][q_], g2)
+                       for kk, g2 in ((0, False), (1, True), (2, False)) for q_ in range(k))
+
+        def drain():
+            for sid in range(4):
+                net.sync(sid)
+            torch.cuda.synchronize()
+
+        def guarded(fn):
+            err, got = None, None
+            try:
+                got = fn()
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)[:300]
+            vals = torch.tensor([0.0 if err else 1.0, 0.0 if err else got[0], 0.0 if err else float(got[1])],
+                                dtype=torch.float64)
+            if dist is not None:
+                okv = vals.clone()
+                dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+                dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+                vals[0], vals[2] = okv[0], okv[2]
+            if float(vals[0]) == 0.0:
+                return None, None, {"error": err or "another rank failed"}
+            return float(vals[1]), bool(float(vals[2])), None
+
+        # batches of 8 proofs per collective call (zk_dist_groth16_prove_batch): every rank runs each of its MSMs once per batch
+        batched = in_flight = None
         if not os.environ.get("ZK_BENCH_NO_BATCH"):
             nbp, nbat = 8, max(2, min(8, args.steps // 8))
             mk_b = None if mct is None else [mct] * nbp
-            bout = {}
 
-            def bstep(i):
-                bout["proofs"] = znet.dist_prove_batch(pp, net, lcrs.ct, [qap] * nbp, [a_sh] * nbp, [ax_sh] * nbp, [r] * nbp,
-                                                       [s] * nbp, wit.log_m, masks=mk_b, seed=5000 + i)
-            bstep(0)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            t0 = time.perf_counter()
-            for i in range(nbat):
-                bstep(1 + i)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            bdt = time.perf_counter() - t0
-            if dist is not None:
-                tt = torch.tensor([bdt], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                bdt = float(tt.item())
-            # every proof of the batch is the same statement: its local shares equal the one-at-a-time proof's as group
-            # elements (compared on this rank's rows)
-            from . import wire
-            eq = True
-            for p_ in bout["proofs"]:
-                for kk, g2 in ((0, False), (1, True), (2, False)):
-                    for q_ in range(k):
-                        eq = eq and wire.jacobian_to_affine(pp, p_[kk][q_], g2) == wire.jacobian_to_affine(pp, out["proof"][kk][q_], g2)
-            flag = torch.tensor([1 if eq else 0], dtype=torch.int32)
-            if dist is not None:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            batched = {"batch": nbp, "batches": nbat, "proofs_per_s": round(nbp * nbat / bdt, 2),
-                       "ms_per_proof": round(bdt / (nbp * nbat) * 1e3, 4), "same_proof": bool(int(flag.item())),
-                       "api": "zk_dist_groth16_prove_batch"}
-        # two proofs in flight per rank (zk_dist_groth16_prove_async / _wait): a proof's king rounds overlap the
-        # previous proof's MSMs.  Rolling window over 2 * steps proofs, every rank in the same order.
-        in_flight = None
-        if not os.environ.get("ZK_BENCH_NO_BATCH"):
+            def leg_batched():
+                proofs = None
+                znet.dist_prove_batch(pp, net, lcrs.ct, [qap] * nbp, [a_sh] * nbp, [ax_sh] * nbp, [r] * nbp, [s] * nbp,
+                                      wit.log_m, masks=mk_b, seed=5000)
+                drain()
+                t0 = time.perf_counter()
+                for i in range(nbat):
+                    proofs = znet.dist_prove_batch(pp, net, lcrs.ct, [qap] * nbp, [a_sh] * nbp, [ax_sh] * nbp, [r] * nbp,
+                                                   [s] * nbp, wit.log_m, masks=mk_b, seed=5001 + i)
+                drain()
+                # every proof of the batch is the same statement: its local shares equal the one-at-a-time proof's as
+                # group elements (compared on this rank's rows)
+                return time.perf_counter() - t0, all(same_as_headline(p_) for p_ in proofs)
+            bdt, eq, err = guarded(leg_batched)
+            batched = err or {"batch": nbp, "batches": nbat, "proofs_per_s": round(nbp * nbat / bdt, 2),
+                              "ms_per_proof": round(bdt / (nbp * nbat) * 1e3, 4), "same_proof": eq,
+                              "api": "zk_dist_groth16_prove_batch"}
+            # two proofs in flight per rank (zk_dist_groth16_prove_async / _wait): a proof's king rounds overlap the
+            # previous proof's MSMs.  Rolling window over 2 * steps proofs, every rank in the same order.
             nfl = max(4, 2 * args.steps)
 
-            def fly(i):
-                return znet.dist_prove_async(pp, net, lcrs.ct, qap, a_sh, ax_sh, r, s, wit.log_m, masks=mct, seed=7000 + i)
-            fly(0).wait()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            t0 = time.perf_counter()
-            prev, last = fly(0), None
-            for i in range(1, nfl):
-                cur = fly(i)
+            def leg_in_flight():
+                def fly(i):
+                    return znet.dist_prove_async(pp, net, lcrs.ct, qap, a_sh, ax_sh, r, s, wit.log_m, masks=mct, seed=7000 + i)
+                fly(0).wait()
+                drain()
+                t0 = time.perf_counter()
+                prev, last = fly(0), None
+                for i in range(1, nfl):
+                    cur = fly(i)
+                    last = prev.wait()
+                    prev = cur
                 last = prev.wait()
-                prev = cur
-            last = prev.wait()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            fdt = time.perf_counter() - t0
-            if dist is not None:
-                tt = torch.tensor([fdt], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                fdt = float(tt.item())
-            from . import wire
-            eq = all(wire.jacobian_to_affine(pp, last[kk][q_], g2) == wire.jacobian_to_affine(pp, out["proof"][kk][q_], g2)
-                     for kk, g2 in ((0, False), (1, True), (2, False)) for q_ in range(k))
-            flag = torch.tensor([1 if eq else 0], dtype=torch.int32)
-            if dist is not None:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            in_flight = {"proofs_in_flight_per_rank": 2, "proofs": nfl, "proofs_per_s": round(nfl / fdt, 2),
-                         "ms_per_proof": round(fdt / nfl * 1e3, 4), "same_proof": bool(int(flag.item())),
-                         "api": "zk_dist_groth16_prove_async / zk_dist_groth16_wait"}
+                drain()
+                return time.perf_counter() - t0, same_as_headline(last)
+            fdt, eq, err = guarded(leg_in_flight)
+            in_flight = err or {"proofs_in_flight_per_rank": 2, "proofs": nfl, "proofs_per_s": round(nfl / fdt, 2),
+                                "ms_per_proof": round(fdt / nfl * 1e3, 4), "same_proof": eq,
+                                "api": "zk_dist_groth16_prove_async / zk_dist_groth16_wait"}
         proofs_per_s = args.steps / dt
         res = dict(base, metric="Groth16 proofs/sec (SHA-256 circuit)", value=round(proofs_per_s, 3), unit="proofs/s",
                    batched=batched, in_flight=in_flight,
