@@ -215,6 +215,21 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
             G2.eq(dec_jacobian(pp, flown[b][1][p], True), dec_jacobian(pp, refs[b][1][sel[p]], True)) and
             G1.eq(dec_jacobian(pp, flown[b][2][p]), dec_jacobian(pp, refs[b][2][sel[p]]))
             for b in range(nbp) for p in range(k))
+        # a third proof while two are in flight, and a second wait on a handle, are refused (BAD_INPUT) without touching
+        # the net -- every rank refuses alike, so the channels stay in step
+        fa, fb = fly(0), fly(1)
+        refused = 0
+        try:
+            fly(2)
+        except zk.ZkError as e:
+            refused += e.code == 4
+        fa.wait()
+        fb.wait()
+        try:
+            fa.wait()
+        except zk.ZkError as e:
+            refused += e.code == 4
+        checks["in_flight_misuse_refused"] = refused == 2
         # circom_h alone: shares identical to the all-in-one call
         h_ref = pp.alloc_fr(n * ((1 << wit.log_m) // 2))
         import ctypes as C
