@@ -449,6 +449,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
 
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL between ranks); the driver exports it, keep it if not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import zksaas_amd as zk
     from zksaas_amd import groth16 as zg
