@@ -354,6 +354,66 @@ struct Fp {
 #endif
   }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  // ---- unreduced (double-width) arithmetic for the lazy-reduction product of the quadratic extension (Fp2T::mul_lazy)
+  // T = a * b as 2N limbs, no reduction (product scanning; N^2 multiply instructions); a, b < 2^(32 N)
+  static ZK_D void mul_wide(const uint32_t* a, const uint32_t* b, uint32_t* T) {
+    uint64_t acc = 0, cy;
+    uint32_t acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); i++) {
+        acc = madc(a[i], b[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      T[k] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+    T[2 * N - 1] = (uint32_t)acc;
+  }
+  // Montgomery reduction of a 2N-limb value T < p * 2^(32 N): T / R mod p, fully reduced (N (N + 1) / 2 + N (N - 1) / 2
+  // multiply instructions by the modulus + N for the quotient digits)
+  static ZK_D Fp redc_wide(const uint32_t* T) {
+    uint32_t m[N], r[N];
+    uint64_t acc = 0, cy;
+    uint32_t acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      acc += T[k];                                   // acc < 2^40 here: no carry out
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      m[k] = (uint32_t)acc * P::N0INV;
+      acc = madc_k(m[k], P::MOD[0], acc, &cy);
+      acc2 = add_cy(acc2, cy);
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+      acc += T[k];
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      r[k - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+    acc += T[2 * N - 1];
+    r[N - 1] = (uint32_t)acc;
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = r[i];
+    return reduce_once(o, (uint32_t)(acc >> 32));
+  }
+#endif
+
   // Dedicated product-scanning SQUARING, measured and NOT adopted (tools/mulbench.hip variant 3,
   // profiles/r03_mulbench_sqr.txt): the off-diagonal products a_i a_j (i < j) of a column are accumulated once and
   // doubled, the diagonal and the Montgomery terms follow -- 36 + 64 + 8 multiply instructions instead of 128 + 8.  The
@@ -502,8 +562,75 @@ struct Fp2T {
   ZK_HD friend Fp2 operator-(const Fp2& a, const Fp2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
   ZK_HD Fp2 neg() const { return {c0.neg(), c1.neg()}; }
   ZK_HD Fp2 dbl() const { return {c0.dbl(), c1.dbl()}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // p^2 as 2N limbs (compile-time), the offset that keeps a0 b0 - a1 b1 non-negative before its reduction
+  struct ModSq {
+    uint32_t v[2 * B::N];
+  };
+  static constexpr ModSq mod_sq() {
+    ModSq r{};
+    for (int i = 0; i < B::N; i++) {
+      uint64_t c = 0;
+      for (int j = 0; j < B::N; j++) {
+        uint64_t t = (uint64_t)r.v[i + j] + (uint64_t)P::MOD[i] * P::MOD[j] + c;
+        r.v[i + j] = (uint32_t)t;
+        c = t >> 32;
+      }
+      r.v[i + B::N] = (uint32_t)c;
+    }
+    return r;
+  }
+  // Karatsuba with LAZY reduction (u^2 = -1): three unreduced 2N-limb products and TWO Montgomery reductions instead of
+  // three full products -- 3 N^2 + 2 (N^2 + N) multiply instructions instead of 3 (2 N^2 + N): 336 vs 408 for N = 8.
+  //   c0 = redc(a0 b0 - a1 b1 + p^2),   c1 = redc((a0 + a1)(b0 + b1) - a0 b0 - a1 b1)
+  // Bounds (p < 2^(32 N - 2)): the sums a0 + a1, b0 + b1 < 2 p fit N limbs; both reduction inputs are in [0, 2 p^2) and
+  // 2 p^2 < p R, which is what redc_wide needs; its output is fully reduced.  Same field elements as the three-product
+  // form, hence bit-identical results.
+  static ZK_D Fp2 mul_lazy(const Fp2& a, const Fp2& b) {
+    constexpr int N = B::N;
+    constexpr ModSq P2 = mod_sq();
+    uint32_t T0[2 * N], T1[2 * N];
+    B::mul_wide(a.c0.v, b.c0.v, T0);
+    B::mul_wide(a.c1.v, b.c1.v, T1);
+    // in place, three interleaved carry chains: T0 <- a0 b0 + p^2 - a1 b1 (c0 before reduction), T1 <- a0 b0 + a1 b1
+    {
+      unsigned c1 = 0, c2 = 0, bw = 0;
+#pragma unroll
+      for (int i = 0; i < 2 * N; i++) {
+        const uint32_t x = T0[i], y = T1[i];
+        T1[i] = __builtin_addc(x, y, c1, &c1);
+        T0[i] = __builtin_subc(__builtin_addc(x, P2.v[i], c2, &c2), y, bw, &bw);
+      }
+    }
+    Fp2 r;
+    r.c0 = B::redc_wide(T0);
+    uint32_t sa[N], sb[N];
+    {
+      unsigned c = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) sa[i] = __builtin_addc(a.c0.v[i], a.c1.v[i], c, &c);
+      c = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) sb[i] = __builtin_addc(b.c0.v[i], b.c1.v[i], c, &c);
+    }
+    B::mul_wide(sa, sb, T0);
+    {
+      unsigned bw = 0;
+#pragma unroll
+      for (int i = 0; i < 2 * N; i++) T0[i] = __builtin_subc(T0[i], T1[i], bw, &bw);
+    }
+    r.c1 = B::redc_wide(T0);
+    return r;
+  }
+#endif
   // (a0 + a1 u)(b0 + b1 u) with u^2 = -1, Karatsuba: 3 base multiplications.
   ZK_HD friend Fp2 operator*(const Fp2& a, const Fp2& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_FQ2_NO_LAZY)
+    // the modulus must leave two spare bits
+    // the MSM hot kernels of 8-limb curves (Fp2I).  The 12-limb form, as one out-of-line copy for the BLS12-381 G2
+    // kernels, was measured and left out: C5 (2^24) 1.587-1.593 s per proof against 1.570-1.579 s.
+    if constexpr (INL && B::N == 8 && (P::MOD[B::N - 1] >> 30) == 0) return mul_lazy(a, b);
+#endif
     B v0 = bmul(a.c0, b.c0);
     B v1 = bmul(a.c1, b.c1);
     B s = bmul(a.c0 + a.c1, b.c0 + b.c1);
