@@ -43,7 +43,7 @@ ZK_HD XYZZ<Fld> xyzz_dbl_affine(const Fld& x, const Fld& y) {
   Fld xx = x.sqr();
   Fld M = xx.dbl() + xx;
   Fld X3 = M.sqr() - S.dbl();
-  Fld Y3 = M * (S - X3) - W * y;
+  Fld Y3 = Fld::mul_sub_mul(M, S - X3, W, y);          // one reduction for the two products (field.hpp)
   return {X3, Y3, V, W};
 }
 
@@ -58,7 +58,7 @@ ZK_HD XYZZ<Fld> xyzz_dbl(const XYZZ<Fld>& p) {
   Fld xx = p.X.sqr();
   Fld M = xx.dbl() + xx;
   Fld X3 = M.sqr() - S.dbl();
-  Fld Y3 = M * (S - X3) - W * p.Y;
+  Fld Y3 = Fld::mul_sub_mul(M, S - X3, W, p.Y);
   return {X3, Y3, V * p.ZZ, W * p.ZZZ};
 }
 
@@ -78,7 +78,7 @@ ZK_HD XYZZ<Fld> xyzz_madd(const XYZZ<Fld>& a, const Fld& x2, const Fld& y2) {
   Fld PPP = P * PP;
   Fld Q = a.X * PP;
   Fld X3 = R.sqr() - PPP - Q.dbl();
-  Fld Y3 = R * (Q - X3) - a.Y * PPP;
+  Fld Y3 = Fld::mul_sub_mul(R, Q - X3, a.Y, PPP);
   return {X3, Y3, a.ZZ * PP, a.ZZZ * PPP};
 }
 
@@ -101,7 +101,7 @@ ZK_HD XYZZ<Fld> xyzz_add(const XYZZ<Fld>& a, const XYZZ<Fld>& b) {
   Fld PPP = P * PP;
   Fld Q = U1 * PP;
   Fld X3 = R.sqr() - PPP - Q.dbl();
-  Fld Y3 = R * (Q - X3) - S1 * PPP;
+  Fld Y3 = Fld::mul_sub_mul(R, Q - X3, S1, PPP);
   return {X3, Y3, a.ZZ * b.ZZ * PP, a.ZZZ * b.ZZZ * PPP};
 }
 

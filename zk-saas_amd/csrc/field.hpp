@@ -354,6 +354,66 @@ struct Fp {
 #endif
   }
 
+  // a*b - c*d (all Montgomery) in ONE product-scanning pass: a*b + (p - c)*d < 2 p^2 < p R is reduced once -- 3 N^2 + N
+  // multiply instructions instead of 2 (2 N^2 + N): 200 vs 272 for N = 8.  Same field element as a*b - c*d.  Used for
+  // Y3 = R (Q - X3) - Y1 PPP of the mixed addition (msm.hpp).  The modulus must leave two spare bits.
+  ZK_HD static Fp mul_sub_mul(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_MUL_SUB_MUL)
+    if constexpr (N <= ZK_MUL_INLINE_LIMBS && (P::MOD[N - 1] >> 30) == 0) {
+      uint32_t nc[N];                               // p - c, in (0, p]
+      {
+        unsigned bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) nc[i] = __builtin_subc(P::MOD[i], c.v[i], bw, &bw);
+      }
+      uint32_t m[N], r[N];
+      uint64_t acc = 0, cy;
+      uint32_t acc2 = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+          acc = madc(a.v[i], b.v[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+          acc = madc(nc[i], d.v[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+          acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+        m[k] = (uint32_t)acc * P::N0INV;
+        acc = madc_k(m[k], P::MOD[0], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+        acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+        acc2 = 0;
+      }
+#pragma unroll
+      for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+          acc = madc(a.v[i], b.v[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+          acc = madc(nc[i], d.v[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+          acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+        r[k - N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+        acc2 = 0;
+      }
+      r[N - 1] = (uint32_t)acc;
+      Fp o;
+#pragma unroll
+      for (int i = 0; i < N; i++) o.v[i] = r[i];
+      return reduce_once(o, (uint32_t)(acc >> 32));
+    }
+#endif
+    return a * b - c * d;
+  }
+
 #if defined(__HIP_DEVICE_COMPILE__)
   // ---- unreduced (double-width) arithmetic for the lazy-reduction product of the quadratic extension (Fp2T::mul_lazy)
   // T = a * b as 2N limbs, no reduction (product scanning; N^2 multiply instructions); a, b < 2^(32 N)
@@ -646,6 +706,7 @@ struct Fp2T {
     return {B::mul_ni(c0, n), B::mul_ni(c1, n).neg()};
   }
   static ZK_HD Fp2 mul_ni(const Fp2& a, const Fp2& b) { return a * b; }
+  ZK_HD static Fp2 mul_sub_mul(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return a * b - c * d; }
 };
 
 // true for the quadratic extension (G2 coordinates)

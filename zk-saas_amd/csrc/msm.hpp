@@ -692,7 +692,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
         const Fld PPP = P * PP;
         const Fld Q = acc.X * PP;
         const Fld X3 = R.sqr() - PPP - Q.dbl();
-        const Fld Y3 = R * (Q - X3) - acc.Y * PPP;
+        const Fld Y3 = Fld::mul_sub_mul(R, Q - X3, acc.Y, PPP);      // one reduction for the two products (field.hpp)
         acc = XYZZ<Fld>{X3, Y3, acc.ZZ * PP, acc.ZZZ * PPP};
       }
     }
