@@ -181,12 +181,14 @@ def identity_fractions(pp, crs):
 
 def proof_alu(adds, offered, proofs, dt):
     """Whole-proof multiplier utilisation: the base-field products of the mixed additions the accumulate kernels of one
-    proof actually PERFORMED (zk_msm_stats: sorted entries; 10 products per addition in G1, 28 in G2 = 8 Fq2 products + 2
-    Fq2 squarings) over the proof's WALL time.  The per-kernel figure in `roofline.alu` divides one launch's products by
+    proof actually PERFORMED (zk_msm_stats: sorted entries; per addition 9.47 products in G1 and 23.76 in G2 -- what the
+    kernels execute, counted in multiply instructions: api.MULS_PER_ADD; the textbook 10 / 28 before the shared
+    reductions) over the proof's WALL time.  The per-kernel figure in `roofline.alu` divides one launch's products by
     that launch's duration while other MSMs share the chip with it; this one does not depend on how the launches
     overlap.  `identity_points_skipped` = (point, window) pairs the sort left out (identity bases of the CRS, zero
     digits).  NTT / king / reduction multiplications (about 20 M per proof) are not counted."""
-    muls = (adds["g1"] * 10 + adds["g2"] * 28) / proofs
+    from zksaas_amd.api import MULS_PER_ADD, ZK_G1, ZK_G2
+    muls = (adds["g1"] * MULS_PER_ADD[ZK_G1] + adds["g2"] * MULS_PER_ADD[ZK_G2]) / proofs
     rate = muls / (dt / proofs) / 1e9
     return {"modmuls_per_proof": int(muls), "additions_per_proof": {k: int(v / proofs) for k, v in adds.items()},
             "identity_points_skipped": {k: int((offered[k] - adds[k]) / proofs) for k in adds},
@@ -227,7 +229,7 @@ def primitives(pp, zk):
     mask = zk.FftMask.sample(pp, False, None, 0, log_m, 11)
     for label, mk, alg in (("masks", mask, 32 * m * 32), ("zero_masks", zk.FftMask.zero(), 16 * m * 32)):
         t = med(pp, lambda: zk.d_fft(pp, sh, mk, False, log_m, seed=3, out=dst), 10)
-        modmul = pp.n * (m // 2) * 10 + (m // 2) * 53       # fft1: 20 stages x 1/2 per element; king: ~53 per chunk
+        modmul = pp.n * (m // 2) * 10 + (m // 2) * 32       # fft1: 19 stages x 1/2 per element + pre-twiddle; king: 32 per chunk (DESIGN.md d_fft)
         out["d_fft_m2^20_bn254_l2_n8_" + label] = {
             "ms": round(t * 1e3, 3), "algorithmic_bytes": alg, "achieved_GBps": round(alg / t / 1e9, 1),
             "frac_hbm": round(alg / t / 8e12, 4), "G_modmul_per_s": round(modmul / t / 1e9, 1),

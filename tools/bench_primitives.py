@@ -56,7 +56,7 @@ def main():
     out["d_fft_2^20"] = {"gpu_ms": round(t_gpu * 1e3, 3), "cpu_port_1thread_ms": round(t_cpu * 1e3, 1),
                          "algorithmic_bytes": alg, "achieved_GBps": round(alg / t_gpu / 1e9, 1),
                          "frac_of_8TBps": round(alg / t_gpu / 8e12, 4),
-                         "modmul_estimate_per_s": round((pp.n * (m // 2) * 10.5 + (m // 2) * 53) / t_gpu / 1e9, 1)}
+                         "modmul_estimate_per_s": round((pp.n * (m // 2) * 10.5 + (m // 2) * 32) / t_gpu / 1e9, 1)}
     # ---- config 3: d_msm, 2^20 G1 points per party (8 parties -> one fused 2^23-point Pippenger)
     ln = 1 << 20
     chain = cp.doubling_chain_g1(BN254.g1, ln)

@@ -339,12 +339,22 @@ def msm_table_info(pp, group, bases_d):
     return {"window_bits": info[0], "windows": info[1]}
 
 
+# Base-field Montgomery products (one product = 2 N^2 + N multiply instructions: 136 v_mad_u64_u32 for 8 limbs) that ONE mixed
+# XYZZ addition of the accumulate kernels costs, counted in multiply instructions (csrc/field.hpp):
+#   G1: 8 products + Y3 = R (Q - X3) - Y1 PPP as one pass with one reduction (3 N^2 + N)      -> 1288 / 136 = 9.47
+#   G2: 8 Fq2 products with lazy reduction (3 N^2 + 2 (N^2 + N) = 336) + 2 Fq2 squarings (272)   -> 3232 / 136 = 23.76
+# (the textbook counts are 10 and 28; the accounting of bench.py uses what the kernels execute)
+MULS_PER_ADD = {ZK_G1: 1288 / 136, ZK_G2: 3232 / 136}
+
+
 def msm_plan(pp, group, length):
-    """The Pippenger plan zk_msm uses for `length` points: dict(window_bits, windows, lane_points, muls_per_add)."""
+    """The Pippenger plan zk_msm uses for `length` points: dict(window_bits, windows, lane_points, muls_per_add,
+    muls_per_add_textbook); muls_per_add = base-field products per mixed addition as executed (MULS_PER_ADD)."""
     import ctypes as C
     plan = (C.c_int * 4)()
     pp._check(pp.lib.zk_msm_plan(pp.h, group, length, plan))
-    return {"window_bits": plan[0], "windows": plan[1], "lane_points": plan[2], "muls_per_add": plan[3]}
+    return {"window_bits": plan[0], "windows": plan[1], "lane_points": plan[2],
+            "muls_per_add": round(MULS_PER_ADD[group], 2), "muls_per_add_textbook": plan[3]}
 
 
 def d_msm(pp, group, bases_d, scalars_d, length, msm_mask=None, stream=None):
