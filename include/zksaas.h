@@ -102,6 +102,12 @@ int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, c
  *          out_d == NULL or == shares_d returns it in shares_d.  The local stages run out of place into a
  *          context-owned vector and the king step writes the destination, so neither form costs a copy. */
 int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream);
+/* Parity-test access to the BASE-field primitives of the group kernels (arkworks' Fq / Fq2 arithmetic, a22; Montgomery Fq
+ * elements on the device): op 0: out[i] = a[i] b[i] - c[i] d[i] (the one-reduction form used for Y3 of every XYZZ
+ * formula); op 1: out[2i], out[2i+1] = (a[i] + b[i] u)(c[i] + d[i] u), u^2 = -1 (the Fq2 product of the G2 kernels: three
+ * unreduced products and two reductions on 8-limb curves). */
+int zk_fq_selftest(zk_ctx* ctx, int op, const void* a_d, const void* b_d, const void* c_d, const void* d_d, size_t len,
+                   void* out_d, void* stream);
 int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int nparties, int log2_m, int inverse,
                  const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out_d,
                  const void* out_mask_d, void* stream);

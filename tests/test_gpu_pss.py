@@ -152,6 +152,49 @@ def test_field_arithmetic_edge_values(curve):
 
 
 
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381", "bls12_377"])
+def test_base_field_primitives_of_the_group_kernels_on_edge_values(curve):
+    """zk_fq_selftest: a*b - c*d with ONE Montgomery reduction (Fp::mul_sub_mul, Y3 of every XYZZ formula) and the Fq2
+    product of the G2 kernels (three unreduced products, two reductions on 8-limb curves) on the values that break a
+    multiplier first -- 0, 1, q-1, q-2, powers of two +- 1, R mod q, R^2 mod q -- in every operand position, plus random
+    ones, against Python integers.  (The MSM parity tests exercise these with the coordinates of real points only.)"""
+    import zksaas_amd as zk
+    from oracle.params import CURVES
+    pp = ctx(curve, 2)
+    q = CURVES[curve].q
+    nb = q.bit_length()
+    R = 1 << (32 * pp.fq.nl * 2)
+    edge = [0, 1, 2, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2, (1 << 32) - 1, 1 << 32, (1 << 64) - 1, (1 << 128) - 1,
+            (1 << (nb - 1)) - 1, (1 << (nb - 1)) % q, R % q, (R - 1) % q, R * R % q, q - (R % q)]
+    edge = [e % q for e in edge]
+    ne = len(edge)
+    a = [edge[i % ne] for i in range(ne ** 2)] + rand_vec(191, 300, q)
+    b = [edge[(i // ne) % ne] for i in range(ne ** 2)] + rand_vec(192, 300, q)
+    c = [edge[(i * 5 + 1) % ne] for i in range(ne ** 2)] + rand_vec(193, 300, q)
+    d = [edge[(i * 11 + 3) % ne] for i in range(ne ** 2)] + rand_vec(194, 300, q)
+    n = len(a)
+
+    def upq(vals):
+        return zk.DeviceBuffer.from_numpy(pp, pp.fq.encode(vals))
+    da, db, dc, dd = upq(a), upq(b), upq(c), upq(d)
+    out = zk.DeviceBuffer(pp, 2 * n * pp.fq.nbytes)
+    pp._check(pp.lib.zk_fq_selftest(pp.h, 0, da.ptr, db.ptr, dc.ptr, dd.ptr, n, out.ptr, None))
+    pp.sync()
+    got = pp.fq.decode(out.to_numpy().reshape(-1, pp.fq.nl)[:n])
+    assert got == [(w * x - y * z) % q for w, x, y, z in zip(a, b, c, d)]
+    if curve == "bls12_377":
+        with pytest.raises(zk.ZkError):
+            pp._check(pp.lib.zk_fq_selftest(pp.h, 1, da.ptr, db.ptr, dc.ptr, dd.ptr, n, out.ptr, None))
+        return
+    pp._check(pp.lib.zk_fq_selftest(pp.h, 1, da.ptr, db.ptr, dc.ptr, dd.ptr, n, out.ptr, None))
+    pp.sync()
+    got = pp.fq.decode(out.to_numpy().reshape(-1, pp.fq.nl))
+    want = []
+    for w, x, y, z in zip(a, b, c, d):                   # (w + x u)(y + z u), u^2 = -1
+        want += [(w * y - x * z) % q, (w * z + x * y) % q]
+    assert got == want
+
+
 def test_host_pointer_forms_equal_the_device_forms():
     """zk_d_fft_host / zk_msm_host / zk_d_msm_host (operands and results in HOST memory, as the reference's own signatures)
     give exactly what the device-pointer entry points give."""

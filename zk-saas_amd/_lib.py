@@ -22,7 +22,7 @@ SYMBOLS = [
     "zk_points_decompress", "zk_points_compress", "zk_libsnark_h", "zk_vec_scale", "zk_deg_red_parties", "zk_d_msm_parties", "zk_pss_pack_points", "zk_msm_plan",
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
     "zk_groth16_prove_batch", "zk_groth16_prove_batch_async", "zk_groth16_batch_wait", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct", "zk_msm_stats", "zk_dist_groth16_prove_batch", "zk_d_fft_host", "zk_msm_host", "zk_d_msm_host",
-    "zk_net_parties", "zk_dist_groth16_prove_async", "zk_dist_groth16_wait",
+    "zk_net_parties", "zk_dist_groth16_prove_async", "zk_dist_groth16_wait", "zk_fq_selftest",
 ]
 
 _lib = None
@@ -155,6 +155,7 @@ def load():
     lib.zk_dist_d_msm.argtypes = [vp, vp, i32, i32, vp, vp, sz, vp, vp, vp, vp]
     lib.zk_dist_circom_h.argtypes = [vp, vp, vp, vp, vp, i32, vp, u64, vp, vp]
     lib.zk_dist_groth16_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, vp, vp, vp]
+    lib.zk_fq_selftest.argtypes = [vp, i32, vp, vp, vp, vp, sz, vp, vp]
     lib.zk_net_parties.argtypes = [vp, i32, C.POINTER(i32)]
     lib.zk_dist_groth16_prove_async.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, C.POINTER(i32)]
     lib.zk_dist_groth16_wait.argtypes = [vp, vp, i32, vp, vp, vp]

@@ -165,6 +165,12 @@ int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, c
   return e->vec_mul_sub(out_d, a_d, b_d, c_d, len, S(stream));
 }
 
+int zk_fq_selftest(zk_ctx* ctx, int op, const void* a_d, const void* b_d, const void* c_d, const void* d_d, size_t len,
+                   void* out_d, void* stream) {
+  CTX_OR_FAIL();
+  return e->fq_selftest(op, a_d, b_d, c_d, d_d, len, out_d, S(stream));
+}
+
 int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream) {
   CTX_OR_FAIL();
   return e->fft1(shares_d, log2_m, inverse, batch, add_d, S(stream));

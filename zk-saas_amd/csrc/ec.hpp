@@ -105,6 +105,24 @@ ZK_HD XYZZ<Fld> xyzz_add(const XYZZ<Fld>& a, const XYZZ<Fld>& b) {
   return {X3, Y3, a.ZZ * b.ZZ * PP, a.ZZZ * b.ZZZ * PPP};
 }
 
+#if defined(__HIPCC__)
+// parity-test kernel for the base-field primitives of the group kernels (engine fq_selftest)
+template <class Fq, bool INL>
+__global__ void fq_selftest_kernel(int op, const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ c,
+                                   const Fq* __restrict__ d, size_t n, Fq* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op == 0) {
+    out[i] = Fq::mul_sub_mul(a[i], b[i], c[i], d[i]);
+  } else {
+    using F2 = Fp2T<typename Fq::Params, INL>;
+    const F2 z = F2{a[i], b[i]} * F2{c[i], d[i]};
+    out[2 * i] = z.c0;
+    out[2 * i + 1] = z.c1;
+  }
+}
+#endif
+
 // Out-of-line forms for cold code (bucket reduction, finalize, host folding).
 template <class Fld>
 ZK_HD_NOINLINE XYZZ<Fld> xyzz_add_ni(const XYZZ<Fld>& a, const XYZZ<Fld>& b) {

@@ -202,6 +202,8 @@ class IEngine {
   virtual int vec_add(void* x, const void* y, size_t len, hipStream_t st) = 0;
   virtual int vec_scale(void* x, const void* k, size_t len, hipStream_t st) = 0;
   virtual int vec_mul_sub(void* out, const void* a, const void* b, const void* c, size_t len, hipStream_t st) = 0;
+  virtual int fq_selftest(int op, const void* a, const void* b, const void* c, const void* d, size_t len, void* out,
+                          hipStream_t st) = 0;
   virtual int fft1(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st) = 0;
   virtual int fft2_king(const void* in, const void* in_mask, const uint32_t* parties, int np, int log_m, int inverse,
                         const void* g, int scale_size_inv, int rearrange, uint64_t seed, void* out,

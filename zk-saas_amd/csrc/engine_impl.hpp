@@ -454,6 +454,22 @@ class Engine : public IEngine {
     return ZK_OK;
   }
 
+  // Base-field primitives of the group kernels, exposed for the parity tests (edge values against Python integers):
+  //   op 0: out[i] = a*b - c*d through Fp::mul_sub_mul (ONE reduction; Y3 of every XYZZ formula)
+  //   op 1: out[2i], out[2i+1] = (a + b u)(c + d u) through the Fq2 product of the MSM kernels (lazy reduction on 8 limbs)
+  int fq_selftest(int op, const void* a, const void* b, const void* c, const void* d, size_t len, void* out,
+                  hipStream_t st) override {
+    using Fq = Fp<typename Cfg::FqP>;
+    if (!len) return ZK_OK;
+    if (!a || !b || !c || !d || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (op != 0 && op != 1) return fail(ZK_ERR_BAD_INPUT, "op must be 0 or 1");
+    if (op == 1 && !Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    fq_selftest_kernel<Fq, (Fq::N == 8)><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>(
+        op, (const Fq*)a, (const Fq*)b, (const Fq*)c, (const Fq*)d, len, (Fq*)out);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+
   // ---------------------------------------------------------------- fft1 (dfft/mod.rs:178-208)
   int fft1(void* shares, int log_m, int inverse, size_t batch, const void* add, hipStream_t st) override {
     return fft1_src(shares, log_m, inverse, batch, add, st, NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1});
