@@ -36,8 +36,8 @@
 namespace zk {
 #if defined(__HIPCC__)
 
-constexpr size_t MSM_RANGE_MIN = 20, MSM_RANGE = 32;        // entries per accumulate lane: fewest (small MSMs), most
-constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 20;  // ... per lane pair of the extension-field kernel
+constexpr size_t MSM_RANGE_MIN = 20, MSM_RANGE = 64;        // entries per accumulate lane: fewest (small MSMs), most
+constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 32;  // ... per lane pair of the extension-field kernel
 constexpr uint32_t FIN_SEQ = 16;      // a bucket spread over more accumulate lanes than this is summed by a workgroup
 constexpr int MSM_WS = 30;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
                                       // streams) + 6 per batch of proofs in flight (zk_groth16_prove_batch)
