@@ -133,6 +133,23 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         znet.dist_d_ifft(pp, net, 2, mine, FftMask.zero(), True, log_m, seed=6)
         pp.sync()
         checks["d_ifft_zero_masks"] = same_rows(mine, full, Lc)
+        # ... and against the ORACLE directly (not only HIP vs HIP): this rank's rows of the collective d_fft equal
+        # oracle.dist.d_fft (dfft/mod.rs:99-134 restated) on the same shares, replay stream 6
+        from oracle import dist as od
+        from oracle.field import Domain
+        from oracle.pss import PackedSharingParams as OPP
+        o_small = OPP(BN254, 2)
+        log_s = 9
+        Ls = (1 << log_s) // 2
+        sh_s = rand_fr(n * Ls)
+        mine = loc(sh_s, Ls)
+        znet.dist_d_fft(pp, net, 2, mine, FftMask.zero(), False, log_s, seed=6)
+        pp.sync()
+        ints = pp.fr.decode(sh_s)
+        want = od.d_fft([ints[p_ * Ls:(p_ + 1) * Ls] for p_ in range(n)], [od.FftMask.zero(Ls)] * n, False,
+                        Domain(BN254, 1 << log_s), o_small, seed=6)
+        got_rows = pp.fr.decode(mine.to_numpy().reshape(-1, 4))
+        checks["d_fft_vs_oracle"] = all(got_rows[i * Ls:(i + 1) * Ls] == want[sel[i]] for i in range(k))
         # ---- deg_red, d_pp
         ln = 777
         x = rand_fr(n * ln)
