@@ -1431,6 +1431,7 @@ class Engine : public IEngine {
   }
   int groth16_wait(int handle, void* pi_a, void* pi_b, void* pi_c) override {
     if (handle < 0 || handle >= NJOBS || !jobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no proof in flight on this handle");
+    if (djobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "a sharded proof is in flight on this handle: zk_dist_groth16_wait joins it");
     if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     return prove_end(jobs_[handle], pi_a, pi_b, pi_c);
   }
