@@ -29,7 +29,11 @@ done
 rm -rf $O/pmc_sq $O/pmc_u $O/pmc_sq_b8
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python3 $R/bench.py --workload c3 --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_u -o p -- python3 $R/bench.py --no-cpu-baseline --no-primitives --steps 10 --warmup 3 > $O/pmc_u.log 2>&1
+rm -rf $O/pmc_c2a $O/pmc_c2b
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/pmc_c2a -o p -- python3 $R/bench.py --workload c2 --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_c2a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $O/pmc_c2b -o p -- python3 $R/bench.py --workload c2 --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_c2b.log 2>&1
 cd $R
+python tools/sq_c2_summary.py $O/pmc_c2a $O/pmc_c2b $O/r03_c2_sq_counters.json > /dev/null
 for v in c4 c4tf c2 c3 b8 b8x2 b8wide; do
   f=$(find $O/prof_$v -name "p_results.db" | head -1)
   python tools/kernel_stats.py $f > $O/r03_${v}_kernel_stats.csv
