@@ -8,6 +8,7 @@
 // a canonical integer; callers convert it to Montgomery form.
 #pragma once
 #include "field.hpp"
+#include "params.hpp"
 
 namespace zk {
 
@@ -47,8 +48,8 @@ ZK_HD Fp<P> rand_fp(uint64_t seed, uint64_t idx) {
 // ---- production stream: ChaCha20 (RFC 7539 block function, original 64-bit counter / 64-bit nonce layout) keyed per
 // context from the operating system's generator.  The t random points of a `pack` are the only thing that hides the
 // secrets, so outside of replay mode (tests that compare shares bit for bit with the oracle) they come from here:
-// value (nonce, idx) = the first candidate below p among the 8-word halves of the blocks with counters 2 idx' ...,
-// masked to the modulus' bit length.  `nonce` is a per-context call counter, never a caller-supplied seed, so no two
+// value (nonce, idx) = the first accepted candidate among the 8-word halves of the blocks with counters idx | attempt << 56
+// (rand_fp_secure below).  `nonce` is a per-context call counter, never a caller-supplied seed, so no two
 // pack streams of a context ever share randomness.
 ZK_HD uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 ZK_HD void chacha20_block(const uint32_t* key, uint64_t counter, uint64_t nonce, uint32_t* out) {
@@ -72,21 +73,83 @@ ZK_HD void chacha20_block(const uint32_t* key, uint64_t counter, uint64_t nonce,
   for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
 
+// Candidate = a whole 32 N-bit half of a block, accepted when it is below K p, K = floor(2^(32 N) / p), and then reduced
+// mod p by conditional subtractions of 2^j p: x uniform on [0, K p) makes x mod p exactly uniform.  Acceptance is K p /
+// 2^(32 N) -- 0.945 for BN254 Fr (K = 5), 0.906 for BLS12-381 Fr (K = 2), 0.948 for BLS12-377 Fr (K = 13) -- against
+// 0.756 for BN254 when candidates are masked to the modulus' bit length: what matters on the GPU is that a WAVE repeats the
+// block function until all 64 lanes hold a value (1.2 blocks per draw on average instead of 2.2; the king kernels spent
+// 15 % of their issue cycles here, profiles/r03_c2_sq_counters.json).
+template <class P>
+struct RandWide {
+  static constexpr int N = P::N;
+  struct Mult {
+    uint32_t v[N];
+  };
+  // floor(2^(32 N) / p), at most 15 (the scalar fields here have at most 3 spare bits + slack)
+  static constexpr int K = []() constexpr {
+    int k = 0;
+    uint64_t acc[N + 1] = {};
+    for (;;) {
+      uint64_t c = 0;
+      for (int i = 0; i < N; i++) {
+        uint64_t t = acc[i] + P::MOD[i] + c;
+        acc[i] = t & 0xffffffffull;
+        c = t >> 32;
+      }
+      acc[N] += c;
+      if (acc[N]) return k;        // (k + 1) p overflowed: K = k
+      k++;
+      if (k == 15) return k;
+    }
+  }();
+  static constexpr Mult times(int m) {
+    Mult r{};
+    for (int j = 0; j < m; j++) {
+      uint64_t c = 0;
+      for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)r.v[i] + P::MOD[i] + c;
+        r.v[i] = (uint32_t)t;
+        c = t >> 32;
+      }
+    }
+    return r;
+  }
+};
+static_assert(RandWide<Bn254Fr>::K == 5 && RandWide<Bls381Fr>::K == 2 && RandWide<Bls377Fr>::K == 13, "acceptance multiples");
+template <class P, int M>
+ZK_HD bool rand_lt_mult(const Fp<P>& x) {            // x < M p
+  constexpr typename RandWide<P>::Mult m = RandWide<P>::times(M);
+  unsigned bw = 0;
+  for (int i = 0; i < P::N; i++) (void)__builtin_subc(x.v[i], m.v[i], bw, &bw);
+  return bw != 0;
+}
+template <class P, int M>
+ZK_HD void rand_sub_mult_if_ge(Fp<P>& x) {           // x -= M p when x >= M p
+  constexpr typename RandWide<P>::Mult m = RandWide<P>::times(M);
+  Fp<P> d;
+  unsigned bw = 0;
+  for (int i = 0; i < P::N; i++) d.v[i] = __builtin_subc(x.v[i], m.v[i], bw, &bw);
+  if (!bw) x = d;
+}
 template <class P>
 ZK_HD Fp<P> rand_fp_secure(const uint32_t* key, uint64_t nonce, uint64_t idx) {
   constexpr int N = P::N;
   static_assert(N <= 8, "scalar fields have at most 8 limbs");
-  constexpr int TOP = P::BITS - 32 * (N - 1);
+  constexpr int K = RandWide<P>::K;
   for (uint64_t attempt = 0;; attempt++) {
     uint32_t blk[16];
-    // counter: low 40 bits... idx in the low 56 bits, the attempt number above (2^8 attempts never happen)
+    // counter: idx in the low 56 bits, the attempt number above (2^8 attempts never happen)
     chacha20_block(key, idx | (attempt << 56), nonce, blk);
     for (int half = 0; half < 2; half++) {
       Fp<P> r;
 #pragma unroll
       for (int i = 0; i < N; i++) r.v[i] = blk[8 * half + i];
-      if (TOP < 32) r.v[N - 1] &= ((1u << TOP) - 1);
-      if (r.is_canonical()) return r.to_mont();
+      if (!rand_lt_mult<P, K>(r)) continue;
+      if constexpr (K >= 8) rand_sub_mult_if_ge<P, 8>(r);
+      if constexpr (K >= 4) rand_sub_mult_if_ge<P, 4>(r);
+      if constexpr (K >= 2) rand_sub_mult_if_ge<P, 2>(r);
+      rand_sub_mult_if_ge<P, 1>(r);
+      return r.to_mont();
     }
   }
 }
