@@ -132,11 +132,11 @@ ZK_HD void rand_sub_mult_if_ge(Fp<P>& x) {           // x -= M p when x >= M p
   if (!bw) x = d;
 }
 template <class P>
-ZK_HD Fp<P> rand_fp_secure(const uint32_t* key, uint64_t nonce, uint64_t idx) {
+ZK_HD Fp<P> rand_fp_secure(const uint32_t* key, uint64_t nonce, uint64_t idx, uint64_t first_attempt = 0) {
   constexpr int N = P::N;
   static_assert(N <= 8, "scalar fields have at most 8 limbs");
   constexpr int K = RandWide<P>::K;
-  for (uint64_t attempt = 0;; attempt++) {
+  for (uint64_t attempt = first_attempt;; attempt++) {
     uint32_t blk[16];
     // counter: idx in the low 56 bits, the attempt number above (2^8 attempts never happen)
     chacha20_block(key, idx | (attempt << 56), nonce, blk);
@@ -164,6 +164,42 @@ struct RngSeed {
 template <class P>
 ZK_HD Fp<P> rand_fp(const RngSeed& rs, uint64_t idx) {
   return rs.key ? rand_fp_secure<P>(rs.key, rs.seed, idx) : rand_fp<P>(rs.seed, idx);
+}
+// first accepted candidate of one block, if any
+template <class P>
+ZK_HD bool rand_candidate(const uint32_t* blk, Fp<P>* out) {
+  constexpr int N = P::N;
+  constexpr int K = RandWide<P>::K;
+  for (int half = 0; half < 2; half++) {
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = blk[8 * half + i];
+    if (!rand_lt_mult<P, K>(r)) continue;
+    if constexpr (K >= 8) rand_sub_mult_if_ge<P, 8>(r);
+    if constexpr (K >= 4) rand_sub_mult_if_ge<P, 4>(r);
+    if constexpr (K >= 2) rand_sub_mult_if_ge<P, 2>(r);
+    rand_sub_mult_if_ge<P, 1>(r);
+    *out = r.to_mont();
+    return true;
+  }
+  return false;
+}
+// The two draws idx, idx + 1 of a chunk (t = 2) -- the SAME values as two rand_fp calls; on the production stream their
+// first blocks are computed side by side (two independent instruction streams for the scheduler: the block function is
+// one long dependent chain), the rare repeats fall back to the one-draw loop.
+template <class P>
+ZK_HD void rand_fp_pair(const RngSeed& rs, uint64_t idx, Fp<P>* a, Fp<P>* b) {
+  if (!rs.key) {
+    *a = rand_fp<P>(rs.seed, idx);
+    *b = rand_fp<P>(rs.seed, idx + 1);
+    return;
+  }
+  uint32_t ba[16], bb[16];
+  chacha20_block(rs.key, idx, rs.seed, ba);
+  chacha20_block(rs.key, idx + 1, rs.seed, bb);
+  const bool oa = rand_candidate<P>(ba, a), ob = rand_candidate<P>(bb, b);
+  if (!oa) *a = rand_fp_secure<P>(rs.key, rs.seed, idx, 1);
+  if (!ob) *b = rand_fp_secure<P>(rs.key, rs.seed, idx + 1, 1);
 }
 
 }  // namespace zk

@@ -324,8 +324,12 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
       sec[i] = lds.get(lp);
     }
     uint32_t j = rearrange ? bitrev32(q, log_lc) : q;
+    if constexpr (T == 2) {
+      rand_fp_pair<P>(seed, (uint64_t)j * T, &sec[L], &sec[L + 1]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
+      for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
+    }
     F sh[N];
     pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
@@ -451,8 +455,12 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
              load_elem(sub_c + (size_t)s * stride + j) + load_elem(in_mask + (size_t)s * stride + j);
     });
   }
+  if constexpr (T == 2) {
+    rand_fp_pair<P>(seed, (uint64_t)(j0 + j) * T, &sec[L], &sec[L + 1]);
+  } else {
 #pragma unroll
-  for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)(j0 + j) * T + i);
+    for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)(j0 + j) * T + i);
+  }
   F sh[N];
   pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
