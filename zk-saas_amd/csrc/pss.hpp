@@ -146,8 +146,12 @@ __global__ __launch_bounds__(KING_THREADS) void pss_pack_kernel(const Fp<P>* __r
 #pragma unroll
   for (int i = 0; i < L; i++) v[i] = load_elem(secrets + (order ? j + (size_t)i * nchunks : j * L + i));
   if (!DET) {
+    if constexpr (T == 2) {
+      rand_fp_pair<P>(seed, (uint64_t)j * T, &v[L], &v[L + 1]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < T; i++) v[L + i] = rand_fp<P>(seed, j * T + i);
+      for (int i = 0; i < T; i++) v[L + i] = rand_fp<P>(seed, j * T + i);
+    }
   }
   F sh[N];
   pack_chunk<P, L, (DET ? L : L + T)>(v, Pm, k2, sh);
