@@ -5,6 +5,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzksaas_hip.so")
+if os.environ.get("ZKSAAS_LIB"):      # A/B runs against another build of the same library (tools/, never the tests)
+    LIB_PATH = os.environ["ZKSAAS_LIB"]
 
 # every symbol include/zksaas.h declares (tests check that the library exports all of them)
 SYMBOLS = [

@@ -18,6 +18,7 @@
 #pragma once
 #include <atomic>
 #include <future>
+#include <map>
 #include <thread>
 #include <algorithm>
 #include <cstdio>
@@ -150,6 +151,19 @@ inline hipError_t msm_zero(void* p, size_t bytes, hipStream_t st, unsigned ny = 
   return hipGetLastError();
 }
 
+// Kernels whose dynamic LDS exceeds the default limit: raise the limit once per (kernel, device)
+inline hipError_t msm_lds_attr(const void* fn, size_t bytes, int device) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> done;
+  std::lock_guard<std::mutex> g(mu);
+  size_t& v = done[std::make_pair(fn, device)];
+  if (v >= bytes) return hipSuccess;
+  const size_t want = std::max(bytes, (size_t)160 * 1024);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+  if (e == hipSuccess) v = want;
+  return e;
+}
+
 // Identity bases contribute nothing: bit i of `skip` is set when base i is the identity in EVERY base vector of the
 // launch, and the sort then emits no entry for point i.  A Groth16 CRS is full of them -- b_query holds the identity for
 // every wire that no B-row mentions (59 % of the SHA-256 circuit's wires; half of the PACKED shares) -- and a lane
@@ -177,23 +191,61 @@ __global__ __launch_bounds__(256) void msm_skip_mask_kernel(const Affine<Fld>* _
   if (lane == 32 && i < npts) skip[i >> 5] = (uint32_t)(m >> 32);
 }
 
+// `cap` = lanes the chip holds at once for this kernel: when the entries make one round of waves or more, the range
+// length is stretched so that the launch is a WHOLE number of rounds -- a last round that is 5 % full costs as much as a
+// full one (measured: 3.05 rounds of a G2 accumulate ran 25 % slower than 2.9)
+ZK_D uint32_t msm_range_len(uint32_t entries, uint32_t nlanes, uint32_t tmin, uint32_t cap) {
+  uint32_t T = (entries + nlanes - 1) / nlanes;
+  if (T < tmin) T = tmin;
+  const uint64_t round_entries = (uint64_t)cap * T;
+  uint32_t rounds = (uint32_t)(entries / round_entries);
+  if (rounds == 1) {
+    // exactly one round is the slow case (79 against 100+ G multiplications/s): two rounds of shorter ranges instead,
+    // unless that makes them shorter than 12 entries
+    // (only when the launch has the lanes for it: ranges shorter than entries / nlanes would leave entries uncovered --
+    // msm_pick_lanes sizes such launches at 2 cap lanes)
+    const uint32_t T2 = (uint32_t)((entries + 2ull * cap - 1) / (2ull * cap));
+    if (T2 >= 12 && (uint64_t)T2 * nlanes >= entries) return T2;
+  }
+  if (rounds >= 1) {
+    const uint64_t lanes = (uint64_t)cap * rounds;
+    const uint32_t Tr = (uint32_t)((entries + lanes - 1) / lanes);
+    if (Tr > T) T = Tr;
+  }
+  return T;
+}
+
 // -------------------------------------------------------------------------------------------------- big sort
 // For multi-million-point MSMs the two atomics-per-(point, window) passes above dominate (measured at 8 x 2^20
 // points: 4.7 ms histogram + 12.2 ms scatter against 15.6 ms of accumulate).  The big-sort path is a two-level
-// counting sort whose global atomics are per (workgroup tile, bin) instead of per entry:
-//   bin = (window, top BIG_HI bits of the bucket index)         nbins = nwin * 2^BIG_HI  (a few thousand)
-//   part_hist   : per tile of BIG_TILE points, LDS histogram over the bins -> one global add per non-empty bin
-//   (scan of the bin totals)
-//   part_scatter: same tile, reserves its range in every bin with one global add, LDS ranks inside the range,
-//                 writes {index|sign, low bucket bits} to tmp[]          (runs of ~16 entries per bin and tile)
-//   bin_sort    : one workgroup per bin: counts of the 2^lo low-bit buckets (written out as the per-key counts the
-//                 rest of the pipeline scans), LDS scan, second sweep places index|sign into sorted[]
+// counting sort whose global atomics are per (workgroup tile, bin) instead of per entry AND WHOSE GLOBAL STORES ARE
+// COALESCED RUNS (round 4): both levels sort their tile in LDS first and then stream it out, consecutive lanes to
+// consecutive addresses.  Round 3 stored every entry from the lane that produced it -- 64 scattered 4- or 8-byte
+// stores per wave instruction, which the L2 does not merge: the counters showed 3.4x (level 1) and 5.7x (level 2) the
+// algorithmic bytes going to memory (profiles/r03_c3_pmc_hbm.json).
+//   bin = (bucket set, top hi_bits of the bucket index)         nbins = nsets * 2^hi_bits  (at most 8192)
+//   hist    : per tile of THR*PPT points of ONE scalar vector, LDS histogram over the bins -> one global add per
+//             non-empty bin; the canonical scalar (times the party coefficient) is computed here once and cached; the
+//             LAST workgroup to finish (ticket) scans the bin totals -> bin_base[], bin_cursor[]
+//   scatter : same tile, scalars in registers.  Counts its entries per bin, reserves its range in every bin with one
+//             global add, then goes over the windows in ROUNDS of `wgroup` windows (bins are set-major, so without a
+//             fixed-base table the bins of a round are contiguous and so are the tile-sorted positions of its
+//             entries; with a table all windows share the bins and the whole tile is one round): entries are ranked
+//             into an LDS stage in bin order and the stage is streamed to tmp[] -- runs of
+//             (tile points / 2^hi_bits) entries.  An entry is ONE 32-bit word {point index, sign, low bucket bits}
+//             when that fits (2^20 points per party x 8 parties with 17-bit windows: 23 + 1 + 8), otherwise a word
+//             plus a 16-bit low part in a second array
+//   binsort : one workgroup per bin: counts of the 2^lo_bits low-bit buckets, LDS scan -> offsets[] of the bin's
+//             keys (= bin_base + local prefix: the separate three-launch scan over all keys is gone) and the first
+//             bucket of every accumulate lane that starts inside the bin (msm_lane_start_kernel's job on this path);
+//             then chunks of THR*EPT entries are ranked into an LDS stage in bucket order and streamed to sorted[]
 // The order inside a bucket is arbitrary, as before; bucket sums do not depend on it.
-constexpr int BIG_HI = 8;                 // top bucket bits of a bin (fewer when a batch has many bucket sets: msm_big_hi)
-constexpr int BIG_MAX_BINS = 8192;        // LDS: 4 B per bin in part_hist, 8 B in part_scatter
-constexpr int BIG_THREADS = 256;
-constexpr int BIG_PTS_PER_THREAD = 16;   // points per thread for multi-million-point MSMs; fewer for small ones so that
-                                         // the tiles (BIG_THREADS * points-per-thread points each) still fill the chip
+constexpr int BIG_HI = 8;                 // top bucket bits of a bin when nothing else decides (msm_big_hi)
+constexpr int BIG_MAX_BINS = 8192;
+constexpr int BIG_THREADS = 256;          // histogram tiles; scatter / binsort: 256 (small launches) or 1024
+constexpr int BIG_PTS_PER_THREAD = 8;     // most points per thread (scalars are held in registers by the scatter)
+constexpr int BIG_EPT = 16;               // entries per thread and chunk of the bin sort
+constexpr size_t BIG_LDS_MAX = 156 * 1024;
 inline int msm_big_hi(size_t nsets) {
   int hi = BIG_HI;
   while (hi > 0 && (nsets << hi) > (size_t)BIG_MAX_BINS) hi--;
@@ -223,197 +275,441 @@ __device__ __forceinline__ void msm_for_each_digit(Fp<FrP> s, int c, int nwin, i
     fn(w, (uint32_t)(neg ? -d : d) - 1, neg);
   }
 }
+// one step of the same walk with its state (shifted scalar, carry) kept by the caller: the scatter kernel goes over
+// the windows in rounds and continues where the previous round stopped
+template <class FrP>
+__device__ __forceinline__ bool msm_next_digit(Fp<FrP>& s, uint32_t& carry, int cw, uint32_t* b, uint32_t* neg) {
+  constexpr int N = FrP::N;
+  const uint32_t val = s.v[0] & ((1u << cw) - 1);
+#pragma unroll
+  for (int q = 0; q < N - 1; q++) s.v[q] = (s.v[q] >> cw) | (s.v[q + 1] << (32 - cw));
+  s.v[N - 1] >>= cw;
+  int32_t d = (int32_t)(val + carry);
+  if ((uint32_t)d > (1u << (cw - 1))) {
+    d -= (int32_t)(1u << cw);
+    carry = 1;
+  } else {
+    carry = 0;
+  }
+  if (d == 0) return false;
+  *neg = d < 0 ? 1u : 0u;
+  *b = (uint32_t)(d < 0 ? -d : d) - 1;
+  return true;
+}
 
-// scalar of global entry g = (vector vb of the batch, point i); identity bases and out-of-range entries give zero
-// The canonical integer (times the party coefficient) costs two field multiplications: the histogram pass computes it
-// once and leaves it in `canon`, the scatter pass reads it back (FIRST = false).
-template <class FrP, bool FIRST>
-__device__ __forceinline__ Fp<FrP> msm_load_scalar(const MsmScalars<Fp<FrP>>& sc, const Fp<FrP>* coef, size_t part_len,
-                                                   size_t g, const uint32_t* skip, Fp<FrP>* canon, uint32_t* vb_out,
-                                                   uint32_t* i_out) {
-  const uint32_t vb = (uint32_t)(g / sc.npts), i = (uint32_t)(g % sc.npts);
-  *vb_out = vb;
-  *i_out = i;
-  if (!FIRST) return load_elem(canon + g);
-  Fp<FrP> s = Fp<FrP>::zero();                                                // identity base: no digit, no entry
+// exclusive scan of one value per thread over the workgroup: wave shuffles + one LDS round over the wave totals
+template <int THR>
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* sh /* THR / 64 words */, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) sh[wv] = inc;
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < THR / 64; i++) {
+    const uint32_t t = sh[i];
+    pre += i < wv ? t : 0u;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + inc - v;
+}
+
+// Layout of the bins block (uint32): counts[nbins], ticket, base[nbins + 1], cursor[nbins]
+ZK_HD size_t msm_bins_words(size_t nbins) { return 3 * nbins + 2; }
+
+// scalar of (vector vb of the batch, point i); identity bases give zero (no digit, no entry)
+template <class FrP>
+__device__ __forceinline__ Fp<FrP> msm_canon_scalar(const MsmScalars<Fp<FrP>>& sc, const Fp<FrP>* coef, size_t part_len,
+                                                    uint32_t vb, uint32_t i, const uint32_t* skip) {
+  Fp<FrP> s = Fp<FrP>::zero();
   if (!(skip && ((skip[i >> 5] >> (i & 31)) & 1u))) {
     s = load_elem(sc.p[vb] + i);
     if (coef) s = s * coef[i / part_len];
     s = s.from_mont();
   }
-  store_elem(canon + g, s);
   return s;
 }
 
+// hist: grid.x = tiles_per_vec * nb tiles of BIG_THREADS * ppt points, each inside ONE scalar vector
 template <class FrP>
-__global__ __launch_bounds__(BIG_THREADS) void msm_part_hist_kernel(MsmScalars<Fp<FrP>> sc,
-                                                                    const Fp<FrP>* __restrict__ coef, size_t part_len,
-                                                                    int c, int nwin, int wide, int hi_bits, int lo_bits,
-                                                                    int ppt /* points per thread */,
-                                                                    uint32_t wmask /* 0: fixed-base table, all windows
-                                                                    share one bucket set; ~0: one set per window */,
-                                                                    uint32_t* __restrict__ bin_counts,
-                                                                    const uint32_t* __restrict__ skip,
-                                                                    Fp<FrP>* __restrict__ canon, size_t ys) {
+__global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP>> sc, const Fp<FrP>* __restrict__ coef,
+                                                               size_t part_len, int c, int nwin, int wide, int hi_bits,
+                                                               int lo_bits, int ppt, uint32_t tiles_per_vec,
+                                                               uint32_t wmask /* 0: fixed-base table, all windows
+                                                               share one bucket set; ~0: one set per window */,
+                                                               uint32_t* __restrict__ bins,
+                                                               const uint32_t* __restrict__ skip,
+                                                               Fp<FrP>* __restrict__ canon, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
-  ZK_YSHIFT(bin_counts);
+  ZK_YSHIFT(bins);
   ZK_YSHIFT(skip);
   ZK_YSHIFT(canon);
   extern __shared__ uint32_t big_lds[];
-  const uint32_t nbins = (sc.nb * sc.sets_per) << hi_bits;
-  const size_t total = (size_t)sc.npts * sc.nb;
-  for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) big_lds[b] = 0;
+  const uint32_t nbl = sc.sets_per << hi_bits;                 // bins of one scalar vector
+  const uint32_t nbins = nbl * sc.nb;
+  const uint32_t vb = blockIdx.x / tiles_per_vec;
+  const uint32_t pt0 = (blockIdx.x % tiles_per_vec) * (uint32_t)(BIG_THREADS * ppt);
+  for (uint32_t b = threadIdx.x; b < nbl; b += BIG_THREADS) big_lds[b] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * BIG_THREADS * ppt;
   for (int k = 0; k < ppt; k++) {
-    size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
-    if (g >= total) break;
-    uint32_t vb, i;
-    Fp<FrP> s = msm_load_scalar<FrP, true>(sc, coef, part_len, g, skip, canon, &vb, &i);
-    const uint32_t set0 = vb * sc.sets_per;
-    msm_for_each_digit<FrP>(s, c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&big_lds[((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits)], 1u); });
+    const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
+    if (i >= sc.npts) break;
+    const Fp<FrP> s = msm_canon_scalar<FrP>(sc, coef, part_len, vb, i, skip);
+    store_elem(canon + (size_t)vb * sc.npts + i, s);
+    msm_for_each_digit<FrP>(s, c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
+      atomicAdd(&big_lds[(((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+    });
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS)
-    if (big_lds[b]) atomicAdd(&bin_counts[b], big_lds[b]);
-}
-
-// exclusive scan of the bin totals by one workgroup: bin_base[0..nbins], bin_cursor = copy of bin_base
-static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_scan_kernel(const uint32_t* __restrict__ bin_counts,
-                                                                          uint32_t nbins,
-                                                                          uint32_t* __restrict__ bin_base,
-                                                                          uint32_t* __restrict__ bin_cursor, size_t ys) {
-  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
-  ZK_YSHIFT(bin_counts);
-  ZK_YSHIFT(bin_base);
-  ZK_YSHIFT(bin_cursor);
-  __shared__ uint32_t sh[BIG_THREADS];
+  uint32_t* bin_counts = bins + (size_t)vb * nbl;
+  uint32_t seen = 0;                 // RETURNING adds: a value that has come back is an add that has been performed
+  for (uint32_t b0 = threadIdx.x; b0 < nbl; b0 += 8 * BIG_THREADS) {       // eight in flight, then their values
+    uint32_t r[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t b = b0 + (uint32_t)u * BIG_THREADS;
+      const uint32_t n = b < nbl ? big_lds[b] : 0u;
+      r[u] = n ? atomicAdd(&bin_counts[b], n) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) seen += r[u];
+  }
+  asm volatile("" ::"v"(seen));      // ... and this makes the wave wait for them before the barrier below
+  // the last workgroup of this sort to get here scans the bin totals (saves the one-workgroup scan launch that sat on
+  // every MSM's dependent chain).  The counts were added by device-scope atomics; they are read back the same way (the
+  // per-XCD L2s are not coherent with each other)
+  // (no __threadfence here: at device scope it writes back and invalidates the whole L2 -- measured 188 us for this
+  // kernel and every concurrent kernel slowed down.  Every wave has its adds' return values before the barrier, the
+  // ticket is taken after it, and the scanning workgroup reads with device-scope loads)
+  __shared__ uint32_t last_sh;
+  __syncthreads();
+  if (threadIdx.x == 0) last_sh = atomicAdd(bins + nbins, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last_sh) return;
+  uint32_t* bin_base = bins + nbins + 1;
+  uint32_t* bin_cursor = bin_base + nbins + 1;
   const uint32_t per = (nbins + BIG_THREADS - 1) / BIG_THREADS;
   const uint32_t b0 = threadIdx.x * per;
   uint32_t sum = 0;
   for (uint32_t j = 0; j < per; j++)
-    if (b0 + j < nbins) sum += bin_counts[b0 + j];
-  sh[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < BIG_THREADS; off <<= 1) {
-    uint32_t t = sh[threadIdx.x];
-    if ((int)threadIdx.x >= off) t += sh[threadIdx.x - off];
-    __syncthreads();
-    sh[threadIdx.x] = t;
-    __syncthreads();
-  }
-  uint32_t run = threadIdx.x ? sh[threadIdx.x - 1] : 0u;
+    if (b0 + j < nbins) sum += __hip_atomic_load(bins + b0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t tot;
+  uint32_t run = block_scan_excl<BIG_THREADS>(sum, big_lds, &tot);
   for (uint32_t j = 0; j < per; j++)
     if (b0 + j < nbins) {
       bin_base[b0 + j] = run;
       bin_cursor[b0 + j] = run;
-      run += bin_counts[b0 + j];
+      run += __hip_atomic_load(bins + b0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  if (threadIdx.x == BIG_THREADS - 1) bin_base[nbins] = sh[BIG_THREADS - 1];
+  if (threadIdx.x == 0) bin_base[nbins] = tot;
 }
 
-template <class FrP>
-__global__ __launch_bounds__(BIG_THREADS) void msm_part_scatter_kernel(MsmScalars<Fp<FrP>> sc,
-                                                                       const Fp<FrP>* __restrict__ coef,
-                                                                       size_t part_len, int c, int nwin, int wide,
-                                                                       int hi_bits, int lo_bits, int ppt, uint32_t wmask,
-                                                                       uint32_t pre_stride, uint32_t pre_off,
-                                                                       uint32_t* __restrict__ bin_cursor,
-                                                                       uint2* __restrict__ tmp,
-                                                                       Fp<FrP>* __restrict__ canon, size_t ys) {
+// Small launches (everything stays in L2 / Infinity Cache; what counts is the latency of a short kernel that has to find
+// room among the accumulate waves of the other MSMs in flight: few registers, little LDS): entries go straight from the
+// lane that produced them to tmp[]
+template <class FrP, bool WIDE>
+__global__ __launch_bounds__(BIG_THREADS) void msm_scatter_direct_kernel(MsmScalars<Fp<FrP>> sc, int c, int nwin, int wide,
+                                                                         int hi_bits, int lo_bits, int ppt,
+                                                                         uint32_t tiles_per_vec, uint32_t wmask,
+                                                                         uint32_t pre_stride, uint32_t pre_off,
+                                                                         int idx_bits, uint32_t* __restrict__ bins,
+                                                                         uint32_t* __restrict__ tmp,
+                                                                         uint16_t* __restrict__ tmp_lo,
+                                                                         const Fp<FrP>* __restrict__ canon, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
-  ZK_YSHIFT(bin_cursor);
+  ZK_YSHIFT(bins);
   ZK_YSHIFT(tmp);
+  ZK_YSHIFT(tmp_lo);
   ZK_YSHIFT(canon);
   extern __shared__ uint32_t big_lds[];
-  const uint32_t nbins = (sc.nb * sc.sets_per) << hi_bits;
-  const size_t total = (size_t)sc.npts * sc.nb;
+  const uint32_t nbl = sc.sets_per << hi_bits;
+  const uint32_t nbins = nbl * sc.nb;
+  const uint32_t vb = blockIdx.x / tiles_per_vec;
+  const uint32_t pt0 = (blockIdx.x % tiles_per_vec) * (uint32_t)(BIG_THREADS * ppt);
+  uint32_t* bin_cursor = bins + 2 * (size_t)nbins + 2 + (size_t)vb * nbl;
   uint32_t* cnt = big_lds;            // per-bin count of this tile, then the running local rank
-  uint32_t* gbase = big_lds + nbins;  // start of this tile's range inside the bin
-  for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) cnt[b] = 0;
+  uint32_t* gbase = big_lds + nbl;    // start of this tile's range inside the bin
+  const Fp<FrP>* __restrict__ my = canon + (size_t)vb * sc.npts;
+  for (uint32_t b = threadIdx.x; b < nbl; b += BIG_THREADS) cnt[b] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * BIG_THREADS * ppt;
   for (int k = 0; k < ppt; k++) {
-    size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
-    if (g >= total) break;
-    uint32_t vb, i;
-    Fp<FrP> s = msm_load_scalar<FrP, false>(sc, coef, part_len, g, nullptr, canon, &vb, &i);
-    const uint32_t set0 = vb * sc.sets_per;
-    msm_for_each_digit<FrP>(s, c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t) { atomicAdd(&cnt[((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits)], 1u); });
+    const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
+    if (i >= sc.npts) break;
+    msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
+      atomicAdd(&cnt[(((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+    });
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS) {
-    uint32_t n = cnt[b];
+  for (uint32_t b = threadIdx.x; b < nbl; b += BIG_THREADS) {
+    const uint32_t n = cnt[b];
     gbase[b] = n ? atomicAdd(&bin_cursor[b], n) : 0u;
     cnt[b] = 0;
   }
   __syncthreads();
   const uint32_t lo_mask = (1u << lo_bits) - 1;
   for (int k = 0; k < ppt; k++) {
-    size_t g = base + (size_t)k * BIG_THREADS + threadIdx.x;
-    if (g >= total) break;
-    uint32_t vb, i;
-    Fp<FrP> s = msm_load_scalar<FrP, false>(sc, coef, part_len, g, nullptr, canon, &vb, &i);
-    const uint32_t set0 = vb * sc.sets_per;
-    msm_for_each_digit<FrP>(s, c, nwin, wide,
-                            [&](int w, uint32_t b, uint32_t neg) {
-                              uint32_t bin = ((set0 + ((uint32_t)w & wmask)) << hi_bits) | (b >> lo_bits);
-                              uint32_t r = atomicAdd(&cnt[bin], 1u);
-                              uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
-                              tmp[gbase[bin] + r] = make_uint2(idx | (neg << 31), b & lo_mask);
-                            });
+    const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
+    if (i >= sc.npts) break;
+    msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t neg) {
+      const uint32_t lbin = (((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits);
+      const uint32_t dst = gbase[lbin] + atomicAdd(&cnt[lbin], 1u);
+      const uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
+      if (WIDE) {
+        tmp[dst] = idx | (neg << 31);
+        tmp_lo[dst] = (uint16_t)(b & lo_mask);
+      } else {
+        tmp[dst] = idx | (neg << idx_bits) | ((b & lo_mask) << (idx_bits + 1));
+      }
+    });
   }
 }
 
-// one workgroup per bin; the bin's keys are [bin << lo_bits, (bin + 1) << lo_bits) in the (set-major) key order
-static __global__ __launch_bounds__(BIG_THREADS) void msm_bin_sort_kernel(const uint2* __restrict__ tmp,
-                                                                          const uint32_t* __restrict__ bin_base,
-                                                                          int hi_bits, int lo_bits,
-                                                                          uint32_t keys_per_set_log2,
-                                                                          uint32_t* __restrict__ counts,
-                                                                          uint32_t* __restrict__ sorted, size_t ys) {
+// Entry formats of tmp[]: packed = {index : idx_bits, sign : 1, low bucket bits}; wide = {index | sign << 31} + 16-bit low part
+template <class FrP, int THR, int PPT, bool WIDE>
+__global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc, int c, int nwin, int wide, int hi_bits,
+                                                          int lo_bits, uint32_t tiles_per_vec, uint32_t wmask,
+                                                          int wgroup /* windows per round */, uint32_t pre_stride,
+                                                          uint32_t pre_off, int idx_bits, uint32_t stage_cap,
+                                                          uint32_t* __restrict__ bins, uint32_t* __restrict__ tmp,
+                                                          uint16_t* __restrict__ tmp_lo,
+                                                          const Fp<FrP>* __restrict__ canon, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(bins);
   ZK_YSHIFT(tmp);
-  ZK_YSHIFT(bin_base);
-  ZK_YSHIFT(counts);
-  ZK_YSHIFT(sorted);
-  __shared__ uint32_t cur[1 << 12];
-  const uint32_t nlo = 1u << lo_bits;
-  const uint32_t bin = blockIdx.x;
-  const uint32_t w = bin >> hi_bits, hi = bin & ((1u << hi_bits) - 1);
-  const size_t key0 = ((size_t)w << keys_per_set_log2) + ((size_t)hi << lo_bits);
-  const uint32_t e0 = bin_base[bin], e1 = bin_base[bin + 1];
-  for (uint32_t j = threadIdx.x; j < nlo; j += BIG_THREADS) cur[j] = 0;
+  ZK_YSHIFT(tmp_lo);
+  ZK_YSHIFT(canon);
+  extern __shared__ uint32_t big_lds[];
+  const uint32_t nbl = sc.sets_per << hi_bits;
+  const uint32_t nbins = nbl * sc.nb;
+  const uint32_t vb = blockIdx.x / tiles_per_vec;
+  const uint32_t pt0 = (blockIdx.x % tiles_per_vec) * (uint32_t)(THR * PPT);
+  uint32_t* bin_cursor = bins + 2 * (size_t)nbins + 2 + (size_t)vb * nbl;
+  uint32_t* cur = big_lds;                    // [nbl] running tile-local position of the next entry of the bin
+  uint32_t* dlt = cur + nbl;                  // [nbl] start of the tile's run inside the bin (global) - tile-local start
+  uint32_t* scr = dlt + nbl;                  // [THR / 64] scan scratch
+  uint32_t* stage = scr + THR / 64;           // [stage_cap]
+  uint16_t* sbin = reinterpret_cast<uint16_t*>(stage + stage_cap);     // [stage_cap] bin of a staged entry - first of round
+  uint16_t* slo = sbin + stage_cap;           // [stage_cap] (wide format)
+  const Fp<FrP>* __restrict__ my = canon + (size_t)vb * sc.npts;
+  for (uint32_t b = threadIdx.x; b < nbl; b += THR) cur[b] = 0;
   __syncthreads();
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += BIG_THREADS) atomicAdd(&cur[tmp[e].y], 1u);
+  // ---- count
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
+    if (i < sc.npts)
+      msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
+        atomicAdd(&cur[(((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+      });
+  }
   __syncthreads();
-  // counts out, exclusive scan in place (nlo <= 4096: one lane per entry, Hillis-Steele over BIG_THREADS-wide strips)
-  __shared__ uint32_t strip[BIG_THREADS];
-  uint32_t carry = 0;
-  for (uint32_t s0 = 0; s0 < nlo; s0 += BIG_THREADS) {
-    uint32_t j = s0 + threadIdx.x;
-    uint32_t v = j < nlo ? cur[j] : 0u;
-    if (j < nlo) counts[key0 + j] = v;
-    strip[threadIdx.x] = v;
+  // ---- reserve the tile's range in every bin; cur <- exclusive scan (tile-sorted position of the bin's first entry)
+  uint32_t tile_total;
+  {
+    const uint32_t per = (nbl + THR - 1) / THR;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++)
+      if (b0 + j < nbl) sum += cur[b0 + j];
+    uint32_t run = block_scan_excl<THR>(sum, scr, &tile_total);
+    for (uint32_t j = 0; j < per; j++)
+      if (b0 + j < nbl) {
+        const uint32_t n = cur[b0 + j];
+        const uint32_t g = n ? atomicAdd(&bin_cursor[b0 + j], n) : 0u;
+        dlt[b0 + j] = g - run;
+        cur[b0 + j] = run;
+        run += n;
+      }
+  }
+  __syncthreads();
+  // ---- rounds of windows: rank into the stage, stream the stage out
+  Fp<FrP> s[PPT];
+  uint32_t carry[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
+    s[k] = i < sc.npts ? load_elem(my + i) : Fp<FrP>::zero();
+    carry[k] = 0;
+  }
+  const uint32_t lo_mask = (1u << lo_bits) - 1;
+  for (int w0 = 0; w0 < nwin; w0 += wgroup) {
+    const int w1 = w0 + wgroup < nwin ? w0 + wgroup : nwin;
+    const uint32_t lb_lo = ((uint32_t)w0 & wmask) << hi_bits, lb_hi = ((((uint32_t)w1 - 1) & wmask) + 1) << hi_bits;
+    const uint32_t r0 = cur[lb_lo], r1 = lb_hi < nbl ? cur[lb_hi] : tile_total;     // untouched so far: bins of this round
     __syncthreads();
-    for (int off = 1; off < BIG_THREADS; off <<= 1) {
-      uint32_t t = strip[threadIdx.x];
-      if ((int)threadIdx.x >= off) t += strip[threadIdx.x - off];
-      __syncthreads();
-      strip[threadIdx.x] = t;
-      __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
+      for (int w = w0; w < w1; w++) {
+        uint32_t b, neg;
+        if (!msm_next_digit<FrP>(s[k], carry[k], w < wide ? c : c - 1, &b, &neg)) continue;
+        const uint32_t lbin = (((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits);
+        const uint32_t j = atomicAdd(&cur[lbin], 1u) - r0;
+        const uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
+        if (WIDE) {
+          stage[j] = idx | (neg << 31);
+          slo[j] = (uint16_t)(b & lo_mask);
+        } else {
+          stage[j] = idx | (neg << idx_bits) | ((b & lo_mask) << (idx_bits + 1));
+        }
+        sbin[j] = (uint16_t)(lbin - lb_lo);
+      }
     }
-    uint32_t incl = strip[threadIdx.x], tot = strip[BIG_THREADS - 1];
     __syncthreads();
-    if (j < nlo) cur[j] = e0 + carry + incl - v;
-    carry += tot;
+    const uint32_t nr = r1 - r0;
+    for (uint32_t j = threadIdx.x; j < nr; j += THR) {
+      const uint32_t dst = dlt[lb_lo + sbin[j]] + r0 + j;
+      tmp[dst] = stage[j];
+      if (WIDE) tmp_lo[dst] = slo[j];
+    }
     __syncthreads();
   }
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += BIG_THREADS) {
-    uint2 t = tmp[e];
-    sorted[atomicAdd(&cur[t.y], 1u)] = t.x;
+}
+
+// one workgroup per bin; the bin's keys are [key0, key0 + 2^lo_bits) in the (set-major) key order
+template <int THR, bool WIDE, bool STAGED>
+__global__ __launch_bounds__(THR) void msm_binsort_kernel(const uint32_t* __restrict__ tmp,
+                                                          const uint16_t* __restrict__ tmp_lo,
+                                                          const uint32_t* __restrict__ bins, uint32_t nbins, int hi_bits,
+                                                          int lo_bits, uint32_t keys_per_set_log2, int idx_bits,
+                                                          uint32_t nkeys, uint32_t nlanes, uint32_t tmin, uint32_t cap,
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
+                                                          uint32_t* __restrict__ k0, size_t ys) {
+  __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
+  ZK_YSHIFT(tmp);
+  ZK_YSHIFT(tmp_lo);
+  ZK_YSHIFT(bins);
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(sorted);
+  ZK_YSHIFT(k0);
+  constexpr uint32_t CH = THR * BIG_EPT;
+  extern __shared__ uint32_t big_lds[];
+  const uint32_t nlo = 1u << lo_bits;
+  uint32_t* cur = big_lds;                  // [nlo] next free slot of the bucket in sorted[]
+  uint32_t* coff = cur + nlo;               // [nlo + 1] chunk-local exclusive offsets
+  uint32_t* scr = coff + nlo + 1;           // [THR / 64]
+  uint32_t* stage = scr + THR / 64;         // [CH]
+  uint16_t* slo = reinterpret_cast<uint16_t*>(stage + CH);       // [CH]
+  const uint32_t* __restrict__ bin_base = bins + nbins + 1;
+  const uint32_t bin = blockIdx.x;
+  const uint32_t set = bin >> hi_bits, hi = bin & ((1u << hi_bits) - 1);
+  const size_t key0 = ((size_t)set << keys_per_set_log2) + ((size_t)hi << lo_bits);
+  const uint32_t e0 = bin_base[bin], e1 = bin_base[bin + 1], total = bin_base[nbins];
+  const uint32_t idx_mask = WIDE ? 0u : (1u << idx_bits) - 1;
+  auto lo_of = [&](uint32_t e, uint32_t word) -> uint32_t { return WIDE ? (uint32_t)tmp_lo[e] : word >> (idx_bits + 1); };
+  for (uint32_t j = threadIdx.x; j < nlo; j += THR) cur[j] = 0;
+  __syncthreads();
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += THR) atomicAdd(&cur[lo_of(e, WIDE ? 0u : tmp[e])], 1u);
+  __syncthreads();
+  {
+    // offsets of the bin's keys; cur <- first slot of every bucket
+    const uint32_t per = (nlo + THR - 1) / THR;
+    const uint32_t j0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++)
+      if (j0 + j < nlo) sum += cur[j0 + j];
+    uint32_t tot;
+    uint32_t run = e0 + block_scan_excl<THR>(sum, scr, &tot);
+    for (uint32_t j = 0; j < per; j++)
+      if (j0 + j < nlo) {
+        const uint32_t n = cur[j0 + j];
+        cur[j0 + j] = run;
+        offsets[key0 + j0 + j] = run;
+        run += n;
+      }
+    if (bin == nbins - 1 && threadIdx.x == 0) offsets[nkeys] = total;
+  }
+  __syncthreads();
+  {
+    // first bucket of every accumulate lane whose range starts inside this bin (msm_bucket_of on the local offsets)
+    const uint32_t T = msm_range_len(total, nlanes, tmin, cap);
+    const uint32_t l0 = (e0 + T - 1) / T, l1 = (e1 + T - 1) / T;       // lanes with e0 <= lane * T < e1
+    for (uint32_t lane = l0 + threadIdx.x; lane < l1 && lane < nlanes; lane += THR) {
+      const uint32_t a = lane * T;
+      uint32_t lo = 0, hi_ = nlo - 1;
+      while (lo < hi_) {
+        const uint32_t mid = (lo + hi_) >> 1;
+        if (cur[mid + 1] <= a) lo = mid + 1;
+        else hi_ = mid;
+      }
+      k0[lane] = (uint32_t)key0 + lo;
+    }
+  }
+  __syncthreads();
+  if (!STAGED) {
+    // small launches: straight from the lane that read an entry to its bucket's next slot
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += THR) {
+      const uint32_t w_ = tmp[e];
+      const uint32_t out = WIDE ? w_ : (w_ & idx_mask) | (((w_ >> idx_bits) & 1u) << 31);
+      sorted[atomicAdd(&cur[lo_of(e, w_)], 1u)] = out;
+    }
+    return;
+  }
+  for (uint32_t cb = e0; cb < e1; cb += CH) {
+    const uint32_t n = e1 - cb < CH ? e1 - cb : CH;
+    for (uint32_t j = threadIdx.x; j <= nlo; j += THR) coff[j] = 0;
+    __syncthreads();
+    uint32_t word[BIG_EPT], lo[BIG_EPT], rk[BIG_EPT];
+#pragma unroll
+    for (int k = 0; k < BIG_EPT; k++) {
+      const uint32_t j = (uint32_t)k * THR + threadIdx.x;
+      if (j < n) {
+        word[k] = tmp[cb + j];
+        lo[k] = lo_of(cb + j, word[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BIG_EPT; k++) {
+      const uint32_t j = (uint32_t)k * THR + threadIdx.x;
+      if (j < n) rk[k] = atomicAdd(&coff[lo[k]], 1u);
+    }
+    __syncthreads();
+    {
+      const uint32_t per = (nlo + THR - 1) / THR;
+      const uint32_t j0 = threadIdx.x * per;
+      uint32_t sum = 0;
+      for (uint32_t j = 0; j < per; j++)
+        if (j0 + j < nlo) sum += coff[j0 + j];
+      uint32_t tot;
+      uint32_t run = block_scan_excl<THR>(sum, scr, &tot);
+      for (uint32_t j = 0; j < per; j++)
+        if (j0 + j < nlo) {
+          const uint32_t c_ = coff[j0 + j];
+          coff[j0 + j] = run;
+          run += c_;
+        }
+      if (threadIdx.x == 0) coff[nlo] = n;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BIG_EPT; k++) {
+      const uint32_t j = (uint32_t)k * THR + threadIdx.x;
+      if (j < n) {
+        const uint32_t p = coff[lo[k]] + rk[k];
+        if (WIDE) {
+          stage[p] = word[k];
+        } else {
+          const uint32_t w_ = word[k];
+          stage[p] = (w_ & idx_mask) | (((w_ >> idx_bits) & 1u) << 31);
+        }
+        slo[p] = (uint16_t)lo[k];
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n; j += THR) {
+      const uint32_t l = slo[j];
+      sorted[cur[l] + j - coff[l]] = stage[j];
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < nlo; j += THR) cur[j] += coff[j + 1] - coff[j];
+    __syncthreads();
   }
 }
 
@@ -564,29 +860,6 @@ __device__ __forceinline__ void store_elem_untracked(F* p, const F& v) {
   zk_store_chunks<0, (int)(sizeof(F) / 16)>((const void*)p, c);
 }
 
-// `cap` = lanes the chip holds at once for this kernel: when the entries make one round of waves or more, the range
-// length is stretched so that the launch is a WHOLE number of rounds -- a last round that is 5 % full costs as much as a
-// full one (measured: 3.05 rounds of a G2 accumulate ran 25 % slower than 2.9)
-ZK_D uint32_t msm_range_len(uint32_t entries, uint32_t nlanes, uint32_t tmin, uint32_t cap) {
-  uint32_t T = (entries + nlanes - 1) / nlanes;
-  if (T < tmin) T = tmin;
-  const uint64_t round_entries = (uint64_t)cap * T;
-  uint32_t rounds = (uint32_t)(entries / round_entries);
-  if (rounds == 1) {
-    // exactly one round is the slow case (79 against 100+ G multiplications/s): two rounds of shorter ranges instead,
-    // unless that makes them shorter than 12 entries
-    // (only when the launch has the lanes for it: ranges shorter than entries / nlanes would leave entries uncovered --
-    // msm_pick_lanes sizes such launches at 2 cap lanes)
-    const uint32_t T2 = (uint32_t)((entries + 2ull * cap - 1) / (2ull * cap));
-    if (T2 >= 12 && (uint64_t)T2 * nlanes >= entries) return T2;
-  }
-  if (rounds >= 1) {
-    const uint64_t lanes = (uint64_t)cap * rounds;
-    const uint32_t Tr = (uint32_t)((entries + lanes - 1) / lanes);
-    if (Tr > T) T = Tr;
-  }
-  return T;
-}
 // bucket that contains entry a (offsets[k] <= a < offsets[k+1]; empty buckets are skipped by construction)
 ZK_D uint32_t msm_bucket_of(const uint32_t* __restrict__ offsets, uint32_t nkeys, uint32_t a) {
   uint32_t lo = 0, hi = nkeys;

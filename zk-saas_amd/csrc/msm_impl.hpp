@@ -79,21 +79,60 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   // registered vectors know whether they hold an identity at all (zk_msm_precompute): without one there is no mask
   const bool none = tab && !tab->any_identity && (NB == 1 || (tab2 && !tab2->any_identity));
   const unsigned NS = (NB == 2 && skip_on && !one_sort && !none) ? 2u : 1u;       // sorts of this launch
+  // ---- big-sort plan (msm.hpp "big sort"): workgroup shape, points per tile, bin split, entry format
+  static const size_t large_min = getenv("ZK_SORT_LARGE_MIN") ? (size_t)atoll(getenv("ZK_SORT_LARGE_MIN")) : ((size_t)4 << 20);
+  const bool large = npts * batch >= large_min;         // multi-million-point launches: 1024-thread workgroups, one per CU
+  const int sthr = large ? 1024 : 256;
+  // small launches: ~1024 tiles so that they still fill the chip, up to 16 points per thread
+  int ppt = large ? BIG_PTS_PER_THREAD : 16;
+  if (!large)
+    while (ppt > 1 && ((npts + (size_t)sthr * ppt - 1) / ((size_t)sthr * ppt)) * batch < 1024) ppt >>= 1;
+  const size_t stage_max = 16384;
+  if (large && tab)
+    while (ppt > 1 && (size_t)nwin * sthr * ppt > stage_max) ppt >>= 1;       // with a table the whole tile is one round
+  int sort_hi = msm_big_hi(nsets), sort_lo;
+  if (large) {
+    // runs of level 1 are (tile entries per bucket set) / 2^hi long, runs of level 2 (chunk) / 2^lo: balance them
+    auto lg = [](size_t v) { int l = 0; while (((size_t)1 << (l + 1)) <= v) l++; return l; };
+    const int tp_eff = lg((size_t)sthr * ppt * (tab ? nwin : 1)), ch = lg((size_t)sthr * BIG_EPT);
+    sort_hi = (c - 1 + tp_eff - ch + 1) / 2;
+    if (sort_hi > c - 2) sort_hi = c - 2;
+    if (c - 1 - sort_hi > 12) sort_hi = c - 1 - 12;
+    while (sort_hi > 0 && (nsets << sort_hi) > (size_t)BIG_MAX_BINS) sort_hi--;
+  }
+  static const int hi_env = getenv("ZK_SORT_HI") ? atoi(getenv("ZK_SORT_HI")) : 0;
+  if (hi_env > 0 && hi_env <= c - 2) sort_hi = hi_env;
+  sort_lo = c - 1 - sort_hi;
+  int idx_bits = 1;
+  {
+    const size_t max_idx = tab ? (size_t)nwin * tab->len : npts;
+    while (((size_t)1 << idx_bits) < max_idx) idx_bits++;
+  }
+  const bool wide_fmt = idx_bits + 1 + sort_lo > 32;
+  const size_t nbl = (size_t)kwin << sort_hi;      // bins of one scalar vector
+  size_t stage_cap = 0;
+  if (large) {
+    const size_t fixed = 8 * nbl + 4 * (size_t)(sthr / 64) + 64;
+    if (BIG_LDS_MAX > fixed) stage_cap = std::min(stage_max, (BIG_LDS_MAX - fixed) / (wide_fmt ? 8 : 6)) & ~(size_t)63;
+  }
+  const size_t tile_pts = (size_t)sthr * ppt;
+  const bool big = npts * batch >= tune.bigsort_min && sort_hi >= 1 && sort_lo >= 1 && sort_lo <= 12 &&
+                   (nsets << sort_hi) <= (size_t)BIG_MAX_BINS &&
+                   (large ? stage_cap >= (tab ? (size_t)nwin * tile_pts : tile_pts) : 8 * nbl <= BIG_LDS_MAX);
+  const int wgroup = tab ? nwin : (int)std::min<size_t>((size_t)nwin, std::max<size_t>(1, stage_cap / tile_pts));
+  const size_t nbins_tot = nsets << sort_hi;
   // ---- sort region (replicated NS times)
-  size_t o_counts = take(nkeys * 4), o_heavy = take(((size_t)nlanes / FIN_SEQ + 8) * 4), o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 4),
-         o_bt = take(iscan_blocks * 4), o_sorted = take(max_sorted * 4);
-  // big-sort path (see the kernels): bins = (window, top BIG_HI bits of the bucket), low bits sorted per bin
-  const int sort_hi = msm_big_hi(nsets);
-  const int sort_lo = c - 1 - sort_hi;
-  const bool big = npts * batch >= tune.bigsort_min && sort_hi >= 1 && sort_lo >= 1 && sort_lo <= 12;
-  const size_t kbin = nsets;                       // set components of the sort bins
+  size_t o_counts = take(nkeys * 4), o_heavy = take(((size_t)nlanes / FIN_SEQ + 8) * 4),
+         o_bins = take(big ? msm_bins_words(nbins_tot) * 4 : 0),     // right behind the heavy list: one zeroing launch
+         o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 4), o_bt = take(iscan_blocks * 4),
+         o_sorted = take(max_sorted * 4);
   const size_t o_skip = take(((npts + 63) / 64) * 8);
   const size_t o_k0 = take((size_t)nlanes * 4);                // first bucket of every accumulate lane
   const size_t o_canon = take(npts * batch * sizeof(Fr));      // canonical scalars (written by the first sort pass)
-  size_t o_bins = 0, o_tmp = 0;
+  size_t o_tmp = 0, o_tmp_lo = 0;
   if (big) {
-    o_bins = take((3 * (kbin << sort_hi) + 1) * 4);
-    o_tmp = take(max_sorted * sizeof(uint2));
+    o_tmp = take(max_sorted * 4);
+    if (wide_fmt) o_tmp_lo = take(max_sorted * 2);
   }
   const size_t sort_region = off;
   const size_t ys = NS == 2 ? sort_region : 0;     // byte distance between the two copies
@@ -142,8 +181,9 @@ do {                                                                           \
   }                                                                            \
 } while (0)
   {
-  // counts (the two-level sort writes every count itself) and the heavy-bucket counter that follows them
-  if (big) MSM_HIP(msm_zero(heavy, 16, st, NS, ys));
+  // counts (the two-level sort writes every offset itself; it needs its bin counters and the ticket zeroed) and the
+  // heavy-bucket counter
+  if (big) MSM_HIP(msm_zero(heavy, o_bins + (nbins_tot + 1) * 4 - o_heavy, st, NS, ys));
   else MSM_HIP(msm_zero(counts, o_heavy + 16 - o_counts, st, NS, ys));
   dim3 pg((unsigned)((npts + 255) / 256), NS), pb(256);
   dim3 pgb((unsigned)((npts * batch + 255) / 256), NS);     // one thread per (scalar vector, point)
@@ -162,42 +202,74 @@ do {                                                                           \
   {
   ProfScope ps_(eng->prof, PROF_MSM_SORT, st, (double)npts * batch);
   if (big) {
-    const uint32_t nbins = (uint32_t)(kbin << sort_hi);
-    uint32_t* bin_counts = (uint32_t*)(ws + o_bins);
-    uint32_t* bin_base = bin_counts + nbins;
-    uint32_t* bin_cursor = bin_base + nbins + 1;
-    uint2* tmp = (uint2*)(ws + o_tmp);
-    MSM_HIP(msm_zero(bin_counts, nbins * 4, st, NS, ys));
-    // tile = BIG_THREADS * ppt points: ~1024 tiles for small MSMs, 16 points per thread for the multi-million ones
-    int ppt = BIG_PTS_PER_THREAD;
-    const size_t tot = npts * batch;
-    while (ppt > 1 && (tot + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt) < 1024) ppt >>= 1;
-    const unsigned tiles = (unsigned)((tot + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
+    uint32_t* bins = (uint32_t*)(ws + o_bins);
+    uint32_t* tmp = (uint32_t*)(ws + o_tmp);
+    uint16_t* tmp_lo = (uint16_t*)(ws + o_tmp_lo);
     const uint32_t wmask = tab ? 0u : ~0u;
-    msm_part_hist_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), nbins * 4, st>>>(sc, coef_d, plen, c, nwin, wide,
-                                                                                    sort_hi, sort_lo, ppt, wmask,
-                                                                                    bin_counts, skip, canon, ys);
-    msm_bin_scan_kernel<<<dim3(1, NS), dim3(BIG_THREADS), 0, st>>>(bin_counts, nbins, bin_base, bin_cursor, ys);
-    msm_part_scatter_kernel<FrP><<<dim3(tiles, NS), dim3(BIG_THREADS), 2 * nbins * 4, st>>>(
-        sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, ppt, wmask, pre_stride, pre_off, bin_cursor, tmp, canon, ys);
-    msm_bin_sort_kernel<<<dim3(nbins, NS), dim3(BIG_THREADS), 0, st>>>(tmp, bin_base, sort_hi, sort_lo, (uint32_t)(c - 1),
-                                                                       counts, sorted, ys);
+    // hist: 256-thread tiles of its own (any tiling of the points gives the same bin totals)
+    {
+      const int hp = ppt;
+      const unsigned tpv = (unsigned)((npts + (size_t)BIG_THREADS * hp - 1) / ((size_t)BIG_THREADS * hp));
+      const size_t hl = std::max<size_t>(nbl, BIG_THREADS / 64) * 4;
+      if (hl > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_hist_kernel<FrP>, hl, eng->device));
+      msm_hist_kernel<FrP><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), hl, st>>>(
+          sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, hp, tpv, wmask, bins, skip, canon, ys);
+    }
+    if (large) {
+      const unsigned tpv = (unsigned)((npts + tile_pts - 1) / tile_pts);
+      const size_t l1 = (2 * nbl + (size_t)(sthr / 64)) * 4 + stage_cap * (wide_fmt ? 8 : 6);
+#define ZK_SCATTER(W_)                                                                                                  \
+  do {                                                                                                                 \
+    if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_>, l1, eng->device)); \
+    msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_><<<dim3(tpv * (unsigned)batch, NS), dim3(1024), l1, st>>>(    \
+        sc, c, nwin, wide, sort_hi, sort_lo, tpv, wmask, wgroup, pre_stride, pre_off, idx_bits, (uint32_t)stage_cap,   \
+        bins, tmp, tmp_lo, canon, ys);                                                                                 \
+  } while (0)
+      if (wide_fmt) ZK_SCATTER(true);
+      else ZK_SCATTER(false);
+#undef ZK_SCATTER
+    } else {
+      const unsigned tpv = (unsigned)((npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
+      const size_t l1 = 2 * nbl * 4;
+      if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr(wide_fmt ? (const void*)msm_scatter_direct_kernel<FrP, true> : (const void*)msm_scatter_direct_kernel<FrP, false>, l1, eng->device));
+      if (wide_fmt)
+        msm_scatter_direct_kernel<FrP, true><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), l1, st>>>(
+            sc, c, nwin, wide, sort_hi, sort_lo, ppt, tpv, wmask, pre_stride, pre_off, idx_bits, bins, tmp, tmp_lo, canon, ys);
+      else
+        msm_scatter_direct_kernel<FrP, false><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), l1, st>>>(
+            sc, c, nwin, wide, sort_hi, sort_lo, ppt, tpv, wmask, pre_stride, pre_off, idx_bits, bins, tmp, tmp_lo, canon, ys);
+    }
+    const size_t l2 = (2 * ((size_t)1 << sort_lo) + 1 + (size_t)(sthr / 64)) * 4 + (large ? (size_t)sthr * BIG_EPT * 6 : 0);
+#define ZK_BINSORT(THR_, W_, S_)                                                                                      \
+  do {                                                                                                                \
+    if (l2 > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_binsort_kernel<THR_, W_, S_>, l2, eng->device));        \
+    msm_binsort_kernel<THR_, W_, S_><<<dim3((unsigned)nbins_tot, NS), dim3(THR_), l2, st>>>(                          \
+        tmp, tmp_lo, bins, (uint32_t)nbins_tot, sort_hi, sort_lo, (uint32_t)(c - 1), idx_bits, (uint32_t)nkeys, nlanes, \
+        tmin, cap, offsets, sorted, k0, ys);                                                                          \
+  } while (0)
+    if (large) {
+      if (wide_fmt) ZK_BINSORT(1024, true, true);
+      else ZK_BINSORT(1024, false, true);
+    } else {
+      if (wide_fmt) ZK_BINSORT(256, true, false);
+      else ZK_BINSORT(256, false, false);
+    }
+#undef ZK_BINSORT
     MSM_STAGE("big sort");
   } else {
     msm_digits_kernel<FrP, 0><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, counts, nullptr,
                                                  nullptr, skip, canon, ys);
     MSM_STAGE("digits/count");
-  }
-  iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
-                                                                                       nullptr, nullptr, 0, ys);
-  iscan_carry_kernel<<<dim3(1, NS), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks, ys);
-  iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(
-      counts, nkeys, nullptr, bt, offsets, big ? nullptr : cursor, 1, ys);
-  MSM_STAGE("scan");
-  msm_lane_start_kernel<<<dim3((nlanes + 255) / 256, NS), dim3(256), 0, st>>>(offsets, (uint32_t)nkeys, nlanes, tmin, cap, k0, ys);
-  if (!big)
+    iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
+                                                                                         nullptr, nullptr, 0, ys);
+    iscan_carry_kernel<<<dim3(1, NS), dim3(ISCAN_THREADS), 0, st>>>(bt, iscan_blocks, ys);
+    iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, nullptr, bt,
+                                                                                         offsets, cursor, 1, ys);
+    MSM_STAGE("scan");
+    msm_lane_start_kernel<<<dim3((nlanes + 255) / 256, NS), dim3(256), 0, st>>>(offsets, (uint32_t)nkeys, nlanes, tmin, cap, k0, ys);
     msm_digits_kernel<FrP, 1><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, nullptr, cursor,
                                                  sorted, skip, canon, ys);
+  }
   }
   }
   MSM_STAGE("scatter");
