@@ -395,18 +395,23 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
   if (!last_sh) return;
   uint32_t* bin_base = bins + nbins + 1;
   uint32_t* bin_cursor = bin_base + nbins + 1;
+  // all counts into LDS first (independent loads, all in flight), then the scan reads LDS
+  uint32_t* cnt = big_lds + BIG_THREADS / 64;
+  for (uint32_t b = threadIdx.x; b < nbins; b += BIG_THREADS)
+    cnt[b] = __hip_atomic_load(bins + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
   const uint32_t per = (nbins + BIG_THREADS - 1) / BIG_THREADS;
   const uint32_t b0 = threadIdx.x * per;
   uint32_t sum = 0;
   for (uint32_t j = 0; j < per; j++)
-    if (b0 + j < nbins) sum += __hip_atomic_load(bins + b0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b0 + j < nbins) sum += cnt[b0 + j];
   uint32_t tot;
   uint32_t run = block_scan_excl<BIG_THREADS>(sum, big_lds, &tot);
   for (uint32_t j = 0; j < per; j++)
     if (b0 + j < nbins) {
       bin_base[b0 + j] = run;
       bin_cursor[b0 + j] = run;
-      run += __hip_atomic_load(bins + b0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      run += cnt[b0 + j];
     }
   if (threadIdx.x == 0) bin_base[nbins] = tot;
 }

@@ -210,7 +210,7 @@ do {                                                                           \
     {
       const int hp = ppt;
       const unsigned tpv = (unsigned)((npts + (size_t)BIG_THREADS * hp - 1) / ((size_t)BIG_THREADS * hp));
-      const size_t hl = std::max<size_t>(nbl, BIG_THREADS / 64) * 4;
+      const size_t hl = (nbins_tot + BIG_THREADS / 64) * 4;      // tile histogram (one vector's bins); all bins for the last workgroup's scan
       if (hl > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_hist_kernel<FrP>, hl, eng->device));
       msm_hist_kernel<FrP><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), hl, st>>>(
           sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, hp, tpv, wmask, bins, skip, canon, ys);
