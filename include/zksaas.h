@@ -57,8 +57,8 @@ int zk_stream_sync(zk_ctx* ctx, void* stream);
  * The t random points of every `pack` (pss.rs:90-122; the reference draws them from thread_rng / test_rng:
  * dfft/mod.rs:251, pack.rs:14, deg_red.rs:108) come from a ChaCha20 stream keyed per context from the operating
  * system's generator; every launch that packs gets fresh nonces, so NO `seed` argument below influences them and two
- * calls never share randomness.  zk_ctx_set_option("rng_replay", 1) (or ZK_RNG_REPLAY=1 in the environment when the
- * context is created) switches to the documented replayable generator (DESIGN.md "Randomness": SplitMix64 over
+ * calls never share randomness.  zk_ctx_set_option("rng_replay", 1) (a context option only: nothing in the
+ * environment can turn it on) switches to the documented replayable generator (DESIGN.md "Randomness": SplitMix64 over
  * (seed, index)) that the parity tests use to compare shares bit for bit with the oracle -- only then do the `seed`
  * arguments matter.  zk_chacha20_block: the block function (RFC 7539 2.3, words 12..15 = counter, nonce), exported
  * for known-answer tests. */
@@ -100,7 +100,10 @@ int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, c
  * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l], masks [n][m/l] each or
  *          NULL for FftMask::zero.  The result is written to out_d [n][m/l] (shares_d is then left as it was);
  *          out_d == NULL or == shares_d returns it in shares_d.  The local stages run out of place into a
- *          context-owned vector and the king step writes the destination, so neither form costs a copy. */
+ *          context-owned vector and the king step writes the destination, so neither form costs a copy.
+ *          That vector is ONE per context: d_fft / d_ifft / libsnark_h calls on the same context must be ordered on
+ *          one stream (or by events); concurrent transforms need separate contexts.  (The prover's own transforms
+ *          use per-proof scratch and are not affected.) */
 int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream);
 /* Parity-test access to the BASE-field primitives of the group kernels (arkworks' Fq / Fq2 arithmetic, a22; Montgomery Fq
  * elements on the device): op 0: out[i] = a[i] b[i] - c[i] d[i] (the one-reduction form used for Y3 of every XYZZ
@@ -290,7 +293,8 @@ int zk_groth16_msms_finish(zk_ctx* ctx, const void* h_share_d, void* const* out,
  * _async enqueues the whole proof -- device pipelines on internal streams, host-side terms on the context's worker
  * pool -- and returns a handle without waiting; _wait joins and writes the shares.  Up to two proofs may be in
  * flight per context (each has its own scratch); inputs must stay valid and unmodified until _wait returns.
- * _abort joins and discards a proof in flight (also safe after a failed call). */
+ * _abort joins and discards a proof in flight (also safe after a failed call); it also releases a handle handed out
+ * by zk_dist_groth16_prove_async (same handle space), which every rank must then abort alike. */
 int zk_groth16_prove_async(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
                            const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r,
                            const void* s, int log2_m, const zk_groth16_masks* masks, uint64_t seed, void* stream,

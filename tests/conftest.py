@@ -5,10 +5,13 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # parity tests compare SHARES bit for bit with the oracle: contexts created by the tests use the documented replayable
-# share-randomness stream instead of the ChaCha20 production stream (include/zksaas.h "share randomness")
-os.environ.setdefault("ZK_RNG_REPLAY", "1")
+# share-randomness stream instead of the ChaCha20 production stream (include/zksaas.h "share randomness").  The option is
+# set through the Python mirror's DEFAULT_OPTIONS; worker processes the tests spawn set it themselves (dist_worker.py)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import zksaas_amd.api as _zk_api  # noqa: E402  (pure Python: the library is loaded by the first context)
+
+_zk_api.DEFAULT_OPTIONS["rng_replay"] = 1
 
 
 def pytest_configure(config):

@@ -34,6 +34,7 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         a2a = scenario.endswith("_a2a")          # the all-to-all king instead of the star (same results, bit for bit)
         if a2a:
             scenario = scenario[:-4]
+        zk.api.DEFAULT_OPTIONS["rng_replay"] = 1     # a spawned process: the parent's conftest does not reach here
         pp = zk.PackedSharingParams("bn254", 2)
         pp.set_option("msm_bigsort_min", 0 if rank % 2 else 1 << 30)      # both sort paths across the ranks
         if a2a:
@@ -247,6 +248,27 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         except zk.ZkError as e:
             refused += e.code == 4
         checks["in_flight_misuse_refused"] = refused == 2
+        # zk_groth16_abort releases a SHARDED proof's handle too: the slot can be used again by either kind of
+        # proof, and the sharded wait refuses the handle of a single-context proof instead of joining it
+        fa = fly(0)
+        pp._check(pp.lib.zk_groth16_abort(pp.h, fa.handle))
+        fa._keep = None
+        fb = fly(1)
+        got = fb.wait()
+        after_abort = all(
+            G1.eq(dec_jacobian(pp, got[0][p]), dec_jacobian(pp, refs[1][0][sel[p]])) and
+            G2.eq(dec_jacobian(pp, got[1][p], True), dec_jacobian(pp, refs[1][1][sel[p]], True)) and
+            G1.eq(dec_jacobian(pp, got[2][p]), dec_jacobian(pp, refs[1][2][sel[p]])) for p in range(k))
+        fl = zg.prove_async(pp, crs, wit, rs_b[0], ss_b[0], masks=mks_b[0], seed=21)
+        wrong_kind = False
+        try:
+            znet.DistProofInFlight(pp, net, fl.handle, None).wait()
+        except zk.ZkError as e:
+            wrong_kind = e.code == 4
+        local = fl.wait()
+        after_abort = after_abort and wrong_kind and all(
+            G1.eq(dec_jacobian(pp, local[0][p]), dec_jacobian(pp, refs[0][0][p])) for p in range(pp.n))
+        checks["abort_releases_sharded_handle"] = after_abort
         # circom_h alone: shares identical to the all-in-one call
         h_ref = pp.alloc_fr(n * ((1 << wit.log_m) // 2))
         import ctypes as C

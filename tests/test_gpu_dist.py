@@ -92,7 +92,6 @@ def test_bench_ranks_as_the_driver_launches_it(workload, ranks):
     stream, and the bench has to deal its inputs from one dealer all the same); for c4 bench.py itself compares the
     sharded proof with the single-context proof."""
     env = dict(os.environ, ZK_NET="shm", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("ZK_RNG_REPLAY", None)
     out = _torchrun(ranks, ["--steps", "2", "--warmup", "1", "--workload", workload], env, 900)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -110,7 +109,6 @@ def test_bench_falls_back_to_shared_memory_when_rccl_cannot_start():
     agree across ranks, and finish over the shared-memory transport with the fact recorded in its line."""
     env = dict(os.environ, ZK_DIST_VIA_CPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ZK_NET", None)
-    env.pop("ZK_RNG_REPLAY", None)
     out = _torchrun(2, ["--steps", "2", "--warmup", "1", "--workload", "c2"], env, 600)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])

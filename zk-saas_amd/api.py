@@ -83,6 +83,12 @@ def _ptr(x):
     return int(x)
 
 
+# Options every context created by THIS process gets right after zk_ctx_create (zk_ctx_set_option): the test suite puts
+# {"rng_replay": 1} here (tests/conftest.py; shares are compared bit for bit with the oracle).  Nothing reads the
+# environment: a deployment cannot end up on the replayable share randomness by inheriting a variable.
+DEFAULT_OPTIONS = {}
+
+
 class Context:
     """zk_ctx: PackedSharingParams + cached tables on one device."""
 
@@ -99,6 +105,8 @@ class Context:
         self.t = self.l
         self.fr = fields.MontCodec(fields.FR[curve])
         self.fq = fields.MontCodec(fields.FQ[curve])
+        for name, value in DEFAULT_OPTIONS.items():
+            self.set_option(name, value)
 
     def _check(self, rc):
         if rc != 0:

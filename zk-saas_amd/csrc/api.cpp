@@ -537,33 +537,33 @@ int zk_net_sync(zk_net* net, int sid) {
 int zk_dist_d_fft(zk_ctx* ctx, zk_net* net, int sid, void* shares_d, const void* in_mask_d, const void* out_mask_d,
                   int rearrange, int log2_m, uint64_t seed, void* stream) {
   NET_OR_FAIL();
-  return e->dist_d_fft(&net->net, sid, shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 0, nullptr, seed, S(stream));
+  return e->dist_finish(&net->net, e->dist_d_fft(&net->net, sid, shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 0, nullptr, seed, S(stream)));
 }
 int zk_dist_d_ifft(zk_ctx* ctx, zk_net* net, int sid, void* shares_d, const void* in_mask_d, const void* out_mask_d,
                    int rearrange, int log2_m, const void* g, uint64_t seed, void* stream) {
   NET_OR_FAIL();
-  return e->dist_d_fft(&net->net, sid, shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 1, g, seed, S(stream));
+  return e->dist_finish(&net->net, e->dist_d_fft(&net->net, sid, shares_d, in_mask_d, out_mask_d, rearrange, log2_m, 1, g, seed, S(stream)));
 }
 int zk_dist_deg_red(zk_ctx* ctx, zk_net* net, int sid, void* x_d, const void* in_mask_d, const void* out_mask_d,
                     size_t len, uint64_t seed, void* stream) {
   NET_OR_FAIL();
-  return e->dist_deg_red(&net->net, sid, x_d, in_mask_d, out_mask_d, len, seed, S(stream));
+  return e->dist_finish(&net->net, e->dist_deg_red(&net->net, sid, x_d, in_mask_d, out_mask_d, len, seed, S(stream)));
 }
 int zk_dist_d_pp(zk_ctx* ctx, zk_net* net, int sid, const void* num_d, const void* den_d, const void* in_mask_d,
                  const void* out_mask_d, size_t len, uint64_t seed, void* out_d, void* stream) {
   NET_OR_FAIL();
-  return e->dist_d_pp(&net->net, sid, num_d, den_d, in_mask_d, out_mask_d, len, seed, out_d, S(stream));
+  return e->dist_finish(&net->net, e->dist_d_pp(&net->net, sid, num_d, den_d, in_mask_d, out_mask_d, len, seed, out_d, S(stream)));
 }
 int zk_dist_d_msm(zk_ctx* ctx, zk_net* net, int sid, int group, const void* bases_d, const void* scalars_d, size_t len,
                   const void* in_mask, const void* out_mask, void* out, void* stream) {
   NET_OR_FAIL();
-  return e->dist_d_msm(&net->net, sid, group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream));
+  return e->dist_finish(&net->net, e->dist_d_msm(&net->net, sid, group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream)));
 }
 int zk_dist_circom_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
                      const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream) {
   const int sid = 0;
   NET_OR_FAIL();
-  return e->dist_circom_h(&net->net, qap_a_d, qap_b_d, qap_c_d, log2_m, masks, seed, h_d, S(stream));
+  return e->dist_finish(&net->net, e->dist_circom_h(&net->net, qap_a_d, qap_b_d, qap_c_d, log2_m, masks, seed, h_d, S(stream)));
 }
 int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
                           const void* qap_c_d, const void* a_share_d, const void* ax_share_d, const void* r, const void* s,
@@ -571,8 +571,8 @@ int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, con
                           void* stream) {
   const int sid = 0;
   NET_OR_FAIL();
-  return e->dist_prove(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed, pi_a,
-                       pi_b, pi_c, S(stream));
+  return e->dist_finish(&net->net, e->dist_prove(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed, pi_a,
+                       pi_b, pi_c, S(stream)));
 }
 
 int zk_dist_groth16_prove_async(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
@@ -581,13 +581,13 @@ int zk_dist_groth16_prove_async(zk_ctx* ctx, zk_net* net, const zk_crs_share* cr
                                 int* handle) {
   const int sid = 0;
   NET_OR_FAIL();
-  return e->dist_prove_async(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
-                             S(stream), handle);
+  return e->dist_finish(&net->net, e->dist_prove_async(&net->net, crs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m, masks, seed,
+                             S(stream), handle));
 }
 int zk_dist_groth16_wait(zk_ctx* ctx, zk_net* net, int handle, void* pi_a, void* pi_b, void* pi_c) {
   const int sid = 0;
   NET_OR_FAIL();
-  return e->dist_prove_wait(&net->net, handle, pi_a, pi_b, pi_c);
+  return e->dist_finish(&net->net, e->dist_prove_wait(&net->net, handle, pi_a, pi_b, pi_c));
 }
 
 int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, int nproofs,
@@ -597,8 +597,8 @@ int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* cr
                                 void* pi_c, void* stream) {
   const int sid = 0;
   NET_OR_FAIL();
-  return e->dist_prove_batch(&net->net, crs, nproofs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m,
-                             masks, seed, pi_a, pi_b, pi_c, S(stream));
+  return e->dist_finish(&net->net, e->dist_prove_batch(&net->net, crs, nproofs, qap_a_d, qap_b_d, qap_c_d, a_share_d, ax_share_d, r, s, log2_m,
+                             masks, seed, pi_a, pi_b, pi_c, S(stream)));
 }
 
 // ---- profiling slots (bench.py roofline leg) ----

@@ -230,6 +230,9 @@ class IEngine {
   virtual int group_add(int group, const void* a, const void* b, void* out) = 0;
   virtual int msm_plan(int group, size_t len, int* plan) = 0;
   virtual int set_option(const char* name, long long value) = 0;
+  // exit of every zk_dist_* entry point: with the option "dist_deadline" the call returns only when the channels'
+  // data-plane work has completed, or fails with ZK_ERR_PROTOCOL once the net's timeout has passed (ser_net.rs:122-125)
+  virtual int dist_finish(Net* net, int rc) = 0;
   virtual int msm_precompute(int group, const void* bases, size_t len, hipStream_t st) = 0;
   virtual int msm_forget(const void* bases) = 0;
   virtual int msm_table_info(int group, const void* bases, int* info) = 0;

@@ -91,8 +91,8 @@ class Engine : public IEngine {
     if (ilog2(n) > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large");
     build_matrices();
     ZK_HIP(hipMalloc(&err_flag_, sizeof(int)));
-    // share randomness: ChaCha20 keyed from the operating system's generator (prng.hpp); ZK_RNG_REPLAY=1 or the option
-    // "rng_replay" selects the documented replayable stream the parity tests compare shares with
+    // share randomness: ChaCha20 keyed from the operating system's generator (prng.hpp); the context option "rng_replay"
+    // selects the documented replayable stream the parity tests compare shares with
     FILE* f = fopen("/dev/urandom", "rb");
     if (!f || fread(rng_key_h_, 1, sizeof(rng_key_h_), f) != sizeof(rng_key_h_)) {
       if (f) fclose(f);
@@ -101,8 +101,7 @@ class Engine : public IEngine {
     fclose(f);
     ZK_HIP(hipMalloc((void**)&rng_key_d_, sizeof(rng_key_h_)));
     ZK_HIP(hipMemcpy(rng_key_d_, rng_key_h_, sizeof(rng_key_h_), hipMemcpyHostToDevice));
-    rng_replay_ = getenv("ZK_RNG_REPLAY") && atoi(getenv("ZK_RNG_REPLAY")) != 0;
-    if (rng_replay_) warn_replay();
+    rng_replay_ = false;        // only zk_ctx_set_option("rng_replay", 1) turns the replay stream on (never the environment)
     return ZK_OK;
   }
   // Replay mode trades the hiding property for reproducible shares (two packs with the same seed reuse their random
@@ -110,7 +109,7 @@ class Engine : public IEngine {
   static void warn_replay() {
     static std::atomic<bool> said{false};
     if (!said.exchange(true))
-      fprintf(stderr, "zksaas: share randomness is in REPLAY mode (ZK_RNG_REPLAY / option rng_replay): shares are "
+      fprintf(stderr, "zksaas: share randomness is in REPLAY mode (option rng_replay): shares are "
                       "reproducible from the caller's seeds and NOT hiding -- tests and parity runs only\n");
   }
   // the randomness of one launch: `span` consecutive stream ids (batch items).  Replay mode: the caller's seed;
@@ -516,7 +515,8 @@ class Engine : public IEngine {
       // large tile: every fourth stage twiddle in LDS (72 KB: two workgroups per CU), see ntt_pass_kernel
       static const int tws_env = getenv("ZK_NTT_TWS") ? atoi(getenv("ZK_NTT_TWS")) : -1;
       const int tws = tws_env >= 0 ? (tws_env <= 2 ? tws_env : 2) : ((TB >= 10 && rbits >= 4) ? 2 : 0);
-      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (TILE + ((((size_t)1 << rbits) / 2) >> tws) + 1);
+      const int tws_eff = rbits >= 4 ? tws : 0;      // one value for the LDS size AND the kernel argument
+      size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (TILE + ((((size_t)1 << rbits) / 2) >> tws_eff) + 1);
       bool& attr_set = ntt_attr_set_[TB == NTT_TILE_BITS_SMALL ? 0 : 1];     // per engine, i.e. per device
       if (!attr_set) {
         ZK_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<Fr, TB>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -527,7 +527,7 @@ class Engine : public IEngine {
       ProfScope ps_(prof, PROF_NTT_PASS, st, (double)nvec * batch);
       ntt_pass_kernel<Fr, TB><<<grid, dim3((unsigned)(TILE / 4)), lds, st>>>(
           data, log_n, ps.s0, ps.s1, ps.cbits, tw, log_l, p == plan.npass - 1 ? add : nullptr,
-          p == 0 ? src : NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1}, rbits >= 4 ? tws : 0);
+          p == 0 ? src : NttSrc<Fr>{{nullptr, nullptr, nullptr}, 1}, tws_eff);
       ZK_HIP(hipGetLastError());
     }
     return ZK_OK;
@@ -1411,7 +1411,7 @@ class Engine : public IEngine {
     if (!qa || !qb || !qc || !a_share || !ax_share || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     int slot = -1;
     for (int i = 0; i < NJOBS; i++)
-      if (!jobs_[i].active) {
+      if (!jobs_[i].active && !djobs_[i].active) {       // (a sharded proof owns its slot until it is joined or aborted)
         slot = i;
         break;
       }
@@ -1448,9 +1448,13 @@ class Engine : public IEngine {
       }
     j.active = false;
   }
+  // also the abort of a sharded proof in flight (zk_dist_groth16_prove_async hands out handles of the same space): the
+  // slot is free for either kind afterwards.  The channels' round counters are NOT rewound -- every rank must abort the
+  // same proof, as every rank must issue the same sequence of collective calls.
   int groth16_abort(int handle) override {
     if (handle < 0 || handle >= NJOBS) return fail(ZK_ERR_BAD_INPUT, "bad handle");
     abort_job(jobs_[handle]);
+    djobs_[handle].active = false;
     return ZK_OK;
   }
 
@@ -1574,15 +1578,18 @@ class Engine : public IEngine {
     B.slot = slot;
     rc = ensure_streams();
     if (rc) return rc;
-    if (!B.ev_in) {
-      ZK_HIP(hipEventCreateWithFlags(&B.ev_in, hipEventDisableTiming));
-      for (int i = 0; i < 4; i++) ZK_HIP(hipEventCreateWithFlags(&B.ev_acc[i], hipEventDisableTiming));
+    {
+      // every handle is checked on its own: a failure half-way leaves the rest to be created by the next call
+      if (!B.ev_in) ZK_HIP(hipEventCreateWithFlags(&B.ev_in, hipEventDisableTiming));
+      for (int i = 0; i < 4; i++)
+        if (!B.ev_acc[i]) ZK_HIP(hipEventCreateWithFlags(&B.ev_acc[i], hipEventDisableTiming));
       // ZK_BATCH_V_CUS=<n> (experiment): the chip is split between the G2 MSM (stream 2: n of the 256 CUs) and
       // everything else (the other CUs), so that the 256-register G2 waves and the 168-register G1 waves never compete
       // for the same SIMDs (see DESIGN.md "batched proving")
       static const int v_cus = getenv("ZK_BATCH_V_CUS") ? atoi(getenv("ZK_BATCH_V_CUS")) : 0;
       B.own_streams = slot != 0 || (v_cus > 0 && v_cus < 256);
       for (int i = 0; i < 6; i++) {
+        if (B.st[i]) continue;
         if (!B.own_streams) {
           B.st[i] = streams_[i];                     // batch slot 0 shares the single-proof stream set
         } else if (v_cus > 0 && v_cus < 256) {
@@ -1937,6 +1944,10 @@ class Engine : public IEngine {
     if (!strcmp(name, "rng_replay")) {
       rng_replay_ = value != 0;
       if (rng_replay_) warn_replay();
+      return ZK_OK;
+    }
+    if (!strcmp(name, "dist_deadline")) {         // zk_dist_* return only with their data-plane work done, or fail
+      dist_deadline_ = value != 0;
       return ZK_OK;
     }
     if (!strcmp(name, "king_alltoall")) {         // every rank of a net must choose alike
@@ -2442,6 +2453,21 @@ class Engine : public IEngine {
   int net_err(Net* net, int rc) {
     if (rc == ZK_OK) return rc;
     return fail(rc, "net: " + net->err, net->err_party);
+  }
+  // Option "dist_deadline": the reference's collectives return Err after their timeout (mpc-net/src/ser_net.rs:122-125);
+  // here a zk_dist_* call has only ENQUEUED its data-plane work when it returns, and a hung RCCL collective would
+  // surface at the caller's next stream synchronisation, without a deadline.  With the option every zk_dist_* entry
+  // point waits for the channels' streams before returning, with the net's timeout as the deadline; on expiry the
+  // communicators are aborted, the call fails with ZK_ERR_PROTOCOL and the net refuses every later round (the process
+  // then opens a new net, or hands over to a fresh child process).
+  bool dist_deadline_ = false;
+  int dist_finish(Net* net, int rc) override {
+    if (rc != ZK_OK || !dist_deadline_) return rc;
+    for (int sid = 0; sid < NET_NSID; sid++) {
+      const int r = net->sync_deadline(sid);
+      if (r) return net_err(net, r);
+    }
+    return ZK_OK;
   }
   // parties of the ranks in `mask`, ascending (the row order the king sees, net.hpp)
   std::vector<uint32_t> parties_of(const Net* net, uint32_t mask) const {
@@ -3043,8 +3069,11 @@ class Engine : public IEngine {
       if (rc) return bail(rc);
     }
     // the U-MSM runs on its own stream of the batch's set, behind everything queued on the caller's stream
-    ZK_HIP(hipEventRecord(B.ev_in, st));
-    ZK_HIP(hipStreamWaitEvent(B.st[5], B.ev_in, 0));
+    {
+      hipError_t he = hipEventRecord(B.ev_in, st);
+      if (he == hipSuccess) he = hipStreamWaitEvent(B.st[5], B.ev_in, 0);
+      if (he != hipSuccess) return bail(hip_fail(he, "batch U-MSM ordering"));
+    }
     rc = batch_launch_u(B, (const Fr*)B.hshare.p, per, B.st[5]);
     if (rc) return bail(rc);
     std::vector<BatchSums> mine;

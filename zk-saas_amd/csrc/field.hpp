@@ -357,14 +357,20 @@ struct Fp {
   // a*b - c*d (all Montgomery) in ONE product-scanning pass: a*b + (p - c)*d < 2 p^2 < p R is reduced once -- 3 N^2 + N
   // multiply instructions instead of 2 (2 N^2 + N): 200 vs 272 for N = 8.  Same field element as a*b - c*d.  Used for
   // Y3 = R (Q - X3) - Y1 PPP of the mixed addition (msm.hpp).  The modulus must leave two spare bits.
-  ZK_HD static Fp mul_sub_mul(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+  ZK_HD static Fp mul_sub_mul(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return mul_pm_mul(a, b, c, d, false); }
+  // a*b + c*d (plus) or a*b - c*d, chosen per lane at run time: the two component products of a quadratic-extension
+  // multiplication held one component per lane (quad.hpp s2_mul) differ only in this sign
+  ZK_HD static Fp mul_pm_mul(const Fp& a, const Fp& b, const Fp& c, const Fp& d, bool plus) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ZK_NO_MUL_SUB_MUL)
     if constexpr (N <= ZK_MUL_INLINE_LIMBS && (P::MOD[N - 1] >> 30) == 0) {
-      uint32_t nc[N];                               // p - c, in (0, p]
+      uint32_t nc[N];                               // minus: p - c, in (0, p]; plus: c itself
       {
         unsigned bw = 0;
 #pragma unroll
-        for (int i = 0; i < N; i++) nc[i] = __builtin_subc(P::MOD[i], c.v[i], bw, &bw);
+        for (int i = 0; i < N; i++) {
+          const uint32_t t = __builtin_subc(P::MOD[i], c.v[i], bw, &bw);
+          nc[i] = plus ? c.v[i] : t;
+        }
       }
       uint32_t m[N], r[N];
       uint64_t acc = 0, cy;
@@ -411,7 +417,7 @@ struct Fp {
       return reduce_once(o, (uint32_t)(acc >> 32));
     }
 #endif
-    return a * b - c * d;
+    return plus ? a * b + c * d : a * b - c * d;
   }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -717,6 +723,17 @@ struct IsExtField {
 template <class P, bool INL>
 struct IsExtField<Fp2T<P, INL>> {
   static constexpr bool value = true;
+};
+// parameters of the base prime field of a coordinate field (Fp<P> -> P, Fp2T<P, I> -> P)
+template <class T>
+struct BaseParams;
+template <class P>
+struct BaseParams<Fp<P>> {
+  using type = P;
+};
+template <class P, bool INL>
+struct BaseParams<Fp2T<P, INL>> {
+  using type = P;
 };
 
 }  // namespace zk

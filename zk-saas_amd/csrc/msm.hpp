@@ -38,7 +38,8 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr size_t MSM_RANGE_MIN = 20, MSM_RANGE = 64;        // entries per accumulate lane: fewest (small MSMs), most
-constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 32;  // ... per lane pair of the extension-field kernel
+constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 64;  // ... per lane quad of the extension-field kernel (32 until
+                                                            // round 4; C5: 1.303 s at 32, 1.286 at 64, 1.280 at 128)
 constexpr uint32_t FIN_SEQ = 16;      // a bucket spread over more accumulate lanes than this is summed by a workgroup
 constexpr int MSM_WS = 30;            // independent workspaces: 6 per proof in flight (concurrent MSMs on separate
                                       // streams) + 6 per batch of proofs in flight (zk_groth16_prove_batch)
@@ -863,6 +864,9 @@ __device__ __forceinline__ void store_elem_untracked(F* p, const F& v) {
   zk_u32x4 c[sizeof(F) / 16];
   __builtin_memcpy(c, &v, sizeof(F));
   zk_store_chunks<0, (int)(sizeof(F) / 16)>((const void*)p, c);
+  // the hazard recogniser does not see these stores either: gfx9-family parts want one wait state between a VMEM store of
+  // more than 64 bits and a VALU write of its data registers (the caller resets the stored sum right afterwards)
+  asm volatile("s_nop 0" ::: "memory");
 }
 
 // bucket that contains entry a (offsets[k] <= a < offsets[k+1]; empty buckets are skipped by construction)
@@ -1047,6 +1051,82 @@ __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kern
       if (!lb && !cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
         heavy[1 + atomicAdd(heavy, 1u)] = k;
       acc = PairAcc<Fld>{Fld::one(), Fld::zero()};
+      cont = false;
+      if (p + 1 < b) {
+        k++;
+        end_k = end_n;
+        while (end_k == p + 1) {                    // empty buckets in between (rare)
+          k++;
+          end_k = offsets[k + 1];
+        }
+        end_n = offsets[k + 2 <= nkeys ? k + 2 : nkeys];
+      }
+    }
+    e = e_next;
+    pt = pt_next;
+  }
+}
+
+// Extension-field variant with ONE BASE-FIELD VALUE PER LANE (quad.hpp split_madd): a QUAD of lanes per range, 128 threads =
+// 32 ranges per workgroup.  P = parameters of the base field; points and partial sums are read and written in the
+// layout of Affine<Fq2> / XYZZ<Fq2> (lane q of a quad owns base-field element q of a point, q and 4 + q of a sum).
+// waves per SIMD the registers allow: 127 VGPRs for 8-limb base fields (four waves), 176 for 12-limb ones (two)
+template <class P>
+constexpr int SPLIT_WAVES = P::N > 8 ? 2 : 4;
+template <class P>
+__global__ __launch_bounds__(128, SPLIT_WAVES<P>) void msm_accumulate_split_kernel(const void* __restrict__ bases0,
+                                                                 const void* __restrict__ bases1,
+                                                                 const uint32_t* __restrict__ sorted,
+                                                                 const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                                 uint32_t nlanes, uint32_t tmin, uint32_t cap,
+                                                                 void* __restrict__ buckets0, void* __restrict__ edge0,
+                                                                 uint32_t* __restrict__ heavy,
+                                                                 const uint32_t* __restrict__ k0, size_t ys) {
+  using F = Fp<P>;
+  constexpr size_t AFF = 4, SUM = 8;                 // base-field elements per affine point / per XYZZ sum
+  ZK_YSHIFT(sorted);
+  ZK_YSHIFT(offsets);
+  ZK_YSHIFT(heavy);
+  ZK_YSHIFT(k0);
+  const F* __restrict__ bases = reinterpret_cast<const F*>(blockIdx.y ? bases1 : bases0);
+  F* __restrict__ buckets = reinterpret_cast<F*>(buckets0) + (size_t)blockIdx.y * nkeys * SUM;
+  F* __restrict__ head = reinterpret_cast<F*>(edge0) + (size_t)blockIdx.y * 2 * nlanes * SUM;
+  F* __restrict__ tail = head + (size_t)nlanes * SUM;
+  const uint32_t total = offsets[nkeys];
+  const uint32_t T = msm_range_len(total, nlanes, tmin, cap);
+  const uint32_t q = threadIdx.x & 3;
+  const bool comp = (q & 1) != 0, half = (q & 2) != 0;
+  const uint32_t lane = blockIdx.x * (blockDim.x / 4) + (threadIdx.x >> 2);        // quad index = range index
+  if (lane >= nlanes || (uint64_t)lane * T >= total) return;
+  const uint32_t a = lane * T, b = a + T < total ? a + T : total;
+  uint32_t k = k0[lane];
+  bool cont = offsets[k] < a;
+  uint32_t end_k = offsets[k + 1];
+  uint32_t end_n = offsets[k + 2 <= nkeys ? k + 2 : nkeys];
+  SplitAcc<P> acc = split_identity<P>(comp);
+  uint32_t e = sorted[a];
+  uint32_t e1 = a + 1 < b ? sorted[a + 1] : e;
+  F pt = load_elem(bases + (size_t)(e & 0x7fffffffu) * AFF + q);
+  for (uint32_t p = a; p < b; p++) {
+    const uint32_t e_next = e1;
+    if (p + 2 < b) e1 = sorted[p + 2];
+    F pt_next = pt;
+    if (p + 1 < b) pt_next = load_elem(bases + (size_t)(e_next & 0x7fffffffu) * AFF + q);
+    // the identity sentinel is (0, 0): all four base-field elements zero (quad-uniform after the exchanges)
+    uint32_t z = pt.is_zero() ? 1u : 0u;
+    z &= qperm_u32<1, 0, 3, 2>(z);
+    z &= qperm_u32<2, 3, 0, 1>(z);
+    if (!z) {
+      const F c = qsel(half && (e >> 31) != 0, pt.neg(), pt);
+      acc = split_madd<P>(acc, c, half, comp);
+    }
+    if (p + 1 == end_k || p + 1 == b) {
+      F* dst = cont ? head + (size_t)lane * SUM : (p + 1 == end_k ? buckets + (size_t)k * SUM : tail + (size_t)lane * SUM);
+      store_elem(dst + q, acc.c0);                         // X | Y
+      store_elem(dst + 4 + q, acc.c1);                     // ZZ | ZZZ
+      if (q == 0 && !cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
+        heavy[1 + atomicAdd(heavy, 1u)] = k;
+      acc = split_identity<P>(comp);
       cont = false;
       if (p + 1 < b) {
         k++;
@@ -1362,10 +1442,17 @@ inline int msm_pick_c(size_t npts, bool g2 = false) {
 struct MsmLanes {
   uint32_t nlanes, tmin, cap;
 };
-inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair) {
+inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair, int lanes_per_range = 0) {
   static const int env_t = getenv("ZK_MSM_RANGE") ? atoi(getenv("ZK_MSM_RANGE")) : 0;
-  const size_t cap = (size_t)1024 * waves * (pair ? 32 : 64);
-  const size_t lo = pair ? MSM_RANGE_MIN_G2 : MSM_RANGE_MIN, hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
+  if (!lanes_per_range) lanes_per_range = pair ? 2 : 1;
+  const size_t cap = (size_t)1024 * waves * (64 / lanes_per_range);
+  static const int env_hi = getenv("ZK_MSM_RANGE_HI") ? atoi(getenv("ZK_MSM_RANGE_HI")) : 0;
+  static const int env_hi2 = getenv("ZK_MSM_RANGE_HI_G2") ? atoi(getenv("ZK_MSM_RANGE_HI_G2")) : 0;
+  static const int env_lo2 = getenv("ZK_MSM_RANGE_LO_G2") ? atoi(getenv("ZK_MSM_RANGE_LO_G2")) : 0;
+  const size_t lo = pair ? (env_lo2 > 0 ? (size_t)env_lo2 : MSM_RANGE_MIN_G2) : MSM_RANGE_MIN;
+  size_t hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
+  if (!pair && env_hi > 0) hi = (size_t)env_hi;
+  if (pair && env_hi2 > 0) hi = (size_t)env_hi2;
   size_t t = env_t >= 1 ? (size_t)env_t : (size_t)((double)max_entries / (2.4 * (double)cap));
   if (env_t < 1) t = std::min(hi, std::max(lo, t));
   size_t nl = std::max<size_t>(1, (max_entries + t - 1) / t);

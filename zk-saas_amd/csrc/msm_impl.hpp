@@ -55,7 +55,14 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   // 370 against 753 us for a 58k-point launch)
   const bool small_launch = max_sorted < (size_t)4 * 1024 * 1024;
   const bool pair = G2FLD && (pair_env >= 0 ? pair_env != 0 : (sizeof(Fld) > 64 || small_launch));
-  const MsmLanes ml = msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair);
+  // Extension field: a QUAD of lanes per range, one base-field value per lane (quad.hpp split_madd).  The pair and
+  // one-lane kernels hold whole Fq2 values per lane: 256 registers with 13-99 spilled dwords (BLS12-381 G2 ran at a third
+  // of the multiplier's peak); measured with the quad form: a 2^24-constraint BLS12-381 proof 1.42 -> 1.28 s, the
+  // SHA-256 proof on BN254 561 -> 593 proofs/s (table-free 395 -> 428).  ZK_ACC_SPLIT=0 restores the older kernels.
+  static const int split_env = getenv("ZK_ACC_SPLIT") ? atoi(getenv("ZK_ACC_SPLIT")) : -1;
+  const bool split = G2FLD && split_env != 0;
+  const MsmLanes ml = split ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4)
+                            : msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair);
   const uint32_t nlanes = ml.nlanes, tmin = ml.tmin, cap = ml.cap;
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
   const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
@@ -282,7 +289,11 @@ do {                                                                           \
   }
   bool launched = false;
   if constexpr (G2FLD) {
-    if (pair) {
+    if (split) {
+      msm_accumulate_split_kernel<typename BaseParams<Fld>::type><<<dim3((nlanes + 31) / 32, NB), dim3(128), 0, st>>>(
+          bases, bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge, heavy, k0, ys);
+      launched = true;
+    } else if (pair) {
       // extension field: a pair of lanes per range (two waves per SIMD instead of one; quad.hpp pair_madd)
       msm_accumulate_pair_kernel<KF><<<dim3((nlanes + 63) / 64, NB), dim3(128), 0, st>>>(
           (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,

@@ -635,7 +635,17 @@ class Net {
       if (e == hipSuccess) return ZK_OK;
       if (e != hipErrorNotReady) return fail("stream error while waiting for a collective");
       if (net_now_ms() > dl) {
+        // abort NOW (ncclCommAbort unblocks the kernels of the hung collective) and refuse every later round
         aborted_ = true;
+        dead_ = true;
+        if (transport == ZK_NET_RCCL) {
+          Rccl& R = Rccl::inst();
+          for (int s = 0; s < NET_NSID; s++)
+            if (comm_[s] && R.CommAbort) {
+              (void)R.CommAbort(comm_[s]);
+              comm_[s] = nullptr;
+            }
+        }
         return fail_party("collective did not complete within the timeout", 0);
       }
       relax();

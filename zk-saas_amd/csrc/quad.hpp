@@ -193,6 +193,93 @@ ZK_D PairAcc<Fld> pair_madd(const PairAcc<Fld>& a, const Fld& in, bool lb) {
   return r;
 }
 
+// ---- mixed addition of an EXTENSION-field point shared by a QUAD of lanes, ONE BASE-FIELD VALUE PER LANE (round 4)
+// The pair form above keeps whole Fq2 values in a lane; for 12-limb base fields that is 24 limbs per value and the
+// kernel ends at the 256-register cap with 99 spilled dwords (BLS12-381 G2: 34 % of the multiplier's peak, a third of a
+// 2^24-constraint proof).  Here lane q of a quad holds component q & 1 (c0 / c1) of the values of half q >> 1 (half 0:
+// X, ZZ, x; half 1: Y, ZZZ, y): every lane works on single base-field values -- the register footprint of a G1 kernel --
+// and an Fq2 product is two base-field products per lane with ONE reduction (mul_pm_mul):
+//   c0 = a0 b0 - a1 b1 (lane 0),   c1 = a1 b0 + a0 b1 (lane 1);     squaring: (a0 + a1)(a0 - a1) | 2 a1 a0
+// i.e. schoolbook (4 products, 2 reductions per Fq2 product over the two lanes) instead of Karatsuba with lazy reduction
+// (3 products, 2 reductions in one lane): 18 % more multiply instructions per addition, none of them spilled.
+// The rounds are those of pair_madd; the other component comes by DPP (cswap), the other half by DPP (hswap).
+template <class F>
+ZK_D F cswap(const F& v) {
+  return qperm<1, 0, 3, 2>(v);
+}
+template <class F>
+ZK_D F hswap(const F& v) {
+  return qperm<2, 3, 0, 1>(v);
+}
+template <class P>
+ZK_D Fp<P> s2_mul(const Fp<P>& a, const Fp<P>& b, bool comp) {
+  const Fp<P> ao = cswap(a), bo = cswap(b);
+  return Fp<P>::mul_pm_mul(a, qsel(comp, bo, b), ao, qsel(comp, b, bo), comp);
+}
+template <class P>
+ZK_D Fp<P> s2_sqr(const Fp<P>& a, bool comp) {
+  const Fp<P> ao = cswap(a);
+  return (a + qsel(comp, a, ao)) * qsel(comp, ao, a - ao);
+}
+// both components zero (the same answer in the two lanes of a value)
+template <class P>
+ZK_D bool s2_is_zero(const Fp<P>& a) {
+  const uint32_t z = a.is_zero() ? 1u : 0u;
+  return (z & qperm_u32<1, 0, 3, 2>(z)) != 0;
+}
+template <class P>
+struct SplitAcc {      // half 0: c0 = X, c1 = ZZ; half 1: c0 = Y, c1 = ZZZ -- this lane's component of each
+  Fp<P> c0, c1;
+};
+template <class P>
+ZK_D SplitAcc<P> split_identity(bool comp) {        // X = Y = 1, ZZ = ZZZ = 0
+  return SplitAcc<P>{qsel(comp, Fp<P>::zero(), Fp<P>::one()), Fp<P>::zero()};
+}
+// acc += (x2, y2); `in` = this lane's component of x2 (half 0) or y2 (half 1).  Control flow is quad-uniform.
+template <class P>
+ZK_D SplitAcc<P> split_madd(const SplitAcc<P>& a, const Fp<P>& in, bool half, bool comp) {
+  using F = Fp<P>;
+  const uint32_t zz = s2_is_zero(a.c1) ? 1u : 0u;
+  SplitAcc<P> r;
+  if (qperm_u32<0, 0, 0, 0>(zz)) {                     // running sum is the identity: the affine point itself
+    r.c0 = in;
+    r.c1 = qsel(comp, F::zero(), F::one());
+    return r;
+  }
+  const F m1 = s2_mul(in, a.c1, comp);                 // 0: U2 = x2 ZZ1        1: S2 = y2 ZZZ1
+  const F d = m1 - a.c0;                               // 0: P                  1: R
+  const F od = hswap(d);                               // 0: R                  1: P
+  const uint32_t dz = s2_is_zero(d) ? 1u : 0u;
+  const bool pz = qperm_u32<0, 0, 0, 0>(dz) != 0, rz = qperm_u32<2, 2, 2, 2>(dz) != 0;
+  if (pz) {
+    if (!rz) return split_identity<P>(comp);           // inverse points
+    // equal points: double the affine addend (mdbl-2008-s-1, see pair_madd)
+    const F u = qsel(half, in.dbl(), in);                 // 0: x                  1: U = 2 y
+    const F m2 = s2_sqr(u, comp);                      // 0: XX                 1: V
+    const F o2 = hswap(m2);                            // 0: V                  1: XX
+    const F m3 = s2_mul(u, qsel(half, m2, o2), comp);    // 0: S = x V            1: W = U V
+    const F M = m2.dbl() + m2;                         // 0: 3 XX
+    const F m4 = s2_sqr(M, comp);                      // 0: MM
+    const F X3 = m4 - m3.dbl();                        // 0: MM - 2 S
+    const F m5 = s2_mul(qsel(half, m3, M), qsel(half, in, m3 - X3), comp);     // 0: M (S - X3)   1: W y
+    const F o5 = hswap(m5);
+    r.c0 = qsel(half, o5 - m5, X3);
+    r.c1 = qsel(half, m3, o2);                           // ZZ3 = V, ZZZ3 = W
+    return r;
+  }
+  const F m2 = s2_sqr(d, comp);                        // 0: PP                 1: RR
+  const F o2 = hswap(m2);                              // 0: RR                 1: PP
+  const F m3 = s2_mul(qsel(half, od, a.c0), qsel(half, o2, m2), comp);       // 0: Q = X1 PP    1: PPP = P PP
+  const F o3 = hswap(m3);                              // 0: PPP                1: Q
+  const F m4 = s2_mul(a.c1, qsel(half, m3, m2), comp);    // 0: ZZ3 = ZZ1 PP       1: ZZZ3 = ZZZ1 PPP
+  const F X3 = o2 - o3 - m3.dbl();                     // 0: RR - PPP - 2 Q
+  const F m5 = s2_mul(qsel(half, a.c0, od), qsel(half, m3, m3 - X3), comp);    // 0: R (Q - X3)   1: Y1 PPP
+  const F o5 = hswap(m5);
+  r.c0 = qsel(half, o5 - m5, X3);
+  r.c1 = m4;
+  return r;
+}
+
 // Tree sum inside aligned sub-blocks of `nvl` (power of two) virtual lanes of a workgroup: every quad contributes the
 // point whose coordinates its lanes hold; afterwards the first quad of each sub-block holds the sub-block's total.
 // `sh` is LDS for blockDim.x / 4 points.  log2(nvl) dependent additions.

@@ -17,6 +17,7 @@ import numpy as np
 
 from . import groth16 as zg
 from . import net as znet
+from . import api
 from .api import ZK_G1, ZK_G2, DeviceBuffer, FftMask
 
 
@@ -220,12 +221,12 @@ def bench(args, rank, local_rank, world):
     # ONE dealer: every rank derives the same dealing (witness / QAP shares, masks) from the seeds below and keeps its
     # parties' rows, so the dealing runs on the replayable stream; a context's production stream is keyed from
     # /dev/urandom and two ranks would otherwise hold rows of two different sharings (found by running 4 ranks without
-    # ZK_RNG_REPLAY: every rank's proof shares were right for ITS dealing and the assembled proof was not a proof).
+    # the replay option: every rank's proof shares were right for ITS dealing and the assembled proof was not a proof).
     # The timed proofs run on the production stream again (the kings' share randomness need not agree).
     pp.set_option("rng_replay", 1)
 
     def timed(step):
-        if not os.environ.get("ZK_RNG_REPLAY"):
+        if not api.DEFAULT_OPTIONS.get("rng_replay"):
             pp.set_option("rng_replay", 0)
         return _timed(dist, torch, step, args.steps, args.warmup)
     if wl == "c2":
