@@ -52,7 +52,11 @@ ZK_HD Fp<P> rand_fp(uint64_t seed, uint64_t idx) {
 // (rand_fp_secure below).  `nonce` is a per-context call counter, never a caller-supplied seed, so no two
 // pack streams of a context ever share randomness.
 ZK_HD uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
-ZK_HD void chacha20_block(const uint32_t* key, uint64_t counter, uint64_t nonce, uint32_t* out) {
+// DR = double rounds: 10 = ChaCha20 (RFC 7539, pinned on the RFC's vector through zk_chacha20_block), 6 = ChaCha12 -- what
+// the production stream runs on: the reference draws its share randomness from rand's StdRng / ThreadRng, which IS
+// ChaCha12 (dist-primitives/src/dfft/mod.rs:251, utils/deg_red.rs:108), same block function with fewer rounds
+template <int DR>
+ZK_HD void chacha_block(const uint32_t* key, uint64_t counter, uint64_t nonce, uint32_t* out) {
   uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
                     key[4],      key[5],      key[6],      key[7],      (uint32_t)counter, (uint32_t)(counter >> 32),
                     (uint32_t)nonce, (uint32_t)(nonce >> 32)};
@@ -64,7 +68,7 @@ ZK_HD void chacha20_block(const uint32_t* key, uint64_t counter, uint64_t nonce,
   x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
   x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  \
   x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < DR; r++) {
     ZK_QR(0, 4, 8, 12) ZK_QR(1, 5, 9, 13) ZK_QR(2, 6, 10, 14) ZK_QR(3, 7, 11, 15)
     ZK_QR(0, 5, 10, 15) ZK_QR(1, 6, 11, 12) ZK_QR(2, 7, 8, 13) ZK_QR(3, 4, 9, 14)
   }
@@ -72,6 +76,10 @@ ZK_HD void chacha20_block(const uint32_t* key, uint64_t counter, uint64_t nonce,
 #pragma unroll
   for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
+ZK_HD void chacha20_block(const uint32_t* key, uint64_t counter, uint64_t nonce, uint32_t* out) {
+  chacha_block<10>(key, counter, nonce, out);
+}
+constexpr int RNG_DOUBLE_ROUNDS = 6;      // the production stream: ChaCha12
 
 // Candidate = a whole 32 N-bit half of a block, accepted when it is below K p, K = floor(2^(32 N) / p), and then reduced
 // mod p by conditional subtractions of 2^j p: x uniform on [0, K p) makes x mod p exactly uniform.  Acceptance is K p /
@@ -131,6 +139,24 @@ ZK_HD void rand_sub_mult_if_ge(Fp<P>& x) {           // x -= M p when x >= M p
   for (int i = 0; i < P::N; i++) d.v[i] = __builtin_subc(x.v[i], m.v[i], bw, &bw);
   if (!bw) x = d;
 }
+// candidate `half` (0 / 1) of a block: accepted below K p, then reduced mod p.  The result is a uniform canonical integer
+// in [0, p), used AS IT STANDS as the Montgomery representation of the (equally uniform) element r / R: the conversion
+// r -> r R of the first three rounds (one Montgomery product per draw) bought nothing
+template <class P>
+ZK_HD bool rand_candidate_half(const uint32_t* blk, int half, Fp<P>* out) {
+  constexpr int N = P::N;
+  constexpr int K = RandWide<P>::K;
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = blk[8 * half + i];
+  if (!rand_lt_mult<P, K>(r)) return false;
+  if constexpr (K >= 8) rand_sub_mult_if_ge<P, 8>(r);
+  if constexpr (K >= 4) rand_sub_mult_if_ge<P, 4>(r);
+  if constexpr (K >= 2) rand_sub_mult_if_ge<P, 2>(r);
+  rand_sub_mult_if_ge<P, 1>(r);
+  *out = r;
+  return true;
+}
 template <class P>
 ZK_HD Fp<P> rand_fp_secure(const uint32_t* key, uint64_t nonce, uint64_t idx, uint64_t first_attempt = 0) {
   constexpr int N = P::N;
@@ -139,17 +165,10 @@ ZK_HD Fp<P> rand_fp_secure(const uint32_t* key, uint64_t nonce, uint64_t idx, ui
   for (uint64_t attempt = first_attempt;; attempt++) {
     uint32_t blk[16];
     // counter: idx in the low 56 bits, the attempt number above (2^8 attempts never happen)
-    chacha20_block(key, idx | (attempt << 56), nonce, blk);
+    chacha_block<RNG_DOUBLE_ROUNDS>(key, idx | (attempt << 56), nonce, blk);
     for (int half = 0; half < 2; half++) {
       Fp<P> r;
-#pragma unroll
-      for (int i = 0; i < N; i++) r.v[i] = blk[8 * half + i];
-      if (!rand_lt_mult<P, K>(r)) continue;
-      if constexpr (K >= 8) rand_sub_mult_if_ge<P, 8>(r);
-      if constexpr (K >= 4) rand_sub_mult_if_ge<P, 4>(r);
-      if constexpr (K >= 2) rand_sub_mult_if_ge<P, 2>(r);
-      rand_sub_mult_if_ge<P, 1>(r);
-      return r.to_mont();
+      if (rand_candidate_half<P>(blk, half, &r)) return r;
     }
   }
 }
@@ -165,28 +184,11 @@ template <class P>
 ZK_HD Fp<P> rand_fp(const RngSeed& rs, uint64_t idx) {
   return rs.key ? rand_fp_secure<P>(rs.key, rs.seed, idx) : rand_fp<P>(rs.seed, idx);
 }
-// first accepted candidate of one block, if any
-template <class P>
-ZK_HD bool rand_candidate(const uint32_t* blk, Fp<P>* out) {
-  constexpr int N = P::N;
-  constexpr int K = RandWide<P>::K;
-  for (int half = 0; half < 2; half++) {
-    Fp<P> r;
-#pragma unroll
-    for (int i = 0; i < N; i++) r.v[i] = blk[8 * half + i];
-    if (!rand_lt_mult<P, K>(r)) continue;
-    if constexpr (K >= 8) rand_sub_mult_if_ge<P, 8>(r);
-    if constexpr (K >= 4) rand_sub_mult_if_ge<P, 4>(r);
-    if constexpr (K >= 2) rand_sub_mult_if_ge<P, 2>(r);
-    rand_sub_mult_if_ge<P, 1>(r);
-    *out = r.to_mont();
-    return true;
-  }
-  return false;
-}
-// The two draws idx, idx + 1 of a chunk (t = 2) -- the SAME values as two rand_fp calls; on the production stream their
-// first blocks are computed side by side (two independent instruction streams for the scheduler: the block function is
-// one long dependent chain), the rare repeats fall back to the one-draw loop.
+// The two draws idx, idx + 1 of a chunk (t = 2).  Replay stream: the same values as two rand_fp calls.  Production
+// stream: the two 256-bit halves of ONE block (counter idx, attempt 0) -- a block has exactly two candidates, each accepted
+// with probability 0.91-0.95; a rejected half is redrawn from blocks of its own (counter idx or idx + 1, attempts >= 1),
+// so no key-stream word is used twice.  (Rounds 2-3 spent a block of its own on every draw: two ChaCha20 blocks per chunk
+// where this is one ChaCha12 block, 30 % of the instructions.)
 template <class P>
 ZK_HD void rand_fp_pair(const RngSeed& rs, uint64_t idx, Fp<P>* a, Fp<P>* b) {
   if (!rs.key) {
@@ -194,10 +196,9 @@ ZK_HD void rand_fp_pair(const RngSeed& rs, uint64_t idx, Fp<P>* a, Fp<P>* b) {
     *b = rand_fp<P>(rs.seed, idx + 1);
     return;
   }
-  uint32_t ba[16], bb[16];
-  chacha20_block(rs.key, idx, rs.seed, ba);
-  chacha20_block(rs.key, idx + 1, rs.seed, bb);
-  const bool oa = rand_candidate<P>(ba, a), ob = rand_candidate<P>(bb, b);
+  uint32_t blk[16];
+  chacha_block<RNG_DOUBLE_ROUNDS>(rs.key, idx, rs.seed, blk);
+  const bool oa = rand_candidate_half<P>(blk, 0, a), ob = rand_candidate_half<P>(blk, 1, b);
   if (!oa) *a = rand_fp_secure<P>(rs.key, rs.seed, idx, 1);
   if (!ob) *b = rand_fp_secure<P>(rs.key, rs.seed, idx + 1, 1);
 }
