@@ -212,8 +212,15 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         lcrs = mg.LocalCrs(pp, crs, first, k, sel)
         qap, a_sh, ax_sh = mg.local_witness(pp, wit, first, k, sel)
         lm = [mg.local_masks(pp, m_, wit.log_m, first, k, sel) for m_ in mks_b]
+        st_b0 = net.stats()
         gots = znet.dist_prove_batch(pp, net, lcrs.ct, [qap] * nbp, [a_sh] * nbp, [ax_sh] * nbp, rs_b, ss_b, wit.log_m,
                                      masks=[x[0] for x in lm], seed=21)
+        st_b1 = net.stats()
+        # ONE king round per phase and channel for the whole batch (ext_wit.rs:127-170: 3 + 3 transforms and deg_red):
+        # 7 gathers and 7 scatters per batch with the star king (world > 1), not 7 per proof
+        if world > 1 and not a2a:
+            checks["batch_king_rounds"] = (st_b1["gathers"] - st_b0["gathers"] == 7 and
+                                           st_b1["scatters"] - st_b0["scatters"] == 7)
         checks["prove_batch"] = all(
             G1.eq(dec_jacobian(pp, gots[b][0][p]), dec_jacobian(pp, refs[b][0][sel[p]])) and
             G2.eq(dec_jacobian(pp, gots[b][1][p], True), dec_jacobian(pp, refs[b][1][sel[p]], True)) and

@@ -2901,6 +2901,123 @@ class Engine : public IEngine {
     if (rc) return rc;
     return net_err(net, net->end(0, st));
   }
+  // circom_h of a whole BATCH of proofs with ONE king round per phase and channel (round 4; round 3 sent the proofs'
+  // rounds over the channels one proof after the other: 7 nb rounds per batch, the star's serial rounds bounded the
+  // sharded throughput mode).  The three joined d_ifft / d_fft of ext_wit.rs:127-170 stay three channels in flight; a
+  // channel's round now carries the vectors of all nb proofs: party rows are [nb][m/l] (KingBatch::row_pitch,
+  // DegredBatch strides), so gather, king kernel and scatter move nb vectors per party at once.  Proof b draws the share
+  // randomness of a single proof with seed + 16 b.  h_all: [nb][k][m/l].  mk: nb mask sets (local rows) or nullptr.
+  DevBuf dist_wb_, dist_hb_;
+  int vec_add2d(Fr* x, size_t xpitch, const Fr* y, size_t ypitch, size_t width, size_t rows, hipStream_t st) {
+    const size_t tot = width * rows;
+    if (!tot) return ZK_OK;
+    vec_add2d_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(x, xpitch, y, ypitch, width, rows);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int dist_circom_h_batch_on(Net* net, const uint32_t* cmask, int nb, const void* const* qa, const void* const* qb,
+                             const void* const* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed, Fr* h_all,
+                             hipStream_t st) {
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l, row = (size_t)nb * Lc, per = (size_t)k * row;   // per channel: [k][nb][Lc]
+    if (nb < 1 || nb > KING_BATCH || nb > DEGRED_BATCH) return fail(ZK_ERR_BAD_INPUT, "bad circom_h batch");
+    ZK_HIP(dist_wb_.ensure(3 * per * sizeof(Fr)));
+    ZK_HIP(dist_hb_.ensure(per * sizeof(Fr)));
+    Fr* W = (Fr*)dist_wb_.p;
+    Fr* H = (Fr*)dist_hb_.p;
+    const void* const* q[3] = {qa, qb, qc};
+    for (int j = 0; j < 3; j++)
+      for (int b = 0; b < nb; b++)
+        ZK_HIP(hipMemcpy2DAsync(W + j * per + (size_t)b * Lc, row * sizeof(Fr), q[j][b], Lc * sizeof(Fr), Lc * sizeof(Fr),
+                                (size_t)k, hipMemcpyDeviceToDevice, st));
+    Fr w2m = root_of_unity(log_m + 1);
+    const bool has_in = mk && mk[0].fft_in[0];
+    int rc;
+    for (int phase = 0; phase < 2; phase++) {
+      const int inverse = phase == 0 ? 1 : 0;
+      if (inverse && has_in) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(W, &c, 3 * per, st);
+        if (rc) return rc;
+      }
+      rc = fft1(W, log_m, inverse, 3 * (size_t)k * nb, nullptr, st);
+      if (rc) return rc;
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->begin(j, st));
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        const int mi = phase * 3 + j;
+        hipStream_t s = net_stream(net, j, nullptr);
+        Fr* Wj = W + j * per;
+        for (int b = 0; b < nb; b++) {
+          if ((mk && mk[b].fft_in[mi] != nullptr) != has_in) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in circom_h");
+          if (has_in) {
+            rc = vec_add2d(Wj + (size_t)b * Lc, row, (const Fr*)mk[b].fft_in[mi], Lc, Lc, (size_t)k, s);
+            if (rc) return rc;
+          }
+        }
+        const int scale = (inverse && !has_in) ? 1 : 0;
+        const void* g = phase == 0 ? (const void*)&w2m : nullptr;
+        rc = king_round(net, j, cmask[j], Wj, row,
+                        [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr*, hipStream_t ks) {
+                          const Fr* U = nullptr;
+                          int r2 = umat_for(ps, np, &U);
+                          if (r2) return r2;
+                          KingBatch<Fr> kb{};
+                          kb.stride = Lc;
+                          kb.row_pitch = row;
+                          kb.items_per = 1;
+                          kb.seed_step = PROOF_SEED_STEP;
+                          return king_dispatch_batch(in, kb, nb, np, log_m, inverse, U, g, scale, phase == 0 ? 1 : 0,
+                                                     seed + (uint64_t)mi, out, false, ks);
+                        });
+        if (rc) return rc;
+        for (int b = 0; b < nb; b++)
+          if (mk && mk[b].fft_out[mi]) {
+            rc = vec_add2d(Wj + (size_t)b * Lc, row, (const Fr*)mk[b].fft_out[mi], Lc, Lc, (size_t)k, s);
+            if (rc) return rc;
+          }
+      }
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->end(j, st));
+        if (rc) return rc;
+      }
+    }
+    rc = vec_mul_sub(H, W, W + per, W + 2 * per, per, st);
+    if (rc) return rc;
+    rc = net_err(net, net->begin(0, st));
+    if (rc) return rc;
+    {
+      hipStream_t s = net_stream(net, 0, nullptr);
+      for (int b = 0; b < nb; b++)
+        if (mk && mk[b].degred_in) {
+          rc = vec_add2d(H + (size_t)b * Lc, row, (const Fr*)mk[b].degred_in, Lc, Lc, (size_t)k, s);
+          if (rc) return rc;
+        }
+      rc = king_round(net, 0, cmask[0], H, row,
+                      [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr*, hipStream_t ks) {
+                        DegredBatch<Fr> db{};
+                        db.in_step = db.out_step = Lc;
+                        db.seed_step = PROOF_SEED_STEP;
+                        return deg_red_batch(in, db, nb, ps, np, Lc, seed + 6, out, ks, row);
+                      },
+                      nullptr, nullptr, true);
+      if (rc) return rc;
+      for (int b = 0; b < nb; b++)
+        if (mk && mk[b].degred_out) {
+          rc = vec_add2d(H + (size_t)b * Lc, row, (const Fr*)mk[b].degred_out, Lc, Lc, (size_t)k, s);
+          if (rc) return rc;
+        }
+    }
+    rc = net_err(net, net->end(0, st));
+    if (rc) return rc;
+    // [k][nb][Lc] -> the batch prover's [nb][k][Lc]
+    for (int b = 0; b < nb; b++)
+      ZK_HIP(hipMemcpy2DAsync(h_all + (size_t)b * k * Lc, Lc * sizeof(Fr), H + (size_t)b * Lc, row * sizeof(Fr),
+                              Lc * sizeof(Fr), (size_t)k, hipMemcpyDeviceToDevice, st));
+    return ZK_OK;
+  }
   int dist_circom_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk,
                     uint64_t seed, void* h, hipStream_t st) override {
     if (log_m < ilog2(l) || log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
@@ -3061,12 +3178,18 @@ class Engine : public IEngine {
       last = keep;
       return code;
     };
-    // circom_h of every proof through the star (the channels carry one proof's rounds at a time; the MSMs of the whole
-    // batch run beside them)
-    for (int b = 0; b < nb; b++) {
-      rc = dist_circom_h_on(net, cmask, qa[b], qb[b], qc[b], log_m, mk ? &mk[b] : nullptr,
-                            seed + (uint64_t)PROOF_SEED_STEP * b, (Fr*)B.hshare.p + (size_t)b * per, st);
+    // circom_h of the whole batch: one king round per phase and channel carries all nb proofs (7 rounds per batch; the MSMs
+    // of the batch run beside them).  ZK_DIST_BATCH_KING=0: one proof's rounds after the other's, as in round 3.
+    static const bool batch_king = !(getenv("ZK_DIST_BATCH_KING") && atoi(getenv("ZK_DIST_BATCH_KING")) == 0);
+    if (batch_king) {
+      rc = dist_circom_h_batch_on(net, cmask, nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, st);
       if (rc) return bail(rc);
+    } else {
+      for (int b = 0; b < nb; b++) {
+        rc = dist_circom_h_on(net, cmask, qa[b], qb[b], qc[b], log_m, mk ? &mk[b] : nullptr,
+                              seed + (uint64_t)PROOF_SEED_STEP * b, (Fr*)B.hshare.p + (size_t)b * per, st);
+        if (rc) return bail(rc);
+      }
     }
     // the U-MSM runs on its own stream of the batch's set, behind everything queued on the caller's stream
     {

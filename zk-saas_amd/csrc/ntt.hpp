@@ -321,6 +321,18 @@ __global__ void vec_add_kernel(F* __restrict__ x, const F* __restrict__ y, size_
   if (i < len) store_elem(x + i, load_elem(x + i) + load_elem(y + i));
 }
 
+// x[r * xpitch + c] += y[r * ypitch + c], c < width, r < rows (rows of two differently pitched matrices: a batch's party
+// rows [items][m/l] against one proof's mask rows [m/l])
+template <class F>
+__global__ void vec_add2d_kernel(F* __restrict__ x, size_t xpitch, const F* __restrict__ y, size_t ypitch, size_t width,
+                                 size_t rows) {
+  __builtin_amdgcn_s_setprio(3);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width * rows) return;
+  const size_t r = i / width, c = i % width;
+  store_elem(x + r * xpitch + c, load_elem(x + r * xpitch + c) + load_elem(y + r * ypitch + c));
+}
+
 template <class F>
 __global__ void vec_scale_kernel(F* __restrict__ x, F k, size_t len) {
   __builtin_amdgcn_s_setprio(3);

@@ -207,6 +207,9 @@ struct KingBatch {
   const F* out_mask[KING_BATCH];
   size_t stride;
   uint32_t items_per, seed_step;
+  // distance between the rows of two parties, in and out (0: the vector length m/l).  A king round that carries the
+  // vectors of a whole batch of proofs has party rows [items][m/l]: stride = m/l, row_pitch = items * m/l
+  size_t row_pitch;
   ZK_HD uint64_t seed_off(uint32_t y) const {
     return items_per ? (uint64_t)(y / items_per) * seed_step + y % items_per : (uint64_t)y;
   }
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     // factor is folded into gtab instead.  One branch-free row function per case: a uniform branch between the loads
     // of a row keeps the compiler from putting the loads of the whole group in flight together.
     const F* __restrict__ col = seg ? in + (blockIdx.x * Wc + tid) : in + k;
-    const size_t pitch = seg ? (size_t)seg : (size_t)1 << log_lc;
+    const size_t pitch = seg ? (size_t)seg : (kb.row_pitch ? kb.row_pitch : (size_t)1 << log_lc);
     if (!in_mask) {
       unpack_accumulate<F, L>(v, U, np, [&](int s) { return load_elem(col + (size_t)s * pitch); });
     } else if (!in_scale) {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
 #pragma unroll
     for (int p = 0; p < N; p++) {
-      size_t o = seg ? (size_t)p * seg + ql : ((size_t)p << log_lc) + j;
+      size_t o = seg ? (size_t)p * seg + ql : (kb.row_pitch ? (size_t)p * kb.row_pitch : (size_t)p << log_lc) + j;
       F acc = sh[p];
       if (out_mask) acc = acc + load_elem(out_mask + o);
       store_elem(out + o, acc);

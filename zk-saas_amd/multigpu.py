@@ -213,7 +213,10 @@ def bench(args, rank, local_rank, world):
     first, k = net.first, net.k
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": "u32 limbs (%s Montgomery)" % ("255-bit Fr / 381-bit Fq" if wl == "c5" else "256-bit"),
-            "transport": transport, "king": king, "parties_per_gpu": k}
+            "transport": transport, "king": king, "parties_per_gpu": k,
+            # size of the RCCL communicators this run actually initialised and used (0: the data plane did NOT run over
+            # RCCL -- one rank, or the shared-memory fallback; see transport_note)
+            "rccl_ranks": world if transport == "rccl" else 0}
     if note:
         base["transport_note"] = note
     eb = pp.fr.nbytes
@@ -399,6 +402,8 @@ def bench(args, rank, local_rank, world):
                            "parties": pp.n, "packing_factor": pp.l, "fixed_base_tables": not args.no_tables},
                    constraints_per_sec=round(proofs_per_s * r1.num_constraints, 1), proof_matches_single_gpu=ok,
                    roofline=roofline_of(prof, ntt_passes=2, masks_on=masks is not None, pp=pp),
+                   cpu_baseline={"value": None, "unit": "proofs/s", "kind": "port",
+                                 "note": "timed on rank 0 at N = 1 only (bench contract): see the N = 1 line"},
                    kernels=[{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]])
     else:   # c5
         from . import synthetic
