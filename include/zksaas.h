@@ -414,6 +414,19 @@ int zk_dist_d_pp(zk_ctx* ctx, zk_net* net, int sid, const void* num_d, const voi
                  const void* out_mask_d, size_t len, uint64_t seed, void* out_d, void* stream);
 int zk_dist_d_msm(zk_ctx* ctx, zk_net* net, int sid, int group, const void* bases_d, const void* scalars_d, size_t len,
                   const void* in_mask, const void* out_mask, void* out, void* stream);
+/* deg_red over GROUP elements per rank (dist-primitives/src/utils/deg_red.rs:80-126 is generic over T: DomainCoeff<F> = F or
+ * G and takes net, sid): x_d, masks, out_d are this rank's k parties' rows [k][len] of affine points (out_d must not alias
+ * x_d); gen_affine as in zk_deg_red_points.  A rank the round left out is handled like for field elements (the king's
+ * unpack2 becomes the Lagrange form over the present parties). */
+int zk_dist_deg_red_points(zk_ctx* ctx, zk_net* net, int sid, int group, const void* x_d, const void* in_mask_d,
+                           const void* out_mask_d, size_t len, const void* gen_affine, uint64_t seed, void* out_d,
+                           void* stream);
+/* libsnark_h per rank (groth16/src/ext_wit.rs:14-102): three d_ifft with the coset shift F::GENERATOR joined on channels
+ * 0..2, three d_fft likewise, (a b - c) / Z(g), d_ifft with g^-1 on channel 0.  qap_*_d, h_d and the seven masks
+ * (arrays of 7 pointers, or NULL for FftMask::zero) are this rank's rows [k][m/l]. */
+int zk_dist_libsnark_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                       const void* const* fft_in_masks, const void* const* fft_out_masks, uint64_t seed, void* h_d,
+                       void* stream);
 int zk_dist_circom_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
                      const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream);
 int zk_dist_groth16_prove(zk_ctx* ctx, zk_net* net, const zk_crs_share* crs, const void* qap_a_d, const void* qap_b_d,
@@ -457,6 +470,22 @@ int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* cr
  * (~4.3 ms at 63 GB/s) around 0.87 ms of compute. */
 int zk_d_fft_host(zk_ctx* ctx, void* shares, const void* in_mask, const void* out_mask, int rearrange, int log2_m,
                   int inverse, const void* g, uint64_t seed, void* stream);
+/* The same staging for the remaining functions whose reference signatures take host vectors (round 4):
+ * zk_deg_red_host      dist-primitives/src/utils/deg_red.rs:80 (px: Vec<T>): x [n][len] in place, masks host [n][len] or NULL
+ * zk_d_pp_host         dist-primitives/src/dpp/mod.rs:15 (num, den: Vec<F>): out [n][len] host
+ * zk_circom_h_host     groth16/src/ext_wit.rs:104 (PackedQAPShare of Vec<F>): qap_* and h host [n][m/l]; the Fr-vector members
+ *                      of `masks` (fft_in / fft_out / degred_*) are HOST pointers here
+ * zk_groth16_prove_host  groth16/examples/sha256.rs:32 (dsha256 over host vectors): the five share vectors of `crs`, the QAP and
+ *                      witness shares and the Fr-vector masks are HOST pointers; the single CRS elements, r, s and the MsmMasks are
+ *                      host values as in zk_groth16_prove.  PCIe-inclusive: never what bench.py times. */
+int zk_deg_red_host(zk_ctx* ctx, void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed, void* stream);
+int zk_d_pp_host(zk_ctx* ctx, const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len,
+                 uint64_t seed, void* out, void* stream);
+int zk_circom_h_host(zk_ctx* ctx, const void* qap_a, const void* qap_b, const void* qap_c, int log2_m,
+                     const zk_groth16_masks* masks, uint64_t seed, void* h, void* stream);
+int zk_groth16_prove_host(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a, const void* qap_b, const void* qap_c,
+                          const void* a_share, const void* ax_share, const void* r, const void* s, int log2_m,
+                          const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c, void* stream);
 int zk_msm_host(zk_ctx* ctx, int group, const void* bases, size_t len_bases, const void* scalars, size_t len_scalars,
                 void* out, void* stream);
 int zk_d_msm_host(zk_ctx* ctx, int group, const void* bases, const void* scalars, size_t len, const void* in_mask,

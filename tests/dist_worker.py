@@ -276,6 +276,29 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         after_abort = after_abort and wrong_kind and all(
             G1.eq(dec_jacobian(pp, local[0][p]), dec_jacobian(pp, refs[0][0][p])) for p in range(pp.n))
         checks["abort_releases_sharded_handle"] = after_abort
+        # ---- deg_red over group elements per rank (zk_dist_deg_red_points, deg_red.rs:80-126 with T = G) and libsnark_h per
+        # rank (zk_dist_libsnark_h, ext_wit.rs:14-102): this rank's rows equal the one-context calls' (replay stream)
+        nchp = 5
+        g_aff = pp.fq.encode([1, 2]).reshape(-1)
+        xs_full = zg.base_points(pp, ZK_G1, DeviceBuffer.from_numpy(pp, rand_fr(n * nchp)), n * nchp)
+        imp, omp, ref_pts = (DeviceBuffer(pp, n * nchp * 64) for _ in range(3))
+        pp._check(pp.lib.zk_degred_mask_sample_points(pp.h, ZK_G1, g_aff.ctypes.data, nchp, 64, imp.ptr, omp.ptr, None))
+        pp._check(pp.lib.zk_deg_red_points(pp.h, ZK_G1, xs_full.ptr, imp.ptr, omp.ptr, nchp, g_aff.ctypes.data, 65,
+                                           ref_pts.ptr, None))
+        prow = lambda buf: mg.rows_of(pp, buf, sel, nchp * 64)
+        got_pts = znet.dist_deg_red_points(pp, net, 1, ZK_G1, prow(xs_full), prow(imp), prow(omp), nchp, g_aff, seed=65)
+        pp.sync()
+        checks["deg_red_points"] = np.array_equal(got_pts.to_numpy().reshape(k, nchp, 8),
+                                                  ref_pts.to_numpy().reshape(n, nchp, 8)[sel])
+        lm_s, Lcs = 10, (1 << 10) // 2
+        qs = [rand_fr(n * Lcs) for _ in range(3)]
+        fms = [FftMask.sample(pp, True, None, 0, lm_s, 300 + i) for i in range(7)]   # any seven mask pairs: both sides add the same
+        href = zg.libsnark_h(pp, [DeviceBuffer.from_numpy(pp, x_) for x_ in qs], fms, lm_s, seed=8)
+        hloc = znet.dist_libsnark_h(pp, net, [loc(x_, Lcs) for x_ in qs], lm_s,
+                                    [mg.rows_of(pp, f.in_mask, sel, Lcs * eb) for f in fms],
+                                    [mg.rows_of(pp, f.out_mask, sel, Lcs * eb) for f in fms], seed=8)
+        pp.sync()
+        checks["libsnark_h"] = same_rows(hloc, href, Lcs)
         # circom_h alone: shares identical to the all-in-one call
         h_ref = pp.alloc_fr(n * ((1 << wit.log_m) // 2))
         import ctypes as C

@@ -242,3 +242,79 @@ def test_host_pointer_forms_equal_the_device_forms():
     got, want = got.reshape(pp.n, -1), np.asarray(want).reshape(pp.n, -1)
     for i in range(pp.n):
         assert wire.jacobian_to_affine(pp, got[i], False) == wire.jacobian_to_affine(pp, want[i], False)
+
+
+def test_host_pointer_forms_of_deg_red_d_pp_circom_h_and_the_prover():
+    """zk_deg_red_host / zk_d_pp_host / zk_circom_h_host / zk_groth16_prove_host (deg_red.rs:80, dpp/mod.rs:15,
+    ext_wit.rs:104 and sha256.rs:32 take and return host vectors): shares bit for bit what the device-pointer entry points
+    give on the replay stream; the proof as group elements."""
+    import ctypes as C
+    import zksaas_amd as zk
+    from zksaas_amd import groth16 as zg, wire
+    from test_oracle_groth16 import small_r1cs
+    from oracle.params import BN254
+    pp = ctx("bn254", 2)
+    rng = np.random.default_rng(19)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    ln = 700
+    x = rand(pp.n * ln)
+    mk = zk.DegRedMask.sample(pp, ln, 41)
+    dev = zk.DeviceBuffer.from_numpy(pp, x)
+    zk.deg_red(pp, dev, mk, ln, seed=9)
+    host = x.copy()
+    im, om = mk.in_mask.to_numpy().copy(), mk.out_mask.to_numpy().copy()
+    pp._check(pp.lib.zk_deg_red_host(pp.h, host.ctypes.data, im.ctypes.data, om.ctypes.data, ln, 9, None))
+    assert np.array_equal(host.reshape(-1), dev.to_numpy().reshape(-1))
+    # d_pp: denominators must be shares of non-zero values: pack ones
+    num = rand(pp.n * ln)
+    ones = pp.pack(pp.upload_fr([1 + (i % 7) for i in range(ln * pp.l)]), ln, 3)
+    want = zk.d_pp(pp, zk.DeviceBuffer.from_numpy(pp, num), ones, mk, ln, seed=10)
+    got = np.zeros_like(num)
+    den_h = ones.to_numpy().copy()
+    pp._check(pp.lib.zk_d_pp_host(pp.h, num.ctypes.data, den_h.ctypes.data, im.ctypes.data, om.ctypes.data, ln, 10,
+                                  got.ctypes.data, None))
+    assert np.array_equal(got.reshape(-1), want.to_numpy().reshape(-1))
+    # circom_h and the whole prover on a small circuit, all masks
+    r1, w = small_r1cs(37)
+    td = [int.from_bytes(rng.bytes(32), "little") % BN254.r for _ in range(5)]
+    setup = zg.SetupScalars("bn254", r1, *td)
+    crs = zg.Crs(pp, setup)
+    wit = zg.Witness(pp, "bn254", r1, w, seed=5)
+    masks = zg.ProofMasks(pp, wit.log_m, seed=70)
+    Lc = (1 << wit.log_m) // pp.l
+    h_dev = pp.alloc_fr(pp.n * Lc)
+    pp._check(pp.lib.zk_circom_h(pp.h, wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr, wit.log_m, C.byref(masks.ct), 4,
+                                 h_dev.ptr, None))
+    keep = []
+
+    def hp(buf):
+        a = buf.to_numpy().copy()
+        keep.append(a)
+        return a.ctypes.data
+    mh = zg.Masks()
+    C.memmove(C.byref(mh), C.byref(masks.ct), C.sizeof(zg.Masks))
+    for i in range(6):
+        mh.fft_in[i], mh.fft_out[i] = hp(masks.fft[i].in_mask), hp(masks.fft[i].out_mask)
+    mh.degred_in, mh.degred_out = hp(masks.degred.in_mask), hp(masks.degred.out_mask)
+    h_host = np.zeros((pp.n * Lc, 4), dtype=np.uint64)
+    pp._check(pp.lib.zk_circom_h_host(pp.h, hp(wit.qap[0]), hp(wit.qap[1]), hp(wit.qap[2]), wit.log_m, C.byref(mh), 4,
+                                      h_host.ctypes.data, None))
+    assert np.array_equal(h_host.reshape(-1), h_dev.to_numpy().reshape(-1))
+    r, s = 123456789, 987654321
+    ref = zg.prove(pp, crs, wit, r, s, masks=masks, seed=6)
+    ch = zg.CrsShare()
+    C.memmove(C.byref(ch), C.byref(crs.ct), C.sizeof(zg.CrsShare))
+    ch.s_d, ch.h_d, ch.v_d, ch.w_d, ch.u_d = hp(crs.s), hp(crs.h), hp(crs.v), hp(crs.w), hp(crs.u)
+    nl = pp.fq.nl
+    pa, pb, pc = (np.zeros((pp.n, c_ * nl), dtype=np.uint64) for c_ in (3, 6, 3))
+    rr, ss = pp.fr.encode_one(r), pp.fr.encode_one(s)
+    pp._check(pp.lib.zk_groth16_prove_host(pp.h, C.byref(ch), hp(wit.qap[0]), hp(wit.qap[1]), hp(wit.qap[2]), hp(wit.a_share),
+                                           hp(wit.ax_share), rr.ctypes.data, ss.ctypes.data, wit.log_m, C.byref(mh), 6,
+                                           pa.ctypes.data, pb.ctypes.data, pc.ctypes.data, None))
+    for got_, ref_, g2 in ((pa, ref[0], False), (pb, ref[1], True), (pc, ref[2], False)):
+        for i in range(pp.n):
+            assert wire.jacobian_to_affine(pp, got_[i], g2) == wire.jacobian_to_affine(pp, ref_[i], g2)

@@ -25,6 +25,8 @@ SYMBOLS = [
     "zk_msm_mask_sample", "zk_r1cs_qap", "zk_fr_to_bytes", "zk_fr_from_bytes", "zk_ctx_set_option", "zk_msm_precompute", "zk_msm_forget", "zk_msm_table_info",
     "zk_groth16_prove_batch", "zk_groth16_prove_batch_async", "zk_groth16_batch_wait", "zk_msm_batch", "zk_pss_unpack_points", "zk_pss_unpack2_points", "zk_groth16_reconstruct", "zk_msm_stats", "zk_dist_groth16_prove_batch", "zk_d_fft_host", "zk_msm_host", "zk_d_msm_host",
     "zk_net_parties", "zk_dist_groth16_prove_async", "zk_dist_groth16_wait", "zk_fq_selftest",
+    "zk_dist_deg_red_points", "zk_dist_libsnark_h", "zk_deg_red_host", "zk_d_pp_host", "zk_circom_h_host",
+    "zk_groth16_prove_host",
 ]
 
 _lib = None
@@ -164,6 +166,12 @@ def load():
     lib.zk_dist_groth16_prove_batch.argtypes = [vp, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                 C.POINTER(vp), vp, vp, i32, vp, u64, vp, vp, vp, vp]
     lib.zk_d_fft_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, u64, vp]
+    lib.zk_deg_red_host.argtypes = [vp, vp, vp, vp, sz, u64, vp]
+    lib.zk_d_pp_host.argtypes = [vp, vp, vp, vp, vp, sz, u64, vp, vp]
+    lib.zk_circom_h_host.argtypes = [vp, vp, vp, vp, i32, vp, u64, vp, vp]
+    lib.zk_groth16_prove_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, u64, vp, vp, vp, vp]
+    lib.zk_dist_deg_red_points.argtypes = [vp, vp, i32, i32, vp, vp, vp, sz, vp, u64, vp, vp]
+    lib.zk_dist_libsnark_h.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(vp), C.POINTER(vp), u64, vp, vp]
     lib.zk_msm_host.argtypes = [vp, i32, vp, sz, vp, sz, vp, vp]
     lib.zk_d_msm_host.argtypes = [vp, i32, vp, vp, sz, vp, vp, vp, vp]
     lib.zk_vec_scale.argtypes = [vp, vp, vp, sz, vp]

@@ -266,6 +266,105 @@ int zk_d_fft_host(zk_ctx* ctx, void* shares /* host [n][m/l], in place */, const
   if (he == hipSuccess) he = hipStreamSynchronize(S(stream));
   return he == hipSuccess ? ZK_OK : e->hip_fail(he, "host staging");
 }
+int zk_deg_red_host(zk_ctx* ctx, void* x /* host [n][len], in place */, const void* in_mask, const void* out_mask, size_t len,
+                    uint64_t seed, void* stream) {
+  CTX_OR_FAIL();
+  if (!len) return ZK_OK;
+  if (!x) return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  const size_t bytes = (size_t)e->n * len * e->fr_bytes();
+  HostStage hs;
+  int rc = ZK_OK;
+  void* xd = hs.up(e, x, bytes, S(stream), &rc);
+  void* im = in_mask ? hs.up(e, in_mask, bytes, S(stream), &rc) : nullptr;
+  void* om = out_mask ? hs.up(e, out_mask, bytes, S(stream), &rc) : nullptr;
+  if (rc) return rc;
+  rc = e->deg_red(xd, im, om, len, seed, S(stream));
+  if (rc) return rc;
+  hipError_t he = hipMemcpyAsync(x, xd, bytes, hipMemcpyDeviceToHost, S(stream));
+  if (he == hipSuccess) he = hipStreamSynchronize(S(stream));
+  return he == hipSuccess ? ZK_OK : e->hip_fail(he, "host staging");
+}
+int zk_d_pp_host(zk_ctx* ctx, const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len,
+                 uint64_t seed, void* out, void* stream) {
+  CTX_OR_FAIL();
+  if (!len) return ZK_OK;
+  if (!num || !den || !out) return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  const size_t bytes = (size_t)e->n * len * e->fr_bytes();
+  HostStage hs;
+  int rc = ZK_OK;
+  void* nd = hs.up(e, num, bytes, S(stream), &rc);
+  void* dd = hs.up(e, den, bytes, S(stream), &rc);
+  void* od = hs.up(e, nullptr, bytes, S(stream), &rc);
+  void* im = in_mask ? hs.up(e, in_mask, bytes, S(stream), &rc) : nullptr;
+  void* om = out_mask ? hs.up(e, out_mask, bytes, S(stream), &rc) : nullptr;
+  if (rc) return rc;
+  rc = e->d_pp(nd, dd, im, om, len, seed, od, S(stream));
+  if (rc) return rc;
+  hipError_t he = hipMemcpyAsync(out, od, bytes, hipMemcpyDeviceToHost, S(stream));
+  if (he == hipSuccess) he = hipStreamSynchronize(S(stream));
+  return he == hipSuccess ? ZK_OK : e->hip_fail(he, "host staging");
+}
+namespace {
+// the Fr-vector masks of a zk_groth16_masks given as HOST pointers -> device copies (the MsmMasks are host values anyway)
+int stage_masks(IEngine* e, HostStage& hs, const zk_groth16_masks* in, size_t bytes, hipStream_t st, zk_groth16_masks* out) {
+  int rc = ZK_OK;
+  *out = *in;
+  for (int i = 0; i < 6; i++) {
+    out->fft_in[i] = in->fft_in[i] ? hs.up(e, in->fft_in[i], bytes, st, &rc) : nullptr;
+    out->fft_out[i] = in->fft_out[i] ? hs.up(e, in->fft_out[i], bytes, st, &rc) : nullptr;
+  }
+  out->degred_in = in->degred_in ? hs.up(e, in->degred_in, bytes, st, &rc) : nullptr;
+  out->degred_out = in->degred_out ? hs.up(e, in->degred_out, bytes, st, &rc) : nullptr;
+  return rc;
+}
+}  // namespace
+int zk_circom_h_host(zk_ctx* ctx, const void* qap_a, const void* qap_b, const void* qap_c, int log2_m,
+                     const zk_groth16_masks* masks, uint64_t seed, void* h, void* stream) {
+  CTX_OR_FAIL();
+  if (!qap_a || !qap_b || !qap_c || !h || log2_m < 0 || log2_m > 40) return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  const size_t bytes = (size_t)e->n * (((size_t)1 << log2_m) / (size_t)e->l) * e->fr_bytes();
+  HostStage hs;
+  int rc = ZK_OK;
+  void* a = hs.up(e, qap_a, bytes, S(stream), &rc);
+  void* b = hs.up(e, qap_b, bytes, S(stream), &rc);
+  void* c = hs.up(e, qap_c, bytes, S(stream), &rc);
+  void* hd = hs.up(e, nullptr, bytes, S(stream), &rc);
+  zk_groth16_masks md;
+  if (!rc && masks) rc = stage_masks(e, hs, masks, bytes, S(stream), &md);
+  if (rc) return rc;
+  rc = e->circom_h(a, b, c, log2_m, masks ? &md : nullptr, seed, hd, S(stream));
+  if (rc) return rc;
+  hipError_t he = hipMemcpyAsync(h, hd, bytes, hipMemcpyDeviceToHost, S(stream));
+  if (he == hipSuccess) he = hipStreamSynchronize(S(stream));
+  return he == hipSuccess ? ZK_OK : e->hip_fail(he, "host staging");
+}
+int zk_groth16_prove_host(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_a, const void* qap_b, const void* qap_c,
+                          const void* a_share, const void* ax_share, const void* r, const void* s, int log2_m,
+                          const zk_groth16_masks* masks, uint64_t seed, void* pi_a, void* pi_b, void* pi_c, void* stream) {
+  CTX_OR_FAIL();
+  if (!crs || !qap_a || !qap_b || !qap_c || !a_share || !ax_share || log2_m < 0 || log2_m > 40)
+    return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  const size_t n = (size_t)e->n, fr = e->fr_bytes(), g1 = 2 * e->fq_bytes(), g2 = 2 * g1;
+  const size_t qbytes = n * (((size_t)1 << log2_m) / (size_t)e->l) * fr;
+  HostStage hs;
+  int rc = ZK_OK;
+  zk_crs_share cd = *crs;
+  cd.s_d = hs.up(e, crs->s_d, n * crs->len_a * g1, S(stream), &rc);
+  cd.h_d = hs.up(e, crs->h_d, n * crs->len_a * g1, S(stream), &rc);
+  cd.v_d = hs.up(e, crs->v_d, n * crs->len_a * g2, S(stream), &rc);
+  cd.w_d = hs.up(e, crs->w_d, n * crs->len_w * g1, S(stream), &rc);
+  cd.u_d = hs.up(e, crs->u_d, n * crs->len_u * g1, S(stream), &rc);
+  void* a = hs.up(e, qap_a, qbytes, S(stream), &rc);
+  void* b = hs.up(e, qap_b, qbytes, S(stream), &rc);
+  void* c = hs.up(e, qap_c, qbytes, S(stream), &rc);
+  void* as = hs.up(e, a_share, n * crs->len_a * fr, S(stream), &rc);
+  void* ax = hs.up(e, ax_share, n * crs->len_w * fr, S(stream), &rc);
+  zk_groth16_masks md;
+  if (!rc && masks) rc = stage_masks(e, hs, masks, qbytes, S(stream), &md);
+  if (rc) return rc;
+  // (groth16_prove returns with the proof on the host and every kernel that read the staged buffers finished)
+  return e->groth16_prove(&cd, a, b, c, as, ax, r, s, log2_m, masks ? &md : nullptr, seed, pi_a, pi_b, pi_c, S(stream));
+}
 int zk_msm_host(zk_ctx* ctx, int group, const void* bases /* host affine [len] */, size_t len_bases, const void* scalars,
                 size_t len_scalars, void* out, void* stream) {
   CTX_OR_FAIL();
@@ -558,6 +657,21 @@ int zk_dist_d_msm(zk_ctx* ctx, zk_net* net, int sid, int group, const void* base
                   const void* in_mask, const void* out_mask, void* out, void* stream) {
   NET_OR_FAIL();
   return e->dist_finish(&net->net, e->dist_d_msm(&net->net, sid, group, bases_d, scalars_d, len, in_mask, out_mask, out, S(stream)));
+}
+int zk_dist_deg_red_points(zk_ctx* ctx, zk_net* net, int sid, int group, const void* x_d, const void* in_mask_d,
+                           const void* out_mask_d, size_t len, const void* gen_affine, uint64_t seed, void* out_d,
+                           void* stream) {
+  NET_OR_FAIL();
+  return e->dist_finish(&net->net, e->dist_deg_red_points(&net->net, sid, group, x_d, in_mask_d, out_mask_d, len, gen_affine,
+                                                          seed, out_d, S(stream)));
+}
+int zk_dist_libsnark_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
+                       const void* const* fft_in_masks, const void* const* fft_out_masks, uint64_t seed, void* h_d,
+                       void* stream) {
+  const int sid = 0;
+  NET_OR_FAIL();
+  return e->dist_finish(&net->net, e->dist_libsnark_h(&net->net, qap_a_d, qap_b_d, qap_c_d, log2_m, fft_in_masks,
+                                                      fft_out_masks, seed, h_d, S(stream)));
 }
 int zk_dist_circom_h(zk_ctx* ctx, zk_net* net, const void* qap_a_d, const void* qap_b_d, const void* qap_c_d, int log2_m,
                      const zk_groth16_masks* masks, uint64_t seed, void* h_d, void* stream) {

@@ -233,6 +233,10 @@ class IEngine {
   // exit of every zk_dist_* entry point: with the option "dist_deadline" the call returns only when the channels'
   // data-plane work has completed, or fails with ZK_ERR_PROTOCOL once the net's timeout has passed (ser_net.rs:122-125)
   virtual int dist_finish(Net* net, int rc) = 0;
+  virtual int dist_deg_red_points(Net* net, int sid, int group, const void* x, const void* in_mask, const void* out_mask,
+                                  size_t len, const void* gen_affine, uint64_t seed, void* out, hipStream_t st) = 0;
+  virtual int dist_libsnark_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m, const void* const* fft_in,
+                              const void* const* fft_out, uint64_t seed, void* h, hipStream_t st) = 0;
   virtual int msm_precompute(int group, const void* bases, size_t len, hipStream_t st) = 0;
   virtual int msm_forget(const void* bases) = 0;
   virtual int msm_table_info(int group, const void* bases, int* info) = 0;

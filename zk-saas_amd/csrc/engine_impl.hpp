@@ -2137,11 +2137,22 @@ class Engine : public IEngine {
   }
   template <class Fld>
   int deg_red_points_t(const void* x, const void* in_mask, const void* out_mask, size_t len, const void* gen_affine,
-                       uint64_t seed, void* out, hipStream_t st) {
+                       uint64_t seed, void* out, hipStream_t st, const uint32_t* parties = nullptr, int np = 0) {
     if (!len) return ZK_OK;
     if (!x || !out || !gen_affine) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     int rc = ensure_canon_mats();
     if (rc) return rc;
+    // only some parties' points reached the king (a rank was left out of the round): x / in_mask are [np][len] and the
+    // unpack2 is the Lagrange form over the present parties (pss.rs:170-221), as for field elements
+    const Fr* u2 = u2c_;
+    if (np && np != n) {
+      Fr* ud = nullptr;
+      rc = ucanon_for(parties, np, 2, &ud);
+      if (rc) return rc;
+      u2 = ud;
+    } else {
+      np = n;
+    }
     using A = Affine<Fld>;
     ZK_HIP(ptw_[0].ensure(len * t * sizeof(Fr)));
     ZK_HIP(ptw_[1].ensure(len * t * sizeof(A)));
@@ -2156,10 +2167,10 @@ class Engine : public IEngine {
     rc = base_mul_t<Fld>(gen_affine, rs_, cnt, rnd, st);
     if (rc) return rc;
     // unpack2 of (x + in_mask): rows = l secrets of the chunk, inputs = the n parties' points
-    PtGroup<Fld> gx{(const A*)x, 1, len, n, 0}, gm{(const A*)in_mask, 1, len, n, 0};
+    PtGroup<Fld> gx{(const A*)x, 1, len, np, 0}, gm{(const A*)in_mask, 1, len, np, 0};
     size_t total = len * (size_t)l;
     points_lincomb_kernel<FrP, Fld><<<dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st>>>(
-        gx, gm, in_mask ? 2 : 1, u2c_, n, l, len, nullptr, 0, sec, 1, (size_t)l);
+        gx, gm, in_mask ? 2 : 1, u2, np, l, len, nullptr, 0, sec, 1, (size_t)l);
     ZK_HIP(hipGetLastError());
     // pack: rows = n parties, inputs = l secrets + t random points, + the party's out-mask
     PtGroup<Fld> gs{sec, (size_t)l, 1, l, 0}, gr{rnd, (size_t)t, 1, t, l};
@@ -2244,11 +2255,8 @@ class Engine : public IEngine {
       }
     return ZK_OK;
   }
-  template <class Fld>
-  int unpack_points_t(const void* shares, const uint32_t* parties, int np, size_t nchunks, int kind, void* out,
-                      hipStream_t st) {
-    if (!nchunks) return ZK_OK;
-    if (!shares || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+  // device copy with CANONICAL entries (what points_lincomb_kernel takes), cached per (party set, kind)
+  int ucanon_for(const uint32_t* parties, int np, int kind, Fr** out) {
     std::vector<Fr> U;
     uint32_t mask = 0;
     int rc = umat_host(parties, np, kind, U, &mask);
@@ -2266,6 +2274,17 @@ class Engine : public IEngine {
       std::lock_guard<std::mutex> lk(mu_);
       ucanon_[key_u(mask, kind)] = Ud;
     }
+    *out = Ud;
+    return ZK_OK;
+  }
+  template <class Fld>
+  int unpack_points_t(const void* shares, const uint32_t* parties, int np, size_t nchunks, int kind, void* out,
+                      hipStream_t st) {
+    if (!nchunks) return ZK_OK;
+    if (!shares || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    Fr* Ud = nullptr;
+    int rc = ucanon_for(parties, np, kind, &Ud);
+    if (rc) return rc;
     using A = Affine<Fld>;
     PtGroup<Fld> g0{(const A*)shares, 1, nchunks, np, 0};
     const size_t total = nchunks * (size_t)l;
@@ -2901,6 +2920,145 @@ class Engine : public IEngine {
     if (rc) return rc;
     return net_err(net, net->end(0, st));
   }
+  // ---- deg_red over GROUP elements as the reference calls it (deg_red.rs:80-126 is generic over T: DomainCoeff<F> and
+  // takes net, sid): this rank's k parties' points x [k][len] (affine), masks likewise.  The parties add their in-mask
+  // (point additions), the king unpack2's and re-packs over points (points_lincomb_kernel), the parties add their out-mask.
+  Fr* one_canon_ = nullptr;
+  DevBuf dist_pt_[NET_NSID];
+  template <class Fld>
+  int points_add_rows(Affine<Fld>* dst, const Affine<Fld>* a, const Affine<Fld>* b, size_t count, hipStream_t st) {
+    if (!one_canon_) {
+      std::vector<Fr> one(1, Fr::one().from_mont());
+      int rc = upload(one, &one_canon_);
+      if (rc) return rc;
+    }
+    PtGroup<Fld> g{a, 1, 0, 1, 0};
+    points_lincomb_kernel<FrP, Fld><<<dim3((unsigned)((count + 127) / 128)), dim3(128), 0, st>>>(g, g, 1, one_canon_, 1, 1, count,
+                                                                                              b, 0, dst, 0, 1);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  template <class Fld>
+  int dist_deg_red_points_t(Net* net, int sid, const void* x, const void* in_mask, const void* out_mask, size_t len,
+                            const void* gen_affine, uint64_t seed, void* out, hipStream_t st) {
+    using A = Affine<Fld>;
+    if (!len) return ZK_OK;
+    if (!x || !out || !gen_affine) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (x == out) return fail(ZK_ERR_BAD_INPUT, "deg_red over points cannot run in place");
+    const int k = net->parties_per_rank();
+    const size_t cnt = (size_t)k * len, bytes = cnt * sizeof(A);
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    hipStream_t s = net_stream(net, sid, st);
+    const A* send = (const A*)x;
+    if (in_mask) {
+      ZK_HIP(dist_pt_[sid].ensure(bytes));
+      rc = points_add_rows<Fld>((A*)dist_pt_[sid].p, (const A*)x, (const A*)in_mask, cnt, s);
+      if (rc) return rc;
+      send = (const A*)dist_pt_[sid].p;
+    }
+    A *fin = nullptr, *fout = nullptr;
+    if (net->rank == 0) {
+      ZK_HIP(dist_in_[sid].ensure((size_t)n * len * sizeof(A)));
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(A)));
+      fin = (A*)dist_in_[sid].p;
+      fout = (A*)dist_out_[sid].p;
+    }
+    rc = net_err(net, net->gather(sid, mask, send, bytes, fin));
+    if (rc) return rc;
+    if (net->rank == 0) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      rc = deg_red_points_t<Fld>(fin, nullptr, nullptr, len, gen_affine, seed, fout, s, ps.data(), (int)ps.size());
+      if (rc) return rc;
+    }
+    rc = net_err(net, net->scatter(sid, mask, fout, bytes, out));
+    if (rc) return rc;
+    if (out_mask) {
+      rc = points_add_rows<Fld>((A*)out, (const A*)out, (const A*)out_mask, cnt, s);
+      if (rc) return rc;
+    }
+    return net_err(net, net->end(sid, st));
+  }
+  int dist_deg_red_points(Net* net, int sid, int group, const void* x, const void* in_mask, const void* out_mask, size_t len,
+                          const void* gen_affine, uint64_t seed, void* out, hipStream_t st) override {
+    if (group == ZK_G1) return dist_deg_red_points_t<Fq_>(net, sid, x, in_mask, out_mask, len, gen_affine, seed, out, st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2)
+        return dist_deg_red_points_t<Fq2_>(net, sid, x, in_mask, out_mask, len, gen_affine, seed, out, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
+  // ---- libsnark_h as the reference calls it (ext_wit.rs:14-102): three d_ifft with the coset shift g = F::GENERATOR on
+  // channels 0..2 (joined), three d_fft likewise, (a b - c) / Z(g) locally, d_ifft with g^-1 on channel 0.  Buffers and
+  // the seven masks: this rank's k parties' rows.
+  int dist_libsnark_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m, const void* const* fft_in,
+                      const void* const* fft_out, uint64_t seed, void* h, hipStream_t st) override {
+    if (log_m < ilog2(l) || log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    uint32_t cmask[3];
+    for (int j = 0; j < 3; j++) {
+      int rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    if (cmask[1] != cmask[0] || cmask[2] != cmask[0])
+      return fail(ZK_ERR_PROTOCOL, "the three channels of libsnark_h saw different parties", -1);
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
+    ZK_HIP(dist_w0_.ensure(3 * per * sizeof(Fr)));
+    Fr* W = (Fr*)dist_w0_.p;
+    const void* q[3] = {qa, qb, qc};
+    for (int j = 0; j < 3; j++) ZK_HIP(hipMemcpyAsync(W + j * per, q[j], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    const Fr g = generator();
+    auto mi = [&](int i) { return fft_in ? (const Fr*)fft_in[i] : nullptr; };
+    auto mo = [&](int i) { return fft_out ? (const Fr*)fft_out[i] : nullptr; };
+    int rc;
+    for (int phase = 0; phase < 2; phase++) {
+      const int inverse = phase == 0 ? 1 : 0;
+      bool any = false, all = true;
+      for (int j = 0; j < 3; j++) {
+        any = any || mi(phase * 3 + j);
+        all = all && mi(phase * 3 + j);
+      }
+      if (any && !all) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in libsnark_h");
+      if (inverse && any) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(W, &c, 3 * per, st);
+        if (rc) return rc;
+      }
+      rc = fft1(W, log_m, inverse, 3 * (size_t)k, nullptr, st);
+      if (rc) return rc;
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->begin(j, st));
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        const int i = phase * 3 + j;
+        rc = dist_d_fft_on(net, j, cmask[j], W + j * per, mi(i), mo(i), 1, log_m, inverse,
+                           phase == 0 ? (const void*)&g : nullptr, seed + i, false);
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->end(j, st));
+        if (rc) return rc;
+      }
+    }
+    rc = vec_mul_sub(h, W, W + per, W + 2 * per, per, st);
+    if (rc) return rc;
+    Fr zinv = (g.pow_u64((uint64_t)1 << log_m) - Fr::one()).inverse();      // 1 / Z(g), Z(x) = x^m - 1 (ext_wit.rs:78-81)
+    rc = vec_scale(h, &zinv, per, st);
+    if (rc) return rc;
+    const Fr ginv = g.inverse();
+    rc = net_err(net, net->begin(0, st));
+    if (rc) return rc;
+    rc = dist_d_fft_on(net, 0, cmask[0], (Fr*)h, mi(6), mo(6), 0, log_m, 1, &ginv, seed + 6, true);
+    if (rc) return rc;
+    return net_err(net, net->end(0, st));
+  }
+
   // circom_h of a whole BATCH of proofs with ONE king round per phase and channel (round 4; round 3 sent the proofs'
   // rounds over the channels one proof after the other: 7 nb rounds per batch, the star's serial rounds bounded the
   // sharded throughput mode).  The three joined d_ifft / d_fft of ext_wit.rs:127-170 stay three channels in flight; a

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import ZkError, load
-from .api import ZK_G2, _ptr
+from .api import ZK_G2, DeviceBuffer, _ptr
 
 TRANSPORTS = {"local": 0, "rccl": 1, "shm": 2}
 ID_BYTES = 512
@@ -158,6 +158,26 @@ def dist_circom_h(pp, net, qap_local, log2_m, masks=None, seed=0, out=None, stre
     out = out or pp.alloc_fr(net.k * ((1 << log2_m) // pp.l))
     pp._check(pp.lib.zk_dist_circom_h(pp.h, net.h, _ptr(qap_local[0]), _ptr(qap_local[1]), _ptr(qap_local[2]), log2_m,
                                       None if masks is None else C.byref(masks), seed, out.ptr, stream))
+    return out
+
+
+def dist_deg_red_points(pp, net, sid, group, x_local, in_mask_local, out_mask_local, length, gen_affine, seed=0, out=None,
+                        stream=None):
+    """zk_dist_deg_red_points (deg_red.rs:80-126 with T = G): this rank's rows [k][length] of affine points."""
+    width = (4 if group == 2 else 2) * pp.fq.nbytes
+    out = out or DeviceBuffer(pp, net.k * length * width)
+    pp._check(pp.lib.zk_dist_deg_red_points(pp.h, net.h, sid, group, _ptr(x_local), _ptr(in_mask_local),
+                                            _ptr(out_mask_local), length, gen_affine.ctypes.data, seed, out.ptr, stream))
+    return out
+
+
+def dist_libsnark_h(pp, net, qap_local, log2_m, fft_in=None, fft_out=None, seed=0, out=None, stream=None):
+    """zk_dist_libsnark_h (ext_wit.rs:14-102): fft_in / fft_out = lists of seven local mask buffers (or None)."""
+    out = out or pp.alloc_fr(net.k * ((1 << log2_m) // pp.l))
+    mi = None if fft_in is None else (C.c_void_p * 7)(*[_ptr(m) for m in fft_in])
+    mo = None if fft_out is None else (C.c_void_p * 7)(*[_ptr(m) for m in fft_out])
+    pp._check(pp.lib.zk_dist_libsnark_h(pp.h, net.h, _ptr(qap_local[0]), _ptr(qap_local[1]), _ptr(qap_local[2]), log2_m,
+                                        mi, mo, seed, out.ptr, stream))
     return out
 
 
