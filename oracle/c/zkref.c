@@ -538,6 +538,44 @@ void zkref_d_fft(const pss_t* P, fe* shares, size_t mbyl, const fe* gen, const f
   free(out);
 }
 
+/* The same with the n parties' local stages on their own threads (the reference's parties ARE concurrent tasks,
+ * mpc-net/src/multi.rs:317-327; same values): what the full-size checks of tests/test_gpu_configs.py run at m = 2^24. */
+typedef struct {
+  const pss_t* P;
+  fe* px;
+  size_t mbyl;
+  const fe *gen, *size_inv, *in_mask;
+} dfft_party_job;
+static void* dfft_party_run(void* a) {
+  dfft_party_job* j = (dfft_party_job*)a;
+  const field_t* F = &j->P->F;
+  if (j->size_inv)
+    for (size_t i = 0; i < j->mbyl; i++) fe_mul(&j->px[i], &j->px[i], j->size_inv, F);
+  zkref_fft1(j->P, j->px, j->mbyl, j->gen);
+  if (j->in_mask)
+    for (size_t i = 0; i < j->mbyl; i++) fe_add(&j->px[i], &j->px[i], &j->in_mask[i], F);
+  return NULL;
+}
+void zkref_d_fft_mt(const pss_t* P, fe* shares, size_t mbyl, const fe* gen, const fe* size_inv, const fe* g,
+                    int rearrange, const fe* in_mask, const fe* out_mask, u64 seed, int fr_bits) {
+  const field_t* F = &P->F;
+  int n = P->n;
+  pthread_t th[MAXN];
+  dfft_party_job jobs[MAXN];
+  for (int p = 0; p < n; p++) {
+    jobs[p] = (dfft_party_job){P, shares + (size_t)p * mbyl, mbyl, gen, size_inv, in_mask ? in_mask + (size_t)p * mbyl : NULL};
+    pthread_create(&th[p], NULL, dfft_party_run, &jobs[p]);
+  }
+  for (int p = 0; p < n; p++) pthread_join(th[p], NULL);
+  fe* out = malloc(sizeof(fe) * n * mbyl);
+  zkref_king_fft2(P, shares, mbyl, gen, g, rearrange, seed, fr_bits, out);
+  for (size_t i = 0; i < (size_t)n * mbyl; i++) {
+    if (out_mask) fe_add(&shares[i], &out[i], &out_mask[i], F);
+    else shares[i] = out[i];
+  }
+  free(out);
+}
+
 /* ------------------------------------------------------------------------------------------------ curves */
 /* y^2 = x^3 + b over Fq (G1) and Fq2 = Fq[u]/(u^2+1) (G2); Jacobian coordinates, Z = 0 identity. */
 typedef struct { fe x, y, z; } g1j;

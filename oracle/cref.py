@@ -109,6 +109,19 @@ class CPss:
                           None if out_mask is None else self._p(out_mask), C.c_uint64(seed), self.fr.bits)
         return shares
 
+    def d_fft_arrays_mt(self, shares, mbyl, gen, size_inv, g, rearrange, in_mask, out_mask, seed, king_threads=64):
+        """d_fft_arrays with the parties' local stages on n threads and the precomputed-matrix king split over
+        `king_threads` threads (zkref_d_fft_mt; same shares): the full-size checks at m = 2^24."""
+        lib().zkref_set_fast_king(1, max(1, king_threads))
+        try:
+            lib().zkref_d_fft_mt(C.byref(self.ct), self._p(shares), C.c_size_t(mbyl), self.fr.mont(gen),
+                                 None if size_inv is None else self.fr.mont(size_inv), None if g is None else self.fr.mont(g),
+                                 int(rearrange), None if in_mask is None else self._p(in_mask),
+                                 None if out_mask is None else self._p(out_mask), C.c_uint64(seed), self.fr.bits)
+        finally:
+            lib().zkref_set_fast_king(0, 1)
+        return shares
+
     def d_fft(self, shares, dom, rearrange, masks=None, seed=0, inverse=False, g=None):
         """list-of-lists front end mirroring oracle.dist.d_fft / d_ifft."""
         n, mbyl = len(shares), len(shares[0])

@@ -287,3 +287,92 @@ def test_c5_bls12_381_full_size_2_24():
         assert np.array_equal(prod.to_numpy()[: m * pp.fr.nl], x.to_numpy()[pp.fr.nl:(m + 1) * pp.fr.nl])
     finally:
         pp.close()
+
+
+def test_c5_bls12_381_d_ifft_d_fft_chain_at_2_24_equals_c_oracle():
+    """BASELINE configs[4] at its real size, EXACT: one masked d_ifft (coset shift, rearranged output)
+    followed by one masked d_fft -- a third of circom_h's transform chain (ext_wit.rs:127-170) -- at m = 2^24 on BLS12-381,
+    n = 8, l = 2: every one of the 2 x 67 M output shares equals the C restatement's (oracle/c zkref_d_fft_mt: the parties'
+    local stages on 8 threads, the king's pack / unpack2 over 64).  Replay share randomness; masks sampled by the library's
+    dealer and handed to the oracle as data."""
+    from oracle.cref import CPss
+    from oracle.params import CURVES
+    cv = CURVES["bls12_381"]
+    log_m = int(os.environ.get("ZK_C5_LOG_M", "24"))
+    m = 1 << log_m
+    pp = zk.PackedSharingParams("bls12_381", 2)
+    try:
+        cp = CPss("bls12_381", 2)
+        dom = Domain(cv, m)
+        g = Domain(cv, 2 * m).element(1)
+        rng = np.random.default_rng(50)
+        shares = rng.integers(0, 1 << 62, size=(pp.n * (m // 2), 4), dtype=np.uint64)
+        shares[:, 3] &= np.uint64((1 << 60) - 1)
+        buf = zk.DeviceBuffer.from_numpy(pp, shares)
+        want = shares
+        for step, (inverse, seed) in enumerate(((True, 123), (False, 124))):
+            mask = zk.FftMask.sample(pp, inverse, g if inverse else None, 1 if inverse else 0, log_m, 200 + step)
+            if inverse:
+                zk.d_ifft(pp, buf, mask, True, log_m, g=g, seed=seed)
+            else:
+                zk.d_fft(pp, buf, mask, False, log_m, seed=seed)
+            im = mask.in_mask.to_numpy().reshape(-1, 4)
+            om = mask.out_mask.to_numpy().reshape(-1, 4)
+            del mask
+            cp.d_fft_arrays_mt(want, m // 2, dom.group_gen_inv if inverse else dom.group_gen,
+                               dom.size_inv if inverse else None, g if inverse else None, inverse, im, om, seed)
+            del im, om
+            got = buf.to_numpy().reshape(-1, 4)
+            assert np.array_equal(got, want), "step %d" % step
+            del got
+    finally:
+        pp.close()
+
+
+def test_c5_bls12_381_d_msm_2_23_per_party_equals_six_limb_c_oracle():
+    """BASELINE configs[4] at its real size, EXACT: the G1 d_msm of a 2^24-constraint proof -- 2^23 points per party, 8
+    parties, ONE 2^26-point Pippenger on the GPU (quad / split kernels, staged sort, wide entry format) -- against arkworks'
+    signed-digit Pippenger restated in C with six 64-bit limbs (oracle/c libzkref6.so), every party's G::msm on its own
+    threads, then the king's unpack2 + sum (dmsm/mod.rs:73-92) through the Python oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.cref import CGroup6
+    from oracle.curve import GroupOps, g1
+    from oracle.params import CURVES
+    from oracle.pss import PackedSharingParams as OPP
+    cv = CURVES["bls12_381"]
+    ln = 1 << int(os.environ.get("ZK_C5_LOG_LEN", "23"))
+    pp = zk.PackedSharingParams("bls12_381", 2)
+    try:
+        cg = CGroup6("bls12_381")
+        rng = np.random.default_rng(51)
+
+        def rand(count):
+            a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+            a[:, 3] &= np.uint64((1 << 60) - 1)
+            return a
+        tot = pp.n * ln
+        bases = zg.base_points(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, rand(tot)), tot)      # distinct multiples of the generator
+        scal = zk.DeviceBuffer.from_numpy(pp, rand(tot))
+        out = zk.d_msm(pp, ZK_G1, bases, scal, ln)
+        G = g1(cv)
+        got = [dec_jacobian(pp, out[p]) for p in range(pp.n)]
+        # the oracle's inputs: the same points (GPU layout = 12 x u32 little-endian = 6 x u64), the same scalars as
+        # residues to the radix 2^384: m6 = m4 * 2^128 mod r, a multiplication by a constant done on the device
+        bases_h = bases.to_numpy().reshape(tot, 12)
+        zk.api.vec_scale(pp, scal, (1 << 128) % cv.r, tot)
+        sc6 = np.zeros((tot, 6), dtype=np.uint64)
+        sc6[:, :4] = scal.to_numpy().reshape(tot, 4)
+        del scal, bases
+
+        def party(p):
+            return cg.msm_g1_arrays(np.ascontiguousarray(bases_h[p * ln:(p + 1) * ln]), np.ascontiguousarray(sc6[p * ln:(p + 1) * ln]),
+                                    ln, nthreads=24)
+        with ThreadPoolExecutor(max_workers=pp.n) as ex:
+            parts = list(ex.map(party, range(pp.n)))
+        dec6 = lambda a: tuple(cg.fq.dec(a))
+        o = OPP(cv, 2)
+        want = G.sum(o.unpack2([dec6(x) for x in parts], GroupOps(G)))
+        for p in range(pp.n):
+            assert G.eq(got[p], want)
+    finally:
+        pp.close()

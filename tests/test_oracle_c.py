@@ -164,3 +164,31 @@ def test_tuned_king_gives_the_reference_kings_shares():
     finally:
         lib().zkref_set_fast_king(0, 1)
     assert all(np.array_equal(res[i], res[i + 3]) for i in range(3))
+
+
+def test_threaded_d_fft_equals_the_serial_restatement():
+    """zkref_d_fft_mt (parties' local stages on n threads, matrix king over several) is what the 2^24 checks of
+    tests/test_gpu_configs.py run: same shares as zkref_d_fft, masks and coset shift included, on both scalar fields."""
+    import numpy as np
+    from oracle.cref import CPss
+    from oracle.field import Domain
+    from oracle.params import CURVES
+    for cv in ("bn254", "bls12_381"):
+        cp, c = CPss(cv, 2), CURVES[cv]
+        m = 1 << 10
+        dom = Domain(c, m)
+        rng = np.random.default_rng(1)
+
+        def rand():
+            a = rng.integers(0, 1 << 62, size=(cp.n * (m // 2), 4), dtype=np.uint64)
+            a[:, 3] &= np.uint64((1 << 60) - 1)
+            return a
+        a, im, om = rand(), rand(), rand()
+        g = Domain(c, 2 * m).element(1)
+        for inverse in (True, False):
+            x, y = a.copy(), a.copy()
+            args = (m // 2, dom.group_gen_inv if inverse else dom.group_gen, dom.size_inv if inverse else None,
+                    g if inverse else None, inverse, im, om, 7)
+            cp.d_fft_arrays(x, *args)
+            cp.d_fft_arrays_mt(y, *args, king_threads=4)
+            assert np.array_equal(x, y)
