@@ -127,14 +127,17 @@ def msm_stats(pp):
     return [int(v) for v in st]
 
 
-def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=None):
-    """The slot with the largest share of the timed region -- also when it is a latency-bound helper."""
-    cands = [e for e in prof if e["launches"]]
+def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=None, slot_bytes=None, limbs=8,
+                exclude=None):
+    """The slot with the largest share of the timed region -- also when it is a latency-bound helper.  slot_bytes: per-unit
+    algorithmic bytes of another curve (BLS12-381: 128 B per G1 point, 224 B per G2 point); limbs: 32-bit limbs of the base
+    field (the multiply-instruction issue bound of a product scales with limbs^2); exclude: slots left out of the choice."""
+    cands = [e for e in prof if e["launches"] and e["kernel"] not in (exclude or ())]
     if not cands:
         return None
     best = max(cands, key=lambda e: e["total_ms"])
     name = best["kernel"]
-    per_unit = SLOT_BYTES.get(name)
+    per_unit = (slot_bytes or SLOT_BYTES).get(name, SLOT_BYTES.get(name))
     if name == "ntt_pass_kernel":
         per_unit = 64.0 / max(1, ntt_passes)
     if name == "king_fft2_kernel" and masks_on:
@@ -156,9 +159,11 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=No
             muls = adds["g2" if "G2" in name else "g1"] / best["launches"] * plan["muls_per_add"]
             plan["additions_per_launch"] = int(adds["g2" if "G2" in name else "g1"] / best["launches"])
         rate = muls / (avg_ms * 1e-3) / 1e9
-        alu = {"achieved": round(rate, 2), "peak": round(MAD_ISSUE_BOUND_G, 1),
-               "unit": "G modmul/s (256-bit Montgomery; peak = v_mad_u64_u32 issue bound)",
-               "frac": round(rate / MAD_ISSUE_BOUND_G, 3), "frac_of_measured_multiplier": round(rate / MUL_MEASURED_G, 3),
+        bound = MAD_ISSUE_BOUND_G * 64.0 / (limbs * limbs)
+        measured = MUL_MEASURED_G if limbs == 8 else 60.1            # profiles/r02_mulbench.txt: 12-limb BLS12-381 Fq
+        alu = {"achieved": round(rate, 2), "peak": round(bound, 1),
+               "unit": "G modmul/s (%d-bit Montgomery; peak = v_mad_u64_u32 issue bound)" % (32 * limbs),
+               "frac": round(rate / bound, 3), "frac_of_measured_multiplier": round(rate / measured, 3),
                "plan": plan}
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_achievable_6.29TBps": round(achieved / HBM_ACHIEVABLE_GBS, 5),

@@ -278,6 +278,13 @@ class CGroup6:
         v = self.fq.dec(self.msm_g1_arrays(b, self.fr.enc(scalars), len(pts), nthreads))
         return (v[0], v[1], v[2])
 
+    def msm_g2_arrays(self, bases, scalars6, n, nthreads=1):
+        """bases uint64 [n][24] affine Montgomery over Fq2 (the GPU layout), scalars6 uint64 [n][6]; returns uint64[36]."""
+        out = np.zeros(36, dtype=np.uint64)
+        lib6().zkref_msm_g2(C.byref(self.fr.ct), C.byref(self.fq.ct), self.fr.bits, self._p(bases), self._p(scalars6),
+                            C.c_size_t(n), nthreads, self._p(out))
+        return out
+
     def doubling_chain_g1(self, p, n):
         base = self.fq.enc(list(p)).reshape(-1)
         out = np.zeros((n, 12), dtype=np.uint64)
