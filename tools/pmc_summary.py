@@ -15,7 +15,8 @@ import re
 import sys
 from collections import defaultdict
 
-STREAMING = ("ntt_pass_kernel", "king_fft2_kernel", "king_degred_kernel", "vec_", "pss_", "bitrev_kernel", "r1cs_qap_kernel")
+STREAMING = ("ntt_pass_kernel", "king_fft2_kernel", "king_degred_kernel", "vec_", "pss_", "bitrev_kernel", "r1cs_qap_kernel",
+             "msm_scatter_kernel<", "msm_hist_kernel")     # 16-byte-per-lane loads of 32-byte scalars (the bin sort reads dwords: uncalibrated)
 
 
 def norm(name):

@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kern
 // layout of Affine<Fq2> / XYZZ<Fq2> (lane q of a quad owns base-field element q of a point, q and 4 + q of a sum).
 // waves per SIMD the registers allow: 127 VGPRs for 8-limb base fields (four waves), 176 for 12-limb ones (two)
 template <class P>
-constexpr int SPLIT_WAVES = P::N > 8 ? 2 : 4;
+constexpr int SPLIT_WAVES = P::N > 8 ? 3 : 4;
 template <class P>
 __global__ __launch_bounds__(128, SPLIT_WAVES<P>) void msm_accumulate_split_kernel(const void* __restrict__ bases0,
                                                                  const void* __restrict__ bases1,
