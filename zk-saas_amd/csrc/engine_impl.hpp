@@ -1242,8 +1242,11 @@ class Engine : public IEngine {
         rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
         if (rc) return rc;
       }
+      // ZK_U_PRIO=1 (measured, off): raised issue priority for the U-MSM's accumulate waves, the last link of the proof's
+      // critical chain -- 541-544 against 591-594 proofs/s: they then starve the reduction tails of the other four MSMs
+      static const int u_prio = getenv("ZK_U_PRIO") ? atoi(getenv("ZK_U_PRIO")) : 0;
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
-                                      ws0 + 0, &j.pU);
+                                      ws0 + 0, &j.pU, nullptr, MsmGate{}, nullptr, u_prio);
       if (rc) return rc;
     }
     return ZK_OK;

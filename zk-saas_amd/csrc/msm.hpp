@@ -906,7 +906,10 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
                                                             XYZZ<Fld>* __restrict__ buckets0,
                                                             XYZZ<Fld>* __restrict__ edge0 /* [NB][2][nlanes]: head, tail */,
                                                             uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
-                                                            const uint32_t* __restrict__ k0, size_t ys) {
+                                                            const uint32_t* __restrict__ k0, size_t ys, int prio) {
+  // prio != 0: the MSM at the END of a proof's critical chain (U, behind circom_h): its waves win issue arbitration against
+  // the accumulate waves of the witness MSMs that still share the SIMDs when it starts (they have slack, it has none)
+  if (prio) __builtin_amdgcn_s_setprio(2);
   ZK_YSHIFT(sorted);
   ZK_YSHIFT(offsets);
   ZK_YSHIFT(heavy);
@@ -1398,6 +1401,7 @@ struct MsmGate {
 struct MsmTuning {
   size_t bigsort_min;
   MsmGate gate;
+  int prio = 0;          // raised issue priority for the G1 accumulate kernel of this launch (see msm_accumulate_kernel)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -1649,10 +1653,10 @@ class MsmRunner {
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
                hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, MsmGate gate = MsmGate{},
-               const MsmBatchArg* batch = nullptr) {
+               const MsmBatchArg* batch = nullptr, int prio = 0) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate};
+    MsmTuning tune{bigsort_min, gate, prio};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }

@@ -304,7 +304,7 @@ do {                                                                           \
   if (!launched)
     msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), 0, st>>>(
         (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
-        heavy, k0, ys);
+        heavy, k0, ys, tune.prio);
   if (tune.gate.signal_ev) {
     MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
     if (tune.gate.signal_flag) tune.gate.signal_flag->store(1, std::memory_order_release);
