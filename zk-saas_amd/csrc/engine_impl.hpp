@@ -2831,13 +2831,13 @@ class Engine : public IEngine {
       ZK_HIP(hipMemcpy(dist_coef_[sid].p, csub.data(), k * sizeof(Fr), hipMemcpyHostToDevice));
       cd = (const Fr*)dist_coef_[sid].p;
     }
-    MsmPending pend;
-    rc = msm_.template launch_t<Fld>(this, bases, scalars, (size_t)k * len, cd, len, st, MSM_WS - 1 - sid, &pend);
+    typename MsmRunner<Cfg>::SplitLaunch sl;       // (a large table-free MSM runs as two window groups on two streams)
+    rc = msm_.template launch_split_t<Fld>(this, bases, scalars, (size_t)k * len, cd, len, st, MSM_WS - 1 - sid, &sl);
     if (rc) return rc;
     XYZZ<Fld> mine = XYZZ<Fld>::identity();
     if (in_mask) mine = msm_.template mask_term<Fld>(in_mask, first, k, csub.empty() ? nullptr : csub.data());
     XYZZ<Fld> r;
-    rc = msm_.template finish_t<Fld>(this, &pend, &r);
+    rc = msm_.template finish_split_t<Fld>(this, &sl, &r);
     if (rc) return rc;
     mine = xyzz_add_ni(mine, r);
     std::vector<XYZZ<Fld>> all((size_t)net->world);

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
                                                                int lo_bits, int ppt, uint32_t tiles_per_vec,
                                                                uint32_t wmask /* 0: fixed-base table, all windows
                                                                share one bucket set; ~0: one set per window */,
+                                                               int w_begin /* the launch sorts windows [w_begin, nwin)
+                                                               only (a window group of a split MSM): set = w - w_begin */,
                                                                uint32_t* __restrict__ bins,
                                                                const uint32_t* __restrict__ skip,
                                                                Fp<FrP>* __restrict__ canon, size_t ys) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
     const Fp<FrP> s = msm_canon_scalar<FrP>(sc, coef, part_len, vb, i, skip);
     store_elem(canon + (size_t)vb * sc.npts + i, s);
     msm_for_each_digit<FrP>(s, c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
-      atomicAdd(&big_lds[(((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+      if (w >= w_begin) atomicAdd(&big_lds[(((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits)], 1u);
     });
   }
   __syncthreads();
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
 template <class FrP, bool WIDE>
 __global__ __launch_bounds__(BIG_THREADS) void msm_scatter_direct_kernel(MsmScalars<Fp<FrP>> sc, int c, int nwin, int wide,
                                                                          int hi_bits, int lo_bits, int ppt,
-                                                                         uint32_t tiles_per_vec, uint32_t wmask,
+                                                                         uint32_t tiles_per_vec, uint32_t wmask, int w_begin,
                                                                          uint32_t pre_stride, uint32_t pre_off,
                                                                          int idx_bits, uint32_t* __restrict__ bins,
                                                                          uint32_t* __restrict__ tmp,
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_scatter_direct_kernel(MsmScal
     const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
     if (i >= sc.npts) break;
     msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
-      atomicAdd(&cnt[(((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+      if (w >= w_begin) atomicAdd(&cnt[(((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits)], 1u);
     });
   }
   __syncthreads();
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_scatter_direct_kernel(MsmScal
     const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
     if (i >= sc.npts) break;
     msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t neg) {
-      const uint32_t lbin = (((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits);
+      if (w < w_begin) return;
+      const uint32_t lbin = (((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits);
       const uint32_t dst = gbase[lbin] + atomicAdd(&cnt[lbin], 1u);
       const uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
       if (WIDE) {
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_scatter_direct_kernel(MsmScal
 // Entry formats of tmp[]: packed = {index : idx_bits, sign : 1, low bucket bits}; wide = {index | sign << 31} + 16-bit low part
 template <class FrP, int THR, int PPT, bool WIDE>
 __global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc, int c, int nwin, int wide, int hi_bits,
-                                                          int lo_bits, uint32_t tiles_per_vec, uint32_t wmask,
+                                                          int lo_bits, uint32_t tiles_per_vec, uint32_t wmask, int w_begin,
                                                           int wgroup /* windows per round */, uint32_t pre_stride,
                                                           uint32_t pre_off, int idx_bits, uint32_t stage_cap,
                                                           uint32_t* __restrict__ bins, uint32_t* __restrict__ tmp,
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc
     const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
     if (i < sc.npts)
       msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
-        atomicAdd(&cur[(((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+        if (w >= w_begin) atomicAdd(&cur[(((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits)], 1u);
       });
   }
   __syncthreads();
@@ -543,11 +546,16 @@ __global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc
     const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
     s[k] = i < sc.npts ? load_elem(my + i) : Fp<FrP>::zero();
     carry[k] = 0;
+    for (int w = 0; w < w_begin; w++) {          // the windows of another group: only their carry matters here
+      uint32_t b, neg;
+      (void)msm_next_digit<FrP>(s[k], carry[k], w < wide ? c : c - 1, &b, &neg);
+    }
   }
   const uint32_t lo_mask = (1u << lo_bits) - 1;
-  for (int w0 = 0; w0 < nwin; w0 += wgroup) {
+  for (int w0 = w_begin; w0 < nwin; w0 += wgroup) {
     const int w1 = w0 + wgroup < nwin ? w0 + wgroup : nwin;
-    const uint32_t lb_lo = ((uint32_t)w0 & wmask) << hi_bits, lb_hi = ((((uint32_t)w1 - 1) & wmask) + 1) << hi_bits;
+    const uint32_t lb_lo = ((uint32_t)(w0 - w_begin) & wmask) << hi_bits,
+                   lb_hi = ((((uint32_t)(w1 - w_begin) - 1) & wmask) + 1) << hi_bits;
     const uint32_t r0 = cur[lb_lo], r1 = lb_hi < nbl ? cur[lb_hi] : tile_total;     // untouched so far: bins of this round
     __syncthreads();
 #pragma unroll
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc
       for (int w = w0; w < w1; w++) {
         uint32_t b, neg;
         if (!msm_next_digit<FrP>(s[k], carry[k], w < wide ? c : c - 1, &b, &neg)) continue;
-        const uint32_t lbin = (((uint32_t)w & wmask) << hi_bits) | (b >> lo_bits);
+        const uint32_t lbin = (((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits);
         const uint32_t j = atomicAdd(&cur[lbin], 1u) - r0;
         const uint32_t idx = pre_stride ? (uint32_t)w * pre_stride + pre_off + i : i;
         if (WIDE) {
@@ -1378,6 +1386,8 @@ struct MsmBatchArg {
 struct MsmPending {
   bool active = false;
   int kwin = 0, c = 0, wide = 0, nb = 1, lo_bits = 0;
+  int w0 = 0;                                    // first window of the launch (a window group of a split MSM)
+  bool tabbed = false;                           // fixed-base table: one bucket set, every window c bits wide
   int batch = 1;                                 // scalar vectors of the launch (results: [base vector][batch])
   size_t stats_off = 0, offered = 0;             // statistics: where the sorts' entry counts land in the pinned buffer;
   int nsorts = 1;                                // (point, window) pairs offered to the sort
@@ -1402,6 +1412,9 @@ struct MsmTuning {
   size_t bigsort_min;
   MsmGate gate;
   int prio = 0;          // raised issue priority for the G1 accumulate kernel of this launch (see msm_accumulate_kernel)
+  int w_begin = 0, w_end = -1;   // digit windows [w_begin, w_end) only (-1: all): one window group of a split MSM
+  bool lean_sort = false;        // the small-workgroup sort kernels whatever the size: this sort has to run BESIDE an
+                                 // accumulate kernel (1024-thread workgroups never find a free CU there, see run_split_t)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -1491,6 +1504,12 @@ template <class FrP, class Fld>
 int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* bases, const void* bases2,
                const void* scalars, size_t npts, const Fp<FrP>* coef_d, size_t part_len, hipStream_t st,
                MsmPending* out, const MsmBatchArg* batch = nullptr);
+// number of digit windows an MSM over npts points will use WITHOUT a fixed-base table
+template <class FrP>
+inline int msm_nwin_of(size_t npts, bool g2) {
+  const int c_req = msm_pick_c<FrP>(npts ? npts : 1, g2);
+  return (FrP::BITS + 1 + c_req - 1) / c_req;
+}
 // zk_msm_precompute's table kernel (same translation units)
 template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,
@@ -1528,7 +1547,7 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
     XYZZ<Fld> total = XYZZ<Fld>::identity();
     for (int w = w_hi; w >= w_lo; w--) {
       const XYZZ<Fld>* sl = h + (size_t)w * nslices;
-      const int cw = (kwin == 1 || w < wide) ? c : c - 1;
+      const int cw = (p.tabbed || w + p.w0 < wide) ? c : c - 1;
       for (int t = cw - 1; t >= 0; t--) {
         total = xyzz_dbl_ni(total);
         const XYZZ<Fld>& s = t >= lo_bits ? sl[t - lo_bits] : sl[hb + 1 + t];
@@ -1539,7 +1558,7 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
   };
   auto width_of = [&](int w_hi, int w_lo) {
     int bits = 0;
-    for (int w = w_hi; w >= w_lo; w--) bits += (kwin == 1 || w < wide) ? c : c - 1;
+    for (int w = w_hi; w >= w_lo; w--) bits += (p.tabbed || w + p.w0 < wide) ? c : c - 1;
     return bits;
   };
   // Table-free MSMs have one bucket set per window: ~250 doublings + ~2c additions per window on one host thread
@@ -1664,11 +1683,86 @@ class MsmRunner {
   int finish_t(IEngine* eng, MsmPending* pend, XYZZ<Fld>* result, XYZZ<Fld>* result2 = nullptr) {
     return msm_fold<Fld>(eng, *pend, result, result2);
   }
+  // ---- EXPERIMENT, measured and left OFF (ZK_MSM_SPLIT=1 enables it): a large table-free MSM that runs ALONE (zk_msm,
+  // zk_d_msm, zk_dist_d_msm: the 8 x 2^20-point d_msm of BASELINE configs[2]) as TWO window groups on two streams, so that
+  // the sort of the upper windows runs under the accumulate kernel of the lower ones and the finalize / reduce tails of the
+  // lower group under the accumulate of the upper one ("pipeline sort(group k+1) under
+  // accumulate(group k)"); the host folds both groups and joins them with one walk of doublings.  Same results (all GPU
+  // tests, incl. the 2^26-point exact check, pass with it on).  Measured on 8 x 2^20 points, same box, against 13.1-13.7 ms
+  // for the single launch: 13.3-13.4 ms with the staged sort kernels for the upper group (their 1024-thread workgroups
+  // never find a free CU beside an accumulate kernel: the sort simply waits, and two accumulate kernels sharing the chip
+  // run worse than one), 15.2-15.3 ms with the small-workgroup sort kernels (they do run beside the accumulate -- and slow it
+  // down by more than they take alone).  The accumulate kernel wants the chip to itself.
+  struct SplitLaunch {
+    MsmPending p[2];
+    bool split = false;
+    int wm = 0;
+  };
+  MsmSlot slots_b_[MSM_WS];
+  hipStream_t split_st_[MSM_WS] = {};
+  hipEvent_t split_ev_[MSM_WS] = {};
+  template <class Fld>
+  int launch_split_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
+                     hipStream_t st, int wslot, SplitLaunch* sl) {
+    static const bool enabled = getenv("ZK_MSM_SPLIT") && atoi(getenv("ZK_MSM_SPLIT")) != 0;
+    static const size_t min_entries = getenv("ZK_MSM_SPLIT_MIN") ? (size_t)atoll(getenv("ZK_MSM_SPLIT_MIN")) : ((size_t)48 << 20);
+    constexpr bool G2FLD = IsExtField<Fld>::value;
+    const int nwin = msm_nwin_of<FrP>(npts, G2FLD);
+    size_t toff = 0;
+    sl->split = enabled && wslot >= 0 && wslot < MSM_WS && nwin >= 4 && npts >= ((size_t)4 << 20) &&
+                npts * (size_t)nwin >= min_entries && !getenv("ZK_MSM_C") && !getenv("ZK_MSM_C_G2") &&
+                !TableRegistry::inst().find(bases, npts, sizeof(Affine<Fld>), FrP::BITS, &toff);
+    if (!sl->split) return launch_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &sl->p[0]);
+    if (sl->p[0].active || sl->p[1].active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
+    if (!split_st_[wslot]) {
+      hipError_t he = hipStreamCreateWithFlags(&split_st_[wslot], hipStreamNonBlocking);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&split_ev_[wslot], hipEventDisableTiming);
+      if (he != hipSuccess) return eng->hip_fail(he, "msm split stream");
+    }
+    hipError_t he = hipEventRecord(split_ev_[wslot], st);          // the operands may still be in flight on the caller's stream
+    if (he == hipSuccess) he = hipStreamWaitEvent(split_st_[wslot], split_ev_[wslot], 0);
+    if (he != hipSuccess) return eng->hip_fail(he, "msm split ordering");
+    sl->wm = (nwin + 1) / 2;
+    // the upper group's sort runs beside the lower group's accumulate kernel: small workgroups (its 3-5x write amplification
+    // is hidden there -- the accumulate is ALU-bound); with the staged kernels the split was SLOWER than one launch
+    // (13.3-13.4 against 13.1 ms: their 1024-thread workgroups wait for a whole free CU until the accumulate has ended)
+    MsmTuning ta{bigsort_min, MsmGate{}, 0, 0, sl->wm, false}, tb{bigsort_min, MsmGate{}, 0, sl->wm, nwin, true};
+    int rc = msm_launch<FrP, Fld>(eng, slots_[wslot], ta, bases, nullptr, scalars, npts, coef_d, part_len, st, &sl->p[0], nullptr);
+    if (rc) return rc;
+    rc = msm_launch<FrP, Fld>(eng, slots_b_[wslot], tb, bases, nullptr, scalars, npts, coef_d, part_len, split_st_[wslot],
+                              &sl->p[1], nullptr);
+    if (rc) {                                       // the lower group is in flight: join it before reporting
+      XYZZ<Fld> dummy;
+      (void)msm_fold<Fld>(eng, sl->p[0], &dummy, nullptr);
+    }
+    return rc;
+  }
+  template <class Fld>
+  int finish_split_t(IEngine* eng, SplitLaunch* sl, XYZZ<Fld>* result) {
+    if (!sl->split) return msm_fold<Fld>(eng, sl->p[0], result, nullptr);
+    XYZZ<Fld> lo, hi;
+    const int c = sl->p[0].c, wide = sl->p[0].wide;
+    int rc = msm_fold<Fld>(eng, sl->p[0], &lo, nullptr);
+    int rc2 = msm_fold<Fld>(eng, sl->p[1], &hi, nullptr);
+    if (rc || rc2) return rc ? rc : rc2;
+    for (int w = 0; w < sl->wm; w++) {
+      const int cw = w < wide ? c : c - 1;
+      for (int i = 0; i < cw; i++) hi = xyzz_dbl_ni(hi);
+    }
+    *result = xyzz_add_ni(hi, lo);
+    return ZK_OK;
+  }
   // blocking form
   template <class Fld>
   int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
             XYZZ<Fld>* result, hipStream_t st, int wslot = 0, const void* bases2 = nullptr,
             XYZZ<Fld>* result2 = nullptr) {
+    if (!bases2) {
+      SplitLaunch sl;
+      int rc = launch_split_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &sl);
+      if (rc) return rc;
+      return finish_split_t<Fld>(eng, &sl, result);
+    }
     MsmPending pend;
     int rc = launch_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &pend, bases2);
     if (rc) return rc;
@@ -1724,13 +1818,13 @@ class MsmRunner {
   template <class Fld>
   int d_msm_range_t(IEngine* eng, const void* bases, const void* scalars, size_t len, int first, int count,
                     const void* in_mask, XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
-    MsmPending pend;
-    int rc = launch_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, st, wslot, &pend);
+    SplitLaunch sl;
+    int rc = launch_split_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, st, wslot, &sl);
     if (rc) return rc;
     XYZZ<Fld> mt = XYZZ<Fld>::identity();
     if (in_mask) mt = mask_term<Fld>(in_mask, first, count);
     XYZZ<Fld> r;
-    rc = finish_t<Fld>(eng, &pend, &r);
+    rc = finish_split_t<Fld>(eng, &sl, &r);
     if (rc) return rc;
     *result = in_mask ? xyzz_add_ni(r, mt) : r;
     return ZK_OK;

@@ -39,10 +39,15 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const int c = (T + nwin - 1) / nwin;            // widest window
   const int wide = T - nwin * (c - 1);            // 1 <= wide <= nwin
   const uint32_t B = 1u << (c - 1);
-  const int kwin = tab ? 1 : nwin;                // bucket sets per scalar vector: with a table all windows share one
+  // a window group of a split MSM (MsmRunner::run_split_t): this launch sorts and sums windows [w_begin, w_end) only
+  const int w_begin = tune.w_begin, w_end = tune.w_end < 0 ? nwin : tune.w_end;
+  if (w_begin < 0 || w_end > nwin || w_begin >= w_end) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm window range");
+  if ((w_begin != 0 || w_end != nwin) && tab) return eng->fail(ZK_ERR_GENERIC, "window groups and fixed-base tables do not mix");
+  const int nwin_r = w_end - w_begin;
+  const int kwin = tab ? 1 : nwin_r;              // bucket sets per scalar vector: with a table all windows share one
   const size_t nsets = batch * (size_t)kwin;      // bucket sets of the launch
   const size_t nkeys = nsets * B;
-  const size_t max_sorted = npts * batch * nwin;
+  const size_t max_sorted = npts * batch * nwin_r;
   if (max_sorted >= ((size_t)1 << 32)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large (points x windows >= 2^32)");
   const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
   // accumulate lanes (msm.hpp "balanced partition"): every lane adds the same number of sorted entries
@@ -88,7 +93,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const unsigned NS = (NB == 2 && skip_on && !one_sort && !none) ? 2u : 1u;       // sorts of this launch
   // ---- big-sort plan (msm.hpp "big sort"): workgroup shape, points per tile, bin split, entry format
   static const size_t large_min = getenv("ZK_SORT_LARGE_MIN") ? (size_t)atoll(getenv("ZK_SORT_LARGE_MIN")) : ((size_t)4 << 20);
-  const bool large = npts * batch >= large_min;         // multi-million-point launches: 1024-thread workgroups, one per CU
+  const bool large = npts * batch >= large_min && !tune.lean_sort;    // multi-million-point launches: 1024-thread workgroups, one per CU
   const int sthr = large ? 1024 : 256;
   // small launches: ~1024 tiles so that they still fill the chip, up to 16 points per thread
   int ppt = large ? BIG_PTS_PER_THREAD : 16;
@@ -128,6 +133,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const bool big = npts * batch >= tune.bigsort_min && sort_hi >= 1 && sort_lo >= 1 && sort_lo <= 12 &&
                    (nsets << sort_hi) <= (size_t)BIG_MAX_BINS &&
                    (large ? stage_cap >= (tab ? (size_t)nwin * tile_pts : tile_pts) : 8 * nbl <= BIG_LDS_MAX);
+  if ((w_begin != 0 || w_end != nwin) && !big) return eng->fail(ZK_ERR_GENERIC, "window groups need the two-level sort");
   const int wgroup = tab ? nwin : (int)std::min<size_t>((size_t)nwin, std::max<size_t>(1, stage_cap / tile_pts));
   const size_t nbins_tot = nsets << sort_hi;
   // ---- sort region (replicated NS times)
@@ -222,7 +228,7 @@ do {                                                                           \
       const size_t hl = (nbins_tot + BIG_THREADS / 64) * 4;      // tile histogram (one vector's bins); all bins for the last workgroup's scan
       if (hl > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_hist_kernel<FrP>, hl, eng->device));
       msm_hist_kernel<FrP><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), hl, st>>>(
-          sc, coef_d, plen, c, nwin, wide, sort_hi, sort_lo, hp, tpv, wmask, bins, skip, canon, ys);
+          sc, coef_d, plen, c, w_end, wide, sort_hi, sort_lo, hp, tpv, wmask, w_begin, bins, skip, canon, ys);
     }
     if (large) {
       const unsigned tpv = (unsigned)((npts + tile_pts - 1) / tile_pts);
@@ -231,7 +237,7 @@ do {                                                                           \
   do {                                                                                                                 \
     if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_>, l1, eng->device)); \
     msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_><<<dim3(tpv * (unsigned)batch, NS), dim3(1024), l1, st>>>(    \
-        sc, c, nwin, wide, sort_hi, sort_lo, tpv, wmask, wgroup, pre_stride, pre_off, idx_bits, (uint32_t)stage_cap,   \
+        sc, c, w_end, wide, sort_hi, sort_lo, tpv, wmask, w_begin, wgroup, pre_stride, pre_off, idx_bits, (uint32_t)stage_cap,   \
         bins, tmp, tmp_lo, canon, ys);                                                                                 \
   } while (0)
       if (wide_fmt) ZK_SCATTER(true);
@@ -243,10 +249,10 @@ do {                                                                           \
       if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr(wide_fmt ? (const void*)msm_scatter_direct_kernel<FrP, true> : (const void*)msm_scatter_direct_kernel<FrP, false>, l1, eng->device));
       if (wide_fmt)
         msm_scatter_direct_kernel<FrP, true><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), l1, st>>>(
-            sc, c, nwin, wide, sort_hi, sort_lo, ppt, tpv, wmask, pre_stride, pre_off, idx_bits, bins, tmp, tmp_lo, canon, ys);
+            sc, c, w_end, wide, sort_hi, sort_lo, ppt, tpv, wmask, w_begin, pre_stride, pre_off, idx_bits, bins, tmp, tmp_lo, canon, ys);
       else
         msm_scatter_direct_kernel<FrP, false><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), l1, st>>>(
-            sc, c, nwin, wide, sort_hi, sort_lo, ppt, tpv, wmask, pre_stride, pre_off, idx_bits, bins, tmp, tmp_lo, canon, ys);
+            sc, c, w_end, wide, sort_hi, sort_lo, ppt, tpv, wmask, w_begin, pre_stride, pre_off, idx_bits, bins, tmp, tmp_lo, canon, ys);
     }
     const size_t l2 = (2 * ((size_t)1 << sort_lo) + 1 + (size_t)(sthr / 64)) * 4 + (large ? (size_t)sthr * BIG_EPT * 6 : 0);
 #define ZK_BINSORT(THR_, W_, S_)                                                                                      \
@@ -376,7 +382,9 @@ do {                                                                           \
   pend->stats_off = out_bytes;
   pend->nsorts = (int)NS;
   pend->g2 = G2FLD;
-  pend->offered = npts * batch * NB * (size_t)nwin;
+  pend->offered = npts * batch * NB * (size_t)nwin_r;
+  pend->w0 = w_begin;
+  pend->tabbed = (bool)tab;
   pend->tab = std::move(tab);
   pend->tab2 = std::move(tab2);
   return ZK_OK;
