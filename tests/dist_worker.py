@@ -39,6 +39,10 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
         pp.set_option("msm_bigsort_min", 0 if rank % 2 else 1 << 30)      # both sort paths across the ranks
         if a2a:
             pp.set_option("king_alltoall", 1)
+        if scenario == "map":
+            # the enforced data-plane deadline (zk_ctx_set_option "dist_deadline"): every zk_dist_* call of this scenario
+            # returns only with its channels' work done -- same results
+            pp.set_option("dist_deadline", 1)
         # "map": an arbitrary party -> rank map (MpcNet ids are arbitrary, mpc-net/src/lib.rs:43-53) instead of the blocks
         pmap = None
         if scenario == "map":

@@ -195,99 +195,6 @@ def _rand_fr(pp, count, seed):
     return DeviceBuffer.from_numpy(pp, a)
 
 
-def _c5_cpu_baseline(pp, zk, log_m_full):
-    """cpu_baseline of the BLS12-381 workload: the plain-C port (oracle/c: libzkref.so for the 255-bit scalar field,
-    libzkref6.so -- the same source with six 64-bit limbs -- for the 381-bit base field) proves the SAME synthetic instance
-    at 2^ZK_C5_CPU_LOG_M constraints (default 2^20) on all host threads: circom_h with the parties' local stages on n
-    threads and the matrix king over 64, the n parties' five G::msm concurrently with window-parallel threads.  The
-    2^24-constraint figure is that time x 2^(24 - 20): an EXTRAPOLATION (FFTs grow by n log n, Pippenger slightly less than
-    linearly), labelled as such.  Checked against the GPU at the reduced size: h shares bit for bit (replay stream), the
-    A-query d_msm as a group element."""
-    import time as _t
-    from concurrent.futures import ThreadPoolExecutor
-    from . import synthetic
-    from oracle.cref import CGroup6, CPss
-    from oracle.curve import GroupOps, g1
-    from oracle.field import Domain
-    from oracle.params import CURVES
-    from oracle.pss import PackedSharingParams as OPP
-    cv = CURVES["bls12_381"]
-    lg = min(log_m_full, int(os.environ.get("ZK_C5_CPU_LOG_M", "20")))
-    m = 1 << lg
-    n, l = pp.n, pp.l
-    Lc = m // l
-    pp.set_option("rng_replay", 1)
-    inst = synthetic.SyntheticInstance(pp, lg, seed=1)
-    wit = inst.witness(seed=100)
-    cp, cg = CPss("bls12_381", l), CGroup6("bls12_381")
-    qap = [q.to_numpy().reshape(-1, 4).copy() for q in wit.qap]
-    h_gpu = pp.alloc_fr(n * Lc)
-    pp._check(pp.lib.zk_circom_h(pp.h, wit.qap[0].ptr, wit.qap[1].ptr, wit.qap[2].ptr, lg, None, 7, h_gpu.ptr, None))
-    h_gpu = h_gpu.to_numpy().reshape(-1, 4)
-
-    def to6(buf, count):          # 4-limb residues (radix 2^256) -> the same values as residues to the radix 2^384
-        tmp = DeviceBuffer.from_numpy(pp, buf.to_numpy().copy())
-        api.vec_scale(pp, tmp, (1 << 128) % cv.r, count)
-        out = np.zeros((count, 6), dtype=np.uint64)
-        out[:, :4] = tmp.to_numpy().reshape(count, 4)
-        return out
-    a6, ax6 = to6(wit.a_share, n * inst.len_a), to6(wit.ax_share, n * inst.len_w)
-    bases = {k: (b.to_numpy().reshape(n, ln_, w).copy(), ln_) for k, b, ln_, w in (
-        ("s", inst.s, inst.len_a, 12), ("h", inst.h, inst.len_a, 12), ("v", inst.v, inst.len_a, 24),
-        ("w", inst.wq, inst.len_w, 12), ("u", inst.u, inst.len_u, 12))}
-    s_gpu = api.d_msm(pp, ZK_G1, inst.s, wit.a_share, inst.len_a)
-    cores = os.cpu_count() or 1
-    per = max(1, min(24, cores // n))
-    dom = Domain(cv, m)
-    w2m = Domain(cv, 2 * m).element(1)
-    t0 = _t.perf_counter()
-    ev = []
-    for k in range(3):                                        # ext_wit.rs:127-170, zero masks
-        x = qap[k]
-        cp.d_fft_arrays_mt(x, Lc, dom.group_gen_inv, dom.size_inv, w2m, True, None, None, 7 + k)
-        cp.d_fft_arrays_mt(x, Lc, dom.group_gen, None, None, False, None, None, 7 + 3 + k)
-        ev.append(x)
-    h = cp.mul_sub_arrays(ev[0], ev[1], ev[2])
-    from oracle.cref import lib as _lib4
-    _lib4().zkref_set_fast_king(1, min(64, cores))
-    try:
-        cp.deg_red_arrays(h, Lc, None, None, 7 + 6)
-    finally:
-        _lib4().zkref_set_fast_king(0, 1)
-    t1 = _t.perf_counter()
-    hd = DeviceBuffer.from_numpy(pp, h)
-    h6 = to6(hd, n * Lc)
-    t1b = _t.perf_counter()
-
-    def party(p):
-        sa, sx, sh = a6[p * inst.len_a:(p + 1) * inst.len_a], ax6[p * inst.len_w:(p + 1) * inst.len_w], h6[p * Lc:(p + 1) * Lc]
-        c_ = np.ascontiguousarray
-        return (cg.msm_g1_arrays(c_(bases["s"][0][p]), c_(sa), inst.len_a, per), cg.msm_g1_arrays(c_(bases["h"][0][p]), c_(sa), inst.len_a, per),
-                cg.msm_g2_arrays(c_(bases["v"][0][p]), c_(sa), inst.len_a, per), cg.msm_g1_arrays(c_(bases["w"][0][p]), c_(sx), inst.len_w, per),
-                cg.msm_g1_arrays(c_(bases["u"][0][p]), c_(sh), Lc, per))
-    with ThreadPoolExecutor(max_workers=n) as ex:
-        parts = list(ex.map(party, range(n)))
-    t2 = _t.perf_counter()
-    total = (t1 - t0) + (t2 - t1b)
-    # checks at the reduced size
-    G = g1(cv)
-    o = OPP(cv, l)
-    want = G.sum(o.unpack2([tuple(cg.fq.dec(parts[p][0])) for p in range(n)], GroupOps(G)))
-    v = pp.fq.decode(np.asarray(s_gpu[0]).reshape(-1, pp.fq.nl))
-    ok = bool(np.array_equal(h, h_gpu)) and bool(G.eq((v[0], v[1], v[2]), want))
-    if not api.DEFAULT_OPTIONS.get("rng_replay"):
-        pp.set_option("rng_replay", 0)
-    scale = 1 << (log_m_full - lg)
-    from bench import cpu_model
-    return {"value": round(1.0 / (total * scale), 6), "unit": "proofs/s", "cores": min(cores, n * per), "kind": "port",
-            "extrapolated": scale > 1,
-            "sample": "one proof of the same synthetic BLS12-381 instance at 2^%d - 2 constraints (zero masks, as the "
-                      "timed GPU workload): %.2f s = circom_h %.2f s + the 5 x %d G::msm %.2f s; `value` = 1 / (that x %d), "
-                      "a LINEAR extrapolation to 2^%d constraints" % (lg, total, t1 - t0, n, t2 - t1b, scale, log_m_full),
-            "measured_s_at_sample": round(total, 3), "sample_constraints": m - 2, "host_cpus": cores,
-            "cpu_model": cpu_model(), "matches_gpu_at_sample": ok}
-
-
 def bench(args, rank, local_rank, world):
     """bench.py's sharded leg (N > 1, or any workload other than the single-GPU c4 line)."""
     import torch
@@ -525,7 +432,8 @@ def bench(args, rank, local_rank, world):
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             del wit
-            cpu = _c5_cpu_baseline(pp, zk, log_m)
+            from bench import cpu_baseline_c5
+            cpu = cpu_baseline_c5(pp, zk, log_m)
         res = dict(base, metric="Groth16 proofs/sec (BLS12-381, 2^%d - 2 constraints)" % log_m,
                    value=round(args.steps / dt, 4), unit="proofs/s", ms_per_step=round(per(dt) * 1e3, 2), scaling="strong",
                    constraints_per_sec=round(inst.nc * args.steps / dt, 1),
