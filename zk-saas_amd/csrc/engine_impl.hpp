@@ -1161,6 +1161,17 @@ class Engine : public IEngine {
       gate_v.wait_ev = gate_g1.wait_ev = ev_gate_[j.slot];      // recorded before any task runs: no host flag needed
       h_done = true;
     }
+    // ZK_H_ENQUEUE_FIRST=1 (round 4, measured, off): circom_h's kernels ENQUEUED before the pool tasks start launching the
+    // witness MSMs' sorts (no gate, only the order of the host's launches) -- 550-555 against 571-596 proofs/s: the two
+    // dozen launches on the calling thread delay the MSM tasks by more than the chain gains
+    static const bool h_enq_first = getenv("ZK_H_ENQUEUE_FIRST") && atoi(getenv("ZK_H_ENQUEUE_FIRST")) != 0;
+    if (full && !h_done && h_enq_first) {
+      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+      if (he != hipSuccess) return hip_fail(he, "h share buffer");
+      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
+      if (rc) return rc;
+      h_done = true;
+    }
     if (v_first) {
       j.v_acc_flag.store(0, std::memory_order_relaxed);
       gate_v.signal_ev = ev_gate_[j.slot];
@@ -1245,8 +1256,10 @@ class Engine : public IEngine {
       // ZK_U_PRIO=1 (measured, off): raised issue priority for the U-MSM's accumulate waves, the last link of the proof's
       // critical chain -- 541-544 against 591-594 proofs/s: they then starve the reduction tails of the other four MSMs
       static const int u_prio = getenv("ZK_U_PRIO") ? atoi(getenv("ZK_U_PRIO")) : 0;
+      // ZK_U_RANGE=<entries per lane>: the U-MSM ends a proof mostly alone on the chip: shorter ranges = more lanes
+      static const int u_range = getenv("ZK_U_RANGE") ? atoi(getenv("ZK_U_RANGE")) : 0;
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
-                                      ws0 + 0, &j.pU, nullptr, MsmGate{}, nullptr, u_prio);
+                                      ws0 + 0, &j.pU, nullptr, MsmGate{}, nullptr, u_prio, u_range);
       if (rc) return rc;
     }
     return ZK_OK;

@@ -1413,6 +1413,7 @@ struct MsmTuning {
   MsmGate gate;
   int prio = 0;          // raised issue priority for the G1 accumulate kernel of this launch (see msm_accumulate_kernel)
   int w_begin = 0, w_end = -1;   // digit windows [w_begin, w_end) only (-1: all): one window group of a split MSM
+  int range = 0;                 // entries per accumulate lane of this launch (0: the rule of msm_pick_lanes)
   bool lean_sort = false;        // the small-workgroup sort kernels whatever the size: this sort has to run BESIDE an
                                  // accumulate kernel (1024-thread workgroups never find a free CU there, see run_split_t)
 };
@@ -1459,8 +1460,9 @@ inline int msm_pick_c(size_t npts, bool g2 = false) {
 struct MsmLanes {
   uint32_t nlanes, tmin, cap;
 };
-inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair, int lanes_per_range = 0) {
-  static const int env_t = getenv("ZK_MSM_RANGE") ? atoi(getenv("ZK_MSM_RANGE")) : 0;
+inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair, int lanes_per_range = 0, int range = 0) {
+  static const int env_t0 = getenv("ZK_MSM_RANGE") ? atoi(getenv("ZK_MSM_RANGE")) : 0;
+  const int env_t = range > 0 ? range : env_t0;
   if (!lanes_per_range) lanes_per_range = pair ? 2 : 1;
   const size_t cap = (size_t)1024 * waves * (64 / lanes_per_range);
   static const int env_hi = getenv("ZK_MSM_RANGE_HI") ? atoi(getenv("ZK_MSM_RANGE_HI")) : 0;
@@ -1672,10 +1674,11 @@ class MsmRunner {
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
                hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, MsmGate gate = MsmGate{},
-               const MsmBatchArg* batch = nullptr, int prio = 0) {
+               const MsmBatchArg* batch = nullptr, int prio = 0, int range = 0) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
     MsmTuning tune{bigsort_min, gate, prio};
+    tune.range = range;
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }
@@ -1726,7 +1729,7 @@ class MsmRunner {
     // the upper group's sort runs beside the lower group's accumulate kernel: small workgroups (its 3-5x write amplification
     // is hidden there -- the accumulate is ALU-bound); with the staged kernels the split was SLOWER than one launch
     // (13.3-13.4 against 13.1 ms: their 1024-thread workgroups wait for a whole free CU until the accumulate has ended)
-    MsmTuning ta{bigsort_min, MsmGate{}, 0, 0, sl->wm, false}, tb{bigsort_min, MsmGate{}, 0, sl->wm, nwin, true};
+    MsmTuning ta{bigsort_min, MsmGate{}, 0, 0, sl->wm, 0, false}, tb{bigsort_min, MsmGate{}, 0, sl->wm, nwin, 0, true};
     int rc = msm_launch<FrP, Fld>(eng, slots_[wslot], ta, bases, nullptr, scalars, npts, coef_d, part_len, st, &sl->p[0], nullptr);
     if (rc) return rc;
     rc = msm_launch<FrP, Fld>(eng, slots_b_[wslot], tb, bases, nullptr, scalars, npts, coef_d, part_len, split_st_[wslot],

@@ -66,8 +66,8 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   // SHA-256 proof on BN254 561 -> 593 proofs/s (table-free 395 -> 428).  ZK_ACC_SPLIT=0 restores the older kernels.
   static const int split_env = getenv("ZK_ACC_SPLIT") ? atoi(getenv("ZK_ACC_SPLIT")) : -1;
   const bool split = G2FLD && split_env != 0;
-  const MsmLanes ml = split ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4)
-                            : msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair);
+  const MsmLanes ml = split ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4, tune.range)
+                            : msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair, 0, tune.range);
   const uint32_t nlanes = ml.nlanes, tmin = ml.tmin, cap = ml.cap;
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
   const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
