@@ -620,7 +620,27 @@ __global__ __launch_bounds__(THR) void msm_binsort_kernel(const uint32_t* __rest
   auto lo_of = [&](uint32_t e, uint32_t word) -> uint32_t { return WIDE ? (uint32_t)tmp_lo[e] : word >> (idx_bits + 1); };
   for (uint32_t j = threadIdx.x; j < nlo; j += THR) cur[j] = 0;
   __syncthreads();
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += THR) atomicAdd(&cur[lo_of(e, WIDE ? 0u : tmp[e])], 1u);
+  // The first two chunks of the bin stay in REGISTERS from this counting pass to the placement pass (packed format): a bin of
+  // the 8 x 2^20-point d_msm is two chunks, so tmp[] is read once instead of twice
+  constexpr bool KEEP = STAGED && !WIDE;
+  uint32_t kept0[KEEP ? BIG_EPT : 1], kept1[KEEP ? BIG_EPT : 1];
+  if constexpr (KEEP) {
+#pragma unroll
+    for (int k = 0; k < BIG_EPT; k++) {
+      const uint32_t ea = e0 + (uint32_t)k * THR + threadIdx.x, eb = ea + CH;
+      kept0[k] = ea < e1 ? tmp[ea] : 0u;
+      kept1[k] = eb < e1 ? tmp[eb] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < BIG_EPT; k++) {
+      const uint32_t ea = e0 + (uint32_t)k * THR + threadIdx.x, eb = ea + CH;
+      if (ea < e1) atomicAdd(&cur[kept0[k] >> (idx_bits + 1)], 1u);
+      if (eb < e1) atomicAdd(&cur[kept1[k] >> (idx_bits + 1)], 1u);
+    }
+    for (uint32_t e = e0 + 2 * CH + threadIdx.x; e < e1; e += THR) atomicAdd(&cur[tmp[e] >> (idx_bits + 1)], 1u);
+  } else {
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += THR) atomicAdd(&cur[lo_of(e, WIDE ? 0u : tmp[e])], 1u);
+  }
   __syncthreads();
   {
     // offsets of the bin's keys; cur <- first slot of every bucket
@@ -666,23 +686,20 @@ __global__ __launch_bounds__(THR) void msm_binsort_kernel(const uint32_t* __rest
     }
     return;
   }
-  for (uint32_t cb = e0; cb < e1; cb += CH) {
-    const uint32_t n = e1 - cb < CH ? e1 - cb : CH;
+  // one chunk: rank its entries into the LDS stage in bucket order, stream the stage out (`load(k, j)` = entry j of the chunk)
+  auto chunk = [&](uint32_t cb, uint32_t n, auto load) {
     for (uint32_t j = threadIdx.x; j <= nlo; j += THR) coff[j] = 0;
     __syncthreads();
-    uint32_t word[BIG_EPT], lo[BIG_EPT], rk[BIG_EPT];
+    uint32_t word[BIG_EPT], rk[BIG_EPT];
 #pragma unroll
     for (int k = 0; k < BIG_EPT; k++) {
       const uint32_t j = (uint32_t)k * THR + threadIdx.x;
-      if (j < n) {
-        word[k] = tmp[cb + j];
-        lo[k] = lo_of(cb + j, word[k]);
-      }
+      word[k] = j < n ? load(k, cb + j) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < BIG_EPT; k++) {
       const uint32_t j = (uint32_t)k * THR + threadIdx.x;
-      if (j < n) rk[k] = atomicAdd(&coff[lo[k]], 1u);
+      if (j < n) rk[k] = atomicAdd(&coff[lo_of(cb + j, word[k])], 1u);
     }
     __syncthreads();
     {
@@ -706,14 +723,15 @@ __global__ __launch_bounds__(THR) void msm_binsort_kernel(const uint32_t* __rest
     for (int k = 0; k < BIG_EPT; k++) {
       const uint32_t j = (uint32_t)k * THR + threadIdx.x;
       if (j < n) {
-        const uint32_t p = coff[lo[k]] + rk[k];
+        const uint32_t l = lo_of(cb + j, word[k]);
+        const uint32_t p = coff[l] + rk[k];
         if (WIDE) {
           stage[p] = word[k];
         } else {
           const uint32_t w_ = word[k];
           stage[p] = (w_ & idx_mask) | (((w_ >> idx_bits) & 1u) << 31);
         }
-        slo[p] = (uint16_t)lo[k];
+        slo[p] = (uint16_t)l;
       }
     }
     __syncthreads();
@@ -724,7 +742,19 @@ __global__ __launch_bounds__(THR) void msm_binsort_kernel(const uint32_t* __rest
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < nlo; j += THR) cur[j] += coff[j + 1] - coff[j];
     __syncthreads();
+  };
+  uint32_t cb = e0;
+  if constexpr (KEEP) {
+    if (cb < e1) {
+      chunk(cb, e1 - cb < CH ? e1 - cb : CH, [&](int k, uint32_t) { return kept0[k]; });
+      cb += CH;
+    }
+    if (cb < e1) {
+      chunk(cb, e1 - cb < CH ? e1 - cb : CH, [&](int k, uint32_t) { return kept1[k]; });
+      cb += CH;
+    }
   }
+  for (; cb < e1; cb += CH) chunk(cb, e1 - cb < CH ? e1 - cb : CH, [&](int, uint32_t e) { return tmp[e]; });
 }
 
 // -------------------------------------------------------------------------------------------------- scan
