@@ -1,5 +1,5 @@
 """One G2 d_msm alone on the chip (counter / timing probe of the extension-field accumulate kernel):
-   python tools/g2_solo.py <curve> <log2 points per party> [reps]      (ZK_ACC_SPLIT=0: the older pair / one-lane kernels)"""
+   python tools/g2_solo.py <curve> <log2 points per party> [reps]      (ZK_SOLO_G1=1: the G1 kernel on the same sizes)"""
 import json
 import os
 import sys

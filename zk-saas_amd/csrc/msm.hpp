@@ -857,13 +857,8 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint3
 #ifndef ZK_ACC_WAVES_8
 #define ZK_ACC_WAVES_8 3
 #endif
-#ifndef ZK_PAIR_WAVES_12
-#define ZK_PAIR_WAVES_12 2
-#endif
 template <class Fld>
-constexpr int ACC_WAVES = sizeof(Fld) > 64 ? 1 : (sizeof(Fld) == 64 ? 2 : (sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8));
-template <class Fld>
-constexpr int PAIR_WAVES = sizeof(Fld) > 64 ? ZK_PAIR_WAVES_12 : 2;
+constexpr int ACC_WAVES = sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8;       // base-field (G1) kernel only
 // BALANCED PARTITION.  The sorted entry array (offsets[nkeys] entries, grouped by bucket) is cut into `nlanes`
 // contiguous ranges of T = ceil(entries / nlanes) entries, one per lane (per lane pair in G2), whatever the bucket
 // boundaries are: every lane of the launch performs the same number of mixed additions, so a wave has no idle lanes
@@ -1033,78 +1028,6 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
       cont = false;
       k += p + 1 == end_k ? 1u : 0u;                // (the last step of the range may leave k one past: unused)
     }
-  }
-}
-
-// Extension-field variant: one PAIR of lanes per range (quad.hpp pair_madd): 128 threads = 64 ranges per workgroup.
-template <class Fld>
-__global__ __launch_bounds__(128, PAIR_WAVES<Fld>) void msm_accumulate_pair_kernel(const Affine<Fld>* __restrict__ bases0,
-                                                                    const Affine<Fld>* __restrict__ bases1,
-                                                                    const uint32_t* __restrict__ sorted,
-                                                                    const uint32_t* __restrict__ offsets, uint32_t nkeys,
-                                                                    uint32_t nlanes, uint32_t tmin, uint32_t cap,
-                                                                    XYZZ<Fld>* __restrict__ buckets0,
-                                                                    XYZZ<Fld>* __restrict__ edge0,
-                                                                    uint32_t* __restrict__ heavy,
-                                                                    const uint32_t* __restrict__ k0, size_t ys) {
-  ZK_YSHIFT(sorted);
-  ZK_YSHIFT(offsets);
-  ZK_YSHIFT(heavy);
-  ZK_YSHIFT(k0);
-  const Affine<Fld>* __restrict__ bases = blockIdx.y ? bases1 : bases0;
-  XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
-  XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
-  XYZZ<Fld>* __restrict__ tail = head + nlanes;
-  const uint32_t total = offsets[nkeys];
-  const uint32_t T = msm_range_len(total, nlanes, tmin, cap);
-  const bool lb = (threadIdx.x & 1) != 0;
-  const uint32_t lane = blockIdx.x * (blockDim.x / 2) + (threadIdx.x >> 1);      // pair index = range index
-  if (lane >= nlanes || (uint64_t)lane * T >= total) return;
-  const uint32_t a = lane * T, b = a + T < total ? a + T : total;
-  uint32_t k = k0[lane];
-  bool cont = offsets[k] < a;
-  uint32_t end_k = offsets[k + 1];
-  // (this kernel requests the next point at the top of a step and has the whole 28-multiplication addition to receive
-  // it, so the simpler bookkeeping -- the end of the next bucket fetched one bucket ahead, ordinary stores -- costs it
-  // nothing: measured 83 G multiplications/s alone against 74 with msm_accumulate_kernel's form)
-  uint32_t end_n = offsets[k + 2 <= nkeys ? k + 2 : nkeys];
-  PairAcc<Fld> acc{Fld::one(), Fld::zero()};               // the identity: X = Y = 1, ZZ = ZZZ = 0
-  uint32_t e = sorted[a];
-  uint32_t e1 = a + 1 < b ? sorted[a + 1] : e;
-  // my coordinate of the affine point: x for the even lane, y for the odd one (a pair reads one whole point)
-  Fld pt = load_elem(reinterpret_cast<const Fld*>(bases + (e & 0x7fffffffu)) + (lb ? 1 : 0));
-  for (uint32_t p = a; p < b; p++) {
-    const uint32_t e_next = e1;
-    if (p + 2 < b) e1 = sorted[p + 2];
-    Fld pt_next = pt;
-    if (p + 1 < b) pt_next = load_elem(reinterpret_cast<const Fld*>(bases + (e_next & 0x7fffffffu)) + (lb ? 1 : 0));
-    // the identity sentinel is (0, 0): both coordinates zero (pair-uniform after the exchange)
-    const bool ident = pt.is_zero() && pswap(pt).is_zero();
-    if (!ident) {
-      const Fld c = qsel(lb && (e >> 31) != 0, pt.neg(), pt);
-      acc = pair_madd(acc, c, lb);
-    }
-    if (p + 1 == end_k || p + 1 == b) {
-      XYZZ<Fld>* dst = cont ? head + lane : (p + 1 == end_k ? buckets + k : tail + lane);
-      Fld* o = reinterpret_cast<Fld*>(dst);                  // X, Y, ZZ, ZZZ
-      store_elem(o + (lb ? 1 : 0), acc.c0);
-      store_elem(o + (lb ? 3 : 2), acc.c1);
-      if (!lb && !cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
-        heavy[1 + atomicAdd(heavy, 1u)] = k;
-      acc = PairAcc<Fld>{Fld::one(), Fld::zero()};
-      cont = false;
-      if (p + 1 < b) {
-        k++;
-        end_k = end_n;
-        while (end_k == p + 1) {                    // empty buckets in between (rare)
-          k++;
-          end_k = offsets[k + 1];
-        }
-        end_n = offsets[k + 2 <= nkeys ? k + 2 : nkeys];
-      }
-    }
-    e = e_next;
-    pt = pt_next;
   }
 }
 

@@ -51,23 +51,12 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   if (max_sorted >= ((size_t)1 << 32)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large (points x windows >= 2^32)");
   const uint32_t pre_stride = tab ? (uint32_t)tab->len : 0u, pre_off = tab ? (uint32_t)toff : 0u;
   // accumulate lanes (msm.hpp "balanced partition"): every lane adds the same number of sorted entries
-  // Extension field: one lane per range for 8-limb base fields (233 registers, two waves per SIMD: 91-106 G
-  // multiplications/s alone against the pair kernel's 81-87 since the accumulate loop requests the next point behind
-  // the first two multiplications), a PAIR of lanes per range (quad.hpp pair_madd) for 12-limb ones, where the one-lane
-  // kernel needs 453 registers.  ZK_ACC_PAIR=0 / 1 forces either.
-  static const int pair_env = getenv("ZK_ACC_PAIR") ? atoi(getenv("ZK_ACC_PAIR")) : -1;
-  // (small launches -- the G2 MSM of ONE proof -- keep the pair kernel: twice the lanes for the same entries; measured
-  // 370 against 753 us for a 58k-point launch)
-  const bool small_launch = max_sorted < (size_t)4 * 1024 * 1024;
-  const bool pair = G2FLD && (pair_env >= 0 ? pair_env != 0 : (sizeof(Fld) > 64 || small_launch));
-  // Extension field: a QUAD of lanes per range, one base-field value per lane (quad.hpp split_madd).  The pair and
-  // one-lane kernels hold whole Fq2 values per lane: 256 registers with 13-99 spilled dwords (BLS12-381 G2 ran at a third
-  // of the multiplier's peak); measured with the quad form: a 2^24-constraint BLS12-381 proof 1.42 -> 1.28 s, the
-  // SHA-256 proof on BN254 561 -> 593 proofs/s (table-free 395 -> 428).  ZK_ACC_SPLIT=0 restores the older kernels.
-  static const int split_env = getenv("ZK_ACC_SPLIT") ? atoi(getenv("ZK_ACC_SPLIT")) : -1;
-  const bool split = G2FLD && split_env != 0;
-  const MsmLanes ml = split ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4, tune.range)
-                            : msm_pick_lanes(max_sorted, pair ? PAIR_WAVES<Fld> : ACC_WAVES<Fld>, pair, 0, tune.range);
+  // Extension field: a QUAD of lanes per range, one base-field value per lane (quad.hpp split_madd).  Rounds 2-3 held whole
+  // Fq2 values per lane -- a pair of lanes per range, or one lane on large launches of 8-limb curves: 256 registers with
+  // 13-99 spilled dwords, BLS12-381 G2 at a third of the multiplier's peak; those kernels are gone (measured with the quad
+  // form: a 2^24-constraint BLS12-381 proof 1.42 -> 1.28 s, the SHA-256 proof 561 -> 593 proofs/s, table-free 395 -> 428)
+  const MsmLanes ml = G2FLD ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4, tune.range)
+                            : msm_pick_lanes(max_sorted, ACC_WAVES<Fld>, false, 0, tune.range);
   const uint32_t nlanes = ml.nlanes, tmin = ml.tmin, cap = ml.cap;
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
   const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
@@ -295,24 +284,14 @@ do {                                                                           \
       while (!tune.gate.wait_flag->load(std::memory_order_acquire)) std::this_thread::yield();
     MSM_HIP(hipStreamWaitEvent(st, tune.gate.wait_ev, 0));
   }
-  bool launched = false;
   if constexpr (G2FLD) {
-    if (split) {
-      msm_accumulate_split_kernel<typename BaseParams<Fld>::type><<<dim3((nlanes + 31) / 32, NB), dim3(128), 0, st>>>(
-          bases, bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge, heavy, k0, ys);
-      launched = true;
-    } else if (pair) {
-      // extension field: a pair of lanes per range (two waves per SIMD instead of one; quad.hpp pair_madd)
-      msm_accumulate_pair_kernel<KF><<<dim3((nlanes + 63) / 64, NB), dim3(128), 0, st>>>(
-          (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
-          heavy, k0, ys);
-      launched = true;
-    }
-  }
-  if (!launched)
+    msm_accumulate_split_kernel<typename BaseParams<Fld>::type><<<dim3((nlanes + 31) / 32, NB), dim3(128), 0, st>>>(
+        bases, bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge, heavy, k0, ys);
+  } else {
     msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), 0, st>>>(
         (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
         heavy, k0, ys, tune.prio);
+  }
   if (tune.gate.signal_ev) {
     MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
     if (tune.gate.signal_flag) tune.gate.signal_flag->store(1, std::memory_order_release);

@@ -120,79 +120,6 @@ ZK_D Fld qadd(const Fld& ca, const Fld& cb, int q) {
   return r;
 }
 
-// ---- mixed addition shared by a PAIR of lanes (the accumulate kernel of extension-field MSMs)
-// Lane A (even) holds X and ZZ of the running sum and x of the affine addend, lane B (odd) holds Y, ZZZ and y.  The ten
-// multiplications of madd-2008-s run as five rounds of one multiplication per lane -- every slot used:
-//   round 1   A: U2 = x2 ZZ1           B: S2 = y2 ZZZ1          A: P = U2 - X1      B: R = S2 - Y1
-//   round 2   A: PP = P^2              B: RR = R^2
-//   round 3   A: Q = X1 PP             B: PPP = P PP
-//   round 4   A: ZZ3 = ZZ1 PP          B: ZZZ3 = ZZZ1 PPP       A: X3 = RR - PPP - 2Q
-//   round 5   A: R (Q - X3)            B: Y1 PPP                B: Y3 = R (Q - X3) - Y1 PPP
-// A lane keeps half of a point (two coordinates) and half of the temporaries, so the Fq2 kernel that needed 453
-// registers and ran one wave per SIMD fits two.  Equal points (P = R = 0) are doubled from the AFFINE addend in the
-// same rounds by switching operands (mdbl-2008-s-1: U = 2y, V = U^2, W = U V, S = x V, M = 3 x^2, X3 = M^2 - 2S,
-// Y3 = M (S - X3) - W y, ZZ3 = V, ZZZ3 = W):
-//   round 2   A: XX = x^2              B: V = U^2
-//   round 3   A: S = x V               B: W = U V
-//   round 4   A: MM = M^2              B: -                     A: X3 = MM - 2S
-//   round 5   A: M (S - X3)            B: W y                   B: Y3 = M (S - X3) - W y
-template <class Fld>
-struct PairAcc {       // lane A: c0 = X, c1 = ZZ; lane B: c0 = Y, c1 = ZZZ
-  Fld c0, c1;
-};
-template <class Fld>
-ZK_D Fld pswap(const Fld& v) {        // the value held by the other lane of the pair
-  return qperm<1, 0, 3, 2>(v);
-}
-// acc += (x2, y2) where this lane holds `in` = x2 (lane A) or y2 (lane B); lb = lane & 1
-template <class Fld>
-ZK_D PairAcc<Fld> pair_madd(const PairAcc<Fld>& a, const Fld& in, bool lb) {
-  // identity of the running sum: ZZ (lane A's c1) is zero
-  const bool za = qperm<0, 0, 2, 2>(a.c1).is_zero();
-  // round 1
-  const Fld m1 = in * a.c1;                                  // A: U2        B: S2
-  const Fld d = m1 - a.c0;                                   // A: P         B: R
-  const Fld od = pswap(d);                                   // A: R         B: P
-  const bool D = d.is_zero() && od.is_zero() && !za;         // equal points: double the affine addend
-  const bool inv = (lb ? od.is_zero() && !d.is_zero() : d.is_zero() && !od.is_zero()) && !za;   // P = 0, R != 0
-  const Fld u = qsel(lb, in.dbl(), in);                         // A: x         B: U = 2y
-  // round 2
-  const Fld s2 = qsel(D, u, d);
-  const Fld m2 = s2.sqr();                                   // A: PP | XX   B: RR | V
-  const Fld o2 = pswap(m2);                                  // A: RR | V    B: PP | XX
-  // round 3
-  //   add: A: X1 * PP (own m2)      B: P (od) * PP (o2)
-  //   dbl: A: x * V (o2)            B: U * V (own m2)
-  const Fld a3 = qsel(D, u, qsel(lb, od, a.c0));
-  const Fld b3 = qsel(D != lb, o2, m2);
-  const Fld m3 = a3 * b3;                                    // A: Q | S     B: PPP | W
-  const Fld o3 = pswap(m3);                                  // A: PPP | W   B: Q | S
-  // round 4
-  //   add: A: ZZ1 * PP              B: ZZZ1 * PPP
-  //   dbl: A: M * M, M = 3 XX       B: (unused)
-  const Fld M = m2.dbl() + m2;                               // lane A, doubling: 3 x^2
-  const Fld a4 = qsel(D, M, a.c1);
-  const Fld b4 = qsel(D, M, qsel(lb, m3, m2));
-  const Fld m4 = a4 * b4;                                    // A: ZZ3 | MM  B: ZZZ3 | -
-  // lane A: X3 = RR - PPP - 2Q  |  MM - 2S
-  const Fld X3 = qsel(D, m4, o2 - o3) - m3.dbl();
-  // round 5
-  //   add: A: R (od) * (Q - X3)     B: Y1 * PPP (own m3)
-  //   dbl: A: M * (S - X3)          B: W (own m3) * y
-  const Fld a5 = qsel(lb, qsel(D, m3, a.c0), qsel(D, M, od));
-  const Fld b5 = qsel(lb, qsel(D, in, m3), m3 - X3);
-  const Fld m5 = a5 * b5;
-  const Fld o5 = pswap(m5);
-  PairAcc<Fld> r;
-  //   lane A: X3, ZZ3 (add: m4; dbl: V = o2)      lane B: Y3 = A's product - own product, ZZZ3 (add: m4; dbl: W = m3)
-  r.c0 = qsel(lb, o5 - m5, X3);
-  r.c1 = qsel(D, qsel(lb, m3, o2), m4);
-  // inverse points: the identity (X = Y = 1, ZZ = ZZZ = 0); running sum was the identity: the affine point itself
-  r.c0 = qsel(za, in, qsel(inv, Fld::one(), r.c0));
-  r.c1 = qsel(za, Fld::one(), qsel(inv, Fld::zero(), r.c1));
-  return r;
-}
-
 // ---- mixed addition of an EXTENSION-field point shared by a QUAD of lanes, ONE BASE-FIELD VALUE PER LANE (round 4)
 // The pair form above keeps whole Fq2 values in a lane; for 12-limb base fields that is 24 limbs per value and the
 // kernel ends at the 256-register cap with 99 spilled dwords (BLS12-381 G2: 34 % of the multiplier's peak, a third of a
@@ -202,7 +129,15 @@ ZK_D PairAcc<Fld> pair_madd(const PairAcc<Fld>& a, const Fld& in, bool lb) {
 //   c0 = a0 b0 - a1 b1 (lane 0),   c1 = a1 b0 + a0 b1 (lane 1);     squaring: (a0 + a1)(a0 - a1) | 2 a1 a0
 // i.e. schoolbook (4 products, 2 reductions per Fq2 product over the two lanes) instead of Karatsuba with lazy reduction
 // (3 products, 2 reductions in one lane): 18 % more multiply instructions per addition, none of them spilled.
-// The rounds are those of pair_madd; the other component comes by DPP (cswap), the other half by DPP (hswap).
+// The ten multiplications of madd-2008-s run as five rounds of one Fq2 product per half:
+//   round 1   half 0: U2 = x2 ZZ1        half 1: S2 = y2 ZZZ1         P = U2 - X1, R = S2 - Y1
+//   round 2   half 0: PP = P^2           half 1: RR = R^2
+//   round 3   half 0: Q = X1 PP          half 1: PPP = P PP
+//   round 4   half 0: ZZ3 = ZZ1 PP       half 1: ZZZ3 = ZZZ1 PPP      X3 = RR - PPP - 2Q
+//   round 5   half 0: R (Q - X3)         half 1: Y1 PPP               Y3 = R (Q - X3) - Y1 PPP
+// (the pair form of rounds 2-3, with whole Fq2 values per lane); equal points are doubled from the AFFINE addend
+// (mdbl-2008-s-1: U = 2y, V = U^2, W = U V, S = x V, M = 3 x^2, X3 = M^2 - 2S, Y3 = M (S - X3) - W y, ZZ3 = V, ZZZ3 = W).
+// The other component of a value comes by DPP (cswap), the other half's value by DPP (hswap).
 template <class F>
 ZK_D F cswap(const F& v) {
   return qperm<1, 0, 3, 2>(v);
@@ -253,7 +188,7 @@ ZK_D SplitAcc<P> split_madd(const SplitAcc<P>& a, const Fp<P>& in, bool half, bo
   const bool pz = qperm_u32<0, 0, 0, 0>(dz) != 0, rz = qperm_u32<2, 2, 2, 2>(dz) != 0;
   if (pz) {
     if (!rz) return split_identity<P>(comp);           // inverse points
-    // equal points: double the affine addend (mdbl-2008-s-1, see pair_madd)
+    // equal points: double the affine addend (mdbl-2008-s-1)
     const F u = qsel(half, in.dbl(), in);                 // 0: x                  1: U = 2 y
     const F m2 = s2_sqr(u, comp);                      // 0: XX                 1: V
     const F o2 = hswap(m2);                            // 0: V                  1: XX
