@@ -4,7 +4,7 @@
 O=$1; F=${2:-.}
 T=$(mktemp -d)
 B=/opt/rocm/lib/llvm/bin
-$B/llvm-objcopy --dump-section .hip_fatbin=$T/fb.bin $O
+$B/llvm-objcopy --dump-section .hip_fatbin=$T/fb.bin $O $T/copy.o
 $B/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fb.bin --output=$T/dev.co --unbundle
 [ -n "$KEEP" ] && cp $T/dev.co $KEEP/$(basename $O .o).co
 $B/llvm-readelf --notes $T/dev.co | python3 -c '
