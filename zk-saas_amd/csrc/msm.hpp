@@ -349,11 +349,16 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
                                                                only (a window group of a split MSM): set = w - w_begin */,
                                                                uint32_t* __restrict__ bins,
                                                                const uint32_t* __restrict__ skip,
-                                                               Fp<FrP>* __restrict__ canon, size_t ys) {
+                                                               Fp<FrP>* __restrict__ canon,
+                                                               uint16_t* __restrict__ tile_counts /* optional
+                                                               [tiles][bins of one vector]: the staged scatter, whose
+                                                               tiles these then are, does not count again */,
+                                                               size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bins);
   ZK_YSHIFT(skip);
   ZK_YSHIFT(canon);
+  ZK_YSHIFT(tile_counts);
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbl = sc.sets_per << hi_bits;                 // bins of one scalar vector
   const uint32_t nbins = nbl * sc.nb;
@@ -372,6 +377,8 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
   }
   __syncthreads();
   uint32_t* bin_counts = bins + (size_t)vb * nbl;
+  if (tile_counts)
+    for (uint32_t b = threadIdx.x; b < nbl; b += BIG_THREADS) tile_counts[(size_t)blockIdx.x * nbl + b] = (uint16_t)big_lds[b];
   uint32_t seen = 0;                 // RETURNING adds: a value that has come back is an add that has been performed
   for (uint32_t b0 = threadIdx.x; b0 < nbl; b0 += 8 * BIG_THREADS) {       // eight in flight, then their values
     uint32_t r[8];
@@ -488,12 +495,14 @@ __global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc
                                                           uint32_t pre_off, int idx_bits, uint32_t stage_cap,
                                                           uint32_t* __restrict__ bins, uint32_t* __restrict__ tmp,
                                                           uint16_t* __restrict__ tmp_lo,
-                                                          const Fp<FrP>* __restrict__ canon, size_t ys) {
+                                                          const Fp<FrP>* __restrict__ canon,
+                                                          const uint16_t* __restrict__ tile_counts, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bins);
   ZK_YSHIFT(tmp);
   ZK_YSHIFT(tmp_lo);
   ZK_YSHIFT(canon);
+  ZK_YSHIFT(tile_counts);
   extern __shared__ uint32_t big_lds[];
   const uint32_t nbl = sc.sets_per << hi_bits;
   const uint32_t nbins = nbl * sc.nb;
@@ -507,16 +516,21 @@ __global__ __launch_bounds__(THR) void msm_scatter_kernel(MsmScalars<Fp<FrP>> sc
   uint16_t* sbin = reinterpret_cast<uint16_t*>(stage + stage_cap);     // [stage_cap] bin of a staged entry - first of round
   uint16_t* slo = sbin + stage_cap;           // [stage_cap] (wide format)
   const Fp<FrP>* __restrict__ my = canon + (size_t)vb * sc.npts;
-  for (uint32_t b = threadIdx.x; b < nbl; b += THR) cur[b] = 0;
-  __syncthreads();
-  // ---- count
+  if (tile_counts) {
+    // ---- the histogram pass counted this very tile (same tiling): take its counts
+    for (uint32_t b = threadIdx.x; b < nbl; b += THR) cur[b] = tile_counts[(size_t)blockIdx.x * nbl + b];
+  } else {
+    for (uint32_t b = threadIdx.x; b < nbl; b += THR) cur[b] = 0;
+    __syncthreads();
+    // ---- count
 #pragma unroll
-  for (int k = 0; k < PPT; k++) {
-    const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
-    if (i < sc.npts)
-      msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
-        if (w >= w_begin) atomicAdd(&cur[(((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits)], 1u);
-      });
+    for (int k = 0; k < PPT; k++) {
+      const uint32_t i = pt0 + (uint32_t)k * THR + threadIdx.x;
+      if (i < sc.npts)
+        msm_for_each_digit<FrP>(load_elem(my + i), c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
+          if (w >= w_begin) atomicAdd(&cur[(((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits)], 1u);
+        });
+    }
   }
   __syncthreads();
   // ---- reserve the tile's range in every bin; cur <- exclusive scan (tile-sorted position of the bin's first entry)

@@ -133,10 +133,16 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const size_t o_skip = take(((npts + 63) / 64) * 8);
   const size_t o_k0 = take((size_t)nlanes * 4);                // first bucket of every accumulate lane
   const size_t o_canon = take(npts * batch * sizeof(Fr));      // canonical scalars (written by the first sort pass)
-  size_t o_tmp = 0, o_tmp_lo = 0;
+  size_t o_tmp = 0, o_tmp_lo = 0, o_tcnt = 0;
+  // staged scatter: the histogram pass runs on the scatter's own tiles and hands over its per-tile counts (2 B per tile and
+  // bin), so that the scatter does not walk the digits a third time (ZK_SORT_TILE_COUNTS=0: it counts again)
+  static const bool tcnt_on = !(getenv("ZK_SORT_TILE_COUNTS") && atoi(getenv("ZK_SORT_TILE_COUNTS")) == 0);
+  const size_t tiles_big = ((npts + tile_pts - 1) / tile_pts) * batch;
+  const bool use_tcnt = big && large && tcnt_on && tile_pts % BIG_THREADS == 0 && tile_pts < 65536;
   if (big) {
     o_tmp = take(max_sorted * 4);
     if (wide_fmt) o_tmp_lo = take(max_sorted * 2);
+    if (use_tcnt) o_tcnt = take(tiles_big * nbl * 2);
   }
   const size_t sort_region = off;
   const size_t ys = NS == 2 ? sort_region : 0;     // byte distance between the two copies
@@ -211,13 +217,14 @@ do {                                                                           \
     uint16_t* tmp_lo = (uint16_t*)(ws + o_tmp_lo);
     const uint32_t wmask = tab ? 0u : ~0u;
     // hist: 256-thread tiles of its own (any tiling of the points gives the same bin totals)
+    uint16_t* tcnt = use_tcnt ? (uint16_t*)(ws + o_tcnt) : nullptr;
     {
-      const int hp = ppt;
+      const int hp = use_tcnt ? (int)(tile_pts / BIG_THREADS) : ppt;          // the scatter's tiles
       const unsigned tpv = (unsigned)((npts + (size_t)BIG_THREADS * hp - 1) / ((size_t)BIG_THREADS * hp));
       const size_t hl = (nbins_tot + BIG_THREADS / 64) * 4;      // tile histogram (one vector's bins); all bins for the last workgroup's scan
       if (hl > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_hist_kernel<FrP>, hl, eng->device));
       msm_hist_kernel<FrP><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), hl, st>>>(
-          sc, coef_d, plen, c, w_end, wide, sort_hi, sort_lo, hp, tpv, wmask, w_begin, bins, skip, canon, ys);
+          sc, coef_d, plen, c, w_end, wide, sort_hi, sort_lo, hp, tpv, wmask, w_begin, bins, skip, canon, tcnt, ys);
     }
     if (large) {
       const unsigned tpv = (unsigned)((npts + tile_pts - 1) / tile_pts);
@@ -227,7 +234,7 @@ do {                                                                           \
     if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_>, l1, eng->device)); \
     msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_><<<dim3(tpv * (unsigned)batch, NS), dim3(1024), l1, st>>>(    \
         sc, c, w_end, wide, sort_hi, sort_lo, tpv, wmask, w_begin, wgroup, pre_stride, pre_off, idx_bits, (uint32_t)stage_cap,   \
-        bins, tmp, tmp_lo, canon, ys);                                                                                 \
+        bins, tmp, tmp_lo, canon, tcnt, ys);                                                                           \
   } while (0)
       if (wide_fmt) ZK_SCATTER(true);
       else ZK_SCATTER(false);
