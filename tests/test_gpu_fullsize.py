@@ -287,3 +287,30 @@ def test_msm_batch_at_every_lane_shape_equals_single_msms(table):
         for nb in (2, 3, 5, 6):
             got = api.msm_batch(pp, group, bases, vecs[:nb], npts)
             assert [wire.jacobian_to_affine(pp, got[b], g2) for b in range(nb)] == single[:nb], (group, nb)
+
+
+def test_table_msm_with_wide_sort_entries_equals_the_table_free_msm():
+    """2^21 points with a fixed-base table: the sorted entry's index (window * stride + point: 25 bits) + sign + low bucket
+    bits no longer fit one 32-bit word, so the sort runs on its WIDE entry format (word + 16-bit low part) through the
+    small-launch kernels -- a combination no other test reaches.  Same group element as the table-free MSM of the same
+    vectors (which the other tests pin on the oracle), and as the sum of its two halves."""
+    from zksaas_amd import api, groth16 as zg, wire
+    from zksaas_amd.api import ZK_G1
+    pp = ctx("bn254", 2)
+    n = 1 << 21
+    rng = np.random.default_rng(8)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 58) - 1)
+        return a
+    pts = zg.base_points(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, rand(n)), n)
+    sc = zk.DeviceBuffer.from_numpy(pp, rand(n))
+    aff = lambda j: wire.jacobian_to_affine(pp, j, False)
+    free = aff(msm(pp, ZK_G1, pts, sc, n))
+    api.msm_precompute(pp, ZK_G1, pts, n)
+    try:
+        assert api.msm_table_info(pp, ZK_G1, pts)["windows"] > 0
+        assert aff(msm(pp, ZK_G1, pts, sc, n)) == free
+    finally:
+        api.msm_forget(pp, pts)
