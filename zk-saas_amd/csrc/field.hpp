@@ -354,6 +354,167 @@ struct Fp {
 #endif
   }
 
+  static constexpr bool LAZY_OK = (P::MOD[N - 1] >> 30) == 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // ---- LAZY residues in [0, 2p) (round 4; moduli with two spare bits, 4p < R: BN254 Fq / Fr, the BLS12 base fields).
+  // The Montgomery product of two such values, (a b + m p) / R < 4 p^2 / R + p < 2p, is again below 2p WITHOUT the final
+  // conditional subtraction; subtraction adds 2p back instead of p, doubling wraps at 2p.  The accumulate kernel of the
+  // Pippenger MSM keeps its running sum in this form (eight of the ten products of a mixed addition lose their
+  // compare-and-select tail) and stores canonical values (canon()).
+  struct Mod2 {
+    uint32_t v[N];
+  };
+  static constexpr Mod2 mod2() {
+    Mod2 r{};
+    uint32_t c = 0;
+    for (int i = 0; i < N; i++) {
+      r.v[i] = (P::MOD[i] << 1) | c;
+      c = P::MOD[i] >> 31;
+    }
+    return r;
+  }
+  static ZK_D Fp mul_lazy(const Fp& a, const Fp& b) {
+    uint32_t m[N], r[N];
+    uint64_t acc = 0, cy;
+    uint32_t acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc = madc(a.v[i], b.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      m[k] = (uint32_t)acc * P::N0INV;
+      acc = madc_k(m[k], P::MOD[0], acc, &cy);
+      acc2 = add_cy(acc2, cy);
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc = madc(a.v[i], b.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      r[k - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+    r[N - 1] = (uint32_t)acc;               // (the word above it is zero: the value is below 2p < 2^(32 N))
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = r[i];
+    return o;
+  }
+  // a - b for a, b in [0, 2p): in [0, 2p)
+  static ZK_D Fp sub_lazy(const Fp& a, const Fp& b) {
+    constexpr Mod2 M2 = mod2();
+    Fp d;
+    unsigned borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) d.v[i] = __builtin_subc(a.v[i], b.v[i], borrow, &borrow);
+    const uint32_t mask = 0u - borrow;
+    unsigned c = 0;
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = __builtin_addc(d.v[i], M2.v[i] & mask, c, &c);
+    return r;
+  }
+  // x - 2p when x >= 2p (x < 4p)
+  static ZK_D Fp wrap2p(const Fp& x) {
+    constexpr Mod2 M2 = mod2();
+    Fp d;
+    unsigned borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) d.v[i] = __builtin_subc(x.v[i], M2.v[i], borrow, &borrow);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = borrow ? x.v[i] : d.v[i];
+    return r;
+  }
+  static ZK_D Fp dbl_lazy(const Fp& a) {          // 2a mod 2p-range: a < 2p, 2a < 4p < 2^(32 N)
+    Fp s;
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) s.v[i] = __builtin_addc(a.v[i], a.v[i], c, &c);
+    return wrap2p(s);
+  }
+  ZK_D Fp canon() const { return reduce_once(*this, 0); }          // [0, 2p) -> [0, p)
+  ZK_D bool is_zero_lazy() const {                                  // 0 or p
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      z |= v[i];
+      e |= v[i] ^ P::MOD[i];
+    }
+    return z == 0 || e == 0;
+  }
+  // a*b - c*d on lazy residues with one reduction: a b + (2p - c) d < 8 p^2, reduced to below 2p + p, wrapped into [0, 2p)
+  static ZK_D Fp mul_sub_mul_lazy(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+    constexpr Mod2 M2 = mod2();
+    uint32_t nc[N];
+    {
+      unsigned bw = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) nc[i] = __builtin_subc(M2.v[i], c.v[i], bw, &bw);
+    }
+    uint32_t m[N], r[N];
+    uint64_t acc = 0, cy;
+    uint32_t acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc = madc(a.v[i], b.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+        acc = madc(nc[i], d.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) {
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      m[k] = (uint32_t)acc * P::N0INV;
+      acc = madc_k(m[k], P::MOD[0], acc, &cy);
+      acc2 = add_cy(acc2, cy);
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        acc = madc(a.v[i], b.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+        acc = madc(nc[i], d.v[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+        acc = madc_k(m[i], P::MOD[k - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      r[k - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+    r[N - 1] = (uint32_t)acc;               // below 3p < 2^(32 N)
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = r[i];
+    return wrap2p(o);
+  }
+#endif
+
   // a*b - c*d (all Montgomery) in ONE product-scanning pass: a*b + (p - c)*d < 2 p^2 < p R is reduced once -- 3 N^2 + N
   // multiply instructions instead of 2 (2 N^2 + N): 200 vs 272 for N = 8.  Same field element as a*b - c*d.  Used for
   // Y3 = R (Q - X3) - Y1 PPP of the mixed addition (msm.hpp).  The modulus must leave two spare bits.

@@ -869,7 +869,7 @@ static __global__ __launch_bounds__(ISCAN_THREADS) void iscan_carry_kernel(uint3
 #define ZK_ACC_WAVES_12 3
 #endif
 #ifndef ZK_ACC_WAVES_8
-#define ZK_ACC_WAVES_8 3
+#define ZK_ACC_WAVES_8 4          // round 4: 128 VGPRs with the lazy mixed addition (4 dwords of scratch, read twice per step)
 #endif
 template <class Fld>
 constexpr int ACC_WAVES = sizeof(Fld) == 48 ? ZK_ACC_WAVES_12 : ZK_ACC_WAVES_8;       // base-field (G1) kernel only
@@ -944,6 +944,21 @@ static __global__ __launch_bounds__(256) void msm_lane_start_kernel(const uint32
   k0[lane] = msm_bucket_of(offsets, nkeys, lane * T);
 }
 
+// Base fields whose running sums the accumulate kernel keeps as lazy residues (field.hpp, LAZY_OK); ZK_ACC_LAZY=0 at build
+// time restores the canonical form.  Same-box A/B on BN254 (gpurun_out/ab_lazy*.log): d_msm 8 x 2^20 12.40 against
+// 12.78 ms (-3 %), C4 599 against 592 proofs/s when compiled for four waves (at three waves the kernel takes 140
+// VGPRs and the table-free proof, whose MSMs overlap, loses 4 %).  The 12-limb base fields are left canonical: there
+// the lazy form spills (20 / 39 dwords at three waves) and C5 measures 1.31 against 1.285 s.
+#ifndef ZK_ACC_LAZY
+#define ZK_ACC_LAZY 1
+#endif
+template <class F>
+constexpr bool acc_lazy_v = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class P>
+constexpr bool acc_lazy_v<Fp<P>> = ZK_ACC_LAZY && Fp<P>::LAZY_OK && P::N <= 8;      // (the lazy operations exist in the device pass only)
+#endif
+
 template <class Fld>
 __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(const Affine<Fld>* __restrict__ bases0,
                                                             const Affine<Fld>* __restrict__ bases1,
@@ -997,6 +1012,9 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
       if (!skip_pt) {
         if (was_id) {
           acc = XYZZ<Fld>{pt.x, y2, Fld::one(), Fld::one()};
+        } else if constexpr (acc_lazy_v<Fld>) {
+          U2 = Fld::mul_lazy(pt.x, acc.ZZ);
+          S2 = Fld::mul_lazy(y2, acc.ZZZ);
         } else {
           U2 = pt.x * acc.ZZ;
           S2 = y2 * acc.ZZZ;
@@ -1009,7 +1027,28 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
     e = e1;
     pt = load_elem(bases + (e & 0x7fffffffu));
     e1 = sorted[p + 2 < b ? p + 2 : b - 1];
-    if (!skip_pt && !was_id) {
+    if constexpr (acc_lazy_v<Fld>) {
+      // the running sum as LAZY residues in [0, 2p) (field.hpp): no conditional subtraction behind eight of the ten products
+      if (!skip_pt && !was_id) {
+        const Fld P = Fld::sub_lazy(U2, acc.X);
+        const Fld R = Fld::sub_lazy(S2, acc.Y);
+        if (P.is_zero_lazy()) {
+          if (R.is_zero_lazy()) {
+            const Affine<Fld> q = load_elem(bases + (e_cur & 0x7fffffffu));
+            acc = xyzz_dbl_affine(q.x, (e_cur >> 31) ? q.y.neg() : q.y);
+          } else {
+            acc = XYZZ<Fld>::identity();
+          }
+        } else {
+          const Fld PP = Fld::mul_lazy(P, P);
+          const Fld PPP = Fld::mul_lazy(P, PP);
+          const Fld Q = Fld::mul_lazy(acc.X, PP);
+          const Fld X3 = Fld::sub_lazy(Fld::sub_lazy(Fld::mul_lazy(R, R), PPP), Fld::dbl_lazy(Q));
+          const Fld Y3 = Fld::mul_sub_mul_lazy(R, Fld::sub_lazy(Q, X3), acc.Y, PPP);
+          acc = XYZZ<Fld>{X3, Y3, Fld::mul_lazy(acc.ZZ, PP), Fld::mul_lazy(acc.ZZZ, PPP)};
+        }
+      }
+    } else if (!skip_pt && !was_id) {
       const Fld P = U2 - acc.X;
       const Fld R = S2 - acc.Y;
       if (P.is_zero()) {
@@ -1034,6 +1073,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
     }
     if (p + 1 == end_k || p + 1 == b) {             // the run ends: with its bucket, or with the range
       XYZZ<Fld>* dst = cont ? head + lane : (p + 1 == end_k ? buckets + k : tail + lane);
+      if constexpr (acc_lazy_v<Fld>) acc = XYZZ<Fld>{acc.X.canon(), acc.Y.canon(), acc.ZZ.canon(), acc.ZZZ.canon()};
       store_elem_untracked(dst, acc);
       // the lane in which a bucket BEGINS reports it when it spreads over many lanes (once per bucket and sort)
       if (!cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
