@@ -108,7 +108,10 @@ int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, 
 /* Parity-test access to the BASE-field primitives of the group kernels (arkworks' Fq / Fq2 arithmetic, a22; Montgomery Fq
  * elements on the device): op 0: out[i] = a[i] b[i] - c[i] d[i] (the one-reduction form used for Y3 of every XYZZ
  * formula); op 1: out[2i], out[2i+1] = (a[i] + b[i] u)(c[i] + d[i] u), u^2 = -1 (the Fq2 product of the G2 kernels: three
- * unreduced products and two reductions on 8-limb curves). */
+ * unreduced products and two reductions on 8-limb curves); op 2 + k, k < 16: the lazy-residue forms ([0, 2p), field.hpp)
+ * the G1 accumulate kernel keeps its running sums in, operand j entered as x + p when bit j of k is set: out[5i .. 5i+4] =
+ * a b, a - b, 2a, a b - c d (canonical; all-ones if a result left [0, 2p)) and the raw word
+ * (a == c mod p) | (a == 0 mod p) << 1 (out_d holds 5 len elements). */
 int zk_fq_selftest(zk_ctx* ctx, int op, const void* a_d, const void* b_d, const void* c_d, const void* d_d, size_t len,
                    void* out_d, void* stream);
 int zk_fft2_king(zk_ctx* ctx, const void* in_d, const uint32_t* parties, int nparties, int log2_m, int inverse,

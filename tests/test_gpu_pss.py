@@ -182,6 +182,20 @@ def test_base_field_primitives_of_the_group_kernels_on_edge_values(curve):
     pp.sync()
     got = pp.fq.decode(out.to_numpy().reshape(-1, pp.fq.nl)[:n])
     assert got == [(w * x - y * z) % q for w, x, y, z in zip(a, b, c, d)]
+    # the lazy residues of the G1 accumulate kernel ([0, 2p): field.hpp mul_lazy / sub_lazy / dbl_lazy / mul_sub_mul_lazy /
+    # is_zero_lazy), every operand entered both as x and as x + p
+    out5 = zk.DeviceBuffer(pp, 5 * n * pp.fq.nbytes)
+    for k in range(16):
+        pp._check(pp.lib.zk_fq_selftest(pp.h, 2 + k, da.ptr, db.ptr, dc.ptr, dd.ptr, n, out5.ptr, None))
+        pp.sync()
+        raw = out5.to_numpy().reshape(-1, 5, pp.fq.nl)
+        assert not (raw[:, :4] == 0xffffffff).all(axis=2).any(), "a lazy result left [0, 2p)"
+        for j, f in enumerate((lambda w, x, y, z: w * x, lambda w, x, y, z: w - x, lambda w, x, y, z: 2 * w,
+                               lambda w, x, y, z: w * x - y * z)):
+            got = pp.fq.decode(np.ascontiguousarray(raw[:, j]))
+            assert got == [f(w, x, y, z) % q for w, x, y, z in zip(a, b, c, d)], (k, j)
+        flags = raw[:, 4, 0].tolist()
+        assert flags == [(1 if w == y else 0) | (2 if w == 0 else 0) for w, y in zip(a, c)], k
     if curve == "bls12_377":
         with pytest.raises(zk.ZkError):
             pp._check(pp.lib.zk_fq_selftest(pp.h, 1, da.ptr, db.ptr, dc.ptr, dd.ptr, n, out.ptr, None))

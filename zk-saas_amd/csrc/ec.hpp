@@ -114,6 +114,37 @@ __global__ void fq_selftest_kernel(int op, const Fq* __restrict__ a, const Fq* _
   if (i >= n) return;
   if (op == 0) {
     out[i] = Fq::mul_sub_mul(a[i], b[i], c[i], d[i]);
+  } else if (op >= 2) {
+    // the lazy-residue operations of the accumulate kernel (field.hpp): operand k enters as x + p when bit k of op - 2 is
+    // set; every result must stay below 2p (all-ones is written otherwise) and is compared in canonical form
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Fq::LAZY_OK) {
+      auto lift = [&](const Fq& x, int k) {
+        if (!(((op - 2) >> k) & 1)) return x;
+        Fq r;
+        unsigned cy = 0;
+        for (int j = 0; j < Fq::N; j++) r.v[j] = __builtin_addc(x.v[j], Fq::Params::MOD[j], cy, &cy);
+        return r;
+      };
+      auto checked = [&](const Fq& x) {
+        const Fq w = Fq::wrap2p(x);                  // unchanged when x < 2p
+        bool same = true;
+        for (int j = 0; j < Fq::N; j++) same = same && w.v[j] == x.v[j];
+        Fq r = x.canon();
+        if (!same)
+          for (int j = 0; j < Fq::N; j++) r.v[j] = 0xffffffffu;
+        return r;
+      };
+      const Fq A = lift(a[i], 0), B = lift(b[i], 1), C = lift(c[i], 2), D = lift(d[i], 3);
+      out[5 * i] = checked(Fq::mul_lazy(A, B));
+      out[5 * i + 1] = checked(Fq::sub_lazy(A, B));
+      out[5 * i + 2] = checked(Fq::dbl_lazy(A));
+      out[5 * i + 3] = checked(Fq::mul_sub_mul_lazy(A, B, C, D));
+      Fq z = Fq::zero();
+      z.v[0] = (Fq::sub_lazy(A, C).is_zero_lazy() ? 1u : 0u) | (A.is_zero_lazy() ? 2u : 0u);
+      out[5 * i + 4] = z;
+    }
+#endif
   } else {
     using F2 = Fp2T<typename Fq::Params, INL>;
     const F2 z = F2{a[i], b[i]} * F2{c[i], d[i]};

@@ -456,12 +456,16 @@ class Engine : public IEngine {
   // Base-field primitives of the group kernels, exposed for the parity tests (edge values against Python integers):
   //   op 0: out[i] = a*b - c*d through Fp::mul_sub_mul (ONE reduction; Y3 of every XYZZ formula)
   //   op 1: out[2i], out[2i+1] = (a + b u)(c + d u) through the Fq2 product of the MSM kernels (lazy reduction on 8 limbs)
+  //   op 2 + k (k < 16): the lazy-residue operations of the G1 accumulate kernel with operand j entered as x + p when bit j
+  //         of k is set: out[5i ..] = a b, a - b, 2a, a b - c d (canonical; all-ones if a result left [0, 2p)), and the
+  //         raw word (a == c) | (a == 0) << 1 as is_zero_lazy sees them
   int fq_selftest(int op, const void* a, const void* b, const void* c, const void* d, size_t len, void* out,
                   hipStream_t st) override {
     using Fq = Fp<typename Cfg::FqP>;
     if (!len) return ZK_OK;
     if (!a || !b || !c || !d || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    if (op != 0 && op != 1) return fail(ZK_ERR_BAD_INPUT, "op must be 0 or 1");
+    if (op < 0 || op > 17) return fail(ZK_ERR_BAD_INPUT, "op must be 0 .. 17");
+    if (op >= 2 && !Fq::LAZY_OK) return fail(ZK_ERR_BAD_INPUT, "this base field has no lazy form");
     if (op == 1 && !Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     fq_selftest_kernel<Fq, (Fq::N == 8)><<<dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st>>>(
         op, (const Fq*)a, (const Fq*)b, (const Fq*)c, (const Fq*)d, len, (Fq*)out);
