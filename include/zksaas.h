@@ -243,7 +243,7 @@ int zk_msm_forget(zk_ctx* ctx, const void* bases_d);
 int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
 /* Tunables of this context (no reference counterpart).  "rng_replay": see "share randomness".  "msm_bigsort_min": point count from which zk_msm sorts with
  * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
- * "msm_table_c": window bits (8..20, default 16 for G1, 15 for G2; "msm_table_c_g2" sets G2 alone) of tables built by later zk_msm_precompute calls.
+ * "msm_table_c": window bits (8..22, default 16 for G1, 15 for G2; "msm_table_c_g2" sets G2 alone) of tables built by later zk_msm_precompute calls.
  * "king_alltoall": 1 = the zk_dist_* king rounds of d_fft / d_ifft / deg_red (and everything composed of them) run as
  * all-to-all: every present rank is king of a contiguous chunk range (zk_net_alltoall twice per round) instead of
  * gather -> rank 0 -> scatter; identical results; every rank of a net must choose alike (default 0, or ZK_KING_ALLTOALL=1).

@@ -289,15 +289,18 @@ def test_msm_batch_at_every_lane_shape_equals_single_msms(table):
             assert [wire.jacobian_to_affine(pp, got[b], g2) for b in range(nb)] == single[:nb], (group, nb)
 
 
-def test_table_msm_with_wide_sort_entries_equals_the_table_free_msm():
+@pytest.mark.parametrize("log_n", [21, 22])
+def test_table_msm_with_wide_sort_entries_equals_the_table_free_msm(log_n):
     """2^21 points with a fixed-base table: the sorted entry's index (window * stride + point: 25 bits) + sign + low bucket
     bits no longer fit one 32-bit word, so the sort runs on its WIDE entry format (word + 16-bit low part) through the
-    small-launch kernels -- a combination no other test reaches.  Same group element as the table-free MSM of the same
-    vectors (which the other tests pin on the oracle), and as the sum of its two halves."""
+    small-launch kernels -- a combination no other test reaches.  2^22 points: the same through the STAGED (1024-thread)
+    sort kernels, whose tile shrinks to one point per thread so that a tile's 16 windows fit the stage (round 4 found
+    that launch shape faulting: the scatter kernel ignored the shrunken tile).  Same group element as the table-free MSM
+    of the same vectors (which the other tests pin on the oracle)."""
     from zksaas_amd import api, groth16 as zg, wire
     from zksaas_amd.api import ZK_G1
     pp = ctx("bn254", 2)
-    n = 1 << 21
+    n = 1 << log_n
     rng = np.random.default_rng(8)
 
     def rand(count):

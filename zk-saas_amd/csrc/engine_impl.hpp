@@ -1162,7 +1162,9 @@ class Engine : public IEngine {
       rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
       if (rc) return rc;
       ZK_HIP(hipEventRecord(ev_gate_[j.slot], streams_[5]));
-      gate_v.wait_ev = gate_g1.wait_ev = ev_gate_[j.slot];      // recorded before any task runs: no host flag needed
+      static const bool gate_v_too = !(getenv("ZK_H_GATE_V") && atoi(getenv("ZK_H_GATE_V")) == 0);
+      gate_g1.wait_ev = ev_gate_[j.slot];                       // recorded before any task runs: no host flag needed
+      if (gate_v_too) gate_v.wait_ev = ev_gate_[j.slot];
       h_done = true;
     }
     // ZK_H_ENQUEUE_FIRST=1 (round 4, measured, off): circom_h's kernels ENQUEUED before the pool tasks start launching the
@@ -1975,12 +1977,12 @@ class Engine : public IEngine {
       return ZK_OK;
     }
     if (!strcmp(name, "msm_table_c")) {
-      if (value < 8 || value > 20) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be in 8..20");
+      if (value < 8 || value > 22) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be in 8..22");
       msm_.table_c = msm_.table_c_g2 = (int)value;
       return ZK_OK;
     }
     if (!strcmp(name, "msm_table_c_g2")) {
-      if (value < 8 || value > 20) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be in 8..20");
+      if (value < 8 || value > 22) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be in 8..22");
       msm_.table_c_g2 = (int)value;
       return ZK_OK;
     }

@@ -1457,7 +1457,8 @@ inline int msm_pick_c(size_t npts, bool g2 = false) {
 
 // Accumulate lanes of a launch with at most `max_entries` sorted entries (msm.hpp "balanced partition"): entries per
 // lane `t` and the lane count that covers max_entries at that length.  Measured on batches of 1 / 2 / 4 / 8 119k-point
-// MSMs alone on the chip (1.9 M .. 15 M entries; the chip holds 196 608 lanes at three waves per SIMD;
+// MSMs alone on the chip (1.9 M .. 15 M entries; the chip holds 196 608 lanes at three waves per SIMD, 262 144 at the four
+// the BN254 kernel is compiled for since round 4;
 // profiles/r03_range_sweep.txt): what matters is how many ROUNDS of waves a launch makes -- >= 1.6 rounds run at
 // 98-116 G multiplications/s, exactly one round at 79 (a grid that just fills the chip leaves the dispatcher no slack and
 // all its waves march in step), fewer than one underfills -- while every lane boundary costs one full addition (14

@@ -229,15 +229,28 @@ do {                                                                           \
     if (large) {
       const unsigned tpv = (unsigned)((npts + tile_pts - 1) / tile_pts);
       const size_t l1 = (2 * nbl + (size_t)(sthr / 64)) * 4 + stage_cap * (wide_fmt ? 8 : 6);
-#define ZK_SCATTER(W_)                                                                                                  \
+      // the points per thread are a template parameter of the staged scatter (its scalars live in registers): with a
+      // table the whole tile is one round of nwin windows and the tile shrinks to fit the stage (ppt 4 / 2 / 1)
+#define ZK_SCATTER(P_, W_)                                                                                              \
   do {                                                                                                                 \
-    if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_>, l1, eng->device)); \
-    msm_scatter_kernel<FrP, 1024, BIG_PTS_PER_THREAD, W_><<<dim3(tpv * (unsigned)batch, NS), dim3(1024), l1, st>>>(    \
+    if (l1 > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_scatter_kernel<FrP, 1024, P_, W_>, l1, eng->device));    \
+    msm_scatter_kernel<FrP, 1024, P_, W_><<<dim3(tpv * (unsigned)batch, NS), dim3(1024), l1, st>>>(                    \
         sc, c, w_end, wide, sort_hi, sort_lo, tpv, wmask, w_begin, wgroup, pre_stride, pre_off, idx_bits, (uint32_t)stage_cap,   \
         bins, tmp, tmp_lo, canon, tcnt, ys);                                                                           \
   } while (0)
-      if (wide_fmt) ZK_SCATTER(true);
-      else ZK_SCATTER(false);
+#define ZK_SCATTER_P(P_)                  \
+  do {                                    \
+    if (wide_fmt) ZK_SCATTER(P_, true);   \
+    else ZK_SCATTER(P_, false);           \
+  } while (0)
+      switch (ppt) {
+        case BIG_PTS_PER_THREAD: ZK_SCATTER_P(BIG_PTS_PER_THREAD); break;
+        case 4: ZK_SCATTER_P(4); break;
+        case 2: ZK_SCATTER_P(2); break;
+        case 1: ZK_SCATTER_P(1); break;
+        default: return eng->fail(ZK_ERR_GENERIC, "msm: unsupported scatter tile");
+      }
+#undef ZK_SCATTER_P
 #undef ZK_SCATTER
     } else {
       const unsigned tpv = (unsigned)((npts + (size_t)BIG_THREADS * ppt - 1) / ((size_t)BIG_THREADS * ppt));
