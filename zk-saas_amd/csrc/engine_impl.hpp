@@ -1977,12 +1977,12 @@ class Engine : public IEngine {
       return ZK_OK;
     }
     if (!strcmp(name, "msm_table_c")) {
-      if (value < 8 || value > 22) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be in 8..22");
+      if (value != 0 && (value < 8 || value > 22)) return fail(ZK_ERR_BAD_INPUT, "msm_table_c must be 0 (by length) or in 8..22");
       msm_.table_c = msm_.table_c_g2 = (int)value;
       return ZK_OK;
     }
     if (!strcmp(name, "msm_table_c_g2")) {
-      if (value < 8 || value > 22) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be in 8..22");
+      if (value != 0 && (value < 8 || value > 22)) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be 0 (by length) or in 8..22");
       msm_.table_c_g2 = (int)value;
       return ZK_OK;
     }

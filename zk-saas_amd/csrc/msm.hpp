@@ -1936,15 +1936,28 @@ class MsmRunner {
   }
 
   // ---- fixed-base tables (zk_msm_precompute): process-wide registry keyed by address (engine.hpp TableRegistry)
-  int table_c = 16;               // window bits of new tables (zk_ctx_set_option "msm_table_c")
-  // ... of G2 tables ("msm_table_c_g2").  15 bits = 17 windows, 16 384 buckets: 6 % more mixed additions than 16 bits but
-  // half the buckets in the G2 reduction, the latency chain a proof ends with (458-477 vs 423-453 proofs/s, same box).
-  int table_c_g2 = getenv("ZK_TABLE_C_G2") ? atoi(getenv("ZK_TABLE_C_G2")) : 15;
+  // Window bits of new tables: 0 = by the vector's length (below), else what zk_ctx_set_option "msm_table_c" /
+  // "msm_table_c_g2" (env ZK_TABLE_C_G2 at start) asked for.  A table folds all windows into ONE set of 2^(c-1) buckets, so a
+  // bucket receives len * nwin / 2^(c-1) entries: once that is more than FIN_SEQ (16) accumulate ranges long, every
+  // bucket goes through the heavy-bucket path meant for degenerate scalars and the MSM is 2-3x slower than table-free
+  // (measured, tools/tab_c3.py, G1 d_msm over 2^19 / 2^20 / 2^23 points: c = 16 2.53 / 3.48 / 18.8 ms, c = 17 1.10 /
+  // 1.95 / 20.7, c = 20 1.45 / 2.2 / 11.8; table-free 1.59 / 2.77 / 12.7; below 2^19 points c = 16 is best: 0.78 against
+  // 1.15 ms table-free at 2^18).  G1: 16 bits below 2^19 points, 17 (15 windows) below 2^22, 20 (13 windows) from there.
+  // G2: 15 bits = 17 windows, 16 384 buckets below 2^20 points (6 % more mixed additions than 16 bits but half the
+  // buckets in the G2 reduction, the latency chain a proof ends with: 458-477 vs 423-453 proofs/s, same box), 19 (14
+  // windows) from there (2^21 points: 11.1 ms against 17.8 at 15 bits and 11.8 table-free).
+  int table_c = 0;
+  int table_c_g2 = getenv("ZK_TABLE_C_G2") ? atoi(getenv("ZK_TABLE_C_G2")) : 0;
+  static int table_c_auto(size_t len, bool g2) {
+    if (g2) return len < ((size_t)1 << 20) ? 15 : 19;
+    return len < ((size_t)1 << 19) ? 16 : len < ((size_t)1 << 22) ? 18 : 20;
+  }
   template <class Fld>
   int precompute_t(IEngine* eng, const void* bases, size_t len, hipStream_t st) {
     if (!bases || !len) return eng->fail(ZK_ERR_BAD_INPUT, "null base vector");
     const int T = FrP::BITS + 1;
-    const int tc = IsExtField<Fld>::value ? table_c_g2 : table_c;
+    const int tc_opt = IsExtField<Fld>::value ? table_c_g2 : table_c;
+    const int tc = tc_opt > 0 ? tc_opt : table_c_auto(len, IsExtField<Fld>::value);
     const int nwin = (T + tc - 1) / tc;
     const int c = (T + nwin - 1) / nwin;
     if ((size_t)nwin * len >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "base vector too long for a table");

@@ -258,6 +258,19 @@ def bench(args, rank, local_rank, world):
         bases = zg.base_points(pp, ZK_G1, _rand_fr(pp, k * ln, 300 + rank), k * ln)
         sc = _rand_fr(pp, k * ln, 200 + rank)
         dt = timed(lambda i: znet.dist_d_msm(pp, net, 0, ZK_G1, bases, sc, ln))
+        # the same d_msm over a REGISTERED base vector (zk_msm_precompute: a prover's CRS is fixed; window bits by the
+        # vector's length): a side figure, `value` stays the reference's call (bases handed over per call, no table)
+        fixed = None
+        if not args.no_tables:
+            from .api import msm_forget, msm_precompute, msm_table_info
+            msm_precompute(pp, ZK_G1, bases, k * ln)
+            try:
+                dtf = timed(lambda i: znet.dist_d_msm(pp, net, 0, ZK_G1, bases, sc, ln))
+                info = msm_table_info(pp, ZK_G1, bases)
+            finally:
+                msm_forget(pp, bases)
+            fixed = {"value": round(args.steps / dtf, 3), "ms_per_step": round(per(dtf) * 1e3, 4), "table": info,
+                     "table_GB_per_rank": round(info["windows"] * k * ln * 2 * pp.fq.nbytes / 2**30, 2)}
         alg = pp.n * ln * 96
         from .api import msm_plan
         plan = msm_plan(pp, ZK_G1, k * ln)
@@ -265,7 +278,7 @@ def bench(args, rank, local_rank, world):
         gbs, gm = alg / per(dt) / 1e9, muls / per(dt) / 1e9
         res = dict(base, metric="d_msm per second (2^20 G1 points per party, BN254)", value=round(args.steps / dt, 3),
                    unit="d_msm/s", ms_per_step=round(per(dt) * 1e3, 4), scaling="strong",
-                   points_per_sec=round(pp.n * ln * args.steps / dt, 1),
+                   points_per_sec=round(pp.n * ln * args.steps / dt, 1), fixed_base=fixed,
                    data="synthetic: seeded random multiples of the generator as bases, seeded scalars",
                    config={"workload": "BASELINE configs[2]: d_msm 2^20 G1 Pippenger per party (BN254), 8 parties",
                            "plan": plan},
