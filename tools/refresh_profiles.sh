@@ -13,7 +13,7 @@ for v in c4 c4tf c2 c3 b8 b8x2 b8wide; do
     c4) A="--no-cpu-baseline --no-primitives --steps 20 --warmup 5";;
     c4tf) A="--no-cpu-baseline --no-primitives --no-tables --steps 20 --warmup 5";;
     c2) A="--workload c2 --no-cpu-baseline --steps 10 --warmup 3";;
-    c3) A="--workload c3 --no-cpu-baseline --steps 5 --warmup 2";;
+    c3) A="--workload c3 --no-cpu-baseline --no-tables --steps 5 --warmup 2";;
     b8) P=tools/batch_probe.py; A="8 --reps 4";;
     b8x2) P=tools/batch_probe.py; A="8 --reps 6 --inflight 2";;
     b8wide) P=tools/batch_probe.py; A="8 --reps 4"; export ZK_QUAD_THREADS=256; export ZK_BATCH_ORDER=-;;
@@ -27,7 +27,7 @@ for v in c4 c4tf c2 c3 b8 b8x2 b8wide; do
   fi
 done
 rm -rf $O/pmc_sq $O/pmc_u $O/pmc_sq_b8
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python3 $R/bench.py --workload c3 --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o p -- python3 $R/bench.py --workload c3 --no-cpu-baseline --no-tables --steps 5 --warmup 2 > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_u -o p -- python3 $R/bench.py --no-cpu-baseline --no-primitives --steps 10 --warmup 3 > $O/pmc_u.log 2>&1
 rm -rf $O/pmc_c2a $O/pmc_c2b
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/pmc_c2a -o p -- python3 $R/bench.py --workload c2 --no-cpu-baseline --steps 5 --warmup 2 > $O/pmc_c2a.log 2>&1

@@ -945,7 +945,7 @@ static __global__ __launch_bounds__(256) void msm_lane_start_kernel(const uint32
 }
 
 // Base fields whose running sums the accumulate kernel keeps as lazy residues (field.hpp, LAZY_OK); ZK_ACC_LAZY=0 at build
-// time restores the canonical form.  Same-box A/B on BN254 (gpurun_out/ab_lazy*.log): d_msm 8 x 2^20 12.40 against
+// time restores the canonical form.  Same-box A/B on BN254 (profiles/r04_acc_lazy_ab.txt): d_msm 8 x 2^20 12.40 against
 // 12.78 ms (-3 %), C4 599 against 592 proofs/s when compiled for four waves (at three waves the kernel takes 140
 // VGPRs and the table-free proof, whose MSMs overlap, loses 4 %).  The 12-limb base fields are left canonical: there
 // the lazy form spills (20 / 39 dwords at three waves) and C5 measures 1.31 against 1.285 s.
