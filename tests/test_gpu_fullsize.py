@@ -77,6 +77,35 @@ def test_msm_2_20_equals_c_oracle():
     assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
 
 
+@pytest.mark.parametrize("table", [False, True])
+def test_msm_2_20_with_repeating_scalars_equals_c_oracle(table):
+    """Real witnesses repeat values (boolean wires): 60 % of the scalars are 1, 25 % are 5, 5 % are r - 1, the rest random.
+    Buckets of hundreds of thousands of entries, spread over thousands of accumulate lanes, go through the heavy list with
+    SEVERAL virtual workgroups each (msm_heavy_kernel's chunk sums + the finalize kernel's extra workgroups: round 4,
+    found as a 135 ms single-workgroup walk in the 2^24-constraint BLS12-381 proof); with a table all windows share the
+    bucket set."""
+    from zksaas_amd import api
+    pp = ctx("bn254", 2)
+    cp = CPss("bn254", 2)
+    n = 1 << 20
+    bases = cp.doubling_chain_g1(BN254.g1, n)
+    scalars = _rand_fr_array(n, 16)
+    sel = np.random.default_rng(17).random(n)
+    for lo, hi, val in ((0.0, 0.6, 1), (0.6, 0.85, 5), (0.85, 0.9, BN254.r - 1)):
+        scalars[(sel >= lo) & (sel < hi)] = pp.fr.encode([val])[0]
+    bd = zk.DeviceBuffer.from_numpy(pp, bases)
+    if table:
+        api.msm_precompute(pp, ZK_G1, bd, n)
+    try:
+        got = msm(pp, ZK_G1, bd, zk.DeviceBuffer.from_numpy(pp, scalars), n)
+    finally:
+        if table:
+            api.msm_forget(pp, bd)
+    want = cp.msm_g1_arrays(bases, scalars, n, nthreads=8)
+    G = g1(BN254)
+    assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
+
+
 def test_d_msm_2_17_per_party_equals_c_oracle():
     """d_msm with 2^17 points per party (8 parties, fused into one 2^20-point Pippenger on the GPU)."""
     pp = ctx("bn254", 2)

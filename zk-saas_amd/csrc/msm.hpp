@@ -944,6 +944,27 @@ static __global__ __launch_bounds__(256) void msm_lane_start_kernel(const uint32
   k0[lane] = msm_bucket_of(offsets, nkeys, lane * T);
 }
 
+// HEAVY LIST (buckets spread over more than FIN_SEQ accumulate lanes).  heavy[0..1] is ONE 64-bit counter {buckets listed :
+// high word | virtual workgroups reserved : low word}; entry i (in the order of the counter's high word) is {bucket id,
+// first virtual workgroup} at heavy[2 + 2 i].  A bucket of L lanes reserves S = 1 + L / 256 virtual workgroups, at most 1024
+// (msm_heavy_kernel: each sums a chunk of L / S lanes; the chunk sums of a bucket with S > 1 go to hpart[] and the finalize
+// kernel's extra workgroups sum them) -- round 4: a 2^24-constraint BLS12-381 proof has buckets of a million lanes
+// (witness values that repeat), and ONE 16-quad workgroup walking such a bucket took 135 ms of a 1.28 s proof.
+ZK_D uint32_t msm_heavy_splits(uint32_t L) {          // (integer only: this sits in the accumulate kernel's flush block)
+  const uint32_t s = 1 + (L >> 8);
+  return s < 1024 ? s : 1024;
+}
+ZK_D void msm_report_heavy(uint32_t* __restrict__ heavy, uint32_t k, uint32_t L) {
+  const unsigned long long old =
+      atomicAdd(reinterpret_cast<unsigned long long*>(heavy), (1ull << 32) | (unsigned long long)msm_heavy_splits(L));
+  const uint32_t slot = (uint32_t)(old >> 32);
+  heavy[2 + 2 * slot] = k;
+  heavy[3 + 2 * slot] = (uint32_t)old;
+}
+// capacity of the list (entries) and of hpart[] (virtual workgroups) for a launch of nlanes accumulate lanes
+inline size_t msm_heavy_cap(size_t nlanes) { return nlanes / FIN_SEQ + 8; }
+inline size_t msm_heavy_vcap(size_t nlanes) { return nlanes / FIN_SEQ + nlanes / 256 + 8; }
+
 // Base fields whose running sums the accumulate kernel keeps as lazy residues (field.hpp, LAZY_OK); ZK_ACC_LAZY=0 at build
 // time restores the canonical form.  Same-box A/B on BN254 (profiles/r04_acc_lazy_ab.txt): d_msm 8 x 2^20 12.40 against
 // 12.78 ms (-3 %), C4 599 against 592 proofs/s when compiled for four waves (at three waves the kernel takes 140
@@ -967,7 +988,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
                                                             uint32_t nlanes, uint32_t tmin, uint32_t cap,
                                                             XYZZ<Fld>* __restrict__ buckets0,
                                                             XYZZ<Fld>* __restrict__ edge0 /* [NB][2][nlanes]: head, tail */,
-                                                            uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
+                                                            uint32_t* __restrict__ heavy /* the heavy list (msm_report_heavy) */,
                                                             const uint32_t* __restrict__ k0, size_t ys, int prio) {
   // prio != 0: the MSM at the END of a proof's critical chain (U, behind circom_h): its waves win issue arbitration against
   // the accumulate waves of the witness MSMs that still share the SIMDs when it starts (they have slack, it has none)
@@ -1077,7 +1098,7 @@ __global__ __launch_bounds__(128, ACC_WAVES<Fld>) void msm_accumulate_kernel(con
       store_elem_untracked(dst, acc);
       // the lane in which a bucket BEGINS reports it when it spreads over many lanes (once per bucket and sort)
       if (!cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
-        heavy[1 + atomicAdd(heavy, 1u)] = k;        // at most nlanes / FIN_SEQ such buckets: the list's capacity
+        msm_report_heavy(heavy, k, (end_k - 1) / T - lane);        // at most nlanes / FIN_SEQ such buckets: the list's capacity
       acc = XYZZ<Fld>::identity();
       cont = false;
       k += p + 1 == end_k ? 1u : 0u;                // (the last step of the range may leave k one past: unused)
@@ -1143,7 +1164,7 @@ __global__ __launch_bounds__(128, SPLIT_WAVES<P>) void msm_accumulate_split_kern
       store_elem(dst + q, acc.c0);                         // X | Y
       store_elem(dst + 4 + q, acc.c1);                     // ZZ | ZZZ
       if (q == 0 && !cont && p + 1 != end_k && (blockIdx.y == 0 || ys != 0) && (end_k - 1) / T - lane > FIN_SEQ)
-        heavy[1 + atomicAdd(heavy, 1u)] = k;
+        msm_report_heavy(heavy, k, (end_k - 1) / T - lane);
       acc = split_identity<P>(comp);
       cont = false;
       if (p + 1 < b) {
@@ -1189,37 +1210,50 @@ inline int quad_threads(bool batched) {
   return batched ? 64 : 256;          // one proof at a time: 256 measured better (451 vs 409 proofs/s)
 }
 
-// Buckets spread over more than FIN_SEQ accumulate lanes (listed by the lanes they begin in): a whole workgroup sums one
-// at a time -- strided accumulation over its 64 quads, then a tree -- so that no quad walks a long chain.  The list is
-// empty for well-spread scalars and the launch ends at once.  grid.y = base vector; with two sorts (ys != 0) each has
-// its own list, with one shared sort both vectors use list 0.
+// Buckets spread over more than FIN_SEQ accumulate lanes (listed by the lanes they begin in, msm_report_heavy): one-wave
+// workgroups, one VIRTUAL workgroup at a time (grid-stride): strided accumulation over its 16 quads, then a tree, so
+// that no quad walks a long chain.  A bucket with one virtual workgroup is finished here; the chunk sums of a longer one go
+// to hpart[] and are summed by the finalize kernel's extra workgroups.  The list is empty for well-spread scalars and the
+// launch ends at once.  grid.y = base vector; with two sorts (ys != 0) each has its own list, with one shared sort both
+// vectors use list 0.
 template <class Fld>
-__global__ __launch_bounds__(QUAD_THREADS, 2) void msm_heavy_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes,
-                                                                uint32_t tmin, uint32_t cap,
-                                                                const uint32_t* __restrict__ offsets, uint32_t nkeys,
-                                                                XYZZ<Fld>* __restrict__ buckets0,
-                                                                const uint32_t* __restrict__ heavy, size_t ys) {
+__global__ __launch_bounds__(64) void msm_heavy_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes, uint32_t tmin,
+                                                       uint32_t cap, const uint32_t* __restrict__ offsets, uint32_t nkeys,
+                                                       XYZZ<Fld>* __restrict__ buckets0,
+                                                       const uint32_t* __restrict__ heavy,
+                                                       XYZZ<Fld>* __restrict__ hpart0, uint32_t vcap, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(offsets);
   ZK_YSHIFT(heavy);
-  const uint32_t nh = heavy[0];
-  if (blockIdx.x >= nh) return;
+  const uint32_t nh = heavy[1], V = heavy[0];                  // (little-endian halves of the 64-bit counter)
+  if (blockIdx.x >= V) return;
   const XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
   const XYZZ<Fld>* __restrict__ tail = head + nlanes;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
+  XYZZ<Fld>* __restrict__ hpart = hpart0 + (size_t)blockIdx.y * vcap;
   extern __shared__ uint4 smem_fin[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
   const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin, cap);
   const int q = threadIdx.x & 3, vl = threadIdx.x >> 2;
-  for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-    const uint32_t kh = heavy[1 + h];
+  const int nq = (int)blockDim.x / 4;                   // quads of this workgroup
+  for (uint32_t v = blockIdx.x; v < V; v += gridDim.x) {
+    // the listed bucket this virtual workgroup belongs to: the last entry whose first virtual workgroup is <= v
+    uint32_t lo = 0, hi = nh;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (heavy[3 + 2 * mid] <= v) lo = mid;
+      else hi = mid;
+    }
+    const uint32_t kh = heavy[2 + 2 * lo], vb = heavy[3 + 2 * lo];
+    const uint32_t S = (lo + 1 < nh ? heavy[3 + 2 * (lo + 1)] : V) - vb, s = v - vb;
     const uint32_t o0 = offsets[kh], o1 = offsets[kh + 1];
     const uint32_t l0 = o0 / T, l1 = (o1 - 1) / T;
-    Fld acc = vl == 0 ? qload(tail + l0, q) : qidentity<Fld>(q);
-    const int nq = (int)blockDim.x / 4;                 // quads of this workgroup
-    for (uint32_t l = l0 + 1 + vl; l <= l1; l += (uint32_t)nq) acc = qadd(acc, qload(head + l, q), q);
+    const uint32_t chunk = (l1 - l0 + S - 1) / S;
+    const uint32_t first = l0 + 1 + s * chunk, last = first + chunk - 1 < l1 ? first + chunk - 1 : l1;
+    Fld acc = (s == 0 && vl == 0) ? qload(tail + l0, q) : qidentity<Fld>(q);
+    for (uint32_t l = first + (uint32_t)vl; l <= last; l += (uint32_t)nq) acc = qadd(acc, qload(head + l, q), q);
     acc = wg_quad_sum(acc, sh, vl, q, nq);
-    if (vl == 0) qstore(buckets + kh, q, acc);
+    if (vl == 0) qstore(S == 1 ? buckets + kh : hpart + v, q, acc);
     __syncthreads();
   }
 }
@@ -1234,18 +1268,40 @@ template <class Fld>
 __global__ __launch_bounds__(FIN_THREADS) void msm_finalize_kernel(const XYZZ<Fld>* __restrict__ edge0, uint32_t nlanes,
                                                                uint32_t tmin, uint32_t cap,
                                                                const uint32_t* __restrict__ offsets, uint32_t nkeys,
-                                                               XYZZ<Fld>* __restrict__ buckets0, size_t ys) {
+                                                               XYZZ<Fld>* __restrict__ buckets0,
+                                                               const uint32_t* __restrict__ heavy,
+                                                               const XYZZ<Fld>* __restrict__ hpart0, uint32_t vcap,
+                                                               uint32_t fin_wgs, size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(offsets);
   const XYZZ<Fld>* __restrict__ head = edge0 + (size_t)blockIdx.y * 2 * nlanes;
   const XYZZ<Fld>* __restrict__ tail = head + nlanes;
   XYZZ<Fld>* __restrict__ buckets = buckets0 + (size_t)blockIdx.y * nkeys;
-  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin, cap);
   const int q = threadIdx.x & 3;
+  if (blockIdx.x >= fin_wgs) {
+    // extra workgroups: the chunk sums msm_heavy_kernel left for buckets with several virtual workgroups
+    ZK_YSHIFT(heavy);
+    const uint32_t nh = heavy[1], V = heavy[0];
+    const XYZZ<Fld>* __restrict__ hpart = hpart0 + (size_t)blockIdx.y * vcap;
+    extern __shared__ uint4 smem_fin[];
+    XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_fin);
+    const int vl = threadIdx.x >> 2;
+    for (uint32_t h = blockIdx.x - fin_wgs; h < nh; h += gridDim.x - fin_wgs) {
+      const uint32_t vb = heavy[3 + 2 * h], S = (h + 1 < nh ? heavy[3 + 2 * (h + 1)] : V) - vb;
+      if (S == 1) continue;                             // (workgroup-uniform)
+      Fld acc = qidentity<Fld>(q);
+      for (uint32_t j = (uint32_t)vl; j < S; j += FIN_THREADS / 4) acc = qadd(acc, qload(hpart + vb + j, q), q);
+      acc = wg_quad_sum(acc, sh, vl, q, FIN_THREADS / 4);
+      if (vl == 0) qstore(buckets + heavy[2 + 2 * h], q, acc);
+      __syncthreads();
+    }
+    return;
+  }
+  const uint32_t T = msm_range_len(offsets[nkeys], nlanes, tmin, cap);
   // grid-stride over the buckets: the launch is capped so that it does not queue thousands of workgroups behind the
   // accumulate waves
   for (size_t k = (size_t)blockIdx.x * (FIN_THREADS / 4) + (threadIdx.x >> 2); k < nkeys;
-       k += (size_t)gridDim.x * (FIN_THREADS / 4)) {
+       k += (size_t)fin_wgs * (FIN_THREADS / 4)) {
     const uint32_t o0 = offsets[k], o1 = offsets[k + 1];
     if (o0 == o1) {
       qstore(buckets + k, q, qidentity<Fld>(q));

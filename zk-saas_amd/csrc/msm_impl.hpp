@@ -126,7 +126,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const int wgroup = tab ? nwin : (int)std::min<size_t>((size_t)nwin, std::max<size_t>(1, stage_cap / tile_pts));
   const size_t nbins_tot = nsets << sort_hi;
   // ---- sort region (replicated NS times)
-  size_t o_counts = take(nkeys * 4), o_heavy = take(((size_t)nlanes / FIN_SEQ + 8) * 4),
+  size_t o_counts = take(nkeys * 4), o_heavy = take(msm_heavy_cap(nlanes) * 8 + 16),
          o_bins = take(big ? msm_bins_words(nbins_tot) * 4 : 0),     // right behind the heavy list: one zeroing launch
          o_cursor = take(nkeys * 4), o_offsets = take((nkeys + 1) * 4), o_bt = take(iscan_blocks * 4),
          o_sorted = take(max_sorted * 4);
@@ -149,6 +149,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   off = sort_region * NS;
   // ---- per base vector
   size_t o_edge = take(NB * 2 * (size_t)nlanes * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
+         o_hpart = take(NB * msm_heavy_vcap(nlanes) * sizeof(XYZZ<Fld>)),      // chunk sums of split heavy buckets
          o_rc = take(NB * nsets * red_groups * sizeof(XYZZ<Fld>)),
          o_out = take(NB * nsets * nslices * sizeof(XYZZ<Fld>));
   hipError_t he = slot.ws.ensure(off);
@@ -173,6 +174,8 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   XYZZ<KF>* edge = (XYZZ<KF>*)(ws + o_edge);         // per base vector: head[nlanes], tail[nlanes]
   XYZZ<KF>* buckets = (XYZZ<KF>*)(ws + o_buckets);
   XYZZ<KF>* rc = (XYZZ<KF>*)(ws + o_rc);
+  XYZZ<KF>* hpart = (XYZZ<KF>*)(ws + o_hpart);
+  const uint32_t vcap = (uint32_t)msm_heavy_vcap(nlanes);
   XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
 
 #define MSM_HIP(x)                                           \
@@ -325,14 +328,17 @@ do {                                                                           \
   // buckets spread over many lanes (none for well-spread scalars: the workgroups read a zero count and leave)
   // (always one-wave workgroups: with 256 threads this launch, which normally reads one word and leaves, waited 90-150 us
   // for four free wave slots on one CU in a single proof's timeline)
-  msm_heavy_kernel<KF><<<dim3(256, NB), dim3(64), (size_t)16 * sizeof(XYZZ<Fld>), st>>>(edge, nlanes, tmin, cap, offsets, (uint32_t)nkeys,
-                                                                   buckets, heavy, ys);
+  msm_heavy_kernel<KF><<<dim3(2048, NB), dim3(64), (size_t)16 * sizeof(XYZZ<Fld>), st>>>(edge, nlanes, tmin, cap, offsets, (uint32_t)nkeys,
+                                                                    buckets, heavy, hpart, vcap, ys);
   MSM_STAGE("heavy buckets");
   {
     // capped grid (grid-stride inside): enough one-wave workgroups to cover the chip a few times over
     const size_t fin_wgs = std::min<size_t>((nkeys + FIN_THREADS / 4 - 1) / (FIN_THREADS / 4), 8192);
-    msm_finalize_kernel<KF><<<dim3((unsigned)fin_wgs, NB), dim3(FIN_THREADS), 0, st>>>(edge, nlanes, tmin, cap, offsets,
-                                                                                    (uint32_t)nkeys, buckets, ys);
+    // + workgroups that sum the chunk sums of split heavy buckets (they read the list's counter and leave, normally)
+    const unsigned fin_extra = 256;
+    msm_finalize_kernel<KF><<<dim3((unsigned)fin_wgs + fin_extra, NB), dim3(FIN_THREADS),
+                              (size_t)(FIN_THREADS / 4) * sizeof(XYZZ<Fld>), st>>>(
+        edge, nlanes, tmin, cap, offsets, (uint32_t)nkeys, buckets, heavy, hpart, vcap, (uint32_t)fin_wgs, ys);
   }
   MSM_STAGE("finalize");
   // quads per group: few groups (one bucket set) -> whole workgroups per group, shortest dependent chain; many groups
