@@ -77,8 +77,8 @@ def test_msm_2_20_equals_c_oracle():
     assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
 
 
-@pytest.mark.parametrize("table", [False, True])
-def test_msm_2_20_with_repeating_scalars_equals_c_oracle(table):
+@pytest.mark.parametrize("table,log_n", [(False, 20), (True, 20), (False, 22)])
+def test_msm_2_20_with_repeating_scalars_equals_c_oracle(table, log_n):
     """Real witnesses repeat values (boolean wires): 60 % of the scalars are 1, 25 % are 5, 5 % are r - 1, the rest random.
     Buckets of hundreds of thousands of entries, spread over thousands of accumulate lanes, go through the heavy list with
     SEVERAL virtual workgroups each (msm_heavy_kernel's chunk sums + the finalize kernel's extra workgroups: round 4,
@@ -87,7 +87,7 @@ def test_msm_2_20_with_repeating_scalars_equals_c_oracle(table):
     from zksaas_amd import api
     pp = ctx("bn254", 2)
     cp = CPss("bn254", 2)
-    n = 1 << 20
+    n = 1 << log_n                  # 2^22: the staged (1024-thread) sort kernels, one bin holding 60 % of the entries
     bases = cp.doubling_chain_g1(BN254.g1, n)
     scalars = _rand_fr_array(n, 16)
     sel = np.random.default_rng(17).random(n)
