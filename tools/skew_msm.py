@@ -10,7 +10,6 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import zksaas_amd as zk  # noqa: E402
 from zksaas_amd import groth16 as zg  # noqa: E402
 from zksaas_amd.api import ZK_G1, msm  # noqa: E402
-from oracle.params import CURVES  # noqa: E402  (the group order only)
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 n = 1 << log_n
@@ -27,7 +26,7 @@ for curve in ("bn254", "bls12_381"):
     sc = rand(n)
     skew = sc.copy()
     sel = rng.random(n)
-    for lo, hi, val in ((0.0, 0.6, 1), (0.6, 0.85, 5), (0.85, 0.9, CURVES[curve].r - 1)):
+    for lo, hi, val in ((0.0, 0.6, 1), (0.6, 0.85, 5), (0.85, 0.9, pp.fr.p - 1)):
         skew[(sel >= lo) & (sel < hi)] = pp.fr.encode([val])[0]
     res = {}
     for name, arr in (("random", sc), ("repeating", skew)):
