@@ -576,6 +576,9 @@ def main():
 
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL between ranks); the driver exports it, keep it if not
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # kernel arguments in device memory: libzksaas_hip.so asks for it when it is loaded (csrc/api.cpp zk_runtime_defaults,
+    # +1.6 % on the headline), but here torch initialises the HIP runtime first, and the runtime reads its environment once
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     import torch
     import zksaas_amd as zk
     from zksaas_amd import groth16 as zg

@@ -1,6 +1,6 @@
 """Per-stream kernel timeline of one proof from a rocprofv3 --kernel-trace result (rocpd sqlite database or csv).
 
-usage: python tools/timeline.py gpurun_out/prof/p_results.db [proof_index_from_end [gap_us]]
+usage: python tools/timeline.py gpurun_out/prof/p_results.db [proof_index_from_end [gap_us [min_kernel_us]]]
 Proof boundaries: gaps of more than gap_us (default 70) with no kernel running.
 """
 import csv
@@ -12,6 +12,7 @@ from collections import defaultdict
 path = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 gap_ns = int(float(sys.argv[3]) * 1000) if len(sys.argv) > 3 else 70_000
+min_ms = float(sys.argv[4]) / 1000 if len(sys.argv) > 4 else 0.02          # kernels shorter than this are left out
 if path.endswith(".db"):
     cur = sqlite3.connect(path).cursor()
     rows = [{"Kernel_Name": r[0], "Start_Timestamp": r[1], "End_Timestamp": r[2], "Stream_Id": r[3], "Grid_Size_X": r[4]}
@@ -52,5 +53,5 @@ for q, rs in sorted(by.items(), key=lambda kv: int(kv[1][0]["Start_Timestamp"]))
     print(f"-- stream/queue {q}")
     for r in rs:
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
-        if e - s >= 0.02:
+        if e - s >= min_ms:
             print(f"   {s:7.3f} -> {e:7.3f}  ({e - s:6.3f})  {short(r['Kernel_Name'])}  grid={r.get('Grid_Size_X', r.get('Grid_Size'))}")

@@ -71,6 +71,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libzksaas_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                           "there is no CPU fallback")
+    # (the library sets this itself when it is loaded; here as well because the HIP runtime preloaded just below reads its
+    # environment once -- api.cpp zk_runtime_defaults says what it buys)
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, sz, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int

@@ -1,6 +1,7 @@
 // C ABI (include/zksaas.h) -> IEngine dispatch.  No compute lives here.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -18,6 +19,12 @@ struct zk_net {
 };
 
 using zk::IEngine;
+
+// Kernel arguments in device memory (the HIP runtime's HIP_FORCE_DEV_KERNARG): a dependent launch then starts without the
+// packet processor fetching its arguments from host memory.  A proof of the SHA-256 circuit is a chain of ~17 dependent
+// launches: 600.6 against 591.2 proofs/s (four same-box pairs, round 4).  Set when the library is loaded, before the first
+// HIP call of an ordinary host program initialises the runtime; never overrides the caller's own setting.
+__attribute__((constructor(101))) static void zk_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
