@@ -726,7 +726,8 @@ int zk_dist_groth16_prove_batch(zk_ctx* ctx, zk_net* net, const zk_crs_share* cr
 static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king_fft2_kernel", "msm_accumulate_kernel<G1>",
                                                          "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",
                                                          "msm_finalize+reduce<G1>", "king_degred_kernel",
-                                                         "msm_finalize+reduce<G2>"};
+                                                         "msm_finalize+reduce<G2>", "dpp_tile_kernel", "dpp_carry_kernel",
+                                                         "dpp_finish_kernel"};
 int zk_profile_enable(zk_ctx* ctx, int on) {
   CTX_OR_FAIL();
   e->prof.reset();

@@ -1,0 +1,287 @@
+// d_pp: the king's part of the distributed partial products (dist-primitives/src/dpp/mod.rs:41-76), three launches.
+//
+// The reference unpacks num || den, divides element by element (one inverse() each, :54-57), runs a serial prefix product
+// (:62-65) and packs.  The same field elements are produced here WITHOUT a division per element:
+//
+//   prefix_i = prod_{k<=i} num_k / den_k = N_i * S_{i+1} / D,   N_i = prod_{k<=i} num_k,  S_i = prod_{k>=i} den_k,
+//                                                                D   = prod_k den_k  (zero iff some den_k is zero)
+//
+// i.e. a prefix scan of the numerators, a suffix scan of the denominators and ONE inversion for the whole vector (field
+// arithmetic is exact, so the shares are bit-identical to the divide-then-scan form; 5 multiplications per element where
+// Montgomery's trick needs 6 plus its inversions).
+//
+//   dpp_tile_kernel   : one workgroup per tile of DPP_TILE elements: unpack2 of num and den (coalesced share loads),
+//                       transposed through LDS so that each thread owns DPP_E consecutive elements; thread-local prefix /
+//                       suffix, the 256 thread totals scanned by one wave each; writes
+//                       y_i = (N_i / N_before_tile) * (S_{i+1} / S_after_tile) and the tile's two totals.
+//   dpp_carry_kernel  : one workgroup: exclusive prefix of the numerator totals, exclusive suffix of the denominator totals,
+//                       the inversion of D  ->  c_tile = N_before_tile * S_after_tile / D;  raises *err when D = 0
+//                       (the reference panics on inverse().unwrap(), dpp/mod.rs:55).
+//   dpp_finish_kernel : prefix_i = y_i * c_tile -> pack (fresh randomness) -> store; when the caller runs all parties on
+//                       this device it also carries the deg_red that follows (dpp/mod.rs:86, deg_red.rs:80-126): the
+//                       king of that round would unpack2(pack(prefix, r1) + in_mask) = prefix + unpack2(in_mask) -- the
+//                       first pack's randomness cancels exactly -- so the kernel adds unpack2 of the in-mask column to the
+//                       prefix products, packs with deg_red's randomness stream and adds the out-mask: the 2 GiB of
+//                       intermediate shares (C5) are never written or read back.
+//
+// Algorithmic bytes: read 2 n (m/l) B, write n (m/l) B, + 2 m B for y.
+#pragma once
+#include "pss.hpp"
+
+namespace zk {
+#if defined(__HIPCC__)
+
+constexpr int DPP_THREADS = 256;
+constexpr int DPP_E = 8;                          // consecutive elements per thread
+constexpr int DPP_TILE = DPP_THREADS * DPP_E;     // elements per workgroup
+constexpr int DPP_LDS_SLOTS = DPP_TILE + DPP_TILE / DPP_E;
+constexpr int DPP_CARRY_THREADS = 1024;
+
+// LDS position of tile element e: one spare slot after every DPP_E elements, so that the per-thread walks (thread t
+// reads element t * DPP_E + i) fall on distinct banks; the spare slots hold the per-thread numerator totals.
+ZK_D int dpp_pos(int e) { return e + e / DPP_E; }
+ZK_D int dpp_spare(int t) { return t * (DPP_E + 1) + DPP_E; }
+
+template <class F>
+ZK_D F wave_up(const F& v, int off) {
+  F r;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) r.v[i] = __shfl_up(v.v[i], (unsigned)off, 64);
+  return r;
+}
+template <class F>
+ZK_D F wave_bcast(const F& v, int lane) {
+  F r;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) r.v[i] = __shfl(v.v[i], lane, 64);
+  return r;
+}
+// inclusive product scan over the 64 lanes of a wave (six multiplications per lane)
+template <class F>
+ZK_D F wave_scan_mul(F v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    F p = wave_up(v, off) * v;
+    if (lane >= off) v = p;
+  }
+  return v;
+}
+
+// ONE wave turns the DPP_THREADS per-thread totals at positions pos(t) of `lds` into their exclusive prefix products (or
+// exclusive suffix products when `reverse`), in place; returns the product of all of them in every lane.
+template <class F, class PosFn>
+ZK_D F dpp_scan_totals(const LdsVec<F>& lds, PosFn pos, bool reverse) {
+  constexpr int Q = DPP_THREADS / 64;
+  const int lane = threadIdx.x & 63;
+  F p[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int idx = lane * Q + q;
+    const F t = lds.get(pos(reverse ? DPP_THREADS - 1 - idx : idx));
+    p[q] = q ? p[q - 1] * t : t;
+  }
+  const F inc = wave_scan_mul(p[Q - 1]);
+  F ex = wave_up(inc, 1);
+  if (lane == 0) ex = F::one();
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int idx = lane * Q + q;
+    lds.put(pos(reverse ? DPP_THREADS - 1 - idx : idx), q ? ex * p[q - 1] : ex);
+  }
+  return wave_bcast(inc, 63);
+}
+
+// shares [np][pitch] of num and den -> y (natural element order j * l + i), tile totals
+template <class P, int L>
+__global__ __launch_bounds__(DPP_THREADS) void dpp_tile_kernel(const Fp<P>* __restrict__ num,
+                                                              const Fp<P>* __restrict__ den, int np, size_t nchunks,
+                                                              size_t pitch, const Fp<P>* __restrict__ U /* [l][np] */,
+                                                              Fp<P>* __restrict__ y, Fp<P>* __restrict__ tile_n,
+                                                              Fp<P>* __restrict__ tile_d) {
+  using F = Fp<P>;
+  constexpr int E = DPP_E, K = E / L;              // chunks per thread
+  static_assert(K >= 1 && K * L == E, "packing factor must divide DPP_E");
+  constexpr int TC = DPP_THREADS * K;              // chunks per tile
+  extern __shared__ uint4 smem[];
+  LdsVec<F> buf;                 // (assigned, not brace-initialised: a constant aggregate holding the LDS address
+  buf.base = smem;               //  would be emitted as a static initialiser, which the backend rejects)
+  buf.stride = DPP_LDS_SLOTS;
+  const int tid = threadIdx.x;
+  const size_t chunk0 = (size_t)blockIdx.x * TC;
+
+  // unpack2 (or the Lagrange form for a party subset) of K chunks per thread, lane-adjacent chunks adjacent in memory;
+  // chunks past the end contribute ones
+  auto unpack_to_lds = [&](const F* __restrict__ sh) {
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+      const int c = k * DPP_THREADS + tid;
+      const size_t j = chunk0 + c;
+      F s[L];
+      if (j < nchunks) {
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = F::zero();
+        unpack_accumulate<F, L>(s, U, np, [&](int r) { return load_elem(sh + (size_t)r * pitch + j); });
+      } else {
+#pragma unroll
+        for (int i = 0; i < L; i++) s[i] = F::one();
+      }
+#pragma unroll
+      for (int i = 0; i < L; i++) buf.put(dpp_pos(c * L + i), s[i]);
+    }
+  };
+
+  // numerators: a[i] = product of this thread's elements 0..i
+  unpack_to_lds(num);
+  __syncthreads();
+  F a[E];
+  a[0] = buf.get(dpp_pos(tid * E));
+#pragma unroll
+  for (int i = 1; i < E; i++) a[i] = a[i - 1] * buf.get(dpp_pos(tid * E + i));
+  const F tot_a = a[E - 1];
+  __syncthreads();
+
+  // denominators: a[i] *= product of this thread's elements i+1..E-1
+  unpack_to_lds(den);
+  __syncthreads();
+  F b = buf.get(dpp_pos(tid * E + E - 1));
+#pragma unroll
+  for (int i = E - 2; i >= 0; i--) {
+    a[i] = a[i] * b;
+    b = b * buf.get(dpp_pos(tid * E + i));
+  }
+  __syncthreads();
+  // thread totals: numerators in the spare slots, denominators over the (dead) element slots
+  buf.put(dpp_spare(tid), tot_a);
+  buf.put(dpp_pos(tid), b);
+  __syncthreads();
+  const int wave = tid >> 6;
+  if (wave == 0) {
+    const F tot = dpp_scan_totals(buf, [](int t) { return dpp_spare(t); }, false);
+    if (tid == 0) store_elem(tile_n + blockIdx.x, tot);
+  } else if (wave == 1) {
+    const F tot = dpp_scan_totals(buf, [](int t) { return dpp_pos(t); }, true);
+    if (tid == 64) store_elem(tile_d + blockIdx.x, tot);
+  }
+  __syncthreads();
+  const F c = buf.get(dpp_spare(tid)) * buf.get(dpp_pos(tid));
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < E; i++) buf.put(dpp_pos(tid * E + i), a[i] * c);
+  __syncthreads();
+  const size_t e0 = chunk0 * L, total = nchunks * L;
+#pragma unroll
+  for (int k = 0; k < E; k++) {
+    const int e = k * DPP_THREADS + tid;
+    if (e0 + e < total) store_elem(y + e0 + e, buf.get(dpp_pos(e)));
+  }
+}
+
+// exclusive product scan over the threads of a (multiple-of-64, <= 1024 thread) workgroup; `sh` holds >= 16 elements
+template <class F>
+ZK_D F block_scan_mul_exclusive(const F& v, F* sh, F* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const F inc = wave_scan_mul(v);
+  __syncthreads();                       // `sh` may still be read from an earlier scan
+  if (lane == 63) sh[wave] = inc;
+  __syncthreads();
+  F before = F::one(), all = F::one();
+#pragma unroll 1
+  for (int w = 0; w < nw; w++) {
+    if (w == wave) before = all;
+    all = all * sh[w];
+  }
+  F ex = wave_up(inc, 1);
+  if (lane == 0) ex = F::one();
+  *total = all;
+  return before * ex;
+}
+
+// tile totals -> c_tile = (product of the numerator totals before the tile) * (product of the denominator totals after it)
+// / (product of all denominators).  tile_n is overwritten with the exclusive prefixes.
+template <class F>
+__global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restrict__ tile_n, const F* __restrict__ tile_d,
+                                                                      size_t ntiles, F* __restrict__ ctile,
+                                                                      int* __restrict__ err) {
+  __shared__ F sh[DPP_CARRY_THREADS / 64];
+  __shared__ F inv_sh;
+  const size_t tid = threadIdx.x, nt = blockDim.x;
+  const size_t q = (ntiles + nt - 1) / nt;
+  // thread t owns the numerator range t and the denominator range nt-1-t: one forward scan serves prefix and suffix
+  const size_t nlo = tid * q < ntiles ? tid * q : ntiles, nhi = nlo + q < ntiles ? nlo + q : ntiles;
+  const size_t r = nt - 1 - tid;
+  const size_t dlo = r * q < ntiles ? r * q : ntiles, dhi = dlo + q < ntiles ? dlo + q : ntiles;
+  F pn = F::one(), pd = F::one();
+  for (size_t i = nlo; i < nhi; i++) pn = pn * load_elem(tile_n + i);
+  for (size_t i = dlo; i < dhi; i++) pd = pd * load_elem(tile_d + i);
+  F tot_n, tot_d;
+  F run = block_scan_mul_exclusive(pn, sh, &tot_n);
+  F sd = block_scan_mul_exclusive(pd, sh, &tot_d);
+  if (tid == 0) {
+    if (tot_d.is_zero()) {
+      atomicExch(err, 1);
+      inv_sh = F::zero();
+    } else {
+      inv_sh = tot_d.inverse();
+    }
+  }
+  for (size_t i = nlo; i < nhi; i++) {
+    const F t = load_elem(tile_n + i);
+    store_elem(tile_n + i, run);
+    run = run * t;
+  }
+  __threadfence_block();
+  __syncthreads();
+  sd = sd * inv_sh;
+  for (size_t i = dhi; i-- > dlo;) {
+    store_elem(ctile + i, load_elem(tile_n + i) * sd);
+    sd = sd * load_elem(tile_d + i);
+  }
+}
+
+// prefix products -> fresh shares [n][nchunks]; with in_mask / out_mask the deg_red round that follows d_pp's king round
+// when all parties live on this device (see the header)
+template <class P, int L>
+__global__ __launch_bounds__(KING_THREADS) void dpp_finish_kernel(const Fp<P>* __restrict__ y,
+                                                                 const Fp<P>* __restrict__ ctile, size_t nchunks,
+                                                                 const Fp<P>* __restrict__ in_mask,
+                                                                 const Fp<P>* __restrict__ out_mask,
+                                                                 const Fp<P>* __restrict__ U /* [l][n], all parties */,
+                                                                 const Fp<P>* __restrict__ Pm,
+                                                                 const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
+                                                                 Fp<P>* __restrict__ out) {
+  using F = Fp<P>;
+  constexpr int T = L, N = 4 * L;
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nchunks) return;
+  const F c = load_elem(ctile + (j * L) / DPP_TILE);
+  F sec[L + T];
+#pragma unroll
+  for (int i = 0; i < L; i++) sec[i] = load_elem(y + j * L + i) * c;
+  if (in_mask) {
+    F mk[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) mk[i] = F::zero();
+    unpack_accumulate<F, L>(mk, U, N, [&](int s) { return load_elem(in_mask + (size_t)s * nchunks + j); });
+#pragma unroll
+    for (int i = 0; i < L; i++) sec[i] = sec[i] + mk[i];
+  }
+  if constexpr (T == 2) {
+    rand_fp_pair<P>(seed, (uint64_t)j * T, &sec[L], &sec[L + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < T; i++) sec[L + i] = rand_fp<P>(seed, (uint64_t)j * T + i);
+  }
+  F sh[N];
+  pack_chunk<P, L, L + T>(sec, Pm, k2, sh);
+#pragma unroll
+  for (int p = 0; p < N; p++) {
+    const size_t o = (size_t)p * nchunks + j;
+    F acc = sh[p];
+    if (out_mask) acc = acc + load_elem(out_mask + o);
+    store_elem(out + o, acc);
+  }
+}
+
+#endif  // __HIPCC__
+}  // namespace zk

@@ -28,7 +28,7 @@ struct Status {
 // Per-kernel timing slots: HIP events recorded on the launching stream around selected kernels, so that a
 // host program can read a kernel's average launch duration over exactly its own timed region (bench.py).
 enum ProfSlot { PROF_NTT_PASS = 0, PROF_KING, PROF_MSM_ACC_G1, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE,
-                PROF_DEGRED, PROF_MSM_REDUCE_G2, PROF_NSLOTS };
+                PROF_DEGRED, PROF_MSM_REDUCE_G2, PROF_DPP_TILE, PROF_DPP_CARRY, PROF_DPP_FINISH, PROF_NSLOTS };
 
 struct Profiler {
   bool on = false;

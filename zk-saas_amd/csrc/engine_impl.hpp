@@ -12,6 +12,7 @@
 #include "msm.hpp"
 #include "hostpool.hpp"
 #include "points.hpp"
+#include "dpp.hpp"
 
 namespace zk {
 
@@ -738,49 +739,75 @@ class Engine : public IEngine {
     return pss_pack(vals, len, 0, seed ^ 0x2222, false, out_mask, st);
   }
 
-  // ---------------------------------------------------------------- d_pp (dpp/mod.rs:15-87)
-  // the king's part up to the fresh shares of the prefix products (dpp/mod.rs:40-73): unpack num and den of the listed
-  // parties, divide (one shared inversion per block instead of :54-57's inverse() per element), scan, pack
-  int d_pp_king(const Fr* num, const Fr* den, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
-                hipStream_t st) {
-    size_t m = len * l;
-    ZK_HIP(scratch_.ensure(3 * m * sizeof(Fr)));
-    Fr* nu = (Fr*)scratch_.p;
-    Fr* de = nu + m;
-    Fr* x = de + m;
-    int rc = pss_unpack(num, parties, np, len, true, nu, st);
-    if (rc) return rc;
-    rc = pss_unpack(den, parties, np, len, true, de, st);
-    if (rc) return rc;
+  // ---------------------------------------------------------------- d_pp (dpp/mod.rs:15-87), csrc/dpp.hpp
+  // The king's part (dpp/mod.rs:40-73) for the listed parties: prefix products of num / den as fresh shares, three launches
+  // (tile scans, carries + the one inversion, finish).  With `fuse_degred` the finish kernel also carries the deg_red round
+  // that follows (:86) -- only valid when every party's share lives on this device.  The zero-denominator flag is read
+  // once, after the last launch.
+  template <int L>
+  int dpp_l(const Fr* num, const Fr* den, int np, size_t len, const Fr* U, const Fr* Ufull, const Fr* in_mask,
+            const Fr* out_mask, const RngSeed& seed, Fr* out, hipStream_t st) {
+    const size_t m = len * L, ntiles = (m + DPP_TILE - 1) / DPP_TILE;
+    ZK_HIP(scratch_.ensure((m + 3 * ntiles) * sizeof(Fr)));
+    Fr* y = (Fr*)scratch_.p;
+    Fr* tile_n = y + m;
+    Fr* tile_d = tile_n + ntiles;
+    Fr* ctile = tile_d + ntiles;
+    constexpr size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * DPP_LDS_SLOTS;
+    if (!dpp_attr_set_) {
+      ZK_HIP(hipFuncSetAttribute((const void*)dpp_tile_kernel<FrP, L>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      dpp_attr_set_ = true;
+    }
     ZK_HIP(hipMemsetAsync(err_flag_, 0, sizeof(int), st));
-    size_t nthreads = (m + DPP_CHUNK - 1) / DPP_CHUNK;
-    dpp_div_kernel<Fr><<<dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, st>>>(nu, de, m, x, err_flag_);
+    {
+      ProfScope ps_(prof, PROF_DPP_TILE, st, (double)m);
+      dpp_tile_kernel<FrP, L><<<dim3((unsigned)ntiles), dim3(DPP_THREADS), lds, st>>>(num, den, np, len, len, U, y,
+                                                                                       tile_n, tile_d);
+    }
     ZK_HIP(hipGetLastError());
+    {
+      ProfScope ps_(prof, PROF_DPP_CARRY, st, (double)ntiles);
+      dpp_carry_kernel<Fr><<<dim3(1), dim3(DPP_CARRY_THREADS), 0, st>>>(tile_n, tile_d, ntiles, ctile, err_flag_);
+    }
+    ZK_HIP(hipGetLastError());
+    {
+      ProfScope ps_(prof, PROF_DPP_FINISH, st, (double)m);
+      dpp_finish_kernel<FrP, L><<<dim3((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), dim3(KING_THREADS), 0, st>>>(
+          y, ctile, len, in_mask, out_mask, Ufull, pmat_, pack2_, seed, out);
+    }
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int d_pp_king(const Fr* num, const Fr* den, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
+                hipStream_t st, bool fuse_degred = false, const Fr* in_mask = nullptr, const Fr* out_mask = nullptr) {
+    const Fr *U = nullptr, *Ufull = nullptr;
+    int rc = umat_for(parties, np, &U);
+    if (rc) return rc;
+    if (fuse_degred && (rc = umat_for(nullptr, n, &Ufull))) return rc;
+    // the shares the caller gets are packed ONCE: by the king round when it stands alone (stream `seed`), by the deg_red
+    // round when that one is fused in (stream seed ^ 0x3333, as the separate call draws: oracle/dist.py d_pp)
+    const RngSeed r = rs(fuse_degred ? seed ^ 0x3333 : seed);
+    if (!fuse_degred) in_mask = out_mask = nullptr;
+    switch (l) {
+      case 1: rc = dpp_l<1>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
+      case 2: rc = dpp_l<2>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
+      case 4: rc = dpp_l<4>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
+      default: rc = dpp_l<8>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
+    }
+    if (rc) return rc;
     int herr = 0;
     ZK_HIP(hipMemcpyAsync(&herr, err_flag_, sizeof(int), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     if (herr) return fail(ZK_ERR_GENERIC, "d_pp: zero denominator (reference panics: dpp/mod.rs:55)");
-    // inclusive prefix product
-    size_t nblocks = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (nblocks == 1) {
-      scan_block_kernel<Fr><<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(x, m, nullptr, nullptr);
-    } else {
-      Fr* bp = nu;   // numerators are dead now
-      scan_block_kernel<Fr><<<dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st>>>(x, m, bp, nullptr);
-      scan_carries_kernel<Fr><<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(bp, nblocks);
-      scan_block_kernel<Fr><<<dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st>>>(x, m, nullptr, bp);
-    }
-    ZK_HIP(hipGetLastError());
-    return pss_pack(x, len, 0, seed, false, out, st);
+    return ZK_OK;
   }
   int d_pp(const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
            void* out, hipStream_t st) override {
     if (!len) return ZK_OK;
     if (!num || !den || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
-    int rc = d_pp_king((const Fr*)num, (const Fr*)den, nullptr, n, len, seed, (Fr*)out, st);
-    if (rc) return rc;
-    return deg_red_np((const Fr*)out, (const Fr*)in_mask, nullptr, n, len, seed ^ 0x3333, (Fr*)out,
-                      (const Fr*)out_mask, st);
+    return d_pp_king((const Fr*)num, (const Fr*)den, nullptr, n, len, seed, (Fr*)out, st, true, (const Fr*)in_mask,
+                     (const Fr*)out_mask);
   }
 
   // ---------------------------------------------------------------- MSM
@@ -3465,6 +3492,7 @@ class Engine : public IEngine {
   bool streams_ready_ = false;
   bool force_simple_ntt = false;
   bool ntt_attr_set_[2] = {false, false};
+  bool dpp_attr_set_ = false;
   std::map<std::string, void*> base_tables_;
   DevBuf hwork_;
   Fr* pmat_ = nullptr;
