@@ -898,3 +898,86 @@ void zkref_deg_red(const pss_t* P, fe* x, size_t len, const fe* in_mask, const f
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------------ d_pp */
+/* dpp/mod.rs:15-87 for all n parties in one address space: num, den, out [n][len].  The king unpacks every chunk of
+ * num || den (:47-52; unpack_missing_shares = unpack2 with all n present), multiplies each numerator by inverse() of its
+ * denominator -- ONE inversion per element, as the reference does (:54-57) --, runs the serial prefix product (:62-65),
+ * packs (pack_vec, :70; randomness stream `seed`), and every party finishes with deg_red (:86; stream seed ^ 0x3333 as
+ * oracle/dist.py d_pp).  s = 1 (:25-26).  Returns 1 when a denominator is zero (the reference panics, :55).
+ * With zkref_set_fast_king the unpack, the inversions and the pack are split over threads (the prefix product stays
+ * serial: it is a chain); the values are the same. */
+typedef struct {
+  const pss_t* P;
+  const king_mats* M;
+  const fe *num, *den;
+  size_t len;
+  fe *x, *dn;   /* [len * l] */
+  fe* out;
+  u64 seed;
+  int fr_bits;
+  volatile int zero;
+} dpp_ctx;
+static void dpp_unpack_span(void* a, size_t lo, size_t hi) {
+  dpp_ctx* c = (dpp_ctx*)a;
+  const int n = c->P->n, l = c->P->l;
+  fe sh[MAXN];
+  for (size_t j = lo; j < hi; j++) {
+    for (int p = 0; p < n; p++) sh[p] = c->num[(size_t)p * c->len + j];
+    if (c->M) mat_unpack2(c->P, c->M, sh, &c->x[j * l]); else pss_unpack2(c->P, sh, &c->x[j * l]);
+    for (int p = 0; p < n; p++) sh[p] = c->den[(size_t)p * c->len + j];
+    if (c->M) mat_unpack2(c->P, c->M, sh, &c->dn[j * l]); else pss_unpack2(c->P, sh, &c->dn[j * l]);
+  }
+}
+static void dpp_div_span(void* a, size_t lo, size_t hi) {
+  dpp_ctx* c = (dpp_ctx*)a;
+  const field_t* F = &c->P->F;
+  for (size_t i = lo; i < hi; i++) {
+    if (fe_is_zero(&c->dn[i])) {
+      c->zero = 1;
+      continue;
+    }
+    fe inv;
+    fe_inv(&inv, &c->dn[i], F);
+    fe_mul(&c->x[i], &c->x[i], &inv, F);
+  }
+}
+static void dpp_pack_span(void* a, size_t lo, size_t hi) {
+  dpp_ctx* c = (dpp_ctx*)a;
+  const field_t* F = &c->P->F;
+  const int n = c->P->n, l = c->P->l, t = c->P->t;
+  fe sh[MAXN], rnd[MAXN];
+  for (size_t j = lo; j < hi; j++) {
+    for (int i = 0; i < t; i++) rand_fe(&rnd[i], c->seed, (u64)j * t + i, c->fr_bits, F);
+    if (c->M) mat_pack(c->P, c->M, &c->x[j * l], rnd, sh); else pss_pack(c->P, &c->x[j * l], rnd, sh);
+    for (int p = 0; p < n; p++) c->out[(size_t)p * c->len + j] = sh[p];
+  }
+}
+int zkref_d_pp(const pss_t* P, const fe* num, const fe* den, size_t len, const fe* in_mask, const fe* out_mask, u64 seed,
+               int fr_bits, fe* out) {
+  const field_t* F = &P->F;
+  const size_t m = len * P->l;
+  king_mats* KM = NULL;
+  if (g_fast_king) {
+    KM = malloc(sizeof(king_mats));
+    king_mats_build(P, KM);
+  }
+  dpp_ctx c = {P, KM, num, den, len, malloc(m * sizeof(fe)), malloc(m * sizeof(fe)), out, seed, fr_bits, 0};
+  if (g_fast_king) {
+    king_parallel(dpp_unpack_span, &c, len);
+    king_parallel(dpp_div_span, &c, m);
+  } else {
+    dpp_unpack_span(&c, 0, len);
+    dpp_div_span(&c, 0, m);
+  }
+  if (!c.zero) {
+    for (size_t i = 1; i < m; i++) fe_mul(&c.x[i], &c.x[i], &c.x[i - 1], F);
+    if (g_fast_king) king_parallel(dpp_pack_span, &c, len); else dpp_pack_span(&c, 0, len);
+  }
+  free(c.x);
+  free(c.dn);
+  free(KM);
+  if (c.zero) return 1;
+  zkref_deg_red(P, out, len, in_mask, out_mask, seed ^ 0x3333ull, fr_bits);
+  return 0;
+}

@@ -151,6 +151,34 @@ class CPss:
         flat = self.fr.dec(a)
         return [flat[i * ln:(i + 1) * ln] for i in range(n)]
 
+    def d_pp_arrays(self, num, den, ln, in_mask, out_mask, seed, threads=1):
+        """dpp/mod.rs:15-87 (zkref_d_pp): num, den uint64 arrays [n*ln][4]; returns the shares [n*ln][4].  threads > 1
+        splits the king's unpack / inversions / pack (same values); ZeroDivisionError on a zero denominator."""
+        out = np.empty_like(num)
+        L = lib()
+        L.zkref_d_pp.restype = C.c_int
+        L.zkref_set_fast_king(1 if threads > 1 else 0, max(1, threads))
+        try:
+            rc = L.zkref_d_pp(C.byref(self.ct), self._p(num), self._p(den), C.c_size_t(ln),
+                              None if in_mask is None else self._p(in_mask),
+                              None if out_mask is None else self._p(out_mask), C.c_uint64(seed), self.fr.bits, self._p(out))
+        finally:
+            L.zkref_set_fast_king(0, 1)
+        if rc:
+            raise ZeroDivisionError("d_pp: zero denominator")
+        return out
+
+    def d_pp(self, num, den, masks, seed, threads=1):
+        """list-of-lists front end mirroring oracle.dist.d_pp."""
+        n, ln = len(num), len(num[0])
+        a, b = self.fr.enc([v for s in num for v in s]), self.fr.enc([v for s in den for v in s])
+        im = om = None
+        if masks is not None:
+            im = self.fr.enc([v for mk in masks for v in mk.in_mask])
+            om = self.fr.enc([v for mk in masks for v in mk.out_mask])
+        flat = self.fr.dec(self.d_pp_arrays(a, b, ln, im, om, seed, threads))
+        return [flat[i * ln:(i + 1) * ln] for i in range(n)]
+
     def mul_sub_arrays(self, a, b, c):
         out = np.empty_like(a)
         lib().zkref_mul_sub(C.byref(self.fr.ct), self._p(a), self._p(b), self._p(c), C.c_size_t(a.shape[0]), self._p(out))

@@ -217,6 +217,29 @@ def test_synthetic_prover_distributed_equals_local_and_ignores_share_randomness(
     assert wire.proof_from_bytes(pp, blob, curve) == ref
 
 
+@pytest.mark.parametrize("curve,masked", [("bn254", True), ("bls12_381", False)])
+def test_d_pp_2_20_shares_equal_c_oracle(curve, masked):
+    """d_pp (dpp/mod.rs:15-87) at m = 2^20: every output SHARE equals the C restatement's, which follows the reference
+    step for step (unpack, one inverse() per element, serial prefix product, pack_vec, deg_red) -- the GPU path reaches
+    the same field elements through a prefix scan of the numerators, a suffix scan of the denominators and one inversion
+    (csrc/dpp.hpp), with the deg_red round fused into its last kernel."""
+    import os
+    pp = ctx(curve, 2)
+    cp = CPss(curve, 2)
+    m = 1 << 20
+    ln = m // 2
+    num, den = _rand_fr_array(pp.n * ln, 31), _rand_fr_array(pp.n * ln, 32)
+    mask, im, om = zk.DegRedMask.zero(), None, None
+    if masked:
+        mask = zk.DegRedMask.sample(pp, ln, 33)
+        im = mask.in_mask.to_numpy().reshape(-1, 4).copy()
+        om = mask.out_mask.to_numpy().reshape(-1, 4).copy()
+        assert im.any() and om.any()
+    res = zk.d_pp(pp, zk.DeviceBuffer.from_numpy(pp, num), zk.DeviceBuffer.from_numpy(pp, den), mask, ln, seed=34)
+    want = cp.d_pp_arrays(num, den, ln, im, om, 34, threads=min(32, os.cpu_count() or 1))
+    assert np.array_equal(res.to_numpy().reshape(-1, 4), want)
+
+
 def test_d_pp_telescopes_bls12_381_2_18():
     """d_pp (dpp/mod.rs:15-87) at 2^18 on the config-5 curve: num_i = x_(i+1), den_i = x_i  =>  prefix product_i
     times x_0 equals x_(i+1) (size-independent property; the small exact comparison is in test_gpu_dfft.py)."""

@@ -65,6 +65,27 @@ def test_fft1_and_deg_red():
     assert cp.deg_red(mul, masks, 11) == od.deg_red(mul, masks, o, seed=11)
 
 
+@pytest.mark.parametrize("name,threads", [("bn254", 1), ("bn254", 3), ("bls12_381", 1)])
+def test_d_pp_c_matches_python_oracle(name, threads):
+    """zkref_d_pp (dpp/mod.rs:15-87 in C, one inverse() per element) == oracle/dist.py d_pp, and the reference's own
+    check: num = den reconstructs to all ones (dpp_test.rs:51,62-65); a zero denominator is an error (:55)."""
+    cp = CPss(name, 2)
+    o = cp.opp
+    m = 2200 if threads > 1 else 64        # > 1024 chunks: the threaded spans really split
+    num, den = rand_vec(20, m, o.p), rand_vec(21, m, o.p)
+    ns, ds = transpose(od.pack_vec(num, o, 22)), transpose(od.pack_vec(den, o, 23))
+    masks = od.DegRedMask.sample(o, 1, m // 2, 24)
+    got = cp.d_pp(ns, ds, masks, 25, threads)
+    assert got == od.d_pp(ns, ds, masks, o, seed=25)
+    x = list(range(1, m + 1))
+    xs = transpose(od.pack_vec(x, o, 26))
+    ones = cp.d_pp(xs, xs, None, 27, threads)
+    assert [v for ch in transpose(ones) for v in o.unpack(ch)] == [1] * m
+    den[5] = 0
+    with pytest.raises(ZeroDivisionError):
+        cp.d_pp(ns, transpose(od.pack_vec(den, o, 28)), None, 29, threads)
+
+
 @pytest.mark.parametrize("count,threads", [(1, 1), (31, 1), (200, 1), (200, 4)])
 def test_msm_g1(count, threads):
     cp = CPss("bn254", 2)

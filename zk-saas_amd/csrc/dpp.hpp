@@ -70,8 +70,8 @@ ZK_D F wave_scan_mul(F v) {
 
 // ONE wave turns the DPP_THREADS per-thread totals at positions pos(t) of `lds` into their exclusive prefix products (or
 // exclusive suffix products when `reverse`), in place; returns the product of all of them in every lane.
-template <class F, class PosFn>
-ZK_D F dpp_scan_totals(const LdsVec<F>& lds, PosFn pos, bool reverse) {
+template <bool reverse, class F, class PosFn>
+ZK_D F dpp_scan_totals(const LdsVec<F>& lds, PosFn pos) {
   constexpr int Q = DPP_THREADS / 64;
   const int lane = threadIdx.x & 63;
   F p[Q];
@@ -92,6 +92,32 @@ ZK_D F dpp_scan_totals(const LdsVec<F>& lds, PosFn pos, bool reverse) {
   return wave_bcast(inc, 63);
 }
 
+// unpack2 (or the Lagrange form for a party subset) of DPP_E / L chunks per thread, lane-adjacent chunks adjacent in memory,
+// into the tile's LDS slots in element order; chunks past the end contribute ones
+template <class P, int L>
+ZK_D void dpp_unpack_to_lds(const Fp<P>* __restrict__ sh, int np, size_t nchunks, size_t pitch,
+                            const Fp<P>* __restrict__ U, size_t chunk0, const LdsVec<Fp<P>>& buf) {
+  using F = Fp<P>;
+  constexpr int K = DPP_E / L;
+  const int tid = threadIdx.x;
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    const int c = k * DPP_THREADS + tid;
+    const size_t j = chunk0 + c;
+    F s[L];
+    if (j < nchunks) {
+#pragma unroll
+      for (int i = 0; i < L; i++) s[i] = F::zero();
+      unpack_accumulate<F, L>(s, U, np, [&](int r) { return load_elem(sh + (size_t)r * pitch + j); });
+    } else {
+#pragma unroll
+      for (int i = 0; i < L; i++) s[i] = F::one();
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) buf.put(dpp_pos(c * L + i), s[i]);
+  }
+}
+
 // shares [np][pitch] of num and den -> y (natural element order j * l + i), tile totals
 template <class P, int L>
 __global__ __launch_bounds__(DPP_THREADS) void dpp_tile_kernel(const Fp<P>* __restrict__ num,
@@ -110,29 +136,8 @@ __global__ __launch_bounds__(DPP_THREADS) void dpp_tile_kernel(const Fp<P>* __re
   const int tid = threadIdx.x;
   const size_t chunk0 = (size_t)blockIdx.x * TC;
 
-  // unpack2 (or the Lagrange form for a party subset) of K chunks per thread, lane-adjacent chunks adjacent in memory;
-  // chunks past the end contribute ones
-  auto unpack_to_lds = [&](const F* __restrict__ sh) {
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {
-      const int c = k * DPP_THREADS + tid;
-      const size_t j = chunk0 + c;
-      F s[L];
-      if (j < nchunks) {
-#pragma unroll
-        for (int i = 0; i < L; i++) s[i] = F::zero();
-        unpack_accumulate<F, L>(s, U, np, [&](int r) { return load_elem(sh + (size_t)r * pitch + j); });
-      } else {
-#pragma unroll
-        for (int i = 0; i < L; i++) s[i] = F::one();
-      }
-#pragma unroll
-      for (int i = 0; i < L; i++) buf.put(dpp_pos(c * L + i), s[i]);
-    }
-  };
-
   // numerators: a[i] = product of this thread's elements 0..i
-  unpack_to_lds(num);
+  dpp_unpack_to_lds<P, L>(num, np, nchunks, pitch, U, chunk0, buf);
   __syncthreads();
   F a[E];
   a[0] = buf.get(dpp_pos(tid * E));
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(DPP_THREADS) void dpp_tile_kernel(const Fp<P>* __re
   __syncthreads();
 
   // denominators: a[i] *= product of this thread's elements i+1..E-1
-  unpack_to_lds(den);
+  dpp_unpack_to_lds<P, L>(den, np, nchunks, pitch, U, chunk0, buf);
   __syncthreads();
   F b = buf.get(dpp_pos(tid * E + E - 1));
 #pragma unroll
@@ -157,10 +162,10 @@ __global__ __launch_bounds__(DPP_THREADS) void dpp_tile_kernel(const Fp<P>* __re
   __syncthreads();
   const int wave = tid >> 6;
   if (wave == 0) {
-    const F tot = dpp_scan_totals(buf, [](int t) { return dpp_spare(t); }, false);
+    const F tot = dpp_scan_totals<false>(buf, [](int t) { return dpp_spare(t); });
     if (tid == 0) store_elem(tile_n + blockIdx.x, tot);
   } else if (wave == 1) {
-    const F tot = dpp_scan_totals(buf, [](int t) { return dpp_pos(t); }, true);
+    const F tot = dpp_scan_totals<true>(buf, [](int t) { return dpp_pos(t); });
     if (tid == 64) store_elem(tile_d + blockIdx.x, tot);
   }
   __syncthreads();
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restr
       atomicExch(err, 1);
       inv_sh = F::zero();
     } else {
-      inv_sh = tot_d.inverse();
+      inv_sh = tot_d.inverse_gcd();
     }
   }
   for (size_t i = nlo; i < nhi; i++) {

@@ -641,6 +641,96 @@ struct Fp {
   }
 #endif
 
+  // ---- dot product with ONE Montgomery reduction (round 5): sum_{s < NT} x_s * k_s for canonical x_s (VGPRs) and
+  // wave-uniform canonical k_s (SGPRs: the rows of the PSS unpack matrices).  Product scanning over all NT products at once:
+  // NT N^2 + N^2 + N multiply instructions instead of NT (2 N^2 + N) -- 584 instead of 1088 for the eight-party unpack2 of
+  // an 8-limb field.  The accumulated value T < NT p^2 reduces to V = (T + m p) / R < (NT p / R + 1) p <= (NT / 2 + 1) p
+  // (every modulus here has its top bit clear), which a ladder of conditional subtractions of 2^j p brings below p:
+  // the same field element as the sum of the NT reduced products.
+  struct ModSh {
+    uint32_t v[N + 1];
+  };
+  static constexpr ModSh mod_shl(int sh) {
+    ModSh r{};
+    uint64_t c = 0;
+    for (int i = 0; i < N; i++) {
+      const uint64_t t = ((uint64_t)P::MOD[i] << sh) | c;
+      r.v[i] = (uint32_t)t;
+      c = t >> 32;
+    }
+    r.v[N] = (uint32_t)c;
+    return r;
+  }
+  template <int NT>
+  ZK_HD static Fp dot_k(const Fp* const* x /* [NT] */, const Fp* __restrict__ k /* [NT], wave-uniform */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m[N], r[N + 1];
+    uint64_t acc = 0, cy;
+    uint32_t acc2 = 0;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+#pragma unroll
+      for (int i = 0; i <= c; i++) {
+#pragma unroll
+        for (int s = 0; s < NT; s++) {
+          acc = madc_k(x[s]->v[i], k[s].v[c - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < c; i++) {
+        acc = madc_k(m[i], P::MOD[c - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      m[c] = (uint32_t)acc * P::N0INV;
+      acc = madc_k(m[c], P::MOD[0], acc, &cy);
+      acc2 = add_cy(acc2, cy);
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+#pragma unroll
+    for (int c = N; c < 2 * N - 1; c++) {
+#pragma unroll
+      for (int i = c - N + 1; i < N; i++) {
+#pragma unroll
+        for (int s = 0; s < NT; s++) {
+          acc = madc_k(x[s]->v[i], k[s].v[c - i], acc, &cy);
+          acc2 = add_cy(acc2, cy);
+        }
+        acc = madc_k(m[i], P::MOD[c - i], acc, &cy);
+        acc2 = add_cy(acc2, cy);
+      }
+      r[c - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)acc2 << 32);
+      acc2 = 0;
+    }
+    r[N - 1] = (uint32_t)acc;
+    r[N] = (uint32_t)(acc >> 32);
+    // V < (NT / 2 + 1) p: subtract 2^j p while it fits, j = J-1 .. 0 with 2^J >= NT / 2 + 1
+    constexpr int B = NT / 2 + 1;
+    constexpr int J = B <= 2 ? 1 : B <= 4 ? 2 : B <= 8 ? 3 : B <= 16 ? 4 : 5;
+    static_assert(NT <= 32 && (P::MOD[N - 1] >> 31) == 0, "dot_k: bound");
+#pragma unroll
+    for (int j = J - 1; j >= 0; j--) {
+      const ModSh M = mod_shl(j);
+      uint32_t d[N + 1];
+      unsigned bw = 0;
+#pragma unroll
+      for (int i = 0; i <= N; i++) d[i] = __builtin_subc(r[i], M.v[i], bw, &bw);
+#pragma unroll
+      for (int i = 0; i <= N; i++) r[i] = bw ? r[i] : d[i];
+    }
+    Fp o;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = r[i];
+    return o;
+#else
+    Fp acc = zero();                                   // host side of the same name: the plain sum
+    for (int s = 0; s < NT; s++) acc = acc + *x[s] * k[s];
+    return acc;
+#endif
+  }
+
   // Dedicated product-scanning SQUARING, measured and NOT adopted (tools/mulbench.hip variant 3,
   // profiles/r03_mulbench_sqr.txt): the off-diagonal products a_i a_j (i < j) of a column are accumulated once and
   // doubled, the diagonal and the Montgomery terms follow -- 36 + 64 + 8 multiply instructions instead of 128 + 8.  The
@@ -745,6 +835,87 @@ struct Fp {
       borrow = (uint32_t)(t >> 63);
     }
     return pow(e, N);
+  }
+  ZK_HD static void limbs_shr1(uint32_t* a) {
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+    a[N - 1] >>= 1;
+  }
+  ZK_HD static void limbs_shl1(uint32_t* a) {
+#pragma unroll
+    for (int i = N - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
+    a[0] <<= 1;
+  }
+  ZK_HD static void limbs_add(uint32_t* a, const uint32_t* b) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i] = __builtin_addc(a[i], b[i], c, &c);
+  }
+  ZK_HD static bool limbs_nonzero(const uint32_t* a) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) acc |= a[i];
+    return acc != 0;
+  }
+  // Inverse by the binary extended Euclid (Kaliski's "almost Montgomery inverse"), for ONE lane that a whole kernel waits
+  // on (d_pp's single inversion, csrc/dpp.hpp): ~1.4 BITS iterations of shifts, one subtraction and one addition on N
+  // limbs -- about a tenth of the instructions of the Fermat ladder above, none of them a multiply.  Phase 1 leaves
+  // x = a^-1 2^k (mod p), BITS <= k <= 2 BITS, for the integer a held in the limbs; the value wanted is the Montgomery form
+  // of (a / R)^-1 = a^-1 R^2, i.e. x 2^(2 * 32 N - k): one product with the Montgomery form of that power of two.
+  // this != 0.  Same field element as inverse().
+  ZK_HD Fp inverse_gcd() const {
+    uint32_t u[N], w[N], r[N], s[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) u[i] = P::MOD[i], w[i] = v[i], r[i] = 0, s[i] = 0;
+    s[0] = 1;
+    int k = 0;
+    while (limbs_nonzero(w)) {
+      if (!(u[0] & 1)) {
+        limbs_shr1(u);
+        limbs_shl1(s);
+      } else if (!(w[0] & 1)) {
+        limbs_shr1(w);
+        limbs_shl1(r);
+      } else {
+        uint32_t d[N];
+        unsigned bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = __builtin_subc(u[i], w[i], bw, &bw);
+        if (!bw && limbs_nonzero(d)) {                // u > w
+#pragma unroll
+          for (int i = 0; i < N; i++) u[i] = d[i];
+          limbs_shr1(u);
+          limbs_add(r, s);
+          limbs_shl1(s);
+        } else {                                // w >= u: w = (w - u) / 2
+          unsigned c = 0;
+#pragma unroll
+          for (int i = 0; i < N; i++) w[i] = __builtin_subc(0u, d[i], c, &c);     // -(u - w), exact in N limbs
+          limbs_shr1(w);
+          limbs_add(s, r);
+          limbs_shl1(r);
+        }
+      }
+      k++;
+    }
+    // r < 2p: x = p - (r mod p)
+    Fp x;
+    {
+      uint32_t d[N];
+      unsigned bw = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) d[i] = __builtin_subc(r[i], P::MOD[i], bw, &bw);
+      if (!bw)
+#pragma unroll
+        for (int i = 0; i < N; i++) r[i] = d[i];
+      bw = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) x.v[i] = __builtin_subc(P::MOD[i], r[i], bw, &bw);
+      // r = 0 cannot happen for a unit (x would be p)
+    }
+    // Montgomery form of 2^e, e = 64 N - k in [2, 32 N + 2]
+    Fp two = one() + one();
+    return mul_ni(x, two.pow_u64((uint64_t)(64 * N - k)));
   }
   ZK_HD static Fp from_u64(uint64_t x) {
     Fp r = zero();

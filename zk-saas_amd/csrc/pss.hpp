@@ -99,6 +99,13 @@ ZK_D void unpack_term(F* sec, const F* __restrict__ U, int np, int s, const F& x
 #pragma unroll
   for (int i = 0; i < L; i++) sec[i] = sec[i] + mulsel<L>(U[i * np + s], x);
 }
+// sec[i] += sum over one group of G rows, as L dot products with one reduction each (Fp::dot_k): the rows of U are
+// wave-uniform, so its limbs are the scalar operands of the multiply instructions
+template <class F, int L, int G>
+ZK_D void unpack_group(F* sec, const F* __restrict__ U, int np, int s0, const F* const* x) {
+#pragma unroll
+  for (int i = 0; i < L; i++) sec[i] = sec[i] + F::template dot_k<G>(x, U + i * np + s0);
+}
 template <class F, int L, class RowFn>
 ZK_D void unpack_accumulate(F* sec, const F* __restrict__ U, int np, RowFn row) {
   constexpr int N = 4 * L, G = N < 8 ? N : 8;
@@ -109,19 +116,22 @@ ZK_D void unpack_accumulate(F* sec, const F* __restrict__ U, int np, RowFn row) 
       const F x0 = row(s0), x1 = row(s0 + 1), x2 = row(s0 + 2), x3 = row(s0 + 3);
       if constexpr (G == 8) {
         const F x4 = row(s0 + 4), x5 = row(s0 + 5), x6 = row(s0 + 6), x7 = row(s0 + 7);
-        unpack_term<F, L>(sec, U, np, s0, x0);
-        unpack_term<F, L>(sec, U, np, s0 + 1, x1);
-        unpack_term<F, L>(sec, U, np, s0 + 2, x2);
-        unpack_term<F, L>(sec, U, np, s0 + 3, x3);
-        unpack_term<F, L>(sec, U, np, s0 + 4, x4);
-        unpack_term<F, L>(sec, U, np, s0 + 5, x5);
-        unpack_term<F, L>(sec, U, np, s0 + 6, x6);
-        unpack_term<F, L>(sec, U, np, s0 + 7, x7);
+        if constexpr (L <= 2) {
+          const F* const xs[8] = {&x0, &x1, &x2, &x3, &x4, &x5, &x6, &x7};
+          unpack_group<F, L, 8>(sec, U, np, s0, xs);
+        } else {
+          unpack_term<F, L>(sec, U, np, s0, x0);
+          unpack_term<F, L>(sec, U, np, s0 + 1, x1);
+          unpack_term<F, L>(sec, U, np, s0 + 2, x2);
+          unpack_term<F, L>(sec, U, np, s0 + 3, x3);
+          unpack_term<F, L>(sec, U, np, s0 + 4, x4);
+          unpack_term<F, L>(sec, U, np, s0 + 5, x5);
+          unpack_term<F, L>(sec, U, np, s0 + 6, x6);
+          unpack_term<F, L>(sec, U, np, s0 + 7, x7);
+        }
       } else {
-        unpack_term<F, L>(sec, U, np, s0, x0);
-        unpack_term<F, L>(sec, U, np, s0 + 1, x1);
-        unpack_term<F, L>(sec, U, np, s0 + 2, x2);
-        unpack_term<F, L>(sec, U, np, s0 + 3, x3);
+        const F* const xs[4] = {&x0, &x1, &x2, &x3};
+        unpack_group<F, L, 4>(sec, U, np, s0, xs);
       }
     }
     return;
