@@ -51,8 +51,10 @@ MUL_MEASURED_G = 123.8
 #                   3 |XYZZ| = 384 B (G1), 768 B (G2) -- a dependent-chain (latency-bound) tree kernel, flagged so
 SLOT_BYTES = {"king_fft2_kernel": 512.0, "msm_accumulate_kernel<G1>": 96.0, "msm_accumulate_kernel<G2>": 160.0,
               "msm_digits+scan+expand": 32.0, "msm_finalize+reduce<G1>": 384.0, "msm_finalize+reduce<G2>": 768.0,
-              "king_degred_kernel": 512.0}
-LATENCY_BOUND = {"msm_finalize+reduce<G1>", "msm_finalize+reduce<G2>", "msm_digits+scan+expand"}
+              "king_degred_kernel": 512.0,
+              # d_pp (units = elements, l = 2): tile reads 2 n/l shares and writes one value; finish reads it and writes n/l
+              "dpp_tile_kernel": 288.0, "dpp_carry_kernel": 96.0, "dpp_finish_kernel": 160.0}
+LATENCY_BOUND = {"msm_finalize+reduce<G1>", "msm_finalize+reduce<G2>", "msm_digits+scan+expand", "dpp_carry_kernel"}
 
 
 def cpu_model():
@@ -96,17 +98,18 @@ def read_profile(pp):
 PMC_KERNEL = {"msm_accumulate_kernel<G1>": "msm_accumulate_kernel<Fp<", "msm_accumulate_kernel<G2>": "msm_accumulate_split_kernel<",
               "ntt_pass_kernel": "ntt_pass_kernel", "king_fft2_kernel": "king_fft2_kernel",
               "king_degred_kernel": "king_degred_kernel", "msm_finalize+reduce<G1>": "msm_finalize_kernel<Fp<",
-              "msm_finalize+reduce<G2>": "msm_finalize_kernel<Fp2"}
-PMC_FILE = "r04_c4_pmc_hbm.json"
+              "msm_finalize+reduce<G2>": "msm_finalize_kernel<Fp2", "dpp_tile_kernel": "dpp_tile_kernel",
+              "dpp_carry_kernel": "dpp_carry_kernel", "dpp_finish_kernel": "dpp_finish_kernel"}
+PMC_FILE = "r05_c4_pmc_hbm.json"
 
 
-def pmc_traffic(slot_name):
+def pmc_traffic(slot_name, pmc_file=None):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC summary of this same command
     (profiles/<PMC_FILE>: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, which cannot run inside this
     process; the summary tool applies the guide's gfx950 correction -- FETCH_SIZE x 2 for the 16-byte-per-lane
     streaming kernels -- and records per kernel whether it did).  The bench line names the file (`traffic_source`):
     it is regenerated by tools/refresh_profiles.sh whenever the kernel changes."""
-    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    path = os.path.join(ROOT, "profiles", pmc_file or PMC_FILE)
     prefix = PMC_KERNEL.get(slot_name)
     if not prefix or not os.path.exists(path):
         return None
@@ -128,7 +131,7 @@ def msm_stats(pp):
 
 
 def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=None, slot_bytes=None, limbs=8,
-                exclude=None):
+                exclude=None, pmc_file=None):
     """The slot with the largest share of the timed region -- also when it is a latency-bound helper.  slot_bytes: per-unit
     algorithmic bytes of another curve (BLS12-381: 128 B per G1 point, 224 B per G2 point); limbs: 32-bit limbs of the base
     field (the multiply-instruction issue bound of a product scales with limbs^2); exclude: slots left out of the choice."""
@@ -167,8 +170,8 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=No
                "plan": plan}
     return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_of_achievable_6.29TBps": round(achieved / HBM_ACHIEVABLE_GBS, 5),
-            "traffic": pmc_traffic(name),
-            "traffic_source": "profiles/" + PMC_FILE,
+            "traffic": pmc_traffic(name, pmc_file),
+            "traffic_source": "profiles/" + (pmc_file or PMC_FILE),
             "slot_times": "HIP-event spans on the launching streams; the MSMs of a proof run on 5 streams and overlap",
             "latency_bound_helper": name in LATENCY_BOUND, "alu": alu,
             "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
@@ -218,8 +221,8 @@ def med(pp, fn, reps):
 
 
 def primitives(pp, zk):
-    """GPU-side timings of BASELINE configs[1] (d_fft, m = 2^20, with sampled masks AND with zero masks) and
-    configs[2] (d_msm, 2^20 G1 points per party, 8 parties) with the achieved fraction of HBM bandwidth on
+    """GPU-side timings of BASELINE configs[1] (d_fft, m = 2^20, with sampled masks AND with zero masks), d_pp at the
+    same size and configs[2] (d_msm, 2^20 G1 points per party, 8 parties) with the achieved fraction of HBM bandwidth on
     SURVEY.md 8d's algorithmic bytes: 32 m B for d_fft WITH masks (mask reads and unmask passes included), 16 m B
     without; 96 B per point for the G1 MSM."""
     from zksaas_amd.api import ZK_G1
@@ -246,6 +249,21 @@ def primitives(pp, zk):
             "frac_hbm": round(alg / t / 8e12, 4), "G_modmul_per_s": round(modmul / t / 1e9, 1),
             "frac_mad_issue_bound": round(modmul / t / 1e9 / MAD_ISSUE_BOUND_G, 3)}
     del sh, dst, mask
+    # d_pp (dpp/mod.rs:15-87) at the same size: all parties on this device, the deg_red round fused into the last kernel.
+    # Algorithmic bytes: read 2 n (m/l) B, write n (m/l) B, two passes of m B for the plaintext vector;
+    # with sampled DegRedMasks the two mask reads (2 n (m/l) B) come on top.  Multiplications per element: the two unpack2
+    # rows count 8 each (one-reduction dot products issue ~0.54 of that), 5 for the scans, 1 + 5 for finish and pack, + 8
+    # for the in-mask's unpack2 when there is one.
+    nm, dn, res = rand_fr(pp.n * m // 2), rand_fr(pp.n * m // 2), pp.alloc_fr(pp.n * m // 2)
+    dmask = zk.DegRedMask.sample(pp, m // 2, 12)
+    for label, mk, alg, mpe in (("masks", dmask, (3 + 2) * pp.n * (m // 2) * 32 + 2 * m * 32, 35),
+                                ("zero_masks", zk.DegRedMask.zero(), 3 * pp.n * (m // 2) * 32 + 2 * m * 32, 27)):
+        t = med(pp, lambda: zk.d_pp(pp, nm, dn, mk, m // 2, seed=4, out=res), 7)
+        out["d_pp_m2^20_bn254_l2_n8_" + label] = {
+            "ms": round(t * 1e3, 3), "algorithmic_bytes": alg, "achieved_GBps": round(alg / t / 1e9, 1),
+            "frac_hbm": round(alg / t / 8e12, 4), "G_modmul_per_s": round(m * mpe / t / 1e9, 1),
+            "frac_mad_issue_bound": round(m * mpe / t / 1e9 / MAD_ISSUE_BOUND_G, 3)}
+    del nm, dn, res, dmask
     ln = 1 << 20
     # DISTINCT bases (seeded random multiples of the generator, as a CRS is).  Round 1 and most of round 2 tiled ONE point
     # 8 x 2^20 times: then every bucket's second addition is a doubling and negated digits cancel -- the rare branches of

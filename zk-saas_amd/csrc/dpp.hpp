@@ -222,12 +222,18 @@ __global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restr
   F tot_n, tot_d;
   F run = block_scan_mul_exclusive(pn, sh, &tot_n);
   F sd = block_scan_mul_exclusive(pd, sh, &tot_d);
-  if (tid == 0) {
-    if (tot_d.is_zero()) {
-      atomicExch(err, 1);
-      inv_sh = F::zero();
-    } else {
-      inv_sh = tot_d.inverse_gcd();
+  if (tid < 64) {
+    // the one inversion, by the binary Euclid on the SCALAR unit: every thread holds the same total, and handing it to
+    // the loop through readfirstlane lets the compiler keep u, v, r, s in SGPRs (64-bit shifts, s_addc chains, scalar
+    // branches) instead of running a one-lane vector loop with execution-mask bookkeeping around each branch
+    F t;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) t.v[i] = __builtin_amdgcn_readfirstlane(tot_d.v[i]);
+    const bool zero = t.is_zero();
+    const F inv = zero ? F::zero() : t.inverse_gcd();
+    if (tid == 0) {
+      if (zero) atomicExch(err, 1);
+      inv_sh = inv;
     }
   }
   for (size_t i = nlo; i < nhi; i++) {

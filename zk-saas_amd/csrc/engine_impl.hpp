@@ -1061,14 +1061,13 @@ class Engine : public IEngine {
     int slot = 0;
     zk_crs_share crs{};
     zk_groth16_masks mk{};
-    bool has_mk = false, r_zero = false, split_v = false, full = true;
-    std::atomic<int> v_acc_flag{0};     // raised once V's accumulate has been enqueued (MsmGate)
+    bool has_mk = false, r_zero = false, full = true;
     int first = 0, count = 0;
     Fr r, s;
     DevBuf hwork, hshare;
-    MsmPending pS, pH, pV0, pV1, pW, pU;
+    MsmPending pS, pV0, pW, pU;
     P1 S, H, W, U, sS, rH;
-    P2 V0, V1;
+    P2 V0;
     P1 rN, sK, rsM, s_cA, r_cB1;
     P2 sK2;
     P1 in1[5], s_in0, r_in1;                        // in-mask sums (index 2 unused) and their multiples
@@ -1136,7 +1135,7 @@ class Engine : public IEngine {
     j.err = Status{};
     for (int i = 0; i < 8; i++) j.rc[i] = 0;
     j.S = j.H = j.W = j.U = j.sS = j.rH = j.s_in0 = j.r_in1 = P1::identity();
-    j.V0 = j.V1 = j.in2 = P2::identity();
+    j.V0 = j.in2 = P2::identity();
     for (int k = 0; k < 5; k++) j.in1[k] = P1::identity();
     j.s_om0.assign(n, P1::identity());
     j.r_om1.assign(n, P1::identity());
@@ -1161,138 +1160,72 @@ class Engine : public IEngine {
     const size_t cstride = crs->len_a;
     // ---- device pipelines: the four MSMs over the witness shares do not depend on h.  Each is enqueued by a pool task
     // (a launch is a dozen kernel launches), which then waits for the slot's event and folds the windows on the host.
-    // V (G2) is the longest chain: issued first, on a high-priority stream.  Round 1 ran it as two halves of the party
-    // range on two streams; with the bucket reduction now a visible share of a G2 MSM (0.8 ms of 2.1 ms alone) the
-    // second reduction costs more than the parallelism gains: 257 -> 279 proofs/s unsplit (ZK_SPLIT_V=1 restores it).
-    static const bool split_v_env = getenv("ZK_SPLIT_V") && atoi(getenv("ZK_SPLIT_V")) != 0;
-    j.split_v = count >= 2 && split_v_env;
-    const int nh = j.split_v ? count / 2 : count;
+    // V (G2) is the longest chain: issued first, on a high-priority stream, as ONE launch over all parties (two halves
+    // on two streams paid a second bucket reduction: 257 vs 279 proofs/s, round 2).
+    // Orders that were measured and dropped (rounds 2-4, DESIGN.md "What bounds one proof"): V's accumulate ahead of the
+    // G1 accumulates (283-285 vs 291-293 proofs/s), circom_h's launches enqueued ahead of the MSM tasks at the SHA-256
+    // size (550-555 vs 571-596), S and H as two MSMs with their own sorts (391 vs 464), raised issue priority or shorter
+    // lane ranges for the U-MSM (541-544 vs 591-594).
     const Fr* cf = msm_.coef_d_ + first;
-    // ZK_V_FIRST=1 (measured, off by default): the accumulate kernels of S/H and W wait for V's.  Issued together, the G1
-    // waves (168 registers, three per SIMD) keep the SIMDs they landed on -- a retiring one frees too few registers for
-    // a 256-register G2 wave, whatever the stream priorities say -- so the G2 accumulate takes 1.9 ms instead of ~1 ms
-    // and its 0.9 ms finalize/reduce tail runs on a nearly empty chip.  Ordering them hides that tail under the G1
-    // accumulates but gives up the overlap at the front: 283-285 vs 291-293 proofs/s with tables, 198-208 vs 208-225
-    // without.
-    static const bool v_first = getenv("ZK_V_FIRST") && atoi(getenv("ZK_V_FIRST")) != 0;
-    MsmGate gate_v{}, gate_g1{};
-    // ZK_H_FIRST_LOG_M=<k> (measured, off by default): for domains of 2^k and more circom_h goes first and the accumulate
-    // kernels of the witness MSMs wait for it.  Its NTT passes are 512-thread / 64 KB workgroups that need a whole CU to
-    // drain; next to four multi-hundred-millisecond accumulate kernels each pass waits ~78 ms (BLS12-381, m = 2^22)
-    // where the whole chain takes a few milliseconds alone.  Ordering it first removes that wait (5.5 ms per pass) and
-    // changes nothing: 0.667 vs 0.666 s per proof -- the proof is bound by the multiplier throughput of the five
-    // accumulates, whichever order they run in.
-    bool h_done = false;
-    if (full && !v_first && h_first(log_m)) {
+    MsmGate gate{};
+    // Large domains (2^h_first_log_m_ and up; 2^20 by default): circom_h and the SORT of the U-MSM that consumes it go
+    // first, and the accumulate kernels of the witness MSMs wait for them (they still sort beside circom_h).  A proof of
+    // this size is bound by the multiplier throughput of its five accumulate kernels whichever order they run in (0.667
+    // vs 0.666 s per proof at 2^22, round 3), but next to four multi-hundred-millisecond accumulates every NTT pass (a
+    // 512-thread / 64 KB workgroup needs a whole CU to drain) and every one-workgroup-per-CU sort kernel sat in the
+    // dispatcher for most of the proof: the HIP-event spans of those slots then measured the wait, not the kernel
+    // (0.43 s per sort against 25 ms of execution, profiles/r04_c5_kernel_stats.csv).
+    bool hu_done = false;
+    if (full && log_m >= h_first_log_m_) {
       hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
       if (he != hipSuccess) return hip_fail(he, "h share buffer");
       rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
       if (rc) return rc;
-      ZK_HIP(hipEventRecord(ev_gate_[j.slot], streams_[5]));
-      static const bool gate_v_too = !(getenv("ZK_H_GATE_V") && atoi(getenv("ZK_H_GATE_V")) == 0);
-      gate_g1.wait_ev = ev_gate_[j.slot];                       // recorded before any task runs: no host flag needed
-      if (gate_v_too) gate_v.wait_ev = ev_gate_[j.slot];
-      h_done = true;
-    }
-    // ZK_H_ENQUEUE_FIRST=1 (round 4, measured, off): circom_h's kernels ENQUEUED before the pool tasks start launching the
-    // witness MSMs' sorts (no gate, only the order of the host's launches) -- 550-555 against 571-596 proofs/s: the two
-    // dozen launches on the calling thread delay the MSM tasks by more than the chain gains
-    static const bool h_enq_first = getenv("ZK_H_ENQUEUE_FIRST") && atoi(getenv("ZK_H_ENQUEUE_FIRST")) != 0;
-    if (full && !h_done && h_enq_first) {
-      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
-      if (he != hipSuccess) return hip_fail(he, "h share buffer");
-      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
+      MsmGate gu{};
+      gu.sorted_ev = ev_gate_[j.slot];            // recorded on this thread, before any pool task can wait for it
+      rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u,
+                                      streams_[5], ws0 + 0, &j.pU, nullptr, gu);
       if (rc) return rc;
-      h_done = true;
+      gate.wait_ev = ev_gate_[j.slot];
+      hu_done = true;
     }
-    if (v_first) {
-      j.v_acc_flag.store(0, std::memory_order_relaxed);
-      gate_v.signal_ev = ev_gate_[j.slot];
-      gate_v.signal_flag = &j.v_acc_flag;
-      gate_g1.wait_ev = ev_gate_[j.slot];
-      gate_g1.wait_flag = &j.v_acc_flag;
-    }
-    auto msm_task = [this, J, dev, gate_v, gate_g1](auto fld_tag, int which, const void* bases, const void* bases2,
-                                                    const void* scal, size_t npts, const Fr* coef, size_t plen,
-                                                    hipStream_t stream, int wslot, MsmPending* pend, auto* out1,
-                                                    auto* out2) {
+    auto msm_task = [this, J, dev, gate](auto fld_tag, int which, const void* bases, const void* bases2, const void* scal,
+                                         size_t npts, const Fr* coef, size_t plen, hipStream_t stream, int wslot,
+                                         MsmPending* pend, auto* out1, auto* out2) {
       using Fld = decltype(fld_tag);
       J->fut.push_back(pool_->submit([=]() {
         (void)hipSetDevice(dev);
-        constexpr bool is_v = std::is_same<Fld, Fq2_>::value;
-        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2,
-                                              is_v ? gate_v : gate_g1);
-        if (is_v && which == 2) J->v_acc_flag.store(1, std::memory_order_release);   // also when the launch failed early
-        static const bool trace = getenv("ZK_TRACE_HOST") != nullptr;
-        auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        if (trace && !rc2) {
-          (void)hipEventSynchronize(pend->slot->ev);
-          t0 = now_us();
-        }
+        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2, gate);
         if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
-        if (trace) t1 = now_us();
         J->rc[which] = rc2;
         if constexpr (std::is_same<Fld, Fq_>::value) {
-          if (!rc2 && J->full) {                      // s*S and r*H off the tail (prove.rs:229-235, linearity)
-            if (which == 0) J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
-            if (trace) t2 = now_us();
-            if ((which == 4 || (which == 0 && out2 != nullptr)) && !J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
-            if (trace) t3 = now_us();
+          if (!rc2 && J->full && which == 0) {        // s*S and r*H off the tail (prove.rs:229-235, linearity)
+            J->sS = host_scalar_mul<FrP, Fq_>(J->S, J->s);
+            if (out2 != nullptr && !J->r_zero) J->rH = host_scalar_mul<FrP, Fq_>(J->H, J->r);
           }
         }
-        if (trace) fprintf(stderr, "[zk host] msm %d: gpu done %.0f, fold %.0f us, s*S %.0f us, r*H %.0f us\n", which, t0, t1 - t0, t2 ? t2 - t1 : 0.0, t3 ? t3 - t2 : 0.0);
       }));
     };
-    const char* vb = (const char*)crs->v_d;
-    const char* as = (const char*)a_share;
-    // (Round 2 measured sharing V's sort with S/H -- ZK_SHARE_SORT -- at 291 vs 289 proofs/s; the experiment went away
-    // with the segment descriptors it shared.)
-    {
-      msm_task(Fq2_{}, 2, vb, nullptr, as, (size_t)nh * cstride, cf, cstride, streams_[2], ws0 + 3, &j.pV0, &j.V0,
-               (P2*)nullptr);
-      if (j.split_v)
-        msm_task(Fq2_{}, 3, vb + (size_t)nh * cstride * sizeof(Affine<Fq2_>), nullptr, as + (size_t)nh * cstride * sizeof(Fr),
-                 (size_t)(count - nh) * cstride, cf + nh, cstride, streams_[4], ws0 + 5, &j.pV1, &j.V1, (P2*)nullptr);
-      // S and H multiply two base vectors by the same witness shares: ONE launch over both vectors (one sort).  The sort
-      // leaves out identity bases, and the two vectors' identities differ -- b_query is the identity for every wire no
-      // B-row mentions (59 % in the SHA-256 circuit), a_query for 7 % -- so the fused launch skips almost nothing and the
-      // H half of its accumulate idles on those lanes.  Running them as two MSMs with their own sorts (ZK_SPLIT_SH=1) does
-      // fewer additions and was still slower, measured: 391 vs 464 proofs/s with tables, 300 vs 351 without -- a sixth
-      // concurrent chain starves circom_h's kernels further (timeline: the U-MSM then ends 0.6 ms after everything else).
-      static const bool fuse_sh = !(getenv("ZK_SPLIT_SH") && atoi(getenv("ZK_SPLIT_SH")) != 0);
-      if (fuse_sh || j.r_zero) {
-        msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride,
-                 streams_[0], ws0 + 1, &j.pS, &j.S, j.r_zero ? (P1*)nullptr : &j.H);
-      } else {
-        msm_task(Fq_{}, 0, crs->s_d, nullptr, a_share, (size_t)count * cstride, cf, cstride, streams_[0], ws0 + 1, &j.pS,
-                 &j.S, (P1*)nullptr);
-        msm_task(Fq_{}, 4, crs->h_d, nullptr, a_share, (size_t)count * cstride, cf, cstride, streams_[1], ws0 + 2, &j.pH,
-                 &j.H, (P1*)nullptr);
-      }
-    }
+    msm_task(Fq2_{}, 2, crs->v_d, nullptr, a_share, (size_t)count * cstride, cf, cstride, streams_[2], ws0 + 3, &j.pV0,
+             &j.V0, (P2*)nullptr);
+    // S and H multiply two base vectors by the same witness shares: ONE launch over both vectors, each with its own sort
+    // (their identity bases differ: b_query is the identity for every wire no B-row mentions, 59 % in the SHA-256 circuit)
+    msm_task(Fq_{}, 0, crs->s_d, j.r_zero ? nullptr : crs->h_d, a_share, (size_t)count * cstride, cf, cstride,
+             streams_[0], ws0 + 1, &j.pS, &j.S, j.r_zero ? (P1*)nullptr : &j.H);
     msm_task(Fq_{}, 1, crs->w_d, nullptr, ax_share, (size_t)count * crs->len_w, cf, crs->len_w, streams_[3], ws0 + 4,
              &j.pW, &j.W, (P1*)nullptr);
     submit_host_terms(J, j.fut, full, first, count);
     // ---- circom_h and the U-MSM that depends on it form a long dependent chain: high-priority internal stream.
     // At the SHA-256 size, holding the other MSM streams (or only their accumulate launches) back until circom_h has
-    // finished was measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once (and at
-    // 2^22 it makes no difference: h_first above).
-    if (full) {
+    // finished was measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
+    if (full && !hu_done) {
       hipStream_t hs = streams_[5];
-      if (!h_done) {
-        hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
-        if (he != hipSuccess) return hip_fail(he, "h share buffer");
-        rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
-        if (rc) return rc;
-      }
-      // ZK_U_PRIO=1 (measured, off): raised issue priority for the U-MSM's accumulate waves, the last link of the proof's
-      // critical chain -- 541-544 against 591-594 proofs/s: they then starve the reduction tails of the other four MSMs
-      static const int u_prio = getenv("ZK_U_PRIO") ? atoi(getenv("ZK_U_PRIO")) : 0;
-      // ZK_U_RANGE=<entries per lane>: the U-MSM ends a proof mostly alone on the chip: shorter ranges = more lanes
-      static const int u_range = getenv("ZK_U_RANGE") ? atoi(getenv("ZK_U_RANGE")) : 0;
+      hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
+      if (he != hipSuccess) return hip_fail(he, "h share buffer");
+      rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
+      if (rc) return rc;
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
-                                      ws0 + 0, &j.pU, nullptr, MsmGate{}, nullptr, u_prio, u_range);
+                                      ws0 + 0, &j.pU);
       if (rc) return rc;
     }
     return ZK_OK;
@@ -1346,11 +1279,6 @@ class Engine : public IEngine {
     }
   }
 
-  static bool h_first(int log_m) {
-    static const int h_first_min = getenv("ZK_H_FIRST_LOG_M") ? atoi(getenv("ZK_H_FIRST_LOG_M")) : 0;
-    return h_first_min > 0 && log_m >= h_first_min;
-  }
-
   // the U-MSM of a partial job (h comes from the caller's king rounds)
   int prove_launch_u(ProveJob& j, const void* h_share, hipStream_t st) {
     return msm_.template launch_t<Fq_>(this, j.crs.u_d, h_share, (size_t)j.count * j.crs.len_u, msm_.coef_d_ + j.first,
@@ -1371,7 +1299,7 @@ class Engine : public IEngine {
     if (j.err.code) return fail(j.err.code, j.err.msg);
     *S = xyzz_add_ni(j.S, j.in1[0]);
     *H = j.r_zero ? P1::identity() : xyzz_add_ni(j.H, j.in1[1]);
-    *V = xyzz_add_ni(xyzz_add_ni(j.V0, j.V1), j.in2);
+    *V = xyzz_add_ni(j.V0, j.in2);
     *W = xyzz_add_ni(j.W, j.in1[3]);
     *U = xyzz_add_ni(j.U, j.in1[4]);
     return ZK_OK;
@@ -1487,7 +1415,7 @@ class Engine : public IEngine {
   // joins a job's tasks and device work and marks it free (after an error, or zk_groth16_abort)
   void abort_job(ProveJob& j) {
     drain(j);
-    MsmPending* ps[6] = {&j.pS, &j.pH, &j.pV0, &j.pV1, &j.pW, &j.pU};
+    MsmPending* ps[4] = {&j.pS, &j.pV0, &j.pW, &j.pU};
     for (MsmPending* p : ps)
       if (p->active) {
         (void)hipEventSynchronize(p->slot->ev);
@@ -2011,6 +1939,11 @@ class Engine : public IEngine {
     if (!strcmp(name, "msm_table_c_g2")) {
       if (value != 0 && (value < 8 || value > 22)) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be 0 (by length) or in 8..22");
       msm_.table_c_g2 = (int)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "h_first_log_m")) {         // domains of 2^value and up: circom_h + the U sort ahead of the accumulates
+      if (value < 1 || value > 64) return fail(ZK_ERR_BAD_INPUT, "h_first_log_m must be in 1..64");
+      h_first_log_m_ = (int)value;
       return ZK_OK;
     }
     return fail(ZK_ERR_BAD_INPUT, "unknown option");
@@ -3488,6 +3421,7 @@ class Engine : public IEngine {
   HostPool* host_pool() override { return pool_.get(); }
   hipEvent_t ev_in_[NJOBS] = {nullptr, nullptr};
   hipEvent_t ev_gate_[NJOBS] = {nullptr, nullptr};
+  int h_first_log_m_ = 20;      // zk_ctx_set_option("h_first_log_m"): see prove_begin_impl
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool streams_ready_ = false;
   bool force_simple_ntt = false;

@@ -836,15 +836,16 @@ struct Fp {
     }
     return pow(e, N);
   }
-  ZK_HD static void limbs_shr1(uint32_t* a) {
+  // a >>= z, a <<= z for 1 <= z <= 31
+  ZK_HD static void limbs_shr(uint32_t* a, int z) {
 #pragma unroll
-    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
-    a[N - 1] >>= 1;
+    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> z) | (a[i + 1] << (32 - z));
+    a[N - 1] >>= z;
   }
-  ZK_HD static void limbs_shl1(uint32_t* a) {
+  ZK_HD static void limbs_shl(uint32_t* a, int z) {
 #pragma unroll
-    for (int i = N - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
-    a[0] <<= 1;
+    for (int i = N - 1; i > 0; i--) a[i] = (a[i] << z) | (a[i - 1] >> (32 - z));
+    a[0] <<= z;
   }
   ZK_HD static void limbs_add(uint32_t* a, const uint32_t* b) {
     unsigned c = 0;
@@ -857,9 +858,17 @@ struct Fp {
     for (int i = 0; i < N; i++) acc |= a[i];
     return acc != 0;
   }
+  // trailing zero bits of a non-zero multi-limb value, capped at 31 (the caller comes back for the rest)
+  ZK_HD static int limbs_ctz31(const uint32_t* a) {
+    const int z = a[0] ? __builtin_ctz(a[0]) : 31;
+    return z > 31 ? 31 : z;
+  }
   // Inverse by the binary extended Euclid (Kaliski's "almost Montgomery inverse"), for ONE lane that a whole kernel waits
-  // on (d_pp's single inversion, csrc/dpp.hpp): ~1.4 BITS iterations of shifts, one subtraction and one addition on N
-  // limbs -- about a tenth of the instructions of the Fermat ladder above, none of them a multiply.  Phase 1 leaves
+  // on (d_pp's single inversion, csrc/dpp.hpp): shifts, one subtraction and one addition on N limbs per step, none of
+  // them a multiply -- about a tenth of the instructions of the Fermat ladder above.  The textbook loop halves once per
+  // iteration (u even: u /= 2, s *= 2; v even: v /= 2, r *= 2; else the larger becomes (larger - smaller) / 2 with
+  // r += s, s *= 2 or s += r, r *= 2; k counts the halvings); here every run of halvings is taken in one shift by the
+  // number of trailing zero bits, the same sequence of states in about half the iterations.  Phase 1 leaves
   // x = a^-1 2^k (mod p), BITS <= k <= 2 BITS, for the integer a held in the limbs; the value wanted is the Montgomery form
   // of (a / R)^-1 = a^-1 R^2, i.e. x 2^(2 * 32 N - k): one product with the Montgomery form of that power of two.
   // this != 0.  Same field element as inverse().
@@ -869,34 +878,39 @@ struct Fp {
     for (int i = 0; i < N; i++) u[i] = P::MOD[i], w[i] = v[i], r[i] = 0, s[i] = 0;
     s[0] = 1;
     int k = 0;
-    while (limbs_nonzero(w)) {
-      if (!(u[0] & 1)) {
-        limbs_shr1(u);
-        limbs_shl1(s);
-      } else if (!(w[0] & 1)) {
-        limbs_shr1(w);
-        limbs_shl1(r);
-      } else {
-        uint32_t d[N];
-        unsigned bw = 0;
+    for (;;) {                                   // u is odd here (p is odd; u only changes below, ending odd)
+      if (!(w[0] & 1)) {                         // w even and non-zero
+        const int z = limbs_ctz31(w);
+        limbs_shr(w, z);
+        limbs_shl(r, z);
+        k += z;
+        continue;
+      }
+      uint32_t d[N];
+      unsigned bw = 0;
 #pragma unroll
-        for (int i = 0; i < N; i++) d[i] = __builtin_subc(u[i], w[i], bw, &bw);
-        if (!bw && limbs_nonzero(d)) {                // u > w
+      for (int i = 0; i < N; i++) d[i] = __builtin_subc(u[i], w[i], bw, &bw);
+      if (!bw && limbs_nonzero(d)) {             // u > w: u = u - w (even), r += s, then the halvings of u
 #pragma unroll
-          for (int i = 0; i < N; i++) u[i] = d[i];
-          limbs_shr1(u);
-          limbs_add(r, s);
-          limbs_shl1(s);
-        } else {                                // w >= u: w = (w - u) / 2
-          unsigned c = 0;
+        for (int i = 0; i < N; i++) u[i] = d[i];
+        limbs_add(r, s);
+        do {
+          const int z = limbs_ctz31(u);
+          limbs_shr(u, z);
+          limbs_shl(s, z);
+          k += z;
+        } while (!(u[0] & 1));
+      } else {                                   // w >= u: w = w - u, s += r
+        unsigned c = 0;
 #pragma unroll
-          for (int i = 0; i < N; i++) w[i] = __builtin_subc(0u, d[i], c, &c);     // -(u - w), exact in N limbs
-          limbs_shr1(w);
-          limbs_add(s, r);
-          limbs_shl1(r);
+        for (int i = 0; i < N; i++) w[i] = __builtin_subc(0u, d[i], c, &c);     // -(u - w), exact in N limbs
+        limbs_add(s, r);
+        if (!limbs_nonzero(w)) {                 // u == w (== 1): the textbook loop's last step, r *= 2
+          limbs_shl(r, 1);
+          k += 1;
+          break;
         }
       }
-      k++;
     }
     // r < 2p: x = p - (r mod p)
     Fp x;
@@ -905,13 +919,13 @@ struct Fp {
       unsigned bw = 0;
 #pragma unroll
       for (int i = 0; i < N; i++) d[i] = __builtin_subc(r[i], P::MOD[i], bw, &bw);
-      if (!bw)
+      if (!bw) {
 #pragma unroll
         for (int i = 0; i < N; i++) r[i] = d[i];
+      }
       bw = 0;
 #pragma unroll
       for (int i = 0; i < N; i++) x.v[i] = __builtin_subc(P::MOD[i], r[i], bw, &bw);
-      // r = 0 cannot happen for a unit (x would be p)
     }
     // Montgomery form of 2^e, e = 64 N - k in [2, 32 N + 2]
     Fp two = one() + one();

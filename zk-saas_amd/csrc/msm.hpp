@@ -1471,6 +1471,7 @@ struct MsmPending {
 // host -- so that the event it then waits for on its stream is this proof's record, not a stale one -- before its own
 // accumulate kernel.
 struct MsmGate {
+  hipEvent_t sorted_ev = nullptr;     // recorded on the launch's stream after its sort, before its accumulate kernel
   hipEvent_t wait_ev = nullptr;
   std::atomic<int>* wait_flag = nullptr;
   hipEvent_t signal_ev = nullptr;

@@ -302,6 +302,7 @@ do {                                                                           \
   MSM_STAGE("scatter");
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB * batch);
+  if (tune.gate.sorted_ev) MSM_HIP(hipEventRecord(tune.gate.sorted_ev, st));
   if (tune.gate.wait_ev) {
     if (tune.gate.wait_flag)
       while (!tune.gate.wait_flag->load(std::memory_order_acquire)) std::this_thread::yield();

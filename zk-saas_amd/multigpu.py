@@ -425,9 +425,15 @@ def bench(args, rank, local_rank, world):
         wit = inst.witness(seed=100)
         r, s = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA0987654321
         out = {}
+        # all twelve masks of a proof (six FftMask, the DegRedMask, five MsmMask), dealt as sha256.rs:226-291 does and
+        # applied, as the c4 line does: 28 GiB of mask vectors at 2^24 (--no-masks: the zero masks the reference's bench
+        # scripts run with)
+        masks = None if args.no_masks else zg.ProofMasks(pp, log_m, seed=77)
+        mct, keep = local_masks(pp, masks, log_m, first, k)
 
         def step(i):
-            out["proof"] = znet.dist_prove(pp, net, inst.crs.ct, wit.qap, wit.a_share, wit.ax_share, r, s, log_m, seed=7 + i)
+            out["proof"] = znet.dist_prove(pp, net, inst.crs.ct, wit.qap, wit.a_share, wit.ax_share, r, s, log_m,
+                                           masks=mct, seed=7 + i)
         step(0)
         pp._check(pp.lib.zk_profile_enable(pp.h, 1))
         dt = timed(step)
@@ -438,10 +444,9 @@ def bench(args, rank, local_rank, world):
         # (the sort slot is left out of the choice: with five multi-hundred-millisecond MSMs in flight its HIP-event span
         # is mostly the time its one-workgroup-per-CU kernels WAIT for CUs the accumulate kernels of the other MSMs hold --
         # 0.43 s per sort against 25 ms of execution, profiles/r04_c5_kernel_stats.csv; `kernels` below still lists it)
-        roof = roofline_of(prof, ntt_passes=3, masks_on=False, pp=pp, limbs=12, exclude=("msm_digits+scan+expand",),
-                           slot_bytes={"msm_accumulate_kernel<G1>": 128.0, "msm_accumulate_kernel<G2>": 224.0})
-        if roof:
-            roof["traffic"], roof["traffic_source"] = None, None
+        roof = roofline_of(prof, ntt_passes=3, masks_on=masks is not None, pp=pp, limbs=12,
+                           slot_bytes={"msm_accumulate_kernel<G1>": 128.0, "msm_accumulate_kernel<G2>": 224.0},
+                           pmc_file="r05_c5_pmc_hbm.json")
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             del wit
@@ -452,7 +457,9 @@ def bench(args, rank, local_rank, world):
                    constraints_per_sec=round(inst.nc * args.steps / dt, 1),
                    data="synthetic R1CS and pseudo-random CRS built on the device (zksaas_amd/synthetic.py)",
                    config={"workload": "BASELINE configs[4]: BLS12-381 2^%d-constraint synthetic R1CS, d_fft + d_msm + "
-                                       "deg_red composed, zero masks" % log_m, "constraints": inst.nc, "parties": pp.n},
+                                       "deg_red composed, %s" % (log_m, "zero masks" if masks is None else
+                                                                 "all 12 masks sampled and applied"),
+                           "masks": masks is not None, "constraints": inst.nc, "parties": pp.n},
                    roofline=roof, cpu_baseline=cpu,
                    kernels=[{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]])
     net.close()
