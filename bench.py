@@ -574,9 +574,10 @@ def main():
     ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c4 = SHA-256 Groth16 (default, the headline metric), c2 = d_fft 2^20, "
                          "c3 = d_msm 2^20 per party, c5 = BLS12-381 2^24-constraint synthetic Groth16")
-    ap.add_argument("--king", default="alltoall", choices=["alltoall", "star"],
-                    help="N > 1: how a king round runs -- every rank king of a chunk range (two all-to-all exchanges; "
-                         "default) or the reference's star through rank 0")
+    ap.add_argument("--king", default="star", choices=["star", "alltoall"],
+                    help="N > 1: how a king round runs -- the reference's star through rank 0 (king on GPU 0, RCCL gather / "
+                         "scatter: north_star's topology, the default; the same run then also times the all-to-all king and "
+                         "reports it as `alltoall`) or every rank king of a chunk range (two all-to-all exchanges)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-masks", action="store_true", help="zero masks (the *::zero() variants the reference's "
                     "micro-benchmarks use); default: all twelve masks sampled, as groth16/examples/sha256.rs")
@@ -615,6 +616,8 @@ def main():
         return
 
     pp = zk.PackedSharingParams("bn254", 2, device=local_rank)
+    for kv in filter(None, os.environ.get("ZK_BENCH_OPTIONS", "").split(",")):     # A/B runs: name=value context options
+        pp.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     r1, w, setup, crs, wit, r, s = build_inputs(pp, zk)
     masks = None if args.no_masks else zg.ProofMasks(pp, wit.log_m, seed=77)
     table_windows = None

@@ -376,3 +376,61 @@ def test_c5_bls12_381_d_msm_2_23_per_party_equals_six_limb_c_oracle():
             assert G.eq(got[p], want)
     finally:
         pp.close()
+
+
+@pytest.mark.parametrize("scalars", ["random", "repeating"])
+def test_c5_bls12_381_g2_d_msm_2_20_per_party_equals_six_limb_c_oracle(scalars):
+    """The G2 d_msm (V = b_g2_query, prove.rs:134-160) at the size the staged path runs, EXACT: 2^20 points per party, 8
+    parties, ONE 2^23-point Pippenger on the GPU -- staged 1024-thread sort, wide entry format, heavy list and the 12-limb
+    lane-quad accumulate (msm_accumulate_split_kernel) -- against arkworks' signed-digit Pippenger over Fq2 restated in C with
+    six 64-bit limbs (oracle/c libzkref6.so zkref_msm_g2), every party's G::msm on its own threads, then the king's
+    unpack2 + sum (dmsm/mod.rs:73-92) through the Python oracle.  `repeating`: witness-like scalars (60 % ones, 25 %
+    fives, 5 % r - 1: buckets of hundreds of thousands of entries through the heavy list)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.cref import CGroup6
+    from oracle.curve import GroupOps, g2
+    from oracle.params import CURVES
+    from oracle.pss import PackedSharingParams as OPP
+    cv = CURVES["bls12_381"]
+    ln = 1 << int(os.environ.get("ZK_C5_G2_LOG_LEN", "20"))
+    pp = zk.PackedSharingParams("bls12_381", 2)
+    try:
+        cg = CGroup6("bls12_381")
+        rng = np.random.default_rng(52)
+
+        def rand(count):
+            a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+            a[:, 3] &= np.uint64((1 << 60) - 1)
+            return a
+        tot = pp.n * ln
+        bases = zg.base_points(pp, ZK_G2, zk.DeviceBuffer.from_numpy(pp, rand(tot)), tot)      # distinct multiples of the generator
+        sc = rand(tot)
+        if scalars == "repeating":
+            sel = rng.random(tot)
+            for lo, hi, val in ((0.0, 0.6, 1), (0.6, 0.85, 5), (0.85, 0.9, cv.r - 1)):
+                sc[(sel >= lo) & (sel < hi)] = pp.fr.encode([val])[0]
+        scal = zk.DeviceBuffer.from_numpy(pp, sc)
+        out = zk.d_msm(pp, ZK_G2, bases, scal, ln)
+        G = g2(cv)
+        got = [dec_jacobian(pp, out[p], True) for p in range(pp.n)]
+        bases_h = bases.to_numpy().reshape(tot, 24)
+        zk.api.vec_scale(pp, scal, (1 << 128) % cv.r, tot)          # residues to the radix 2^384 (see the G1 test above)
+        sc6 = np.zeros((tot, 6), dtype=np.uint64)
+        sc6[:, :4] = scal.to_numpy().reshape(tot, 4)
+        del scal, bases
+
+        def party(p):
+            return cg.msm_g2_arrays(np.ascontiguousarray(bases_h[p * ln:(p + 1) * ln]), np.ascontiguousarray(sc6[p * ln:(p + 1) * ln]),
+                                    ln, nthreads=24)
+        with ThreadPoolExecutor(max_workers=pp.n) as ex:
+            parts = list(ex.map(party, range(pp.n)))
+
+        def dec6(a):
+            v = cg.fq.dec(a)
+            return ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+        o = OPP(cv, 2)
+        want = G.sum(o.unpack2([dec6(x) for x in parts], GroupOps(G)))
+        for p in range(pp.n):
+            assert G.eq(got[p], want)
+    finally:
+        pp.close()

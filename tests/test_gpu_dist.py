@@ -96,7 +96,11 @@ def test_bench_ranks_as_the_driver_launches_it(workload, ranks):
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == ranks and res["parties_per_gpu"] == 8 // ranks and res["value"] > 0
-    assert res["king"] == "alltoall" and "transport_note" not in res
+    # the headline runs north_star's topology (star: king on GPU 0); the all-to-all king is timed in the same run beside it
+    assert res["king"] == "star" and "transport_note" not in res
+    if workload != "c3":
+        assert res["alltoall"]["king"] == "alltoall" and res["alltoall"]["value"] > 0, res["alltoall"]
+        assert "king on GPU 0" in res["config"]["workload"]
     if workload == "c4":
         assert res["proof_matches_single_gpu"] is True and res["config"]["masks"] is True
         # throughput modes of the sharded prover: a batch per collective call, and two proofs in flight per rank

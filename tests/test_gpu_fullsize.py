@@ -273,7 +273,7 @@ def test_msm_2_20_on_12_limb_curves_equals_six_limb_c_oracle(curve):
     assert G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want))
 
 
-@pytest.mark.parametrize("curve,g2", [("bn254", False), ("bls12_381", False), ("bn254", True)])
+@pytest.mark.parametrize("curve,g2", [("bn254", False), ("bls12_381", False), ("bn254", True), ("bls12_381", True)])
 def test_msm_at_every_lane_shape_equals_the_sum_of_small_msms(curve, g2):
     """Sizes across the accumulate kernel's lane shapes (fewer than one round of waves, between one and two -- the
     case that once left entries uncovered: 2^18 .. 2^19 points at 15-bit windows --, several rounds), both kernels

@@ -242,6 +242,9 @@ namespace {
 struct HostStage {
   std::vector<void*> bufs;
   ~HostStage() {
+    // on an error path kernels that read the staged buffers may still be enqueued: make their end explicit instead of
+    // leaning on hipFree's implicit synchronisation
+    if (!bufs.empty()) (void)hipDeviceSynchronize();
     for (void* p : bufs) (void)hipFree(p);
   }
   void* up(IEngine* e, const void* h, size_t bytes, hipStream_t st, int* rc) {
@@ -351,6 +354,9 @@ int zk_groth16_prove_host(zk_ctx* ctx, const zk_crs_share* crs, const void* qap_
   CTX_OR_FAIL();
   if (!crs || !qap_a || !qap_b || !qap_c || !a_share || !ax_share || log2_m < 0 || log2_m > 40)
     return e->fail(ZK_ERR_BAD_INPUT, "null pointer");
+  // a NULL query vector with a non-zero length would be staged as uninitialised device memory
+  if ((crs->len_a && (!crs->s_d || !crs->h_d || !crs->v_d)) || (crs->len_w && !crs->w_d) || (crs->len_u && !crs->u_d))
+    return e->fail(ZK_ERR_BAD_INPUT, "null CRS query vector");
   const size_t n = (size_t)e->n, fr = e->fr_bytes(), g1 = 2 * e->fq_bytes(), g2 = 2 * g1;
   const size_t qbytes = n * (((size_t)1 << log2_m) / (size_t)e->l) * fr;
   HostStage hs;

@@ -1061,7 +1061,8 @@ class Engine : public IEngine {
     int slot = 0;
     zk_crs_share crs{};
     zk_groth16_masks mk{};
-    bool has_mk = false, r_zero = false, full = true;
+    bool has_mk = false, r_zero = false, full = true, gate_sorts = false;
+    std::atomic<int> sorted_cnt{0};     // witness MSMs of this proof whose sort has been enqueued and recorded (MsmGate)
     int first = 0, count = 0;
     Fr r, s;
     DevBuf hwork, hshare;
@@ -1111,9 +1112,11 @@ class Engine : public IEngine {
   // buffers: every such return goes through abort_job (the job is free again, the error message is kept).
   int prove_begin(ProveJob& j, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
                   const void* a_share, const void* ax_share, const Fr& r, const Fr& s, int log_m,
-                  const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st) {
+                  const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st,
+                  bool gate_sorts = false) {
     if (j.active) return fail(ZK_ERR_BAD_INPUT, "a proof is already in flight on this slot");
-    int rc = prove_begin_impl(j, crs, qa, qb, qc, a_share, ax_share, r, s, log_m, mk, seed, full, first, count, st);
+    int rc = prove_begin_impl(j, crs, qa, qb, qc, a_share, ax_share, r, s, log_m, mk, seed, full, first, count, st,
+                              gate_sorts);
     if (rc && j.active) {
       Status keep = last;
       abort_job(j);
@@ -1140,9 +1143,19 @@ class Engine : public IEngine {
     j.s_om0.assign(n, P1::identity());
     j.r_om1.assign(n, P1::identity());
   }
+  // the gate of a proof's U-MSM: its sort is event 3 of the "all sorts first" barrier (prove_begin_impl)
+  MsmGate u_gate(ProveJob& j) {
+    MsmGate g{};
+    if (j.gate_sorts) {
+      g.sorted_ev = ev_sorted_[j.slot][3];
+      g.sorted_cnt = &j.sorted_cnt;
+    }
+    return g;
+  }
   int prove_begin_impl(ProveJob& j, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
                        const void* a_share, const void* ax_share, const Fr& r, const Fr& s, int log_m,
-                       const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st) {
+                       const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st,
+                       bool gate_sorts) {
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     int rc = ensure_streams();
     if (rc) return rc;
@@ -1175,18 +1188,26 @@ class Engine : public IEngine {
     // 512-thread / 64 KB workgroup needs a whole CU to drain) and every one-workgroup-per-CU sort kernel sat in the
     // dispatcher for most of the proof: the HIP-event spans of those slots then measured the wait, not the kernel
     // (0.43 s per sort against 25 ms of execution, profiles/r04_c5_kernel_stats.csv).
+    // The witness MSMs also wait for EACH OTHER's sorts (V's accumulate alone holds every CU for 0.46 s at 2^24): every
+    // launch of the proof records an event after its sort and counts itself in; an accumulate kernel is enqueued once all
+    // four are on record, behind all four events.  The sharded prover (full == false) does the same: there the U sort is
+    // enqueued by prove_launch_u once the king rounds of circom_h have been.
+    const bool gated = j.gate_sorts = (full || gate_sorts) && log_m >= h_first_log_m_;
+    j.sorted_cnt.store(0, std::memory_order_relaxed);
+    if (gated) {
+      gate.sorted_cnt = &j.sorted_cnt;
+      gate.wait_sorted = ev_sorted_[j.slot];
+      gate.n_wait_sorted = gate.sorted_need = 4;
+    }
     bool hu_done = false;
-    if (full && log_m >= h_first_log_m_) {
+    if (full && gated) {
       hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
       if (he != hipSuccess) return hip_fail(he, "h share buffer");
       rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, streams_[5]);
       if (rc) return rc;
-      MsmGate gu{};
-      gu.sorted_ev = ev_gate_[j.slot];            // recorded on this thread, before any pool task can wait for it
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u,
-                                      streams_[5], ws0 + 0, &j.pU, nullptr, gu);
+                                      streams_[5], ws0 + 0, &j.pU, nullptr, u_gate(j));
       if (rc) return rc;
-      gate.wait_ev = ev_gate_[j.slot];
       hu_done = true;
     }
     auto msm_task = [this, J, dev, gate](auto fld_tag, int which, const void* bases, const void* bases2, const void* scal,
@@ -1195,7 +1216,10 @@ class Engine : public IEngine {
       using Fld = decltype(fld_tag);
       J->fut.push_back(pool_->submit([=]() {
         (void)hipSetDevice(dev);
-        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2, gate);
+        MsmGate g = gate;
+        if (g.n_wait_sorted) g.sorted_ev = ev_sorted_[J->slot][which];          // which = 0 (S/H), 1 (W), 2 (V); 3 = U
+        int rc2 = msm_.template launch_t<Fld>(this, bases, scal, npts, coef, plen, stream, wslot, pend, bases2, g);
+        if (rc2 && g.sorted_cnt) g.sorted_cnt->fetch_add(1, std::memory_order_release);   // never leave the others spinning
         if (!rc2) rc2 = msm_.template finish_t<Fld>(this, pend, out1, out2);
         J->rc[which] = rc2;
         if constexpr (std::is_same<Fld, Fq_>::value) {
@@ -1282,7 +1306,7 @@ class Engine : public IEngine {
   // the U-MSM of a partial job (h comes from the caller's king rounds)
   int prove_launch_u(ProveJob& j, const void* h_share, hipStream_t st) {
     return msm_.template launch_t<Fq_>(this, j.crs.u_d, h_share, (size_t)j.count * j.crs.len_u, msm_.coef_d_ + j.first,
-                                      j.crs.len_u, st, j.slot * 6 + 0, &j.pU);
+                                      j.crs.len_u, st, j.slot * 6 + 0, &j.pU, nullptr, u_gate(j));
   }
 
   // joins everything; sums[0..4] = S, H, V, W, U including the in-mask terms
@@ -1414,6 +1438,7 @@ class Engine : public IEngine {
   }
   // joins a job's tasks and device work and marks it free (after an error, or zk_groth16_abort)
   void abort_job(ProveJob& j) {
+    j.sorted_cnt.fetch_add(1 << 20, std::memory_order_release);      // tasks waiting at the sort barrier go on (and fail or finish)
     drain(j);
     MsmPending* ps[4] = {&j.pS, &j.pV0, &j.pW, &j.pU};
     for (MsmPending* p : ps)
@@ -3219,7 +3244,7 @@ class Engine : public IEngine {
     ProveJob& j = jobs_[slot];
     j.slot = slot;
     // the four MSMs over the witness shares start now and overlap the king rounds of circom_h (prove.rs try_join!)
-    rc = prove_begin(j, crs, nullptr, nullptr, nullptr, a_share, ax_share, r, s, log_m, mk, seed, false, first, k, st);
+    rc = prove_begin(j, crs, nullptr, nullptr, nullptr, a_share, ax_share, r, s, log_m, mk, seed, false, first, k, st, true);
     auto bail = [&](int code) {
       Status keep = last;
       abort_job(j);
@@ -3405,6 +3430,7 @@ class Engine : public IEngine {
     for (int i = 0; i < NJOBS; i++) {
       ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
       ZK_HIP(hipEventCreateWithFlags(&ev_gate_[i], hipEventDisableTiming));
+      for (int k = 0; k < 4; k++) ZK_HIP(hipEventCreateWithFlags(&ev_sorted_[i][k], hipEventDisableTiming));
     }
     // host workers: the MSM tasks block on their events while the scalar-multiple tasks run
     int nthreads = getenv("ZK_HOST_THREADS") ? atoi(getenv("ZK_HOST_THREADS")) : 0;
@@ -3421,6 +3447,7 @@ class Engine : public IEngine {
   HostPool* host_pool() override { return pool_.get(); }
   hipEvent_t ev_in_[NJOBS] = {nullptr, nullptr};
   hipEvent_t ev_gate_[NJOBS] = {nullptr, nullptr};
+  hipEvent_t ev_sorted_[NJOBS][4] = {};
   int h_first_log_m_ = 20;      // zk_ctx_set_option("h_first_log_m"): see prove_begin_impl
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool streams_ready_ = false;

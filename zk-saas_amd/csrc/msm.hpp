@@ -400,7 +400,11 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
   // ticket is taken after it, and the scanning workgroup reads with device-scope loads)
   __shared__ uint32_t last_sh;
   __syncthreads();
-  if (threadIdx.x == 0) last_sh = atomicAdd(bins + nbins, 1u) == gridDim.x - 1 ? 1u : 0u;
+  // acq_rel at agent scope on the ticket only: the release half orders this workgroup's count adds (all returned,
+  // see above) before its ticket, the acquire half orders the last workgroup's reads after every earlier ticket -- the
+  // formal edge the relaxed form lacked; unlike __threadfence() it does not write back / invalidate the L2
+  if (threadIdx.x == 0)
+    last_sh = __hip_atomic_fetch_add(bins + nbins, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!last_sh) return;
   uint32_t* bin_base = bins + nbins + 1;
@@ -1471,7 +1475,12 @@ struct MsmPending {
 // host -- so that the event it then waits for on its stream is this proof's record, not a stale one -- before its own
 // accumulate kernel.
 struct MsmGate {
-  hipEvent_t sorted_ev = nullptr;     // recorded on the launch's stream after its sort, before its accumulate kernel
+  hipEvent_t sorted_ev = nullptr;     // recorded on the launch's stream after its sort, before its accumulate kernel,
+  std::atomic<int>* sorted_cnt = nullptr;   // ... and counted here once recorded
+  // "all sorts first": before its accumulate kernel the launch waits (host: until `sorted_cnt` reaches `sorted_need`, so
+  // that every event below is THIS proof's record; then on its stream) for the sorts of the proof's other MSMs
+  const hipEvent_t* wait_sorted = nullptr;
+  int n_wait_sorted = 0, sorted_need = 0;
   hipEvent_t wait_ev = nullptr;
   std::atomic<int>* wait_flag = nullptr;
   hipEvent_t signal_ev = nullptr;
@@ -2000,17 +2009,18 @@ class MsmRunner {
 
   // ---- fixed-base tables (zk_msm_precompute): process-wide registry keyed by address (engine.hpp TableRegistry)
   // Window bits of new tables: 0 = by the vector's length (below), else what zk_ctx_set_option "msm_table_c" /
-  // "msm_table_c_g2" (env ZK_TABLE_C_G2 at start) asked for.  A table folds all windows into ONE set of 2^(c-1) buckets, so a
+  // "msm_table_c_g2" asked for (validated there: 0 or 8..22).  A table folds all windows into ONE set of 2^(c-1) buckets, so a
   // bucket receives len * nwin / 2^(c-1) entries: once that is more than FIN_SEQ (16) accumulate ranges long, every
   // bucket goes through the heavy-bucket path meant for degenerate scalars and the MSM is 2-3x slower than table-free
   // (measured, tools/tab_c3.py, G1 d_msm over 2^19 / 2^20 / 2^23 points: c = 16 2.53 / 3.48 / 18.8 ms, c = 17 1.10 /
   // 1.95 / 20.7, c = 20 1.45 / 2.2 / 11.8; table-free 1.59 / 2.77 / 12.7; below 2^19 points c = 16 is best: 0.78 against
-  // 1.15 ms table-free at 2^18).  G1: 16 bits below 2^19 points, 17 (15 windows) below 2^22, 20 (13 windows) from there.
+  // 1.15 ms table-free at 2^18).  G1: 16 bits below 2^19 points, 18 below 2^22 (re-rounded to evenly spread windows: 17 bits
+  // = 15 windows on BN254's 254-bit Fr, 18 bits on BLS12-381's 255-bit Fr), 20 (13 windows) from there.
   // G2: 15 bits = 17 windows, 16 384 buckets below 2^20 points (6 % more mixed additions than 16 bits but half the
   // buckets in the G2 reduction, the latency chain a proof ends with: 458-477 vs 423-453 proofs/s, same box), 19 (14
   // windows) from there (2^21 points: 11.1 ms against 17.8 at 15 bits and 11.8 table-free).
   int table_c = 0;
-  int table_c_g2 = getenv("ZK_TABLE_C_G2") ? atoi(getenv("ZK_TABLE_C_G2")) : 0;
+  int table_c_g2 = 0;
   static int table_c_auto(size_t len, bool g2) {
     if (g2) return len < ((size_t)1 << 20) ? 15 : 19;
     return len < ((size_t)1 << 19) ? 16 : len < ((size_t)1 << 22) ? 18 : 20;

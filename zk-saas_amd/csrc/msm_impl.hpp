@@ -302,7 +302,14 @@ do {                                                                           \
   MSM_STAGE("scatter");
   {
   ProfScope ps_(eng->prof, G2FLD ? PROF_MSM_ACC_G2 : PROF_MSM_ACC_G1, st, (double)npts * NB * batch);
-  if (tune.gate.sorted_ev) MSM_HIP(hipEventRecord(tune.gate.sorted_ev, st));
+  if (tune.gate.sorted_ev) {
+    MSM_HIP(hipEventRecord(tune.gate.sorted_ev, st));
+    if (tune.gate.sorted_cnt) tune.gate.sorted_cnt->fetch_add(1, std::memory_order_release);
+  }
+  if (tune.gate.n_wait_sorted) {
+    while (tune.gate.sorted_cnt->load(std::memory_order_acquire) < tune.gate.sorted_need) std::this_thread::yield();
+    for (int i = 0; i < tune.gate.n_wait_sorted; i++) MSM_HIP(hipStreamWaitEvent(st, tune.gate.wait_sorted[i], 0));
+  }
   if (tune.gate.wait_ev) {
     if (tune.gate.wait_flag)
       while (!tune.gate.wait_flag->load(std::memory_order_acquire)) std::this_thread::yield();

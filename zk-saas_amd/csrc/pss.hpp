@@ -19,6 +19,12 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int KING_THREADS = 256;
+// The king kernels of d_fft / deg_red reach unpack2 through the one-reduction dot product (Fp::dot_k) or through one
+// product per term: build-time choice for same-box A/B runs (tools/ab.sh), see DESIGN.md "unpack2 as dot products".
+#ifndef ZK_KING_DOT
+#define ZK_KING_DOT 1
+#endif
+constexpr bool KING_DOT = ZK_KING_DOT != 0;
 // One-wave workgroups for the short kernels of a Groth16 proof (NTT passes on 2^8-element tiles, king / deg_red / vec
 // kernels, workspace zeroing), so that a workgroup fits any single wave slot the concurrent MSM accumulate kernels free:
 // a 512-thread / 64 KB NTT workgroup needs a whole CU to drain and waited 0.7-1.9 ms for a 0.07 ms pass.  While the proof
@@ -106,7 +112,7 @@ ZK_D void unpack_group(F* sec, const F* __restrict__ U, int np, int s0, const F*
 #pragma unroll
   for (int i = 0; i < L; i++) sec[i] = sec[i] + F::template dot_k<G>(x, U + i * np + s0);
 }
-template <class F, int L, class RowFn>
+template <class F, int L, bool DOT = true, class RowFn>
 ZK_D void unpack_accumulate(F* sec, const F* __restrict__ U, int np, RowFn row) {
   constexpr int N = 4 * L, G = N < 8 ? N : 8;
   if (np % G == 0) {
@@ -116,7 +122,7 @@ ZK_D void unpack_accumulate(F* sec, const F* __restrict__ U, int np, RowFn row) 
       const F x0 = row(s0), x1 = row(s0 + 1), x2 = row(s0 + 2), x3 = row(s0 + 3);
       if constexpr (G == 8) {
         const F x4 = row(s0 + 4), x5 = row(s0 + 5), x6 = row(s0 + 6), x7 = row(s0 + 7);
-        if constexpr (L <= 2) {
+        if constexpr (L <= 2 && DOT) {
           const F* const xs[8] = {&x0, &x1, &x2, &x3, &x4, &x5, &x6, &x7};
           unpack_group<F, L, 8>(sec, U, np, s0, xs);
         } else {
@@ -129,9 +135,14 @@ ZK_D void unpack_accumulate(F* sec, const F* __restrict__ U, int np, RowFn row) 
           unpack_term<F, L>(sec, U, np, s0 + 6, x6);
           unpack_term<F, L>(sec, U, np, s0 + 7, x7);
         }
-      } else {
+      } else if constexpr (DOT) {
         const F* const xs[4] = {&x0, &x1, &x2, &x3};
         unpack_group<F, L, 4>(sec, U, np, s0, xs);
+      } else {
+        unpack_term<F, L>(sec, U, np, s0, x0);
+        unpack_term<F, L>(sec, U, np, s0 + 1, x1);
+        unpack_term<F, L>(sec, U, np, s0 + 2, x2);
+        unpack_term<F, L>(sec, U, np, s0 + 3, x3);
       }
     }
     return;
@@ -226,7 +237,7 @@ struct KingBatch {
 };
 
 template <class P, int L, bool NEGATE>
-__global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
+__global__ __launch_bounds__(KING_THREADS, 4) void king_fft2_kernel(
     const Fp<P>* __restrict__ in0, KingBatch<Fp<P>> kb, int np, uint32_t log_lc,
     const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const Fp<P>* __restrict__ gentab,
     const Fp<P>* __restrict__ gtab, const Fp<P>* __restrict__ gstep, const Fp<P>* __restrict__ in_scale,
@@ -268,14 +279,14 @@ __global__ __launch_bounds__(KING_THREADS) void king_fft2_kernel(
     const F* __restrict__ col = seg ? in + (blockIdx.x * Wc + tid) : in + k;
     const size_t pitch = seg ? (size_t)seg : (kb.row_pitch ? kb.row_pitch : (size_t)1 << log_lc);
     if (!in_mask) {
-      unpack_accumulate<F, L>(v, U, np, [&](int s) { return load_elem(col + (size_t)s * pitch); });
+      unpack_accumulate<F, L, KING_DOT>(v, U, np, [&](int s) { return load_elem(col + (size_t)s * pitch); });
     } else if (!in_scale) {
-      unpack_accumulate<F, L>(v, U, np, [&](int s) {
+      unpack_accumulate<F, L, KING_DOT>(v, U, np, [&](int s) {
         return load_elem(col + (size_t)s * pitch) + load_elem(in_mask + ((size_t)s << log_lc) + k);
       });
     } else {
       const F sc = load_elem(in_scale);
-      unpack_accumulate<F, L>(v, U, np, [&](int s) {
+      unpack_accumulate<F, L, KING_DOT>(v, U, np, [&](int s) {
         return mulsel<L>(load_elem(col + (size_t)s * pitch), sc) + load_elem(in_mask + ((size_t)s << log_lc) + k);
       });
     }
@@ -428,7 +439,7 @@ struct DegredBatch {
   uint32_t seed_step;
 };
 template <class P, int L>
-__global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
+__global__ __launch_bounds__(KING_THREADS, 4) void king_degred_kernel(
     const Fp<P>* in /* may alias out: a thread reads and writes only its own column */, DegredBatch<Fp<P>> db, int np,
     size_t len, const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm, const PackL2<Fp<P>>* __restrict__ k2,
     RngSeed seed, Fp<P>* out, size_t stride, size_t j0,
@@ -456,18 +467,18 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
   for (int i = 0; i < L; i++) sec[i] = F::zero();
   // one branch-free row function per case (see king_fft2_kernel)
   if (!mul_b && !in_mask) {
-    unpack_accumulate<F, L>(sec, U, np, [&](int s) { return load_elem(in + (size_t)s * stride + j); });
+    unpack_accumulate<F, L, KING_DOT>(sec, U, np, [&](int s) { return load_elem(in + (size_t)s * stride + j); });
   } else if (!mul_b) {
-    unpack_accumulate<F, L>(sec, U, np, [&](int s) {
+    unpack_accumulate<F, L, KING_DOT>(sec, U, np, [&](int s) {
       return load_elem(in + (size_t)s * stride + j) + load_elem(in_mask + (size_t)s * stride + j);
     });
   } else if (!in_mask) {
-    unpack_accumulate<F, L>(sec, U, np, [&](int s) {
+    unpack_accumulate<F, L, KING_DOT>(sec, U, np, [&](int s) {
       return load_elem(in + (size_t)s * stride + j) * load_elem(mul_b + (size_t)s * stride + j) -
              load_elem(sub_c + (size_t)s * stride + j);
     });
   } else {
-    unpack_accumulate<F, L>(sec, U, np, [&](int s) {
+    unpack_accumulate<F, L, KING_DOT>(sec, U, np, [&](int s) {
       return load_elem(in + (size_t)s * stride + j) * load_elem(mul_b + (size_t)s * stride + j) -
              load_elem(sub_c + (size_t)s * stride + j) + load_elem(in_mask + (size_t)s * stride + j);
     });
@@ -489,109 +500,7 @@ __global__ __launch_bounds__(KING_THREADS) void king_degred_kernel(
   }
 }
 
-// ---- d_pp king pieces (dpp/mod.rs:41-76) ------------------------------------------------------------
-// x[i] = num[i] / den[i] with one Fermat inversion per DPP_CHUNK elements (Montgomery's trick inside the
-// thread); zero denominators raise `*err`.
-constexpr int DPP_CHUNK = 32;
-template <class F>
-__global__ void dpp_div_kernel(const F* __restrict__ num, const F* __restrict__ den, size_t len, F* __restrict__ x,
-                               int* __restrict__ err) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t b = t * DPP_CHUNK;
-  if (b >= len) return;
-  size_t e = b + DPP_CHUNK < len ? b + DPP_CHUNK : len;
-  // prefix products of den into x (scratch), then walk back
-  F acc = F::one();
-  for (size_t i = b; i < e; i++) {
-    F d = load_elem(den + i);
-    if (d.is_zero()) {
-      atomicExch(err, 1);
-      return;
-    }
-    store_elem(x + i, acc);       // product of den[b..i)
-    acc = acc * d;
-  }
-  F inv = acc.inverse();           // 1 / prod den[b..e)
-  for (size_t i = e; i-- > b;) {
-    F d = load_elem(den + i);
-    F pre = load_elem(x + i);
-    store_elem(x + i, load_elem(num + i) * inv * pre);
-    inv = inv * d;
-  }
-}
-
-// Inclusive multiplicative scan in three launches: block products, scan of block products, apply.
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_PER_THREAD = 8;
-constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_PER_THREAD;
-
-template <class F>
-ZK_D F block_scan_exclusive(F v, F* sh /* [SCAN_THREADS] as F */, F* total) {
-  // Hillis-Steele over the block in shared memory (F values)
-  int tid = threadIdx.x;
-  sh[tid] = v;
-  __syncthreads();
-  for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-    F t = sh[tid];
-    if (tid >= off) t = sh[tid - off] * t;
-    __syncthreads();
-    sh[tid] = t;
-    __syncthreads();
-  }
-  F ex = tid ? sh[tid - 1] : F::one();
-  if (total) *total = sh[SCAN_THREADS - 1];
-  return ex;
-}
-
-template <class F>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_block_kernel(F* __restrict__ x, size_t len,
-                                                                 F* __restrict__ block_prod, const F* __restrict__ carry) {
-  __shared__ F sh[SCAN_THREADS];
-  size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
-  F loc[SCAN_PER_THREAD];
-  F acc = F::one();
-#pragma unroll
-  for (int i = 0; i < SCAN_PER_THREAD; i++) {
-    loc[i] = base + i < len ? load_elem(x + base + i) : F::one();
-    acc = acc * loc[i];
-    loc[i] = acc;
-  }
-  F tot;
-  F ex = block_scan_exclusive(acc, sh, &tot);
-  if (carry) ex = ex * load_elem(carry + blockIdx.x);
-  if (block_prod) {
-    if (threadIdx.x == 0) store_elem(block_prod + blockIdx.x, tot);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < SCAN_PER_THREAD; i++)
-    if (base + i < len) store_elem(x + base + i, ex * loc[i]);
-}
-
-// exclusive scan of up to SCAN_BLOCK block products by one workgroup (in place -> carries)
-template <class F>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_carries_kernel(F* __restrict__ bp, size_t nblocks) {
-  __shared__ F sh[SCAN_THREADS];
-  F running = F::one();
-  for (size_t base0 = 0; base0 < nblocks; base0 += SCAN_BLOCK) {
-    size_t base = base0 + (size_t)threadIdx.x * SCAN_PER_THREAD;
-    F loc[SCAN_PER_THREAD];
-    F acc = F::one();
-#pragma unroll
-    for (int i = 0; i < SCAN_PER_THREAD; i++) {
-      F v = base + i < nblocks ? load_elem(bp + base + i) : F::one();
-      loc[i] = acc;               // exclusive within thread
-      acc = acc * v;
-    }
-    F tot;
-    F ex = block_scan_exclusive(acc, sh, &tot) * running;
-#pragma unroll
-    for (int i = 0; i < SCAN_PER_THREAD; i++)
-      if (base + i < nblocks) store_elem(bp + base + i, ex * loc[i]);
-    running = running * tot;
-    __syncthreads();
-  }
-}
+// (the king-side kernels of d_pp live in dpp.hpp)
 
 #endif  // __HIPCC__
 }  // namespace zk

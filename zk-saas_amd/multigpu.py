@@ -188,6 +188,33 @@ def _timed(dist, torch, step, steps, warmup):
     return dt
 
 
+def _alltoall_leg(pp, dist, torch, step, steps, warmup, unit_scale=1.0):
+    """N > 1, informational, after the headline (north_star's star: king on GPU 0, gather / scatter): the same K steps with
+    every rank king of a chunk range (option king_alltoall, two all-to-all exchanges per round).  Every rank switches
+    alike; a failure on any rank is reported in the leg's place and every rank returns to the star."""
+    from .api import ZkError
+    err, dt = None, None
+    try:
+        pp.set_option("king_alltoall", 1)
+        dt = _timed(dist, torch, step, steps, max(1, warmup // 2))
+    except ZkError as e:
+        err = "%s" % (e,)
+    finally:
+        pp.set_option("king_alltoall", 0)
+    flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        return {"king": "alltoall", "error": err or "another rank failed"}
+    return {"king": "alltoall", "value": round(unit_scale * steps / dt, 4), "ms_per_step": round(dt / steps * 1e3, 4)}
+
+
+def _king_words(king, world):
+    if world == 1:
+        return "all parties on one GPU"
+    return ("king on GPU 0, RCCL gather / scatter (the reference's star)" if king == "star"
+            else "all-to-all king: every GPU reconstructs and re-packs a chunk range")
+
+
 def _rand_fr(pp, count, seed):
     rng = np.random.default_rng(seed)
     a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
@@ -208,7 +235,7 @@ def bench(args, rank, local_rank, world):
     pp = zk.PackedSharingParams(curve, 2, device=local_rank)
     if pp.n % world:
         raise SystemExit("the number of GPUs must divide n = %d parties" % pp.n)
-    king = os.environ.get("ZK_KING", getattr(args, "king", "alltoall"))
+    king = os.environ.get("ZK_KING", getattr(args, "king", "star"))
     net, transport, king, note = _open_net(pp, rank, world, dist, net_id, transport, king)
     first, k = net.first, net.k
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
@@ -240,14 +267,15 @@ def bench(args, rank, local_rank, world):
         full_mask = None if args.no_masks else FftMask.sample(pp, False, None, 0, log_m, 11)
         mk = FftMask.zero() if full_mask is None else FftMask(rows(full_mask.in_mask, first, k, Lc * eb),
                                                              rows(full_mask.out_mask, first, k, Lc * eb))
-        dt = timed(lambda i: znet.dist_d_fft(pp, net, 0, sh, mk, False, log_m, seed=i))
+        step = lambda i: znet.dist_d_fft(pp, net, 0, sh, mk, False, log_m, seed=i)
+        dt = timed(step)
         alg = (32 if full_mask is not None else 16) * m * 32          # all parties, with / without masks
         gbs = alg / per(dt) / 1e9
         res = dict(base, metric="d_fft per second (m = 2^20, BN254 Fr, l = 2, n = 8)", value=round(args.steps / dt, 3),
                    unit="d_fft/s", ms_per_step=round(per(dt) * 1e3, 4), scaling="strong",
                    data="synthetic: seeded random share vectors",
-                   config={"workload": "BASELINE configs[1]: d_fft 2^20-point BN254 Fr NTT, king on GPU 0", "m": m,
-                           "masks": full_mask is not None},
+                   config={"workload": "BASELINE configs[1]: d_fft 2^20-point BN254 Fr NTT, %s" % _king_words(king, world),
+                           "m": m, "masks": full_mask is not None},
                    roofline={"bound": "hbm", "kernel": "d_fft end to end (all ranks)", "achieved": round(gbs, 1),
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
                              "traffic": None, "algorithmic_bytes_per_launch": alg})
@@ -408,8 +436,9 @@ def bench(args, rank, local_rank, world):
                    data="synthetic: SHA-256(a=1,b=2) circuit rebuilt from its semantics and padded to the reference "
                         "fixture's 29 823 wires, seeded trapdoor CRS, seeded shares and masks",
                    config={"workload": "BASELINE configs[3]: full distributed Groth16 on the SHA-256 circuit, BN254, l=2, "
-                                       "n=8 parties sharded over %d GPUs (king on GPU 0), %s" % (
-                                           world, "zero masks" if masks is None else "all 12 masks sampled and applied"),
+                                       "n=8 parties sharded over %d GPUs (%s), %s" % (
+                                           world, _king_words(king, world),
+                                           "zero masks" if masks is None else "all 12 masks sampled and applied"),
                            "masks": masks is not None, "constraints": r1.num_constraints, "wires": r1.num_variables,
                            "domain": 1 << wit.log_m, "len_a": crs.len_a, "len_w": crs.len_w, "len_u": crs.len_u,
                            "parties": pp.n, "packing_factor": pp.l, "fixed_base_tables": not args.no_tables},
@@ -462,5 +491,9 @@ def bench(args, rank, local_rank, world):
                            "masks": masks is not None, "constraints": inst.nc, "parties": pp.n},
                    roofline=roof, cpu_baseline=cpu,
                    kernels=[{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]])
+    # N > 1: the headline ran in the mode `king` names (default: north_star's star); the other stage of SURVEY.md 8e in the
+    # same run, beside it
+    if world > 1 and king == "star" and wl in ("c2", "c4", "c5"):
+        res["alltoall"] = _alltoall_leg(pp, dist, torch, step, args.steps, args.warmup)
     net.close()
     return res
