@@ -249,8 +249,12 @@ int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
  *   heavy-bucket path; csrc/msm.hpp table_c_auto).
  * "king_alltoall": 1 = the zk_dist_* king rounds of d_fft / d_ifft / deg_red (and everything composed of them) run as
  * all-to-all: every present rank is king of a contiguous chunk range (zk_net_alltoall twice per round) instead of
- * gather -> rank 0 -> scatter; identical results; every rank of a net must choose alike (default 0, or ZK_KING_ALLTOALL=1).
- * Unknown name -> ZK_ERR_BAD_INPUT. */
+ * gather -> rank 0 -> scatter; identical results; every rank of a net must choose alike (default 0).
+ * "msm_c" / "msm_c_g2": window bits (2..20, 0 = the cost model) of table-free MSMs (tests force widths with it).
+ * "h_first_log_m": domains of 2^value and up run circom_h and every MSM's sort ahead of the accumulate kernels (default 20).
+ * "host_threads": workers of the context's host pool (0 = by the core count, else >= 4; before the first proof).
+ * "dist_deadline": 1 = the zk_dist_* calls return only with their data-plane work done (zk_net_sync inside).
+ * Nothing is read from the environment.  Unknown name or value out of range -> ZK_ERR_BAD_INPUT. */
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
 /* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value
  * -(sum), both packed with t random group elements each (streams seed^0x1111, seed^0x2222; a random group element

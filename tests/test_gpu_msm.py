@@ -71,8 +71,10 @@ def test_msm_length_mismatch_is_generic_error():  # dmsm/mod.rs:73 `G::msm(..)?`
     assert e.value.code == 1 and e.value.msg == "1"
 
 
-def test_msm_window_sizes(monkeypatch):
-    """Exercise several window widths, including multi-workgroup bucket reduction (c = 14 -> 8192 buckets)."""
+def test_msm_window_sizes():
+    """Exercise several window widths (context option "msm_c"), including multi-workgroup bucket reduction (c = 14 -> 8192
+    buckets); the plan reports the forced width."""
+    from zksaas_amd.api import msm_plan
     c = CURVES["bn254"]
     pp = ctx("bn254", 2)
     G = g1(c)
@@ -80,9 +82,33 @@ def test_msm_window_sizes(monkeypatch):
     sc = rand_vec(66, 50, c.r)
     want = G.msm(pts, sc)
     bases = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts))
-    for cc in ("2", "5", "9", "13", "14"):
-        monkeypatch.setenv("ZK_MSM_C", cc)
-        assert G.eq(dec_jacobian(pp, msm(pp, ZK_G1, bases, up(pp, sc), 50)), want)
+    try:
+        for cc in (2, 5, 9, 13, 14):
+            pp.set_option("msm_c", cc)
+            assert G.eq(dec_jacobian(pp, msm(pp, ZK_G1, bases, up(pp, sc), 50)), want)
+            assert msm_plan(pp, ZK_G1, 50)["window_bits"] <= cc
+    finally:
+        pp.set_option("msm_c", 0)
+
+
+def test_context_options_are_validated():
+    """zk_ctx_set_option: every tunable the library keeps is a named, range-checked context option (nothing is read from the
+    environment); an unknown name or a value out of range is BAD_INPUT."""
+    pp = zk.PackedSharingParams("bn254", 2)
+    try:
+        for name, good, bad in (("msm_c", 12, 21), ("msm_c_g2", 10, 1), ("msm_table_c", 16, 5), ("msm_table_c_g2", 0, 30),
+                                ("msm_bigsort_min", 1 << 14, -1), ("h_first_log_m", 20, 0), ("host_threads", 8, 2),
+                                ("king_alltoall", 1, None), ("dist_deadline", 1, None), ("rng_replay", 0, None)):
+            pp.set_option(name, good)
+            if bad is not None:
+                with pytest.raises(zk.ZkError) as e:
+                    pp.set_option(name, bad)
+                assert e.value.code == 4, name
+        with pytest.raises(zk.ZkError) as e:
+            pp.set_option("no_such_option", 1)
+        assert e.value.code == 4
+    finally:
+        pp.close()
 
 
 @pytest.mark.parametrize("group", [ZK_G1, ZK_G2])

@@ -3,7 +3,8 @@ tools/sq_summary.py for d_msm and tools/sq_c2_summary.py for d_fft).
 usage: python tools/sq_generic.py <dir of the pass> <out.json> "<command that was profiled>" [top N = 8]
 Derived per kernel: issue-cycle split of the wave cycles (active / issue stall / parked on waitcnt), VALU instructions per
 SIMD cycle (1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs), effective shader clock when a kernel-trace duration is
-not at hand is left out."""
+not at hand is left out.  SQ_WAVE_CYCLES counts in units of FOUR cycles on this ROCm (a kernel compiled for 4 waves per
+SIMD that fills the chip reads 0.9-1.0 wave-cycles per SIMD cycle), hence the factor in waves_in_flight_per_simd."""
 import collections
 import csv
 import glob
@@ -32,7 +33,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))
                         "wave_cycle_split": {"active": round(d.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
                                              "issue_stall": round(d.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
                                              "parked_waitcnt": round(d.get("SQ_WAIT_ANY", 0) / wc, 3)},
-                        "waves_in_flight_per_simd": round(wc / simd_cycles, 2)}
+                        "waves_in_flight_per_simd": round(4 * wc / simd_cycles, 2)}
     out.append(e)
 json.dump({"command": command, "note": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; per_launch = counter sum / launches",
            "kernels": out}, open(out_path, "w"), indent=1)

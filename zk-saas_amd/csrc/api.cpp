@@ -622,7 +622,7 @@ int zk_net_scatter(zk_net* net, int sid, uint32_t mask, const void* full, size_t
 }
 int zk_net_stats(const zk_net* net, uint64_t stats[4]) {
   if (!net || !stats) return ZK_ERR_BAD_INPUT;
-  for (int i = 0; i < 4; i++) stats[i] = net->net.stats[i];
+  for (int i = 0; i < 4; i++) stats[i] = net->net.stats[i].load(std::memory_order_relaxed);
   return ZK_OK;
 }
 int zk_net_alltoall(zk_net* net, int sid, uint32_t mask, const void* send, size_t bytes_per_peer, void* recv) {

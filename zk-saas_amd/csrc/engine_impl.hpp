@@ -518,8 +518,7 @@ class Engine : public IEngine {
       const NttPass& ps = plan.pass[p];
       int rbits = ps.s1 - ps.s0;
       // large tile: every fourth stage twiddle in LDS (72 KB: two workgroups per CU), see ntt_pass_kernel
-      static const int tws_env = getenv("ZK_NTT_TWS") ? atoi(getenv("ZK_NTT_TWS")) : -1;
-      const int tws = tws_env >= 0 ? (tws_env <= 2 ? tws_env : 2) : ((TB >= 10 && rbits >= 4) ? 2 : 0);
+      const int tws = (TB >= 10 && rbits >= 4) ? 2 : 0;
       const int tws_eff = rbits >= 4 ? tws : 0;      // one value for the LDS size AND the kernel argument
       size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * (TILE + ((((size_t)1 << rbits) / 2) >> tws_eff) + 1);
       bool& attr_set = ntt_attr_set_[TB == NTT_TILE_BITS_SMALL ? 0 : 1];     // per engine, i.e. per device
@@ -1585,21 +1584,13 @@ class Engine : public IEngine {
       if (!B.ev_in) ZK_HIP(hipEventCreateWithFlags(&B.ev_in, hipEventDisableTiming));
       for (int i = 0; i < 4; i++)
         if (!B.ev_acc[i]) ZK_HIP(hipEventCreateWithFlags(&B.ev_acc[i], hipEventDisableTiming));
-      // ZK_BATCH_V_CUS=<n> (experiment): the chip is split between the G2 MSM (stream 2: n of the 256 CUs) and
-      // everything else (the other CUs), so that the 256-register G2 waves and the 168-register G1 waves never compete
-      // for the same SIMDs (see DESIGN.md "batched proving")
-      static const int v_cus = getenv("ZK_BATCH_V_CUS") ? atoi(getenv("ZK_BATCH_V_CUS")) : 0;
-      B.own_streams = slot != 0 || (v_cus > 0 && v_cus < 256);
+      // (splitting the chip between the G2 MSM and the rest with CU masks was measured in round 3 and dropped: DESIGN.md
+      // "batched proving")
+      B.own_streams = slot != 0;
       for (int i = 0; i < 6; i++) {
         if (B.st[i]) continue;
         if (!B.own_streams) {
           B.st[i] = streams_[i];                     // batch slot 0 shares the single-proof stream set
-        } else if (v_cus > 0 && v_cus < 256) {
-          uint32_t mask[8];
-          for (int w = 0; w < 8; w++) mask[w] = 0;
-          for (int cu = 0; cu < 256; cu++)
-            if ((cu < v_cus) == (i == 2)) mask[cu >> 5] |= 1u << (cu & 31);
-          ZK_HIP(hipExtStreamCreateWithCUMask(&B.st[i], 8, mask));
         } else {
           int pr = 0;
           ZK_HIP(hipStreamGetPriority(streams_[i], &pr));
@@ -1644,11 +1635,9 @@ class Engine : public IEngine {
     // run beside it -- and spares them each other: issued together, four kernels' waves interleave on every SIMD, the
     // 256-register G2 waves are crowded out by the 168-register G1 waves (which fit any slot a G1 wave frees) and V's
     // accumulate ends alone long after the others with its reduction tail on an empty chip
-    // (profiles/r03_b8_timeline_*.txt).  ZK_BATCH_ORDER: letters of the chain in order, V S W U (S = the S + H launch);
-    // an MSM not named runs unchained; "-" = no chain.
-    static const std::string order_env = getenv("ZK_BATCH_ORDER") ? getenv("ZK_BATCH_ORDER") : "";
+    // (profiles/r03_b8_timeline_*.txt).  Letters of the chain in order, V S W U (S = the S + H launch); "-" = no chain.
     // (a small batch does not fill the chip with one accumulate: its kernels run side by side as in a single proof)
-    const std::string order = !order_env.empty() ? order_env : (nb >= 4 ? "VSWU" : "-");
+    const std::string order = nb >= 4 ? "VSWU" : "-";
     MsmGate gates[4];                                  // V, S, W, U
     {
       int prev = -1;
@@ -1964,6 +1953,20 @@ class Engine : public IEngine {
     if (!strcmp(name, "msm_table_c_g2")) {
       if (value != 0 && (value < 8 || value > 22)) return fail(ZK_ERR_BAD_INPUT, "msm_table_c_g2 must be 0 (by length) or in 8..22");
       msm_.table_c_g2 = (int)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "host_threads")) {          // workers of the host pool (MSM launch / fold tasks, scalar multiples)
+      if (value < 0 || value > 256) return fail(ZK_ERR_BAD_INPUT, "host_threads must be in 0..256");
+      if (value && value < 4) return fail(ZK_ERR_BAD_INPUT, "host_threads must be 0 (automatic) or at least 4");
+      std::lock_guard<std::mutex> lk(mu_);
+      if (streams_ready_) return fail(ZK_ERR_BAD_INPUT, "host_threads must be set before the first proof");
+      host_threads_ = (int)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "msm_c") || !strcmp(name, "msm_c_g2")) {      // window bits of table-free MSMs (0 = cost model)
+      if (value != 0 && (value < 2 || value > 20)) return fail(ZK_ERR_BAD_INPUT, "msm_c must be 0 or in 2..20");
+      if (name[5] == 0) msm_.c_g1 = msm_.c_g2 = (int)value;
+      else msm_.c_g2 = (int)value;
       return ZK_OK;
     }
     if (!strcmp(name, "h_first_log_m")) {         // domains of 2^value and up: circom_h + the U sort ahead of the accumulates
@@ -2579,7 +2582,7 @@ class Engine : public IEngine {
   // brings a range's input chunks of all parties to its owner, the king kernel runs on the range, a second all-to-all
   // returns every party's output shares.  Per link a round carries 1/W of the star's bytes and no rank does more than
   // 1/W of the king's arithmetic.  Option "king_alltoall" (or ZK_KING_ALLTOALL=1), set alike on every rank.
-  bool king_a2a_ = getenv("ZK_KING_ALLTOALL") && atoi(getenv("ZK_KING_ALLTOALL")) != 0;
+  bool king_a2a_ = false;        // zk_ctx_set_option("king_alltoall")
   DevBuf a2a_send_[NET_NSID], a2a_back_[NET_NSID];
   struct A2aPlan {
     A2aMap map;
@@ -2835,13 +2838,13 @@ class Engine : public IEngine {
       ZK_HIP(hipMemcpy(dist_coef_[sid].p, csub.data(), k * sizeof(Fr), hipMemcpyHostToDevice));
       cd = (const Fr*)dist_coef_[sid].p;
     }
-    typename MsmRunner<Cfg>::SplitLaunch sl;       // (a large table-free MSM runs as two window groups on two streams)
-    rc = msm_.template launch_split_t<Fld>(this, bases, scalars, (size_t)k * len, cd, len, st, MSM_WS - 1 - sid, &sl);
+    MsmPending pend;
+    rc = msm_.template launch_t<Fld>(this, bases, scalars, (size_t)k * len, cd, len, st, MSM_WS - 1 - sid, &pend);
     if (rc) return rc;
     XYZZ<Fld> mine = XYZZ<Fld>::identity();
     if (in_mask) mine = msm_.template mask_term<Fld>(in_mask, first, k, csub.empty() ? nullptr : csub.data());
     XYZZ<Fld> r;
-    rc = msm_.template finish_split_t<Fld>(this, &sl, &r);
+    rc = msm_.template finish_t<Fld>(this, &pend, &r);
     if (rc) return rc;
     mine = xyzz_add_ni(mine, r);
     std::vector<XYZZ<Fld>> all((size_t)net->world);
@@ -3344,18 +3347,9 @@ class Engine : public IEngine {
       return code;
     };
     // circom_h of the whole batch: one king round per phase and channel carries all nb proofs (7 rounds per batch; the MSMs
-    // of the batch run beside them).  ZK_DIST_BATCH_KING=0: one proof's rounds after the other's, as in round 3.
-    static const bool batch_king = !(getenv("ZK_DIST_BATCH_KING") && atoi(getenv("ZK_DIST_BATCH_KING")) == 0);
-    if (batch_king) {
-      rc = dist_circom_h_batch_on(net, cmask, nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, st);
-      if (rc) return bail(rc);
-    } else {
-      for (int b = 0; b < nb; b++) {
-        rc = dist_circom_h_on(net, cmask, qa[b], qb[b], qc[b], log_m, mk ? &mk[b] : nullptr,
-                              seed + (uint64_t)PROOF_SEED_STEP * b, (Fr*)B.hshare.p + (size_t)b * per, st);
-        if (rc) return bail(rc);
-      }
-    }
+    // of the batch run beside them; round 3 ran one proof's rounds after the other's).
+    rc = dist_circom_h_batch_on(net, cmask, nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, st);
+    if (rc) return bail(rc);
     // the U-MSM runs on its own stream of the batch's set, behind everything queued on the caller's stream
     {
       hipError_t he = hipEventRecord(B.ev_in, st);
@@ -3407,33 +3401,18 @@ class Engine : public IEngine {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);     // hi = numerically lowest = highest priority
     // high priority: the G2 stream(s) and the circom_h -> U chain (short kernels the bulk accumulates would otherwise
-    // starve; measured 291 vs 242 proofs/s without priorities, a third level gains nothing).  ZK_STREAM_PRIO = six
-    // letters h / n / l overrides.
-    const char* pe = getenv("ZK_STREAM_PRIO");
-    const char* pdef = "llhlhh";
-    if (!pe || strlen(pe) != 6) pe = pdef;
-    // ZK_CU_RESERVE=<n> (experiment): the MSM streams 0..4 are kept off n of the chip's CUs (spread evenly), which stay
-    // free for the circom_h -> U chain on stream 5 (its multi-wave workgroups otherwise wait for a CU to drain)
-    const int reserve = getenv("ZK_CU_RESERVE") ? atoi(getenv("ZK_CU_RESERVE")) : 0;
-    for (int i = 0; i < 6; i++) {
-      int pr = pe[i] == 'h' ? hi : (pe[i] == 'l' ? lo : (lo + hi) / 2);
-      if (reserve > 0 && reserve < 256 && i < 5) {
-        uint32_t mask[8];
-        for (int w = 0; w < 8; w++) mask[w] = 0xffffffffu;
-        const int step = 256 / reserve;
-        for (int cu = 0; cu < 256; cu += step) mask[cu >> 5] &= ~(1u << (cu & 31));
-        ZK_HIP(hipExtStreamCreateWithCUMask(&streams_[i], 8, mask));
-      } else {
-        ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, pr));
-      }
-    }
+    // starve; measured 291 vs 242 proofs/s without priorities, a third level gains nothing; keeping CUs free for the
+    // chain with CU masks was measured in round 4 and dropped).  Streams 0..5: S+H, (spare), V, W, (spare), circom_h -> U.
+    const char* pe = "llhlhh";
+    for (int i = 0; i < 6; i++)
+      ZK_HIP(hipStreamCreateWithPriority(&streams_[i], hipStreamNonBlocking, pe[i] == 'h' ? hi : lo));
     for (int i = 0; i < NJOBS; i++) {
       ZK_HIP(hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming));
       ZK_HIP(hipEventCreateWithFlags(&ev_gate_[i], hipEventDisableTiming));
       for (int k = 0; k < 4; k++) ZK_HIP(hipEventCreateWithFlags(&ev_sorted_[i][k], hipEventDisableTiming));
     }
     // host workers: the MSM tasks block on their events while the scalar-multiple tasks run
-    int nthreads = getenv("ZK_HOST_THREADS") ? atoi(getenv("ZK_HOST_THREADS")) : 0;
+    int nthreads = host_threads_;                        // zk_ctx_set_option("host_threads"), before the first proof
     if (nthreads <= 0) {
       unsigned hc = std::thread::hardware_concurrency();
       nthreads = hc >= 32 ? 16 : (hc >= 8 ? 8 : 4);
@@ -3449,6 +3428,7 @@ class Engine : public IEngine {
   hipEvent_t ev_gate_[NJOBS] = {nullptr, nullptr};
   hipEvent_t ev_sorted_[NJOBS][4] = {};
   int h_first_log_m_ = 20;      // zk_ctx_set_option("h_first_log_m"): see prove_begin_impl
+  int host_threads_ = 0;        // zk_ctx_set_option("host_threads"): workers of the host pool (0 = by the core count)
   hipStream_t streams_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool streams_ready_ = false;
   bool force_simple_ntt = false;

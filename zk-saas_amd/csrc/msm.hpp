@@ -1213,10 +1213,8 @@ constexpr int QUAD_VL = QUAD_THREADS / 4;
 // Threads per workgroup of the heavy / reduce kernels.  256 (64 quads: shortest trees) when an MSM runs alone; 64 -- ONE
 // wave -- by default: a four-wave workgroup needs four free wave slots with registers on ONE CU at the same moment, and
 // among the accumulate waves of a BATCH's MSMs it waits for them (profiles/r03_b8_timeline_wide_tails.txt: 1.0-1.3 ms
-// for a heavy-bucket launch that reads one word and exits, 0.6-1.8 ms per reduce stage).  ZK_QUAD_THREADS overrides.
+// for a heavy-bucket launch that reads one word and exits, 0.6-1.8 ms per reduce stage).
 inline int quad_threads(bool batched) {
-  static const int v = getenv("ZK_QUAD_THREADS") ? atoi(getenv("ZK_QUAD_THREADS")) : 0;
-  if (v == 64 || v == 128 || v == 256) return v;
   return batched ? 64 : 256;          // one proof at a time: 256 measured better (451 vs 409 proofs/s)
 }
 
@@ -1490,27 +1488,15 @@ struct MsmGate {
 struct MsmTuning {
   size_t bigsort_min;
   MsmGate gate;
-  int prio = 0;          // raised issue priority for the G1 accumulate kernel of this launch (see msm_accumulate_kernel)
-  int w_begin = 0, w_end = -1;   // digit windows [w_begin, w_end) only (-1: all): one window group of a split MSM
-  int range = 0;                 // entries per accumulate lane of this launch (0: the rule of msm_pick_lanes)
-  bool lean_sort = false;        // the small-workgroup sort kernels whatever the size: this sort has to run BESIDE an
-                                 // accumulate kernel (1024-thread workgroups never find a free CU there, see run_split_t)
+  int c_force = 0;       // window bits asked for by zk_ctx_set_option "msm_c" / "msm_c_g2" (0: the cost model)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
 // with nwin = ceil((BITS+1)/c) windows of evenly spread width (see msm_launch); ties go to the wider window
 // (more buckets = more lanes with shorter chains).
 template <class FrP>
-inline int msm_pick_c(size_t npts, bool g2 = false) {
-  if (g2)
-    if (const char* e = getenv("ZK_MSM_C_G2")) {
-      int c = atoi(e);
-      if (c >= 2 && c <= 20) return c;
-    }
-  if (const char* e = getenv("ZK_MSM_C")) {
-    int c = atoi(e);
-    if (c >= 2 && c <= 20) return c;
-  }
+inline int msm_pick_c(size_t npts, bool g2 = false, int c_force = 0) {
+  if (c_force >= 2 && c_force <= 20) return c_force;      // zk_ctx_set_option "msm_c" / "msm_c_g2" (tests force widths)
   int best = 4;
   double best_cost = 1e300;
   for (int c = 4; c <= 20; c++) {                     // > 17 only pays from ~2^25 points on (cost model below)
@@ -1536,24 +1522,15 @@ inline int msm_pick_c(size_t npts, bool g2 = false) {
 // all its waves march in step), fewer than one underfills -- while every lane boundary costs one full addition (14
 // multiplications; 42 in G2) in the finalize kernel.  So: ~2.4 rounds, but never fewer than `lo` entries per lane (small
 // launches: the MSMs of ONE proof run four at a time and fill the chip together) nor more than `hi`.
-// ZK_MSM_RANGE=<entries per lane> overrides (experiments).
 struct MsmLanes {
   uint32_t nlanes, tmin, cap;
 };
-inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair, int lanes_per_range = 0, int range = 0) {
-  static const int env_t0 = getenv("ZK_MSM_RANGE") ? atoi(getenv("ZK_MSM_RANGE")) : 0;
-  const int env_t = range > 0 ? range : env_t0;
+inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair, int lanes_per_range = 0) {
   if (!lanes_per_range) lanes_per_range = pair ? 2 : 1;
   const size_t cap = (size_t)1024 * waves * (64 / lanes_per_range);
-  static const int env_hi = getenv("ZK_MSM_RANGE_HI") ? atoi(getenv("ZK_MSM_RANGE_HI")) : 0;
-  static const int env_hi2 = getenv("ZK_MSM_RANGE_HI_G2") ? atoi(getenv("ZK_MSM_RANGE_HI_G2")) : 0;
-  static const int env_lo2 = getenv("ZK_MSM_RANGE_LO_G2") ? atoi(getenv("ZK_MSM_RANGE_LO_G2")) : 0;
-  const size_t lo = pair ? (env_lo2 > 0 ? (size_t)env_lo2 : MSM_RANGE_MIN_G2) : MSM_RANGE_MIN;
-  size_t hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
-  if (!pair && env_hi > 0) hi = (size_t)env_hi;
-  if (pair && env_hi2 > 0) hi = (size_t)env_hi2;
-  size_t t = env_t >= 1 ? (size_t)env_t : (size_t)((double)max_entries / (2.4 * (double)cap));
-  if (env_t < 1) t = std::min(hi, std::max(lo, t));
+  const size_t lo = pair ? MSM_RANGE_MIN_G2 : MSM_RANGE_MIN;
+  const size_t hi = pair ? MSM_RANGE_G2 : MSM_RANGE;
+  size_t t = std::min(hi, std::max(lo, (size_t)((double)max_entries / (2.4 * (double)cap))));
   size_t nl = std::max<size_t>(1, (max_entries + t - 1) / t);
   // between one and two rounds at this length msm_range_len splits the entries over TWO rounds of shorter ranges: the
   // launch needs the lanes of two rounds then (found by the 2^18-point BLS12-381 prover test: 4.4 M entries at 20 per
@@ -1564,8 +1541,8 @@ inline MsmLanes msm_pick_lanes(size_t max_entries, int waves, bool pair, int lan
 }
 
 template <class FrP>
-inline void msm_plan_of(size_t npts, bool g2, int* out) {
-  const int c_req = msm_pick_c<FrP>(npts ? npts : 1, g2);
+inline void msm_plan_of(size_t npts, bool g2, int* out, int c_force = 0) {
+  const int c_req = msm_pick_c<FrP>(npts ? npts : 1, g2, c_force);
   const int T = FrP::BITS + 1;
   const int nwin = (T + c_req - 1) / c_req;
   out[0] = (T + nwin - 1) / nwin;
@@ -1586,12 +1563,6 @@ template <class FrP, class Fld>
 int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* bases, const void* bases2,
                const void* scalars, size_t npts, const Fp<FrP>* coef_d, size_t part_len, hipStream_t st,
                MsmPending* out, const MsmBatchArg* batch = nullptr);
-// number of digit windows an MSM over npts points will use WITHOUT a fixed-base table
-template <class FrP>
-inline int msm_nwin_of(size_t npts, bool g2) {
-  const int c_req = msm_pick_c<FrP>(npts ? npts : 1, g2);
-  return (FrP::BITS + 1 + c_req - 1) / c_req;
-}
 // zk_msm_precompute's table kernel (same translation units)
 template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,
@@ -1649,7 +1620,7 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
   // critical path.  (With a fixed-base table there is one window and nothing to split.)
   constexpr int FOLD_PARTS = 4;
   HostPool* pool = eng->host_pool();
-  static const bool par_fold = !(getenv("ZK_PAR_FOLD") && atoi(getenv("ZK_PAR_FOLD")) == 0);
+  constexpr bool par_fold = true;
   // bucket sets of (base vector v, scalar vector b) start at hall + ((v * batch + b) * kwin) * nslices
   auto sets_of = [&](int v, int b) { return hall + ((size_t)v * batch + b) * kwin * nslices; };
   // only with free workers for every sub-task: this may itself be a pool task, and waiting for sub-tasks that nobody can
@@ -1748,17 +1719,17 @@ class MsmRunner {
   using Fq = Fp<typename Cfg::FqP>;
   using Fq2 = Fp2<typename Cfg::FqP>;
 
-  static void plan(size_t npts, bool g2, int* out) { msm_plan_of<FrP>(npts, g2, out); }
+  void plan(size_t npts, bool g2, int* out) const { msm_plan_of<FrP>(npts, g2, out, g2 ? c_g2 : c_g1); }
+  int c_g1 = 0, c_g2 = 0;        // zk_ctx_set_option "msm_c" / "msm_c_g2": forced window bits of table-free MSMs (0 = cost model)
 
   // launch on workspace slot `wslot`; the result is collected with finish_t
   template <class Fld>
   int launch_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
                hipStream_t st, int wslot, MsmPending* pend, const void* bases2 = nullptr, MsmGate gate = MsmGate{},
-               const MsmBatchArg* batch = nullptr, int prio = 0, int range = 0) {
+               const MsmBatchArg* batch = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate, prio};
-    tune.range = range;
+    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }
@@ -1766,86 +1737,14 @@ class MsmRunner {
   int finish_t(IEngine* eng, MsmPending* pend, XYZZ<Fld>* result, XYZZ<Fld>* result2 = nullptr) {
     return msm_fold<Fld>(eng, *pend, result, result2);
   }
-  // ---- EXPERIMENT, measured and left OFF (ZK_MSM_SPLIT=1 enables it): a large table-free MSM that runs ALONE (zk_msm,
-  // zk_d_msm, zk_dist_d_msm: the 8 x 2^20-point d_msm of BASELINE configs[2]) as TWO window groups on two streams, so that
-  // the sort of the upper windows runs under the accumulate kernel of the lower ones and the finalize / reduce tails of the
-  // lower group under the accumulate of the upper one ("pipeline sort(group k+1) under
-  // accumulate(group k)"); the host folds both groups and joins them with one walk of doublings.  Same results (all GPU
-  // tests, incl. the 2^26-point exact check, pass with it on).  Measured on 8 x 2^20 points, same box, against 13.1-13.7 ms
-  // for the single launch: 13.3-13.4 ms with the staged sort kernels for the upper group (their 1024-thread workgroups
-  // never find a free CU beside an accumulate kernel: the sort simply waits, and two accumulate kernels sharing the chip
-  // run worse than one), 15.2-15.3 ms with the small-workgroup sort kernels (they do run beside the accumulate -- and slow it
-  // down by more than they take alone).  The accumulate kernel wants the chip to itself.
-  struct SplitLaunch {
-    MsmPending p[2];
-    bool split = false;
-    int wm = 0;
-  };
-  MsmSlot slots_b_[MSM_WS];
-  hipStream_t split_st_[MSM_WS] = {};
-  hipEvent_t split_ev_[MSM_WS] = {};
-  template <class Fld>
-  int launch_split_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
-                     hipStream_t st, int wslot, SplitLaunch* sl) {
-    static const bool enabled = getenv("ZK_MSM_SPLIT") && atoi(getenv("ZK_MSM_SPLIT")) != 0;
-    static const size_t min_entries = getenv("ZK_MSM_SPLIT_MIN") ? (size_t)atoll(getenv("ZK_MSM_SPLIT_MIN")) : ((size_t)48 << 20);
-    constexpr bool G2FLD = IsExtField<Fld>::value;
-    const int nwin = msm_nwin_of<FrP>(npts, G2FLD);
-    size_t toff = 0;
-    sl->split = enabled && wslot >= 0 && wslot < MSM_WS && nwin >= 4 && npts >= ((size_t)4 << 20) &&
-                npts * (size_t)nwin >= min_entries && !getenv("ZK_MSM_C") && !getenv("ZK_MSM_C_G2") &&
-                !TableRegistry::inst().find(bases, npts, sizeof(Affine<Fld>), FrP::BITS, &toff);
-    if (!sl->split) return launch_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &sl->p[0]);
-    if (sl->p[0].active || sl->p[1].active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    if (!split_st_[wslot]) {
-      hipError_t he = hipStreamCreateWithFlags(&split_st_[wslot], hipStreamNonBlocking);
-      if (he == hipSuccess) he = hipEventCreateWithFlags(&split_ev_[wslot], hipEventDisableTiming);
-      if (he != hipSuccess) return eng->hip_fail(he, "msm split stream");
-    }
-    hipError_t he = hipEventRecord(split_ev_[wslot], st);          // the operands may still be in flight on the caller's stream
-    if (he == hipSuccess) he = hipStreamWaitEvent(split_st_[wslot], split_ev_[wslot], 0);
-    if (he != hipSuccess) return eng->hip_fail(he, "msm split ordering");
-    sl->wm = (nwin + 1) / 2;
-    // the upper group's sort runs beside the lower group's accumulate kernel: small workgroups (its 3-5x write amplification
-    // is hidden there -- the accumulate is ALU-bound); with the staged kernels the split was SLOWER than one launch
-    // (13.3-13.4 against 13.1 ms: their 1024-thread workgroups wait for a whole free CU until the accumulate has ended)
-    MsmTuning ta{bigsort_min, MsmGate{}, 0, 0, sl->wm, 0, false}, tb{bigsort_min, MsmGate{}, 0, sl->wm, nwin, 0, true};
-    int rc = msm_launch<FrP, Fld>(eng, slots_[wslot], ta, bases, nullptr, scalars, npts, coef_d, part_len, st, &sl->p[0], nullptr);
-    if (rc) return rc;
-    rc = msm_launch<FrP, Fld>(eng, slots_b_[wslot], tb, bases, nullptr, scalars, npts, coef_d, part_len, split_st_[wslot],
-                              &sl->p[1], nullptr);
-    if (rc) {                                       // the lower group is in flight: join it before reporting
-      XYZZ<Fld> dummy;
-      (void)msm_fold<Fld>(eng, sl->p[0], &dummy, nullptr);
-    }
-    return rc;
-  }
-  template <class Fld>
-  int finish_split_t(IEngine* eng, SplitLaunch* sl, XYZZ<Fld>* result) {
-    if (!sl->split) return msm_fold<Fld>(eng, sl->p[0], result, nullptr);
-    XYZZ<Fld> lo, hi;
-    const int c = sl->p[0].c, wide = sl->p[0].wide;
-    int rc = msm_fold<Fld>(eng, sl->p[0], &lo, nullptr);
-    int rc2 = msm_fold<Fld>(eng, sl->p[1], &hi, nullptr);
-    if (rc || rc2) return rc ? rc : rc2;
-    for (int w = 0; w < sl->wm; w++) {
-      const int cw = w < wide ? c : c - 1;
-      for (int i = 0; i < cw; i++) hi = xyzz_dbl_ni(hi);
-    }
-    *result = xyzz_add_ni(hi, lo);
-    return ZK_OK;
-  }
+  // (Round 4 measured a large lone MSM as TWO window groups on two streams -- the sort of the upper windows under the
+  // accumulate of the lower ones: 13.3-13.4 ms with the staged sort kernels, 15.2-15.3 with small-workgroup ones, against
+  // 13.1-13.7 for the single launch: the accumulate kernel wants the chip to itself.  The path was removed in round 5.)
   // blocking form
   template <class Fld>
   int run_t(IEngine* eng, const void* bases, const void* scalars, size_t npts, const Fr* coef_d, size_t part_len,
             XYZZ<Fld>* result, hipStream_t st, int wslot = 0, const void* bases2 = nullptr,
             XYZZ<Fld>* result2 = nullptr) {
-    if (!bases2) {
-      SplitLaunch sl;
-      int rc = launch_split_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &sl);
-      if (rc) return rc;
-      return finish_split_t<Fld>(eng, &sl, result);
-    }
     MsmPending pend;
     int rc = launch_t<Fld>(eng, bases, scalars, npts, coef_d, part_len, st, wslot, &pend, bases2);
     if (rc) return rc;
@@ -1901,13 +1800,13 @@ class MsmRunner {
   template <class Fld>
   int d_msm_range_t(IEngine* eng, const void* bases, const void* scalars, size_t len, int first, int count,
                     const void* in_mask, XYZZ<Fld>* result, hipStream_t st, int wslot = 0) {
-    SplitLaunch sl;
-    int rc = launch_split_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, st, wslot, &sl);
+    MsmPending pend;
+    int rc = launch_t<Fld>(eng, bases, scalars, (size_t)count * len, coef_d_ + first, len, st, wslot, &pend);
     if (rc) return rc;
     XYZZ<Fld> mt = XYZZ<Fld>::identity();
     if (in_mask) mt = mask_term<Fld>(in_mask, first, count);
     XYZZ<Fld> r;
-    rc = finish_split_t<Fld>(eng, &sl, &r);
+    rc = finish_t<Fld>(eng, &pend, &r);
     if (rc) return rc;
     *result = in_mask ? xyzz_add_ni(r, mt) : r;
     return ZK_OK;
@@ -2080,8 +1979,8 @@ class MsmRunner {
     out[1] = t ? t->nwin : 0;
   }
 
-  // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min"; env ZK_MSM_BIGSORT_MIN at start)
-  size_t bigsort_min = getenv("ZK_MSM_BIGSORT_MIN") ? (size_t)atoll(getenv("ZK_MSM_BIGSORT_MIN")) : ((size_t)1 << 14);
+  // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min")
+  size_t bigsort_min = (size_t)1 << 14;
   MsmSlot slots_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;

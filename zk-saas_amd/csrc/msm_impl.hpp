@@ -30,7 +30,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     else bases2 = tab2->data;
   }
   if (tab) bases = tab->data;
-  const int c_req = tab ? tab->c : msm_pick_c<FrP>(npts, G2FLD);
+  const int c_req = tab ? tab->c : msm_pick_c<FrP>(npts, G2FLD, tune.c_force);
   // BITS+1 bits (room for the signed-digit carry) are spread EVENLY over the windows: `wide` windows of c bits and
   // nwin-wide of c-1.  A plain c-bit split leaves a top window of a few bits (254 = 19*13 + 7) whose 64 buckets
   // each receive npts/64 points: hot atomics in the sort, long chains, and a heavy-bucket pass in every MSM.
@@ -39,10 +39,9 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const int c = (T + nwin - 1) / nwin;            // widest window
   const int wide = T - nwin * (c - 1);            // 1 <= wide <= nwin
   const uint32_t B = 1u << (c - 1);
-  // a window group of a split MSM (MsmRunner::run_split_t): this launch sorts and sums windows [w_begin, w_end) only
-  const int w_begin = tune.w_begin, w_end = tune.w_end < 0 ? nwin : tune.w_end;
-  if (w_begin < 0 || w_end > nwin || w_begin >= w_end) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm window range");
-  if ((w_begin != 0 || w_end != nwin) && tab) return eng->fail(ZK_ERR_GENERIC, "window groups and fixed-base tables do not mix");
+  // the kernels sort and sum a window range [w_begin, w_end): every launch covers all of them (a split into window groups
+  // on two streams was measured in round 4 and removed, see MsmRunner)
+  const int w_begin = 0, w_end = nwin;
   const int nwin_r = w_end - w_begin;
   const int kwin = tab ? 1 : nwin_r;              // bucket sets per scalar vector: with a table all windows share one
   const size_t nsets = batch * (size_t)kwin;      // bucket sets of the launch
@@ -55,8 +54,8 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   // Fq2 values per lane -- a pair of lanes per range, or one lane on large launches of 8-limb curves: 256 registers with
   // 13-99 spilled dwords, BLS12-381 G2 at a third of the multiplier's peak; those kernels are gone (measured with the quad
   // form: a 2^24-constraint BLS12-381 proof 1.42 -> 1.28 s, the SHA-256 proof 561 -> 593 proofs/s, table-free 395 -> 428)
-  const MsmLanes ml = G2FLD ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4, tune.range)
-                            : msm_pick_lanes(max_sorted, ACC_WAVES<Fld>, false, 0, tune.range);
+  const MsmLanes ml = G2FLD ? msm_pick_lanes(max_sorted, SPLIT_WAVES<typename BaseParams<Fld>::type>, true, 4)
+                            : msm_pick_lanes(max_sorted, ACC_WAVES<Fld>, false, 0);
   const uint32_t nlanes = ml.nlanes, tmin = ml.tmin, cap = ml.cap;
   // reduction geometry (msm.hpp "reduce stage A / B"): digit magnitudes k = hi * LO + lo in [1, B]
   const int lo_bits = c / 2;                       // LO = 2^lo_bits columns, HI = B / LO rows (+ the row of k = B)
@@ -71,18 +70,17 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
-  // identity bases are left out of the sort (msm_skip_mask_kernel); ZK_MSM_SKIP_IDENTITY=0 keeps them (A/B runs).
+  // identity bases are left out of the sort (msm_skip_mask_kernel).
   // Two base vectors over the same scalars then get their OWN sorts (their identities differ: a fused sort could only
   // skip a point that is the identity in both) -- same kernels, grid.y = 2, the sort-stage arrays in two copies of one
-  // workspace region (ZK_YSHIFT in the kernels); ZK_MSM_ONE_SORT=1 keeps the single shared sort.
-  static const bool skip_on = !(getenv("ZK_MSM_SKIP_IDENTITY") && atoi(getenv("ZK_MSM_SKIP_IDENTITY")) == 0);
-  static const bool one_sort = getenv("ZK_MSM_ONE_SORT") && atoi(getenv("ZK_MSM_ONE_SORT")) != 0;
+  // workspace region (ZK_YSHIFT in the kernels).
+  constexpr bool skip_on = true;
   // registered vectors know whether they hold an identity at all (zk_msm_precompute): without one there is no mask
   const bool none = tab && !tab->any_identity && (NB == 1 || (tab2 && !tab2->any_identity));
-  const unsigned NS = (NB == 2 && skip_on && !one_sort && !none) ? 2u : 1u;       // sorts of this launch
+  const unsigned NS = (NB == 2 && !none) ? 2u : 1u;       // sorts of this launch
   // ---- big-sort plan (msm.hpp "big sort"): workgroup shape, points per tile, bin split, entry format
-  static const size_t large_min = getenv("ZK_SORT_LARGE_MIN") ? (size_t)atoll(getenv("ZK_SORT_LARGE_MIN")) : ((size_t)4 << 20);
-  const bool large = npts * batch >= large_min && !tune.lean_sort;    // multi-million-point launches: 1024-thread workgroups, one per CU
+  constexpr size_t large_min = (size_t)4 << 20;
+  const bool large = npts * batch >= large_min;    // multi-million-point launches: 1024-thread workgroups, one per CU
   const int sthr = large ? 1024 : 256;
   // small launches: ~1024 tiles so that they still fill the chip, up to 16 points per thread
   int ppt = large ? BIG_PTS_PER_THREAD : 16;
@@ -103,8 +101,6 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     if (c - 1 - sort_hi > 12) sort_hi = c - 1 - 12;
     while (sort_hi > 0 && (nsets << sort_hi) > (size_t)BIG_MAX_BINS) sort_hi--;
   }
-  static const int hi_env = getenv("ZK_SORT_HI") ? atoi(getenv("ZK_SORT_HI")) : 0;
-  if (hi_env > 0 && hi_env <= c - 2) sort_hi = hi_env;
   sort_lo = c - 1 - sort_hi;
   int idx_bits = 1;
   {
@@ -122,7 +118,6 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const bool big = npts * batch >= tune.bigsort_min && sort_hi >= 1 && sort_lo >= 1 && sort_lo <= 12 &&
                    (nsets << sort_hi) <= (size_t)BIG_MAX_BINS &&
                    (large ? stage_cap >= (tab ? (size_t)nwin * tile_pts : tile_pts) : 8 * nbl <= BIG_LDS_MAX);
-  if ((w_begin != 0 || w_end != nwin) && !big) return eng->fail(ZK_ERR_GENERIC, "window groups need the two-level sort");
   const int wgroup = tab ? nwin : (int)std::min<size_t>((size_t)nwin, std::max<size_t>(1, stage_cap / tile_pts));
   const size_t nbins_tot = nsets << sort_hi;
   // ---- sort region (replicated NS times)
@@ -135,10 +130,9 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   const size_t o_canon = take(npts * batch * sizeof(Fr));      // canonical scalars (written by the first sort pass)
   size_t o_tmp = 0, o_tmp_lo = 0, o_tcnt = 0;
   // staged scatter: the histogram pass runs on the scatter's own tiles and hands over its per-tile counts (2 B per tile and
-  // bin), so that the scatter does not walk the digits a third time (ZK_SORT_TILE_COUNTS=0: it counts again)
-  static const bool tcnt_on = !(getenv("ZK_SORT_TILE_COUNTS") && atoi(getenv("ZK_SORT_TILE_COUNTS")) == 0);
+  // bin), so that the scatter does not walk the digits a third time
   const size_t tiles_big = ((npts + tile_pts - 1) / tile_pts) * batch;
-  const bool use_tcnt = big && large && tcnt_on && tile_pts % BIG_THREADS == 0 && tile_pts < 65536;
+  const bool use_tcnt = big && large && tile_pts % BIG_THREADS == 0 && tile_pts < 65536;
   if (big) {
     o_tmp = take(max_sorted * 4);
     if (wide_fmt) o_tmp_lo = take(max_sorted * 2);
@@ -183,16 +177,18 @@ do {                                                       \
   hipError_t _e = (x);                                     \
   if (_e != hipSuccess) return eng->hip_fail(_e, #x);      \
 } while (0)
-  const bool dbg = getenv("ZK_DEBUG_SYNC") != nullptr;
+// stage marker: with -DZK_MSM_DEBUG_SYNC (debug builds only) the stream is synchronised and checked after every stage
+#ifdef ZK_MSM_DEBUG_SYNC
 #define MSM_STAGE(name)                                                          \
 do {                                                                           \
-  if (dbg) {                                                                   \
-    hipError_t _e = hipStreamSynchronize(st);                                  \
-    fprintf(stderr, "[zk msm] %s done (%s) npts=%zu c=%d nwin=%d\n", name,     \
-            hipGetErrorString(_e), npts, c, nwin);                             \
-    if (_e != hipSuccess) return eng->hip_fail(_e, name);                      \
-  }                                                                            \
+  hipError_t _e = hipStreamSynchronize(st);                                    \
+  fprintf(stderr, "[zk msm] %s done (%s) npts=%zu c=%d nwin=%d\n", name,       \
+          hipGetErrorString(_e), npts, c, nwin);                               \
+  if (_e != hipSuccess) return eng->hip_fail(_e, name);                        \
 } while (0)
+#else
+#define MSM_STAGE(name) do { } while (0)
+#endif
   {
   // counts (the two-level sort writes every offset itself; it needs its bin counters and the ticket zeroed) and the
   // heavy-bucket counter
@@ -321,7 +317,7 @@ do {                                                                           \
   } else {
     msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), 0, st>>>(
         (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
-        heavy, k0, ys, tune.prio);
+        heavy, k0, ys, 0);
   }
   if (tune.gate.signal_ev) {
     MSM_HIP(hipEventRecord(tune.gate.signal_ev, st));
@@ -353,7 +349,7 @@ do {                                                                           \
   // (one bucket set per window) -> 4 quads per group, waves stay full
   // As many quads per group as keep the whole launch resident at once (a second generation of workgroups doubles a
   // kernel that is one dependent chain): the chip holds 1024 SIMDs x (2 waves of the extension-field kernels, 3 of the
-  // base-field ones) x 16 quads.  ZK_RED_NVL_A / _B override (experiments).
+  // base-field ones) x 16 quads.
   const size_t tot_groups = (size_t)red_groups * NB * nsets;
   const size_t tot_slices = (size_t)nslices * NB * nsets;
   const size_t cap_quads = (size_t)1024 * (G2FLD ? 2 : 3) * 16;
@@ -362,11 +358,7 @@ do {                                                                           \
     while (v > 4 && groups * (size_t)v > cap_quads) v >>= 1;
     return v;
   };
-  static const int env_a = getenv("ZK_RED_NVL_A") ? atoi(getenv("ZK_RED_NVL_A")) : 0;
-  static const int env_b = getenv("ZK_RED_NVL_B") ? atoi(getenv("ZK_RED_NVL_B")) : 0;
   int nvl_a = pick_nvl(tot_groups), nvl_b = pick_nvl(tot_slices);
-  if (env_a == 4 || env_a == 8 || env_a == 16 || env_a == 32 || env_a == 64) nvl_a = env_a;
-  if (env_b == 4 || env_b == 8 || env_b == 16 || env_b == 32 || env_b == 64) nvl_b = env_b;
   if (nvl_a > qvl) nvl_a = qvl;
   if (nvl_b > qvl) nvl_b = qvl;
   const unsigned gpw_a = (unsigned)(qvl / nvl_a), gpw_b = (unsigned)(qvl / nvl_b);

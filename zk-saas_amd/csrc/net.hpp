@@ -37,6 +37,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -289,18 +290,16 @@ class Net {
     if (rank == 0) {
       uint64_t dl = net_now_ms() + timeout_ms;
       uint32_t m = 1;
-      if (!alive_init_) {
-        alive_ = full_mask();
-        alive_init_ = true;
-      }
+      // (alive_ is shared by the channels, which are driven by different host threads: atomic, and only ever narrowed)
       for (;;) {
+        const uint32_t alive = alive_.load(std::memory_order_acquire);
         m = 0;
         for (int r = 0; r < world; r++)
-          if ((alive_ & (1u << r)) && c.arrive[r].load(std::memory_order_acquire) >= s) m |= 1u << r;
-        if (m == alive_ || net_now_ms() > dl) break;
+          if ((alive & (1u << r)) && c.arrive[r].load(std::memory_order_acquire) >= s) m |= 1u << r;
+        if (m == alive || net_now_ms() > dl) break;
         relax();
       }
-      alive_ = m;
+      alive_.fetch_and(m, std::memory_order_acq_rel);
       c.verdict_mask.store(m, std::memory_order_relaxed);
       c.verdict_seq.store(s, std::memory_order_release);
       *mask = m;
@@ -338,12 +337,12 @@ class Net {
   // ---- data plane.  bytes = bytes PER RANK (k parties' rows); the king's `full` holds the present ranks' blocks
   // compacted in rank order (so that a dropout leaves the [np][len] layout the king kernels take).
   // verb counters since creation: gathers, scatters, all-to-alls, payload bytes this rank sent (zk_net_stats)
-  uint64_t stats[4] = {0, 0, 0, 0};
+  std::atomic<uint64_t> stats[4] = {};          // (bumped by the channel threads)
 
   int gather(int sid, uint32_t mask, const void* local, size_t bytes, void* full) {
     const int op = op_[sid]++;
-    stats[0]++;
-    if (rank != 0) stats[3] += bytes;
+    stats[0].fetch_add(1, std::memory_order_relaxed);
+    if (rank != 0) stats[3].fetch_add(bytes, std::memory_order_relaxed);
     if (transport == ZK_NET_LOCAL) return copy_dd(full, local, bytes, sid);
     const int k = parties_per_rank();
     const size_t rb = bytes / (size_t)k;                 // bytes of one party row (general maps move rows)
@@ -428,8 +427,8 @@ class Net {
 
   int scatter(int sid, uint32_t mask, const void* full, size_t bytes, void* local) {
     const int op = op_[sid]++;
-    stats[1]++;
-    if (rank == 0) stats[3] += bytes * (size_t)(__builtin_popcount(mask) - 1);
+    stats[1].fetch_add(1, std::memory_order_relaxed);
+    if (rank == 0) stats[3].fetch_add(bytes * (size_t)(__builtin_popcount(mask) - 1), std::memory_order_relaxed);
     if (transport == ZK_NET_LOCAL) return copy_dd(local, full, bytes, sid);
     const int k = parties_per_rank();
     const size_t rb = bytes / (size_t)k;
@@ -512,8 +511,8 @@ class Net {
   //          kernels take after a dropout)
   int alltoall(int sid, uint32_t mask, const void* send, size_t bytes, void* recv) {
     const int op = op_[sid]++;
-    stats[2]++;
-    stats[3] += bytes * (size_t)(__builtin_popcount(mask) - 1);
+    stats[2].fetch_add(1, std::memory_order_relaxed);
+    stats[3].fetch_add(bytes * (size_t)(__builtin_popcount(mask) - 1), std::memory_order_relaxed);
     if (transport == ZK_NET_LOCAL) return copy_dd(recv, send, bytes, sid);
     int present[NET_MAXR], np_r = 0, me = -1;
     for (int r = 0; r < world; r++)
@@ -652,25 +651,35 @@ class Net {
     }
   }
 
+  // (channels fail independently and from different threads: the message fields are written under a lock)
   int fail(const std::string& m, int code = ZK_ERR_GENERIC) {
+    std::lock_guard<std::mutex> lk(err_mu_);
     err = m;
     err_party = -1;
     last_code = code;
     return code;
   }
   int fail_party(const std::string& m, int party) {
+    std::lock_guard<std::mutex> lk(err_mu_);
     err = m;
     err_party = party;
     last_code = ZK_ERR_PROTOCOL;
     return ZK_ERR_PROTOCOL;
   }
+  std::mutex err_mu_;
   int last_code = ZK_OK;
 
  private:
   // waits are short when every rank is alive (a few microseconds between neighbours on one node): spin first, then
   // back off to 20 us sleeps so that a long wait (a dead peer, up to the timeout) does not burn a core
+  // (the spin counter is per THREAD: the three channels of a rank are driven by three host threads at once,
+  // ext_wit.rs:158-170 -- a member counter was a data race between them, found by tests/test_sanitizers.py under TSan)
+  static uint32_t& spins() {
+    static thread_local uint32_t s = 0;
+    return s;
+  }
   void relax() {
-    if (++spins_ < 4000) {
+    if (++spins() < 4000) {
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
@@ -679,8 +688,7 @@ class Net {
     timespec ts{0, 20000};
     nanosleep(&ts, nullptr);
   }
-  void relax_reset() { spins_ = 0; }
-  uint32_t spins_ = 0;
+  void relax_reset() { spins() = 0; }
   uint64_t tick(int sid, int op, size_t chunk) const { return (seq_[sid] << 24) | ((uint64_t)(op & 0xff) << 16) | (chunk & 0xffff); }
   bool wait_ge(std::atomic<uint64_t>& a, uint64_t v, const char* what) {
     // ticks are ordered by (round, operation, chunk)
@@ -792,10 +800,9 @@ class Net {
   uint64_t last_g_[NET_NSID] = {0, 0, 0, 0};
   uint64_t last_s_[NET_NSID][NET_MAXR] = {};
   int op_[NET_NSID] = {0, 0, 0, 0};
-  bool aborted_ = false;
-  bool dead_ = false;                 // this rank was left out of a round
-  uint32_t alive_ = 0;                // king: ranks still taking part
-  bool alive_init_ = false;
+  std::atomic<bool> aborted_{false};
+  std::atomic<bool> dead_{false};     // this rank was left out of a round
+  std::atomic<uint32_t> alive_{0xffffffffu};   // king: ranks still taking part (narrowed by every round's verdict)
 };
 
 }  // namespace zk

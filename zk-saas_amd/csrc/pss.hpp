@@ -31,11 +31,8 @@ constexpr bool KING_DOT = ZK_KING_DOT != 0;
 // was bound by the chip's multiplier throughput this changed nothing (the earlier U-MSM only displaced the other
 // accumulates: 290 vs 290 proofs/s, profiles/r02_small_groups_timeline.txt); with the faster multiplier and the
 // identity-free sorts the circom_h -> U chain became the last to finish and it is worth +8.6 % (500 vs 460 proofs/s with
-// tables, 366 vs 360 without).  ZK_SMALL_GROUPS=0 restores the wide groups.
-inline bool small_groups() {
-  static const bool on = !(getenv("ZK_SMALL_GROUPS") && atoi(getenv("ZK_SMALL_GROUPS")) == 0);
-  return on;
-}
+// tables, 366 vs 360 without).
+constexpr bool small_groups() { return true; }
 inline int king_block(size_t chunks) { return (small_groups() && chunks <= ((size_t)1 << 16)) ? 64 : KING_THREADS; }
 
 // The l = 2 kernels (the configuration every reference example runs) inline their multiplies; larger
