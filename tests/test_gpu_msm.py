@@ -402,3 +402,50 @@ def test_table_registry_is_process_wide_across_contexts():
     again.ctx = B                                                          # B.h is None now: zk_free(NULL, p)
     again.free()
     A.close()
+
+
+def test_concurrent_sorts_stress():
+    """msm_hist_kernel's last-workgroup scan of the bin totals rests on relaxed device-scope atomics + a barrier + a relaxed
+    ticket (csrc/msm.hpp; ADVICE r4 asked for acq_rel, which costs every concurrent sort an L2 write-back: measured and
+    kept behind -DZK_HIST_TICKET_ACQ_REL).  Stress: four host threads, each with its own context (own streams and
+    workspaces), run 160 MSMs of assorted two-level-sort sizes AT THE SAME TIME on the one GPU; every result must equal the
+    one the same context computed alone beforehand (a stale bin total would misplace sorted entries and change the sum)."""
+    import threading
+    from zksaas_amd import groth16 as zg
+    sizes = [20000, 33000, 70001, 150000]
+    rng = np.random.default_rng(9)
+
+    def rand(count):
+        a = rng.integers(0, 1 << 62, size=(count, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 58) - 1)
+        return a
+    ctxs = [zk.PackedSharingParams("bn254", 2) for _ in range(4)]
+    G = g1(CURVES["bn254"])
+    try:
+        work = []
+        for pp in ctxs:
+            mx = max(sizes)
+            pts = zg.base_points(pp, ZK_G1, zk.DeviceBuffer.from_numpy(pp, rand(mx)), mx)
+            sc = zk.DeviceBuffer.from_numpy(pp, rand(mx))
+            want = {n_: msm(pp, ZK_G1, pts, sc, n_).copy() for n_ in sizes}
+            work.append((pp, pts, sc, want))
+        bad = []
+
+        def run(t):
+            pp, pts, sc, want = work[t]
+            for i in range(40):
+                n_ = sizes[(i + t) % len(sizes)]
+                got = msm(pp, ZK_G1, pts, sc, n_)
+                # compared as group elements (the order of a bucket's entries, hence the Jacobian coordinates of the sum,
+                # may differ between runs)
+                if not G.eq(dec_jacobian(pp, got), dec_jacobian(pp, want[n_])):
+                    bad.append((t, i, n_))
+        ths = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not bad, bad[:5]
+    finally:
+        for pp in ctxs:
+            pp.close()

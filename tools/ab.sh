@@ -4,8 +4,8 @@
 OTHER=$1; N=$2; shift 2
 for i in $(seq 1 $N); do
   for v in A B; do
-    if [ $v = B ]; then export ZKSAAS_LIB=$OTHER; else unset ZKSAAS_LIB; fi
-    python bench.py "$@" 2>/dev/null | tail -1 | python -c "
+    if [ $v = B ]; then RUN="python tools/ab_run.py $OTHER bench.py"; else RUN="python bench.py"; fi
+    $RUN "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 o={'v':'$v','value':d.get('value'),'ms':d.get('ms_per_step')}

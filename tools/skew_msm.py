@@ -1,5 +1,5 @@
 """One G1 MSM whose scalars repeat like a real witness's (60 % ones, 25 % fives, 5 % r - 1, the rest random) against one with
-random scalars, BN254 and BLS12-381:   python tools/skew_msm.py [log2 points]      (ZKSAAS_LIB=<other build> for an A/B)"""
+random scalars, BN254 and BLS12-381:   python tools/skew_msm.py [log2 points]      (python tools/ab_run.py <other build> tools/skew_msm.py .. for an A/B)"""
 import json
 import sys
 import time

@@ -24,10 +24,10 @@ for d in (dir_a, dir_b):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[(k, r["Counter_Name"])] += 1
 spec = {"king_fft2_kernel<Bn254Fr, 2, false>": dict(
-            waves=8192, mads_per_wave=30 * 136,
-            what="2^19 chunks, one per lane; ~30 Montgomery products per chunk (16 unpack2, 4 butterfly / g^pos, 10 structured "
-                 "pack) + two ChaCha20 draws (1.2 blocks each on average: a wave repeats until all 64 lanes hold an accepted "
-                 "candidate) + 2 to_mont"),
+            waves=8192, mads_per_wave=2 * 584 + 14 * 136,
+            what="2^19 chunks, one per lane; unpack2 as two 8-term dot products with one reduction each (Fp::dot_k, 584 multiply "
+                 "instructions each instead of 8 x 136), 4 products of butterfly / g^pos, 10 of the structured pack, one "
+                 "ChaCha12 block for the two draws of a chunk"),
         "ntt_pass_kernel<Fp<Bn254Fr>, 11>": dict(
             waves=16384, mads_per_wave=24 * 136,
             what="8 x 2^19 elements, 4 per lane; 22-26 Montgomery products per lane (stages / 2 x 4 + the pre-twiddle of the "

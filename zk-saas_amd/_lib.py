@@ -4,9 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The one library this package loads.  Nothing in the environment can point it elsewhere; same-box A/B runs
+# against another build go through tools/ab_run.py, which sets this attribute before anything is loaded.
 LIB_PATH = os.path.join(_HERE, "libzksaas_hip.so")
-if os.environ.get("ZKSAAS_LIB"):      # A/B runs against another build of the same library (tools/, never the tests)
-    LIB_PATH = os.environ["ZKSAAS_LIB"]
 
 # every symbol include/zksaas.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -76,6 +76,9 @@ def load():
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
+    missing = [name for name in SYMBOLS if not hasattr(lib, name)]
+    if missing:                       # an older or foreign build: refuse it rather than call into a different ABI
+        raise ImportError("%s does not export %s: rebuild it (include/zksaas.h is the ABI)" % (LIB_PATH, ", ".join(missing[:5])))
     vp, sz, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
     lib.zk_version.restype = C.c_char_p
     lib.zk_ctx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]

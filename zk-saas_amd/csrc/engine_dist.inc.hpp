@@ -1,0 +1,919 @@
+// Part of class Engine<Cfg> (engine_impl.hpp includes this file INSIDE the class body): the per-rank collective forms (zk_dist_*) over the star network of net.hpp.
+// Split out of engine_impl.hpp in round 5 (one 3 400-line class body had stopped being navigable); not a stand-alone header.
+
+  // ---------------------------------------------------------------- per-rank collective forms (net.hpp)
+  // Every rank calls these collectively with the rows of ITS k = n / world parties ([k][len] buffers, masks
+  // likewise); rank 0 hosts the king.  A call first enters the round on the control plane (net.enter): ranks that do
+  // not show up within the timeout are left out and the king goes through lagrange_unpack (pss.rs:170-221) like
+  // ser_net.rs:57-94 does with `Partial` results.
+  DevBuf dist_in_[NET_NSID], dist_out_[NET_NSID], dist_coef_[NET_NSID];
+  DevBuf dist_w0_, dist_w1_, dist_h_;
+
+  int net_err(Net* net, int rc) {
+    if (rc == ZK_OK) return rc;
+    return fail(rc, "net: " + net->err, net->err_party);
+  }
+  // Option "dist_deadline": the reference's collectives return Err after their timeout (mpc-net/src/ser_net.rs:122-125);
+  // here a zk_dist_* call has only ENQUEUED its data-plane work when it returns, and a hung RCCL collective would
+  // surface at the caller's next stream synchronisation, without a deadline.  With the option every zk_dist_* entry
+  // point waits for the channels' streams before returning, with the net's timeout as the deadline; on expiry the
+  // communicators are aborted, the call fails with ZK_ERR_PROTOCOL and the net refuses every later round (the process
+  // then opens a new net, or hands over to a fresh child process).
+  bool dist_deadline_ = false;
+  int dist_finish(Net* net, int rc) override {
+    if (rc != ZK_OK || !dist_deadline_) return rc;
+    for (int sid = 0; sid < NET_NSID; sid++) {
+      const int r = net->sync_deadline(sid);
+      if (r) return net_err(net, r);
+    }
+    return ZK_OK;
+  }
+  // parties of the ranks in `mask`, ascending (the row order the king sees, net.hpp)
+  std::vector<uint32_t> parties_of(const Net* net, uint32_t mask) const {
+    std::vector<uint32_t> ps;
+    const int k = net->parties_per_rank();
+    for (int r = 0; r < net->world; r++)
+      if (mask & (1u << r))
+        for (int p = 0; p < k; p++) ps.push_back((uint32_t)net->party(r, p));
+    std::sort(ps.begin(), ps.end());
+    return ps;
+  }
+  // Index of this rank's first party in the d_msm coefficient table.  The parties of a contiguous map are a range of
+  // the table; those of a general party_to_rank map are copied to the window behind its n entries (msm.hpp set_window),
+  // so that everything taking (first, count) works on either.
+  int local_window(Net* net, int* first) {
+    if (net->contiguous()) {
+      *first = net->first_party(net->rank);
+      return ZK_OK;
+    }
+    const int k = net->parties_per_rank();
+    std::vector<int> mine((size_t)k);
+    for (int i = 0; i < k; i++) mine[i] = net->party(net->rank, i);
+    for (int i = 0; i < NJOBS; i++)
+      if (jobs_[i].active && mine != msm_.window_) return fail(ZK_ERR_BAD_INPUT, "a proof over another party map is in flight");
+    int rc = msm_.set_window(this, mine);
+    if (rc) return rc;
+    *first = n;
+    return ZK_OK;
+  }
+  hipStream_t net_stream(Net* net, int sid, hipStream_t st) { return net->stream(sid) ? net->stream(sid) : st; }
+
+  // one king round on channel sid: gather the local rows -> king step on rank 0 -> scatter.  `king` is called on rank 0
+  // with (in [np][len], parties, np, out [n][len], stream).
+  // `out_mask` (optional, this rank's rows): added to the scattered result.  With the LOCAL transport (one rank holds all
+  // parties) the king reads the caller's rows directly and the result comes back through ONE pass that adds the mask,
+  // instead of a gather copy, a scatter copy and an addition (d_fft 2^20 on one GPU: 0.96 -> 0.87 ms).
+  template <class KingFn>
+  int king_round(Net* net, int sid, uint32_t mask, Fr* local, size_t len, KingFn king, const Fr* out_mask = nullptr,
+                 const Fr* king_in = nullptr, bool in_place_ok = false) {
+    const int k = net->parties_per_rank();
+    const size_t bytes = (size_t)k * len * sizeof(Fr);
+    hipStream_t ks = net_stream(net, sid, nullptr);
+    if (net->transport == ZK_NET_LOCAL) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      // one rank holds all parties: no gather / scatter.  The king writes the caller's rows directly (out-mask added in
+      // its store) when its input lives elsewhere (king_in: d_fft's local stages went out of place) or when it only
+      // touches its own column (in_place_ok: deg_red); otherwise through a scratch vector and one pass back.
+      if (king_in || in_place_ok) return king(king_in ? king_in : local, ps.data(), (int)ps.size(), local, out_mask, ks);
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      Fr* fout = (Fr*)dist_out_[sid].p;
+      int rc = king(local, ps.data(), (int)ps.size(), fout, nullptr, ks);
+      if (rc) return rc;
+      const size_t cnt = (size_t)k * len;
+      if (out_mask) {
+        vec_sum_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ks>>>(local, fout, out_mask, cnt);
+        ZK_HIP(hipGetLastError());
+      } else {
+        ZK_HIP(hipMemcpyAsync(local, fout, bytes, hipMemcpyDeviceToDevice, ks));
+      }
+      return ZK_OK;
+    }
+    Fr *fin = nullptr, *fout = nullptr;
+    if (net->rank == 0) {
+      ZK_HIP(dist_in_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      fin = (Fr*)dist_in_[sid].p;
+      fout = (Fr*)dist_out_[sid].p;
+    }
+    int rc = net_err(net, net->gather(sid, mask, local, bytes, fin));
+    if (rc) return rc;
+    if (net->rank == 0) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      rc = king(fin, ps.data(), (int)ps.size(), fout, nullptr, ks);
+      if (rc) return rc;
+    }
+    rc = net_err(net, net->scatter(sid, mask, fout, bytes, local));
+    if (rc) return rc;
+    if (out_mask) return vec_add(local, out_mask, (size_t)k * len, ks);
+    return ZK_OK;
+  }
+
+  // ---- second-stage king: every present rank is king of a contiguous range of chunks.  One all-to-all
+  // brings a range's input chunks of all parties to its owner, the king kernel runs on the range, a second all-to-all
+  // returns every party's output shares.  Per link a round carries 1/W of the star's bytes and no rank does more than
+  // 1/W of the king's arithmetic.  Option "king_alltoall" (or ZK_KING_ALLTOALL=1), set alike on every rank.
+  bool king_a2a_ = false;        // zk_ctx_set_option("king_alltoall")
+  DevBuf a2a_send_[NET_NSID], a2a_back_[NET_NSID];
+  struct A2aPlan {
+    A2aMap map;
+    int me;
+    uint32_t seg, rs, cnt;
+  };
+  // ranges of `gran`-aligned columns over the present ranks; false when there is less than one granule per rank
+  bool a2a_plan(const Net* net, uint32_t mask, size_t len, size_t gran, A2aPlan* pl) const {
+    pl->map.nranks = net->world;
+    pl->map.npresent = 0;
+    pl->me = -1;
+    for (int r = 0; r < 16; r++) pl->map.idx_of_rank[r] = -1;
+    for (int r = 0; r < net->world; r++)
+      if (mask & (1u << r)) {
+        if (r == net->rank) pl->me = pl->map.npresent;
+        pl->map.idx_of_rank[r] = pl->map.npresent++;
+      }
+    const size_t np_r = (size_t)pl->map.npresent;
+    if (pl->me < 0 || np_r < 2 || len / gran < np_r || len % gran) return false;
+    const size_t seg = ((len / gran + np_r - 1) / np_r) * gran;
+    if (seg > 0xffffffffull) return false;
+    pl->seg = (uint32_t)seg;
+    const size_t rs0 = (size_t)pl->me * seg;
+    pl->rs = (uint32_t)(rs0 < len ? rs0 : len);
+    pl->cnt = (uint32_t)(rs0 >= len ? 0 : (len - rs0 < seg ? len - rs0 : seg));
+    return true;
+  }
+  static constexpr int A2A_NOT_APPLICABLE = -1000;
+  // king(in [np][seg], parties, np, out [n][seg], plan, stream); shift / unpack: see pss.hpp a2a_*_kernel
+  template <class KingFn, class UnpackFn>
+  int king_round_a2a(Net* net, int sid, uint32_t mask, Fr* local, size_t len, size_t gran, uint32_t shift, KingFn king,
+                     UnpackFn unpack) {
+    A2aPlan pl;
+    if (!a2a_plan(net, mask, len, gran, &pl)) return A2A_NOT_APPLICABLE;
+    const int k = net->parties_per_rank();
+    const size_t blk = (size_t)k * pl.seg;                       // elements per (rank, rank) block
+    const int npres = pl.map.npresent;
+    hipStream_t s = net_stream(net, sid, nullptr);
+    ZK_HIP(a2a_send_[sid].ensure((size_t)net->world * blk * sizeof(Fr)));
+    ZK_HIP(a2a_back_[sid].ensure((size_t)npres * blk * sizeof(Fr)));
+    ZK_HIP(dist_in_[sid].ensure((size_t)npres * blk * sizeof(Fr)));
+    ZK_HIP(dist_out_[sid].ensure((size_t)n * pl.seg * sizeof(Fr)));
+    Fr* send = (Fr*)a2a_send_[sid].p;
+    Fr* back = (Fr*)a2a_back_[sid].p;
+    Fr* fin = (Fr*)dist_in_[sid].p;
+    Fr* fout = (Fr*)dist_out_[sid].p;
+    {
+      const size_t tot = (size_t)net->world * blk;
+      a2a_pack_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(local, k, len, pl.seg, shift, pl.map, send);
+      ZK_HIP(hipGetLastError());
+    }
+    int rc = net_err(net, net->alltoall(sid, mask, send, blk * sizeof(Fr), fin));
+    if (rc) return rc;
+    std::vector<uint32_t> ps = parties_of(net, mask);
+    rc = king(fin, ps.data(), (int)ps.size(), fout, pl, s);
+    if (rc) return rc;
+    rc = net_err(net, net->alltoall(sid, mask, fout, blk * sizeof(Fr), back));
+    if (rc) return rc;
+    return unpack(back, pl, s);
+  }
+
+  int dist_d_fft_on(Net* net, int sid, uint32_t mask, Fr* shares, const Fr* in_mask, const Fr* out_mask, int rearrange,
+                    int log_m, int inverse, const void* g, uint64_t seed, bool do_fft1) {
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l;
+    hipStream_t s = net_stream(net, sid, nullptr);
+    int rc;
+    const Fr* king_in = nullptr;
+    if (do_fft1) {
+      // d_ifft scales by 1/m before anything else (dfft/mod.rs:159); without an in-mask the king folds the factor
+      // into its g^i table (same field values), with one it has to come before the mask is added (:254-258)
+      if (inverse && in_mask) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(shares, &c, (size_t)k * Lc, s);
+        if (rc) return rc;
+      }
+      if (net->transport == ZK_NET_LOCAL) {
+        // one rank: the first NTT pass reads the caller's rows and writes a work vector, the king reads that and writes
+        // the caller's rows -- no copy back (d_fft 2^20: one 60 us pass less)
+        ZK_HIP(dist_in_[sid].ensure((size_t)k * Lc * sizeof(Fr)));
+        NttSrc<Fr> src{};
+        src.p[0] = shares;
+        src.per = (uint32_t)k;
+        rc = fft1_src(dist_in_[sid].p, log_m, inverse, (size_t)k, in_mask, s, src);
+        king_in = (const Fr*)dist_in_[sid].p;
+      } else {
+        rc = fft1(shares, log_m, inverse, (size_t)k, in_mask, s);
+      }
+      if (rc) return rc;
+    } else if (in_mask) {
+      rc = vec_add(shares, in_mask, (size_t)k * Lc, s);
+      if (rc) return rc;
+    }
+    const int scale = (inverse && !in_mask) ? 1 : 0;
+    rc = A2A_NOT_APPLICABLE;
+    if (king_a2a_ && net->contiguous() && net->transport != ZK_NET_LOCAL) {
+      const size_t kbk = (size_t)king_block(Lc);
+      const size_t Wc = Lc < kbk ? Lc : kbk;
+      const int log_lc = log_m - ilog2(l);
+      if (Wc < Lc)
+        rc = king_round_a2a(
+            net, sid, mask, shares, Lc, Wc, 1u,
+            [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const A2aPlan& pl, hipStream_t ks) {
+              const Fr* U = nullptr;
+              int r2 = umat_for(ps, np, &U);
+              if (r2) return r2;
+              KingRange rg{pl.rs, pl.seg, pl.cnt};
+              return king_dispatch(in, nullptr, np, log_m, inverse, U, g, scale, rearrange, seed, out, nullptr, false, ks, &rg);
+            },
+            [&](const Fr* back, const A2aPlan& pl, hipStream_t ks) {
+              const size_t tot = (size_t)pl.map.npresent * k * pl.seg;
+              a2a_unpack_fft_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ks>>>(
+                  back, k, (uint32_t)log_lc, pl.seg, l, ilog2(l), rearrange, pl.map.npresent, shares);
+              ZK_HIP(hipGetLastError());
+              return (int)ZK_OK;
+            });
+    }
+    if (rc == A2A_NOT_APPLICABLE)
+    rc = king_round(net, sid, mask, shares, Lc, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr* om, hipStream_t ks) {
+      const Fr* U = nullptr;
+      int r2 = umat_for(ps, np, &U);
+      if (r2) return r2;
+      return king_dispatch(in, nullptr, np, log_m, inverse, U, g, scale, rearrange, seed, out, om, false, ks);
+    }, out_mask, king_in);
+    else if (!rc && out_mask) rc = vec_add(shares, out_mask, (size_t)k * Lc, s);       // after the all-to-all king
+    return rc;
+  }
+  int dist_d_fft(Net* net, int sid, void* shares, const void* in_mask, const void* out_mask, int rearrange, int log_m,
+                 int inverse, const void* g, uint64_t seed, hipStream_t st) override {
+    if (!shares) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (log_m < ilog2(l) || log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    rc = dist_d_fft_on(net, sid, mask, (Fr*)shares, (const Fr*)in_mask, (const Fr*)out_mask, rearrange, log_m, inverse, g,
+                       seed, true);
+    if (rc) return rc;
+    return net_err(net, net->end(sid, st));
+  }
+
+  int dist_deg_red_on(Net* net, int sid, uint32_t mask, Fr* x, const Fr* in_mask, const Fr* out_mask, size_t len,
+                      uint64_t seed) {
+    const int k = net->parties_per_rank();
+    hipStream_t s = net_stream(net, sid, nullptr);
+    int rc;
+    if (in_mask) {
+      rc = vec_add(x, in_mask, (size_t)k * len, s);
+      if (rc) return rc;
+    }
+    rc = A2A_NOT_APPLICABLE;
+    if (king_a2a_ && net->contiguous() && net->transport != ZK_NET_LOCAL)
+      rc = king_round_a2a(
+          net, sid, mask, x, len, 1, 0u,
+          [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const A2aPlan& pl, hipStream_t ks) {
+            return deg_red_np(in, nullptr, ps, np, pl.cnt, seed, out, nullptr, ks, pl.seg, pl.rs);
+          },
+          [&](const Fr* back, const A2aPlan& pl, hipStream_t ks) {
+            const size_t tot = (size_t)pl.map.npresent * k * pl.seg;
+            a2a_unpack_rows_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ks>>>(back, k, len, pl.seg,
+                                                                                                pl.map.npresent, x);
+            ZK_HIP(hipGetLastError());
+            return (int)ZK_OK;
+          });
+    if (rc == A2A_NOT_APPLICABLE)
+      return king_round(net, sid, mask, x, len, [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr* om, hipStream_t ks) {
+        return deg_red_np(in, nullptr, ps, np, len, seed, out, om, ks);
+      }, out_mask, nullptr, true);
+    if (rc) return rc;
+    if (out_mask) return vec_add(x, out_mask, (size_t)k * len, s);        // after the all-to-all king
+    return ZK_OK;
+  }
+  int dist_deg_red(Net* net, int sid, void* x, const void* in_mask, const void* out_mask, size_t len, uint64_t seed,
+                   hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!x) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    rc = dist_deg_red_on(net, sid, mask, (Fr*)x, (const Fr*)in_mask, (const Fr*)out_mask, len, seed);
+    if (rc) return rc;
+    return net_err(net, net->end(sid, st));
+  }
+
+  // d_pp (dpp/mod.rs:15-87): round 1 gathers num || den, the king divides, scans and packs fresh shares of the prefix
+  // products, round 2 is deg_red (:84-86)
+  int dist_d_pp(Net* net, int sid, const void* num, const void* den, const void* in_mask, const void* out_mask, size_t len,
+                uint64_t seed, void* out, hipStream_t st) override {
+    if (!len) return ZK_OK;
+    if (!num || !den || !out) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const int k = net->parties_per_rank();
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    hipStream_t s = net_stream(net, sid, nullptr);
+    const size_t bytes = (size_t)k * len * sizeof(Fr);
+    Fr *fin = nullptr, *fout = nullptr;
+    const std::vector<uint32_t> ps = parties_of(net, mask);
+    const int np = (int)ps.size();
+    if (net->rank == 0) {
+      ZK_HIP(dist_in_[sid].ensure((size_t)2 * n * len * sizeof(Fr)));
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(Fr)));
+      fin = (Fr*)dist_in_[sid].p;
+      fout = (Fr*)dist_out_[sid].p;
+    }
+    rc = net_err(net, net->gather(sid, mask, num, bytes, fin));
+    if (rc) return rc;
+    rc = net_err(net, net->gather(sid, mask, den, bytes, fin ? fin + (size_t)np * len : nullptr));
+    if (rc) return rc;
+    if (net->rank == 0) {
+      rc = d_pp_king(fin, fin + (size_t)np * len, ps.data(), np, len, seed, fout, s);
+      if (rc) return rc;
+    }
+    rc = net_err(net, net->scatter(sid, mask, fout, bytes, out));
+    if (rc) return rc;
+    rc = dist_deg_red_on(net, sid, mask, (Fr*)out, (const Fr*)in_mask, (const Fr*)out_mask, len, seed ^ 0x3333);
+    if (rc) return rc;
+    return net_err(net, net->end(sid, st));
+  }
+
+  // d_msm (dmsm/mod.rs:59-102): this rank's fused contribution sum_p coef_p (msm_p + in_mask_p) goes to the king as ONE
+  // point; the king sums the ranks' points (= unpack2 + sum over all parties) and sends the result to everyone.
+  template <class Fld>
+  int dist_d_msm_t(Net* net, int sid, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                   const void* out_mask, void* out, hipStream_t st) {
+    const int k = net->parties_per_rank();
+    int first = 0;
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = local_window(net, &first);
+    if (rc) return rc;
+    // coefficients of my parties in the king's linear form; they depend on who takes part (pss.rs:170-221)
+    const Fr* cd = msm_.coef_d_ + first;
+    std::vector<Fr> csub;
+    if (mask != net->full_mask()) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      std::vector<Fr> coef;
+      rc = coefs_for(ps.data(), (int)ps.size(), coef);
+      if (rc) return rc;
+      csub.resize((size_t)k);
+      for (int i = 0; i < k; i++) {
+        size_t pos = 0;
+        while (pos < ps.size() && ps[pos] != (uint32_t)net->party(net->rank, i)) pos++;
+        csub[i] = coef[pos];
+      }
+      ZK_HIP(dist_coef_[sid].ensure(k * sizeof(Fr)));
+      ZK_HIP(hipMemcpy(dist_coef_[sid].p, csub.data(), k * sizeof(Fr), hipMemcpyHostToDevice));
+      cd = (const Fr*)dist_coef_[sid].p;
+    }
+    MsmPending pend;
+    rc = msm_.template launch_t<Fld>(this, bases, scalars, (size_t)k * len, cd, len, st, MSM_WS - 1 - sid, &pend);
+    if (rc) return rc;
+    XYZZ<Fld> mine = XYZZ<Fld>::identity();
+    if (in_mask) mine = msm_.template mask_term<Fld>(in_mask, first, k, csub.empty() ? nullptr : csub.data());
+    XYZZ<Fld> r;
+    rc = msm_.template finish_t<Fld>(this, &pend, &r);
+    if (rc) return rc;
+    mine = xyzz_add_ni(mine, r);
+    std::vector<XYZZ<Fld>> all((size_t)net->world);
+    rc = net_err(net, net->gather_host(sid, mask, &mine, sizeof(mine), all.data()));
+    if (rc) return rc;
+    XYZZ<Fld> total = XYZZ<Fld>::identity();
+    if (net->rank == 0) {
+      int cnt = 0;
+      for (int rr = 0; rr < net->world; rr++)
+        if (mask & (1u << rr)) total = xyzz_add_ni(total, all[cnt++]);
+    }
+    rc = net_err(net, net->bcast_host(sid, mask, &total, sizeof(total)));
+    if (rc) return rc;
+    const Jacobian<Fld>* om = (const Jacobian<Fld>*)out_mask;
+    Jacobian<Fld>* o = (Jacobian<Fld>*)out;
+    for (int p = 0; p < k; p++) {
+      XYZZ<Fld> v = total;
+      if (om) v = xyzz_add_ni(v, jacobian_to_xyzz(om[p]));
+      o[p] = xyzz_to_jacobian(v);
+    }
+    return ZK_OK;
+  }
+  int dist_d_msm(Net* net, int sid, int group, const void* bases, const void* scalars, size_t len, const void* in_mask,
+                 const void* out_mask, void* out, hipStream_t st) override {
+    if (!out) return fail(ZK_ERR_BAD_INPUT, "null output");
+    if (len && (!bases || !scalars)) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (group == ZK_G1) return dist_d_msm_t<Fq_>(net, sid, bases, scalars, len, in_mask, out_mask, out, st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2) return dist_d_msm_t<Fq2_>(net, sid, bases, scalars, len, in_mask, out_mask, out, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
+  // circom_h (ext_wit.rs:104-181): the three d_ifft, then the three d_fft, each triple in flight together on channels
+  // 0..2 (ext_wit.rs:158-170 joins them); then a*b - c and deg_red on channel 0.  masks: LOCAL rows.
+  int dist_circom_h_on(Net* net, const uint32_t* cmask, const void* qa, const void* qb, const void* qc, int log_m,
+                       const zk_groth16_masks* mk, uint64_t seed, void* h, hipStream_t st, DevBuf* wb = nullptr) {
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
+    if (!wb) wb = &dist_w0_;
+    ZK_HIP(wb->ensure(3 * per * sizeof(Fr)));
+    Fr* W = (Fr*)wb->p;
+    const void* q[3] = {qa, qb, qc};
+    for (int j = 0; j < 3; j++) ZK_HIP(hipMemcpyAsync(W + j * per, q[j], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    Fr w2m = root_of_unity(log_m + 1);
+    const bool has_in = mk && mk->fft_in[0];
+    int rc;
+    for (int phase = 0; phase < 2; phase++) {
+      const int inverse = phase == 0 ? 1 : 0;
+      // the local stages of the three vectors as one batched launch on the caller's stream
+      if (inverse && has_in) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(W, &c, 3 * per, st);
+        if (rc) return rc;
+      }
+      rc = fft1(W, log_m, inverse, 3 * (size_t)k, nullptr, st);
+      if (rc) return rc;
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->begin(j, st));
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        const int mi = phase * 3 + j;
+        const bool masked = mk && mk->fft_in[mi];
+        if ((mk && mk->fft_in[mi] != nullptr) != has_in) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in circom_h");
+        (void)masked;
+        rc = dist_d_fft_on(net, j, cmask[j], W + j * per, mk ? (const Fr*)mk->fft_in[mi] : nullptr,
+                           mk ? (const Fr*)mk->fft_out[mi] : nullptr, phase == 0 ? 1 : 0, log_m, inverse,
+                           phase == 0 ? (const void*)&w2m : nullptr, seed + mi, false);
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->end(j, st));
+        if (rc) return rc;
+      }
+    }
+    rc = vec_mul_sub(h, W, W + per, W + 2 * per, per, st);
+    if (rc) return rc;
+    rc = net_err(net, net->begin(0, st));
+    if (rc) return rc;
+    rc = dist_deg_red_on(net, 0, cmask[0], (Fr*)h, mk ? (const Fr*)mk->degred_in : nullptr,
+                         mk ? (const Fr*)mk->degred_out : nullptr, Lc, seed + 6);
+    if (rc) return rc;
+    return net_err(net, net->end(0, st));
+  }
+  // ---- deg_red over GROUP elements as the reference calls it (deg_red.rs:80-126 is generic over T: DomainCoeff<F> and
+  // takes net, sid): this rank's k parties' points x [k][len] (affine), masks likewise.  The parties add their in-mask
+  // (point additions), the king unpack2's and re-packs over points (points_lincomb_kernel), the parties add their out-mask.
+  DevBuf dist_pt_[NET_NSID];
+  template <class Fld>
+  int points_add_rows(Affine<Fld>* dst, const Affine<Fld>* a, const Affine<Fld>* b, size_t count, hipStream_t st) {
+    points_add_kernel<Fld><<<dim3((unsigned)((count + 127) / 128)), dim3(128), 0, st>>>(a, b, count, dst);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  template <class Fld>
+  int dist_deg_red_points_t(Net* net, int sid, const void* x, const void* in_mask, const void* out_mask, size_t len,
+                            const void* gen_affine, uint64_t seed, void* out, hipStream_t st) {
+    using A = Affine<Fld>;
+    if (!len) return ZK_OK;
+    if (!x || !out || !gen_affine) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (x == out) return fail(ZK_ERR_BAD_INPUT, "deg_red over points cannot run in place");
+    const int k = net->parties_per_rank();
+    const size_t cnt = (size_t)k * len, bytes = cnt * sizeof(A);
+    uint32_t mask = 0;
+    int rc = net_err(net, net->enter(sid, &mask));
+    if (rc) return rc;
+    rc = net_err(net, net->begin(sid, st));
+    if (rc) return rc;
+    hipStream_t s = net_stream(net, sid, st);
+    const A* send = (const A*)x;
+    if (in_mask) {
+      ZK_HIP(dist_pt_[sid].ensure(bytes));
+      rc = points_add_rows<Fld>((A*)dist_pt_[sid].p, (const A*)x, (const A*)in_mask, cnt, s);
+      if (rc) return rc;
+      send = (const A*)dist_pt_[sid].p;
+    }
+    A *fin = nullptr, *fout = nullptr;
+    if (net->rank == 0) {
+      ZK_HIP(dist_in_[sid].ensure((size_t)n * len * sizeof(A)));
+      ZK_HIP(dist_out_[sid].ensure((size_t)n * len * sizeof(A)));
+      fin = (A*)dist_in_[sid].p;
+      fout = (A*)dist_out_[sid].p;
+    }
+    rc = net_err(net, net->gather(sid, mask, send, bytes, fin));
+    if (rc) return rc;
+    if (net->rank == 0) {
+      std::vector<uint32_t> ps = parties_of(net, mask);
+      rc = deg_red_points_t<Fld>(fin, nullptr, nullptr, len, gen_affine, seed, fout, s, ps.data(), (int)ps.size());
+      if (rc) return rc;
+    }
+    rc = net_err(net, net->scatter(sid, mask, fout, bytes, out));
+    if (rc) return rc;
+    if (out_mask) {
+      rc = points_add_rows<Fld>((A*)out, (const A*)out, (const A*)out_mask, cnt, s);
+      if (rc) return rc;
+    }
+    return net_err(net, net->end(sid, st));
+  }
+  int dist_deg_red_points(Net* net, int sid, int group, const void* x, const void* in_mask, const void* out_mask, size_t len,
+                          const void* gen_affine, uint64_t seed, void* out, hipStream_t st) override {
+    if (group == ZK_G1) return dist_deg_red_points_t<Fq_>(net, sid, x, in_mask, out_mask, len, gen_affine, seed, out, st);
+    if (group == ZK_G2) {
+      if constexpr (Cfg::HAS_G2)
+        return dist_deg_red_points_t<Fq2_>(net, sid, x, in_mask, out_mask, len, gen_affine, seed, out, st);
+    }
+    return fail(ZK_ERR_BAD_INPUT, "bad group");
+  }
+
+  // ---- libsnark_h as the reference calls it (ext_wit.rs:14-102): three d_ifft with the coset shift g = F::GENERATOR on
+  // channels 0..2 (joined), three d_fft likewise, (a b - c) / Z(g) locally, d_ifft with g^-1 on channel 0.  Buffers and
+  // the seven masks: this rank's k parties' rows.
+  int dist_libsnark_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m, const void* const* fft_in,
+                      const void* const* fft_out, uint64_t seed, void* h, hipStream_t st) override {
+    if (log_m < ilog2(l) || log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    uint32_t cmask[3];
+    for (int j = 0; j < 3; j++) {
+      int rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    if (cmask[1] != cmask[0] || cmask[2] != cmask[0])
+      return fail(ZK_ERR_PROTOCOL, "the three channels of libsnark_h saw different parties", -1);
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
+    ZK_HIP(dist_w0_.ensure(3 * per * sizeof(Fr)));
+    Fr* W = (Fr*)dist_w0_.p;
+    const void* q[3] = {qa, qb, qc};
+    for (int j = 0; j < 3; j++) ZK_HIP(hipMemcpyAsync(W + j * per, q[j], per * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    const Fr g = generator();
+    auto mi = [&](int i) { return fft_in ? (const Fr*)fft_in[i] : nullptr; };
+    auto mo = [&](int i) { return fft_out ? (const Fr*)fft_out[i] : nullptr; };
+    int rc;
+    for (int phase = 0; phase < 2; phase++) {
+      const int inverse = phase == 0 ? 1 : 0;
+      bool any = false, all = true;
+      for (int j = 0; j < 3; j++) {
+        any = any || mi(phase * 3 + j);
+        all = all && mi(phase * 3 + j);
+      }
+      if (any && !all) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in libsnark_h");
+      if (inverse && any) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(W, &c, 3 * per, st);
+        if (rc) return rc;
+      }
+      rc = fft1(W, log_m, inverse, 3 * (size_t)k, nullptr, st);
+      if (rc) return rc;
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->begin(j, st));
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        const int i = phase * 3 + j;
+        rc = dist_d_fft_on(net, j, cmask[j], W + j * per, mi(i), mo(i), 1, log_m, inverse,
+                           phase == 0 ? (const void*)&g : nullptr, seed + i, false);
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->end(j, st));
+        if (rc) return rc;
+      }
+    }
+    rc = vec_mul_sub(h, W, W + per, W + 2 * per, per, st);
+    if (rc) return rc;
+    Fr zinv = (g.pow_u64((uint64_t)1 << log_m) - Fr::one()).inverse();      // 1 / Z(g), Z(x) = x^m - 1 (ext_wit.rs:78-81)
+    rc = vec_scale(h, &zinv, per, st);
+    if (rc) return rc;
+    const Fr ginv = g.inverse();
+    rc = net_err(net, net->begin(0, st));
+    if (rc) return rc;
+    rc = dist_d_fft_on(net, 0, cmask[0], (Fr*)h, mi(6), mo(6), 0, log_m, 1, &ginv, seed + 6, true);
+    if (rc) return rc;
+    return net_err(net, net->end(0, st));
+  }
+
+  // circom_h of a whole BATCH of proofs with ONE king round per phase and channel (round 4; round 3 sent the proofs'
+  // rounds over the channels one proof after the other: 7 nb rounds per batch, the star's serial rounds bounded the
+  // sharded throughput mode).  The three joined d_ifft / d_fft of ext_wit.rs:127-170 stay three channels in flight; a
+  // channel's round now carries the vectors of all nb proofs: party rows are [nb][m/l] (KingBatch::row_pitch,
+  // DegredBatch strides), so gather, king kernel and scatter move nb vectors per party at once.  Proof b draws the share
+  // randomness of a single proof with seed + 16 b.  h_all: [nb][k][m/l].  mk: nb mask sets (local rows) or nullptr.
+  DevBuf dist_wb_, dist_hb_;
+  int vec_add2d(Fr* x, size_t xpitch, const Fr* y, size_t ypitch, size_t width, size_t rows, hipStream_t st) {
+    const size_t tot = width * rows;
+    if (!tot) return ZK_OK;
+    vec_add2d_kernel<Fr><<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(x, xpitch, y, ypitch, width, rows);
+    ZK_HIP(hipGetLastError());
+    return ZK_OK;
+  }
+  int dist_circom_h_batch_on(Net* net, const uint32_t* cmask, int nb, const void* const* qa, const void* const* qb,
+                             const void* const* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed, Fr* h_all,
+                             hipStream_t st) {
+    const int k = net->parties_per_rank();
+    const size_t Lc = ((size_t)1 << log_m) / l, row = (size_t)nb * Lc, per = (size_t)k * row;   // per channel: [k][nb][Lc]
+    if (nb < 1 || nb > KING_BATCH || nb > DEGRED_BATCH) return fail(ZK_ERR_BAD_INPUT, "bad circom_h batch");
+    ZK_HIP(dist_wb_.ensure(3 * per * sizeof(Fr)));
+    ZK_HIP(dist_hb_.ensure(per * sizeof(Fr)));
+    Fr* W = (Fr*)dist_wb_.p;
+    Fr* H = (Fr*)dist_hb_.p;
+    const void* const* q[3] = {qa, qb, qc};
+    for (int j = 0; j < 3; j++)
+      for (int b = 0; b < nb; b++)
+        ZK_HIP(hipMemcpy2DAsync(W + j * per + (size_t)b * Lc, row * sizeof(Fr), q[j][b], Lc * sizeof(Fr), Lc * sizeof(Fr),
+                                (size_t)k, hipMemcpyDeviceToDevice, st));
+    Fr w2m = root_of_unity(log_m + 1);
+    const bool has_in = mk && mk[0].fft_in[0];
+    int rc;
+    for (int phase = 0; phase < 2; phase++) {
+      const int inverse = phase == 0 ? 1 : 0;
+      if (inverse && has_in) {
+        Fr c = Fr::from_u64((uint64_t)1 << log_m).inverse();
+        rc = vec_scale(W, &c, 3 * per, st);
+        if (rc) return rc;
+      }
+      rc = fft1(W, log_m, inverse, 3 * (size_t)k * nb, nullptr, st);
+      if (rc) return rc;
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->begin(j, st));
+        if (rc) return rc;
+      }
+      for (int j = 0; j < 3; j++) {
+        const int mi = phase * 3 + j;
+        hipStream_t s = net_stream(net, j, nullptr);
+        Fr* Wj = W + j * per;
+        for (int b = 0; b < nb; b++) {
+          if ((mk && mk[b].fft_in[mi] != nullptr) != has_in) return fail(ZK_ERR_BAD_INPUT, "mixed in-masks in circom_h");
+          if (has_in) {
+            rc = vec_add2d(Wj + (size_t)b * Lc, row, (const Fr*)mk[b].fft_in[mi], Lc, Lc, (size_t)k, s);
+            if (rc) return rc;
+          }
+        }
+        const int scale = (inverse && !has_in) ? 1 : 0;
+        const void* g = phase == 0 ? (const void*)&w2m : nullptr;
+        rc = king_round(net, j, cmask[j], Wj, row,
+                        [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr*, hipStream_t ks) {
+                          const Fr* U = nullptr;
+                          int r2 = umat_for(ps, np, &U);
+                          if (r2) return r2;
+                          KingBatch<Fr> kb{};
+                          kb.stride = Lc;
+                          kb.row_pitch = row;
+                          kb.items_per = 1;
+                          kb.seed_step = PROOF_SEED_STEP;
+                          return king_dispatch_batch(in, kb, nb, np, log_m, inverse, U, g, scale, phase == 0 ? 1 : 0,
+                                                     seed + (uint64_t)mi, out, false, ks);
+                        });
+        if (rc) return rc;
+        for (int b = 0; b < nb; b++)
+          if (mk && mk[b].fft_out[mi]) {
+            rc = vec_add2d(Wj + (size_t)b * Lc, row, (const Fr*)mk[b].fft_out[mi], Lc, Lc, (size_t)k, s);
+            if (rc) return rc;
+          }
+      }
+      for (int j = 0; j < 3; j++) {
+        rc = net_err(net, net->end(j, st));
+        if (rc) return rc;
+      }
+    }
+    rc = vec_mul_sub(H, W, W + per, W + 2 * per, per, st);
+    if (rc) return rc;
+    rc = net_err(net, net->begin(0, st));
+    if (rc) return rc;
+    {
+      hipStream_t s = net_stream(net, 0, nullptr);
+      for (int b = 0; b < nb; b++)
+        if (mk && mk[b].degred_in) {
+          rc = vec_add2d(H + (size_t)b * Lc, row, (const Fr*)mk[b].degred_in, Lc, Lc, (size_t)k, s);
+          if (rc) return rc;
+        }
+      rc = king_round(net, 0, cmask[0], H, row,
+                      [&](const Fr* in, const uint32_t* ps, int np, Fr* out, const Fr*, hipStream_t ks) {
+                        DegredBatch<Fr> db{};
+                        db.in_step = db.out_step = Lc;
+                        db.seed_step = PROOF_SEED_STEP;
+                        return deg_red_batch(in, db, nb, ps, np, Lc, seed + 6, out, ks, row);
+                      },
+                      nullptr, nullptr, true);
+      if (rc) return rc;
+      for (int b = 0; b < nb; b++)
+        if (mk && mk[b].degred_out) {
+          rc = vec_add2d(H + (size_t)b * Lc, row, (const Fr*)mk[b].degred_out, Lc, Lc, (size_t)k, s);
+          if (rc) return rc;
+        }
+    }
+    rc = net_err(net, net->end(0, st));
+    if (rc) return rc;
+    // [k][nb][Lc] -> the batch prover's [nb][k][Lc]
+    for (int b = 0; b < nb; b++)
+      ZK_HIP(hipMemcpy2DAsync(h_all + (size_t)b * k * Lc, Lc * sizeof(Fr), H + (size_t)b * Lc, row * sizeof(Fr),
+                              Lc * sizeof(Fr), (size_t)k, hipMemcpyDeviceToDevice, st));
+    return ZK_OK;
+  }
+  int dist_circom_h(Net* net, const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk,
+                    uint64_t seed, void* h, hipStream_t st) override {
+    if (log_m < ilog2(l) || log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
+    if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    uint32_t cmask[3];
+    for (int j = 0; j < 3; j++) {
+      int rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    if (cmask[1] != cmask[0] || cmask[2] != cmask[0])
+      return fail(ZK_ERR_PROTOCOL, "the three channels of circom_h saw different parties", -1);
+    return dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, h, st);
+  }
+
+  // dsha256 per rank (sha256.rs:32-129): all shares and masks are this rank's k parties' rows; pi_*: k Jacobian points.
+  // Two halves, so that a rank can keep NJOBS proofs in flight (the reference's parties are concurrent tasks,
+  // mpc-net/src/multi.rs:317-327; prove.rs:209-227 joins the W and U d_msm):
+  //   dist_prove_async  admits the proof on the control plane, starts the four witness MSMs on the job's streams, runs
+  //                     circom_h's king rounds over channels 0..2 and queues the U-MSM behind them; returns with all of
+  //                     that ENQUEUED (the host only waited for the peers' staging ticks);
+  //   dist_prove_wait   joins the MSMs, sends this rank's five partial sums to the king on channel 3 (d_msm's king step
+  //                     for all five products in one message, dmsm/mod.rs:76-92) and assembles the k proof shares.
+  // Every rank issues the same sequence of calls (channels are ordered, multi.rs:418-445): async(A), async(B), wait(A),
+  // wait(B) overlaps B's king rounds with A's MSMs.
+  struct DistJob {
+    bool active = false;
+    int k = 0;
+    uint32_t cmask3 = 0;
+  };
+  DistJob djobs_[NJOBS];
+  DevBuf dist_wj_[NJOBS], dist_hj_[NJOBS];
+  int dist_prove_async(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc,
+                       const void* a_share, const void* ax_share, const void* r_, const void* s_, int log_m,
+                       const zk_groth16_masks* mk, uint64_t seed, hipStream_t st, int* handle) override {
+    int rc = check_prove_args(crs, r_, s_, log_m);
+    if (rc) return rc;
+    if (!qa || !qb || !qc || !a_share || !ax_share || !handle) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int slot = -1;
+    for (int i = 0; i < NJOBS; i++)
+      if (!jobs_[i].active && !djobs_[i].active) {
+        slot = i;
+        break;
+      }
+    if (slot < 0) return fail(ZK_ERR_BAD_INPUT, "too many proofs in flight (zk_dist_groth16_wait one first)");
+    const int k = net->parties_per_rank();
+    int first = 0;
+    rc = local_window(net, &first);
+    if (rc) return rc;
+    const size_t Lc = ((size_t)1 << log_m) / l;
+    uint32_t cmask[NET_NSID];
+    for (int j = 0; j < NET_NSID; j++) {
+      rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    for (int j = 0; j < NET_NSID; j++)
+      if (cmask[j] != net->full_mask())
+        return fail(ZK_ERR_PROTOCOL, "a party did not show up for the proof (timed out)", -1);
+    Fr r = Fr::from_limbs((const uint32_t*)r_), s = Fr::from_limbs((const uint32_t*)s_);
+    ProveJob& j = jobs_[slot];
+    j.slot = slot;
+    // the four MSMs over the witness shares start now and overlap the king rounds of circom_h (prove.rs try_join!)
+    rc = prove_begin(j, crs, nullptr, nullptr, nullptr, a_share, ax_share, r, s, log_m, mk, seed, false, first, k, st, true);
+    auto bail = [&](int code) {
+      Status keep = last;
+      abort_job(j);
+      last = keep;
+      return code;
+    };
+    if (rc) return bail(rc);
+    {
+      hipError_t he = dist_hj_[slot].ensure((size_t)k * Lc * sizeof(Fr));
+      if (he != hipSuccess) return bail(hip_fail(he, "h share buffer"));
+    }
+    rc = dist_circom_h_on(net, cmask, qa, qb, qc, log_m, mk, seed, dist_hj_[slot].p, st, &dist_wj_[slot]);
+    if (rc) return bail(rc);
+    rc = prove_launch_u(j, dist_hj_[slot].p, st);
+    if (rc) return bail(rc);
+    djobs_[slot].active = true;
+    djobs_[slot].k = k;
+    djobs_[slot].cmask3 = cmask[3];
+    *handle = slot;
+    return ZK_OK;
+  }
+  int dist_prove_wait(Net* net, int handle, void* pi_a, void* pi_b, void* pi_c) override {
+    if (handle < 0 || handle >= NJOBS || !djobs_[handle].active) return fail(ZK_ERR_BAD_INPUT, "no sharded proof in flight on this handle");
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    ProveJob& j = jobs_[handle];
+    DistJob& d = djobs_[handle];
+    d.active = false;
+    struct Sums {
+      P1 S, H, W, U;
+      P2 V;
+    } mine, total;
+    int rc = prove_join(j, &mine.S, &mine.H, &mine.V, &mine.W, &mine.U);
+    if (rc) return rc;
+    static_assert(sizeof(Sums) <= NET_PAYLOAD, "payload");
+    std::vector<Sums> all((size_t)net->world);
+    rc = net_err(net, net->gather_host(3, d.cmask3, &mine, sizeof(mine), all.data()));
+    if (rc) return rc;
+    total = mine;
+    if (net->rank == 0)
+      for (int rr = 1; rr < net->world; rr++) {
+        total.S = xyzz_add_ni(total.S, all[rr].S);
+        total.H = xyzz_add_ni(total.H, all[rr].H);
+        total.V = xyzz_add_ni(total.V, all[rr].V);
+        total.W = xyzz_add_ni(total.W, all[rr].W);
+        total.U = xyzz_add_ni(total.U, all[rr].U);
+      }
+    rc = net_err(net, net->bcast_host(3, d.cmask3, &total, sizeof(total)));
+    if (rc) return rc;
+    return assemble_points(&j.crs, j.r, j.s, total.S, total.H, total.V, total.W, total.U, j.has_mk ? &j.mk : nullptr, d.k, pi_a,
+                           pi_b, pi_c);
+  }
+  int dist_prove(Net* net, const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
+                 const void* ax_share, const void* r_, const void* s_, int log_m, const zk_groth16_masks* mk,
+                 uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
+    if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    int h = -1;
+    int rc = dist_prove_async(net, crs, qa, qb, qc, a_share, ax_share, r_, s_, log_m, mk, seed, st, &h);
+    if (rc) return rc;
+    return dist_prove_wait(net, h, pi_a, pi_b, pi_c);
+  }
+
+  // A batch of proofs per rank (zk_dist_groth16_prove_batch): the throughput mode of the sharded prover.  One round of
+  // the control plane admits the whole batch; every rank runs each of its five MSMs ONCE over the nb witnesses (the
+  // batched Pippenger of msm.hpp) while the king rounds of the proofs' circom_h go over the channels one proof after the
+  // other; the partial sums of the whole batch cross in ONE host message per rank and one answer.  Shares and masks: this
+  // rank's k parties' rows of every proof; pi_*: [nb][k] Jacobian points.  Proof b draws the share randomness
+  // zk_dist_groth16_prove draws with seed + 16 b.
+  int dist_prove_batch(Net* net, const zk_crs_share* crs, int nb, const void* const* qa, const void* const* qb,
+                       const void* const* qc, const void* const* a_share, const void* const* ax_share, const void* r_,
+                       const void* s_, int log_m, const zk_groth16_masks* mk, uint64_t seed, void* pi_a, void* pi_b,
+                       void* pi_c, hipStream_t st) override {
+    if (!qa || !qb || !qc || !pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    if (nb < 1 || nb > MAX_PROOF_BATCH) return fail(ZK_ERR_BAD_INPUT, "batch size must be in 1.." + std::to_string(MAX_PROOF_BATCH));
+    for (int b = 0; b < nb; b++)
+      if (!qa[b] || !qb[b] || !qc[b]) return fail(ZK_ERR_BAD_INPUT, "null pointer");
+    const int k = net->parties_per_rank();
+    int first = 0;
+    const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)k * Lc;
+    uint32_t cmask[NET_NSID];
+    int rc = local_window(net, &first);
+    if (rc) return rc;
+    for (int j = 0; j < NET_NSID; j++) {
+      rc = net_err(net, net->enter(j, &cmask[j]));
+      if (rc) return rc;
+    }
+    for (int j = 0; j < NET_NSID; j++)
+      if (cmask[j] != net->full_mask())
+        return fail(ZK_ERR_PROTOCOL, "a party did not show up for the batch (timed out)", -1);
+    int slot = -1;
+    rc = batch_begin(crs, nb, a_share, ax_share, r_, s_, log_m, mk, false, first, k, st, &slot);
+    if (rc) return rc;
+    BatchJobX& B = bjobs_[slot];
+    auto bail = [&](int code) {
+      Status keep = last;
+      abort_batch(B);
+      last = keep;
+      return code;
+    };
+    // circom_h of the whole batch: one king round per phase and channel carries all nb proofs (7 rounds per batch; the MSMs
+    // of the batch run beside them; round 3 ran one proof's rounds after the other's).
+    rc = dist_circom_h_batch_on(net, cmask, nb, qa, qb, qc, log_m, mk, seed, (Fr*)B.hshare.p, st);
+    if (rc) return bail(rc);
+    // the U-MSM runs on its own stream of the batch's set, behind everything queued on the caller's stream
+    {
+      hipError_t he = hipEventRecord(B.ev_in, st);
+      if (he == hipSuccess) he = hipStreamWaitEvent(B.st[5], B.ev_in, 0);
+      if (he != hipSuccess) return bail(hip_fail(he, "batch U-MSM ordering"));
+    }
+    rc = batch_launch_u(B, (const Fr*)B.hshare.p, per, B.st[5]);
+    if (rc) return bail(rc);
+    std::vector<BatchSums> mine;
+    rc = batch_join(B, mine);
+    if (rc) return rc;
+    // d_msm's king step for the 5 nb products (dmsm/mod.rs:76-92): host messages of as many proofs as fit the payload
+    std::vector<BatchSums> total = mine;
+    const int per_msg = (int)(NET_PAYLOAD / sizeof(BatchSums));
+    static_assert(sizeof(BatchSums) <= NET_PAYLOAD, "payload");
+    std::vector<BatchSums> all((size_t)net->world * per_msg);
+    for (int b0 = 0; b0 < nb; b0 += per_msg) {
+      const int cnt = nb - b0 < per_msg ? nb - b0 : per_msg;
+      const size_t bytes = (size_t)cnt * sizeof(BatchSums);
+      rc = net_err(net, net->gather_host(3, cmask[3], mine.data() + b0, bytes, all.data()));
+      if (rc) return rc;
+      if (net->rank == 0)
+        for (int rr = 1; rr < net->world; rr++)
+          for (int i = 0; i < cnt; i++) {
+            const BatchSums& o = *(const BatchSums*)((const char*)all.data() + (size_t)rr * bytes + (size_t)i * sizeof(BatchSums));
+            BatchSums& t_ = total[b0 + i];
+            t_.S = xyzz_add_ni(t_.S, o.S);
+            t_.H = xyzz_add_ni(t_.H, o.H);
+            t_.V = xyzz_add_ni(t_.V, o.V);
+            t_.W = xyzz_add_ni(t_.W, o.W);
+            t_.U = xyzz_add_ni(t_.U, o.U);
+          }
+      rc = net_err(net, net->bcast_host(3, cmask[3], total.data() + b0, bytes));
+      if (rc) return rc;
+    }
+    for (int b = 0; b < nb; b++) {
+      const ProveJob& j = *B.pj[b];
+      rc = assemble_points(crs, j.r, j.s, total[b].S, total[b].H, total[b].V, total[b].W, total[b].U, mk ? &mk[b] : nullptr, k,
+                           (char*)pi_a + (size_t)b * k * sizeof(Jacobian<Fq_>), (char*)pi_b + (size_t)b * k * sizeof(Jacobian<Fq2_>),
+                           (char*)pi_c + (size_t)b * k * sizeof(Jacobian<Fq_>));
+      if (rc) return rc;
+    }
+    return ZK_OK;
+  }
+

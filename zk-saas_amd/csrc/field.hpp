@@ -661,8 +661,25 @@ struct Fp {
     r.v[N] = (uint32_t)c;
     return r;
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  template <bool KS>
+  static ZK_D uint64_t mad_sel(uint32_t a, uint32_t b, uint64_t add, uint64_t* cy) {
+    if constexpr (KS) return madc_k(a, b, add, cy);
+    else return madc(a, b, add, cy);
+  }
+#endif
   template <int NT>
   ZK_HD static Fp dot_k(const Fp* const* x /* [NT] */, const Fp* __restrict__ k /* [NT], wave-uniform */) {
+    return dot_impl<NT, true>(x, k);
+  }
+  // the same with per-lane coefficients (VGPR operands): the lane-cooperative king kernels, where lane p applies row p of
+  // the pack matrix
+  template <int NT>
+  ZK_HD static Fp dot_v(const Fp* const* x /* [NT] */, const Fp* k /* [NT] */) {
+    return dot_impl<NT, false>(x, k);
+  }
+  template <int NT, bool KS>
+  ZK_HD static Fp dot_impl(const Fp* const* x, const Fp* k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t m[N], r[N + 1];
     uint64_t acc = 0, cy;
@@ -673,7 +690,7 @@ struct Fp {
       for (int i = 0; i <= c; i++) {
 #pragma unroll
         for (int s = 0; s < NT; s++) {
-          acc = madc_k(x[s]->v[i], k[s].v[c - i], acc, &cy);
+          acc = mad_sel<KS>(x[s]->v[i], k[s].v[c - i], acc, &cy);
           acc2 = add_cy(acc2, cy);
         }
       }
@@ -694,7 +711,7 @@ struct Fp {
       for (int i = c - N + 1; i < N; i++) {
 #pragma unroll
         for (int s = 0; s < NT; s++) {
-          acc = madc_k(x[s]->v[i], k[s].v[c - i], acc, &cy);
+          acc = mad_sel<KS>(x[s]->v[i], k[s].v[c - i], acc, &cy);
           acc2 = add_cy(acc2, cy);
         }
         acc = madc_k(m[i], P::MOD[c - i], acc, &cy);

@@ -400,11 +400,21 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
   // ticket is taken after it, and the scanning workgroup reads with device-scope loads)
   __shared__ uint32_t last_sh;
   __syncthreads();
-  // acq_rel at agent scope on the ticket only: the release half orders this workgroup's count adds (all returned,
-  // see above) before its ticket, the acquire half orders the last workgroup's reads after every earlier ticket -- the
-  // formal edge the relaxed form lacked; unlike __threadfence() it does not write back / invalidate the L2
+  // The ticket stays a RELAXED add.  ADVICE r4 asked for acq_rel at agent scope (the formal release / acquire edge between
+  // the workgroups' count adds and the last workgroup's reads); built and measured in round 5: every workgroup's release
+  // writes back its XCD's L2, and with the three witness sorts of a proof running side by side msm_hist went from 22-57 to
+  // 101-112 us per launch (profiles/r05_c4_timeline.txt of that build) -- on every MSM's dependent chain.  What makes the
+  // relaxed form correct on gfx950: the counts are device-scope atomic RMWs performed at the L2 / memory side (never in a
+  // CU's L1), a wave has the RETURN VALUE of each of its adds before it reaches the barrier (so the adds have been
+  // performed), the ticket is taken after the barrier, and the scanning workgroup reads the counts with device-scope
+  // atomic loads.  -DZK_HIST_TICKET_ACQ_REL=1 builds the fenced form; tests/test_gpu_msm.py::
+  // test_concurrent_sorts_stress compares hundreds of concurrent sorts' results with serial ones.
+#if defined(ZK_HIST_TICKET_ACQ_REL) && ZK_HIST_TICKET_ACQ_REL
   if (threadIdx.x == 0)
     last_sh = __hip_atomic_fetch_add(bins + nbins, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+#else
+  if (threadIdx.x == 0) last_sh = atomicAdd(bins + nbins, 1u) == gridDim.x - 1 ? 1u : 0u;
+#endif
   __syncthreads();
   if (!last_sh) return;
   uint32_t* bin_base = bins + nbins + 1;

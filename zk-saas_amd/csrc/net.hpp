@@ -158,6 +158,7 @@ class Net {
     device = device_;
     host_mode = host_mode_;
     if (world < 1 || world > NET_MAXR || rank < 0 || rank >= world || n % world) return fail("bad rank / world size (world must divide n)");
+    alive_.store(full_mask(), std::memory_order_relaxed);      // every rank counts as alive until a verdict leaves it out
     if (party_to_rank) {
       const int k = n / world;
       if (n > NET_MAXR * 64) return fail("too many parties for a party_to_rank map", ZK_ERR_BAD_INPUT);

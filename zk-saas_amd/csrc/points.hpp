@@ -21,6 +21,23 @@ struct PtGroup {
   int count, off;
 };
 
+// dst[i] = a[i] + b[i] over affine points ((0,0) = identity): the mask additions of deg_red over group elements
+// (deg_red.rs:94-100, :121-125 with T = G).  One mixed addition and one inversion per point (round 4 went through
+// points_lincomb_kernel with the coefficient 1: a 256-step double-and-add walk per point).  dst may alias a or b.
+template <class Fld>
+__global__ __launch_bounds__(128) void points_add_kernel(const Affine<Fld>* a, const Affine<Fld>* b, size_t count,
+                                                        Affine<Fld>* dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const Affine<Fld> pa = a[i], pb = b[i];
+  const bool ia = pa.x.is_zero() && pa.y.is_zero(), ib = pb.x.is_zero() && pb.y.is_zero();
+  Affine<Fld> r;
+  if (ia) r = pb;
+  else if (ib) r = pa;
+  else r = xyzz_to_affine(xyzz_madd(XYZZ<Fld>::from_affine(pa), pb.x, pb.y));
+  dst[i] = r;
+}
+
 // out[r * out_rs + j * out_cs] = sum over groups, i: coef[r][off + i] * in[j, i]   (+ addend[r * add_rs + j])
 // coef: canonical (non-Montgomery) scalars [rows][ncoef].  One lane per (chunk j, row r): MSB-first double-and-add
 // over all inputs at once (one shared doubling chain), affine output (one inversion per output).

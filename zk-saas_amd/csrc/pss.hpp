@@ -497,6 +497,78 @@ __global__ __launch_bounds__(KING_THREADS, 4) void king_degred_kernel(
   }
 }
 
+// ---- lane-cooperative deg_red for SHORT vectors (l = 2, all n = 8 parties present) -----------------------------------
+// king_degred_kernel gives a lane a whole chunk: eight share loads' worth of products, a ChaCha block and the pack, ~17
+// multiplication times in a row.  On the 2^14-chunk vector of a SHA-256-sized proof that launch is 256 waves on 1024 SIMDs --
+// a quarter of the chip, pure latency: 43 us ALONE (profiles/r05_circom_h_solo_kernel_stats.csv), 75-79 us next to the
+// proof's accumulate kernels, on the proof's critical chain.  Here a chunk is worked on by EIGHT lanes, one per party: lane p
+// loads party p's share (forms a*b - c for its party), multiplies it by column p of the unpack2 matrix, the partial sums are
+// added across the eight lanes (three xor-shuffle steps), the random draws are computed by all eight lanes alike (same
+// instruction stream: no extra time), and lane p forms share p as ONE four-term dot product with row p of the dense pack
+// matrix (Fp::dot_v).  ~6 multiplication times per lane, two waves per SIMD: 24 us alone, 56-62 us inside a proof (same-box
+// A/B).  Same linear maps, exact arithmetic: the shares are bit-identical.
+// The same form was built for king_fft2_kernel and REMOVED: its launch covers three vectors (49 152 chunks), eight lanes per
+// chunk make six waves per SIMD with 1.8x the multiply instructions per chunk -- issue-bound at 54 us alone against 42 us for
+// the lane-per-chunk kernel, 126-140 against 112-121 us inside a proof.
+constexpr int KING_COOP_LANES = 8;
+#ifndef ZK_KING_COOP
+#define ZK_KING_COOP 1                                 // build-time switch for same-box A/B runs (tools/ab.sh)
+#endif
+constexpr size_t KING_COOP_MAX = ZK_KING_COOP ? (size_t)1 << 16 : 0;      // chunks per vector up to which the cooperative kernels are used
+template <class F>
+ZK_D F lanes8_sum(F v) {
+#pragma unroll
+  for (int m = 1; m < KING_COOP_LANES; m <<= 1) {
+    F o;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) o.v[i] = __shfl_xor(v.v[i], m, 64);
+    v = v + o;
+  }
+  return v;
+}
+// share p of pack([s0, s1, r0, r1]) = row p of the dense pack matrix Pm [n][l + t] times the vector
+template <class F>
+ZK_D F pack_row(const F* __restrict__ Pm, int p, const F& s0, const F& s1, const F& r0, const F& r1) {
+  const F k[4] = {load_elem(Pm + p * 4), load_elem(Pm + p * 4 + 1), load_elem(Pm + p * 4 + 2), load_elem(Pm + p * 4 + 3)};
+  const F* const xs[4] = {&s0, &s1, &r0, &r1};
+  return F::template dot_v<4>(xs, k);
+}
+
+// king_degred_kernel for l = 2, np = n = 8: blockDim.x / 8 chunks per workgroup
+template <class P>
+__global__ __launch_bounds__(64) void king_degred_coop_kernel(
+    const Fp<P>* in, DegredBatch<Fp<P>> db, size_t len, const Fp<P>* __restrict__ U, const Fp<P>* __restrict__ Pm,
+    RngSeed seed, Fp<P>* out, size_t stride, size_t j0, const Fp<P>* __restrict__ mul_b,
+    const Fp<P>* __restrict__ sub_c) {
+  __builtin_amdgcn_s_setprio(3);
+  using F = Fp<P>;
+  constexpr int NP = 8;
+  const F* __restrict__ in_mask = db.in_mask[blockIdx.y];
+  const F* __restrict__ out_mask = db.out_mask[blockIdx.y];
+  in += blockIdx.y * db.in_step;
+  out += blockIdx.y * db.out_step;
+  if (mul_b) {
+    mul_b += blockIdx.y * db.in_step;
+    sub_c += blockIdx.y * db.in_step;
+  }
+  seed = seed.plus((uint64_t)blockIdx.y * db.seed_step);
+  const uint32_t p = threadIdx.x % NP;
+  const size_t j = (size_t)blockIdx.x * (blockDim.x / NP) + threadIdx.x / NP;
+  const bool live = j < len;                    // (the eight lanes of a chunk agree; dead lanes still join the shuffles)
+  const size_t jj = live ? j : 0;
+  const size_t o = (size_t)p * stride + jj;
+  F x = load_elem(in + o);
+  if (mul_b) x = x * load_elem(mul_b + o) - load_elem(sub_c + o);      // circom_h's a*b - c at the load (ext_wit.rs:173-177)
+  if (in_mask) x = x + load_elem(in_mask + o);
+  const F s0 = lanes8_sum(load_elem(U + p) * x);
+  const F s1 = lanes8_sum(load_elem(U + NP + p) * x);
+  F r0, r1;
+  rand_fp_pair<P>(seed, (uint64_t)(j0 + jj) * 2, &r0, &r1);
+  F sh = pack_row<F>(Pm, (int)p, s0, s1, r0, r1);
+  if (out_mask) sh = sh + load_elem(out_mask + o);
+  if (live) store_elem(out + o, sh);
+}
+
 // (the king-side kernels of d_pp live in dpp.hpp)
 
 #endif  // __HIPCC__
