@@ -1,4 +1,5 @@
-// Host-side check of csrc/field.hpp's binary-GCD inversion (Fp::inverse_gcd, the one inversion of d_pp's carry kernel) against
+// Host-side check of csrc/field.hpp's inversions by the binary Euclid (Fp::inverse_gcd) and by batched divsteps
+// (Fp::inverse_safegcd, the one inversion of d_pp's carry kernel) against
 // the Fermat ladder (Fp::inverse) and against a * a^-1 = 1, on the six fields of the library: 3 000 values each, incl. small
 // ones, 1 and p - 1.  Built and run by tests/test_native_field.py with the host compiler (the same source compiles for the
 // device).
@@ -19,8 +20,8 @@ template <class P> int run(const char* name) {
     if (it == 41) { a = F::zero() - F::one(); }
     if (it == 42) { a = F::one(); }
     if (a.is_zero()) continue;
-    F g = a.inverse_gcd(), f = a.inverse();
-    if (!(g == f) || !(a * g == F::one())) bad++;
+    F g = a.inverse_gcd(), f = a.inverse(), h = a.inverse_safegcd();
+    if (!(g == f) || !(h == f) || !(a * g == F::one())) bad++;
   }
   printf("%s: %d mismatches\n", name, bad);
   return bad;

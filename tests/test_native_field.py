@@ -1,5 +1,6 @@
-"""csrc/field.hpp is host + device code: its binary-GCD inversion (round 5, the single inversion of d_pp) is checked on the CPU
-against the Fermat ladder on all six fields (tests/native/field_host_test.cpp)."""
+"""csrc/field.hpp is host + device code: its two inversions beside the Fermat ladder (round 5: binary GCD, and the
+batched-divstep form that d_pp's single inversion runs) are checked on the CPU against that ladder on all six fields
+(tests/native/field_host_test.cpp)."""
 import os
 import subprocess
 
@@ -9,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def test_inverse_gcd_equals_fermat_on_all_fields():
+def test_inverse_gcd_and_safegcd_equal_fermat_on_all_fields():
     if not os.path.exists(CXX):
         pytest.skip("ROCm host compiler not found (field.hpp uses clang's __builtin_addc / __builtin_subc)")
     out = os.path.join(ROOT, "tests", "native", "_build")

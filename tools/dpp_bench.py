@@ -28,6 +28,8 @@ def slots(pp):
 
 def run(curve, log_m, reps):
     pp = zk.PackedSharingParams(curve, 2)
+    for kv in filter(None, os.environ.get("ZK_BENCH_OPTIONS", "").split(",")):       # A/B runs: name=value context options
+        pp.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     m, l, eb = 1 << log_m, pp.l, pp.fr.nbytes
     x = synthetic.rand_fr_device(pp, m + 1, 77)
     num_sh, den_sh = pp.pack(x.view(eb), m // l, 78), pp.pack(x, m // l, 79)

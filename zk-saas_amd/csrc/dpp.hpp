@@ -10,8 +10,8 @@
 // arithmetic is exact, so the shares are bit-identical to the divide-then-scan form; 5 multiplications per element where
 // Montgomery's trick needs 6 plus its inversions).
 //
-//   dpp_tile_kernel   : one workgroup per tile of DPP_TILE elements: unpack2 of num and den (coalesced share loads),
-//                       transposed through LDS so that each thread owns DPP_E consecutive elements; thread-local prefix /
+//   dpp_tile_kernel   : one workgroup per tile of 256 E elements (E = 8, or 4 for short vectors): unpack2 of num and den (coalesced share loads),
+//                       transposed through LDS so that each thread owns E consecutive elements; thread-local prefix /
 //                       suffix, the 256 thread totals scanned by one wave each; writes
 //                       y_i = (N_i / N_before_tile) * (S_{i+1} / S_after_tile) and the tile's two totals.
 //   dpp_carry_kernel  : one workgroup: exclusive prefix of the numerator totals, exclusive suffix of the denominator totals,
@@ -32,15 +32,22 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr int DPP_THREADS = 256;
-constexpr int DPP_E = 8;                          // consecutive elements per thread
-constexpr int DPP_TILE = DPP_THREADS * DPP_E;     // elements per workgroup
-constexpr int DPP_LDS_SLOTS = DPP_TILE + DPP_TILE / DPP_E;
+// consecutive elements per thread (template parameter E of the tile kernel): 8 -> 2048-element tiles, the thread-total scans
+// amortised over 8 elements.  E = 4 was measured (same box): slower at 2^20 (more tiles for the carry kernel), a tie at 2^24.
+constexpr int DPP_E_LONG = 8;
 constexpr int DPP_CARRY_THREADS = 1024;
+template <int E>
+struct DppGeom {
+  static constexpr int TILE = DPP_THREADS * E;            // elements per workgroup
+  static constexpr int LDS_SLOTS = TILE + TILE / E;
+};
 
-// LDS position of tile element e: one spare slot after every DPP_E elements, so that the per-thread walks (thread t
+// LDS position of tile element e: one spare slot after every E elements, so that the per-thread walks (thread t
 // reads element t * DPP_E + i) fall on distinct banks; the spare slots hold the per-thread numerator totals.
-ZK_D int dpp_pos(int e) { return e + e / DPP_E; }
-ZK_D int dpp_spare(int t) { return t * (DPP_E + 1) + DPP_E; }
+template <int E>
+ZK_D int dpp_pos(int e) { return e + e / E; }
+template <int E>
+ZK_D int dpp_spare(int t) { return t * (E + 1) + E; }
 
 template <class F>
 ZK_D F wave_up(const F& v, int off) {
@@ -92,13 +99,13 @@ ZK_D F dpp_scan_totals(const LdsVec<F>& lds, PosFn pos) {
   return wave_bcast(inc, 63);
 }
 
-// unpack2 (or the Lagrange form for a party subset) of DPP_E / L chunks per thread, lane-adjacent chunks adjacent in memory,
+// unpack2 (or the Lagrange form for a party subset) of E / L chunks per thread, lane-adjacent chunks adjacent in memory,
 // into the tile's LDS slots in element order; chunks past the end contribute ones
-template <class P, int L>
+template <class P, int L, int E>
 ZK_D void dpp_unpack_to_lds(const Fp<P>* __restrict__ sh, int np, size_t nchunks, size_t pitch,
                             const Fp<P>* __restrict__ U, size_t chunk0, const LdsVec<Fp<P>>& buf) {
   using F = Fp<P>;
-  constexpr int K = DPP_E / L;
+  constexpr int K = E / L;
   const int tid = threadIdx.x;
 #pragma unroll 1
   for (int k = 0; k < K; k++) {
@@ -114,75 +121,77 @@ ZK_D void dpp_unpack_to_lds(const Fp<P>* __restrict__ sh, int np, size_t nchunks
       for (int i = 0; i < L; i++) s[i] = F::one();
     }
 #pragma unroll
-    for (int i = 0; i < L; i++) buf.put(dpp_pos(c * L + i), s[i]);
+    for (int i = 0; i < L; i++) buf.put(dpp_pos<E>(c * L + i), s[i]);
   }
 }
 
 // shares [np][pitch] of num and den -> y (natural element order j * l + i), tile totals
-template <class P, int L>
+template <class P, int L, int E>
 __global__ __launch_bounds__(DPP_THREADS) void dpp_tile_kernel(const Fp<P>* __restrict__ num,
                                                               const Fp<P>* __restrict__ den, int np, size_t nchunks,
                                                               size_t pitch, const Fp<P>* __restrict__ U /* [l][np] */,
                                                               Fp<P>* __restrict__ y, Fp<P>* __restrict__ tile_n,
                                                               Fp<P>* __restrict__ tile_d) {
   using F = Fp<P>;
-  constexpr int E = DPP_E, K = E / L;              // chunks per thread
-  static_assert(K >= 1 && K * L == E, "packing factor must divide DPP_E");
+  constexpr int K = E / L;                         // chunks per thread
+  static_assert(K >= 1 && K * L == E, "packing factor must divide E");
   constexpr int TC = DPP_THREADS * K;              // chunks per tile
   extern __shared__ uint4 smem[];
   LdsVec<F> buf;                 // (assigned, not brace-initialised: a constant aggregate holding the LDS address
   buf.base = smem;               //  would be emitted as a static initialiser, which the backend rejects)
-  buf.stride = DPP_LDS_SLOTS;
+  buf.stride = DppGeom<E>::LDS_SLOTS;
   const int tid = threadIdx.x;
   const size_t chunk0 = (size_t)blockIdx.x * TC;
 
   // numerators: a[i] = product of this thread's elements 0..i
-  dpp_unpack_to_lds<P, L>(num, np, nchunks, pitch, U, chunk0, buf);
+  dpp_unpack_to_lds<P, L, E>(num, np, nchunks, pitch, U, chunk0, buf);
   __syncthreads();
   F a[E];
-  a[0] = buf.get(dpp_pos(tid * E));
+  a[0] = buf.get(dpp_pos<E>(tid * E));
 #pragma unroll
-  for (int i = 1; i < E; i++) a[i] = a[i - 1] * buf.get(dpp_pos(tid * E + i));
+  for (int i = 1; i < E; i++) a[i] = a[i - 1] * buf.get(dpp_pos<E>(tid * E + i));
   const F tot_a = a[E - 1];
   __syncthreads();
 
   // denominators: a[i] *= product of this thread's elements i+1..E-1
-  dpp_unpack_to_lds<P, L>(den, np, nchunks, pitch, U, chunk0, buf);
+  dpp_unpack_to_lds<P, L, E>(den, np, nchunks, pitch, U, chunk0, buf);
   __syncthreads();
-  F b = buf.get(dpp_pos(tid * E + E - 1));
+  F b = buf.get(dpp_pos<E>(tid * E + E - 1));
 #pragma unroll
   for (int i = E - 2; i >= 0; i--) {
     a[i] = a[i] * b;
-    b = b * buf.get(dpp_pos(tid * E + i));
+    b = b * buf.get(dpp_pos<E>(tid * E + i));
   }
   __syncthreads();
   // thread totals: numerators in the spare slots, denominators over the (dead) element slots
-  buf.put(dpp_spare(tid), tot_a);
-  buf.put(dpp_pos(tid), b);
+  buf.put(dpp_spare<E>(tid), tot_a);
+  buf.put(dpp_pos<E>(tid), b);
   __syncthreads();
   const int wave = tid >> 6;
   if (wave == 0) {
-    const F tot = dpp_scan_totals<false>(buf, [](int t) { return dpp_spare(t); });
+    const F tot = dpp_scan_totals<false>(buf, [](int t) { return dpp_spare<E>(t); });
     if (tid == 0) store_elem(tile_n + blockIdx.x, tot);
   } else if (wave == 1) {
-    const F tot = dpp_scan_totals<true>(buf, [](int t) { return dpp_pos(t); });
+    const F tot = dpp_scan_totals<true>(buf, [](int t) { return dpp_pos<E>(t); });
     if (tid == 64) store_elem(tile_d + blockIdx.x, tot);
   }
   __syncthreads();
-  const F c = buf.get(dpp_spare(tid)) * buf.get(dpp_pos(tid));
+  const F c = buf.get(dpp_spare<E>(tid)) * buf.get(dpp_pos<E>(tid));
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < E; i++) buf.put(dpp_pos(tid * E + i), a[i] * c);
+  for (int i = 0; i < E; i++) buf.put(dpp_pos<E>(tid * E + i), a[i] * c);
   __syncthreads();
   const size_t e0 = chunk0 * L, total = nchunks * L;
 #pragma unroll
   for (int k = 0; k < E; k++) {
     const int e = k * DPP_THREADS + tid;
-    if (e0 + e < total) store_elem(y + e0 + e, buf.get(dpp_pos(e)));
+    if (e0 + e < total) store_elem(y + e0 + e, buf.get(dpp_pos<E>(e)));
   }
 }
 
-// exclusive product scan over the threads of a (multiple-of-64, <= 1024 thread) workgroup; `sh` holds >= 16 elements
+// exclusive product scan over the threads of a (multiple-of-64, <= 1024 thread) workgroup; `sh` holds 2 x 16 elements.
+// Wave scans (six products per lane), then ONE wave scans the <= 16 wave totals while the others wait at the barrier (a
+// loop over the wave totals in every wave made sixteen waves issue the same sixteen products on four SIMDs: ~40 us per scan).
 template <class F>
 ZK_D F block_scan_mul_exclusive(const F& v, F* sh, F* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -190,15 +199,16 @@ ZK_D F block_scan_mul_exclusive(const F& v, F* sh, F* total) {
   __syncthreads();                       // `sh` may still be read from an earlier scan
   if (lane == 63) sh[wave] = inc;
   __syncthreads();
-  F before = F::one(), all = F::one();
-#pragma unroll 1
-  for (int w = 0; w < nw; w++) {
-    if (w == wave) before = all;
-    all = all * sh[w];
+  if (wave == 0) {
+    const F t = lane < nw ? sh[lane] : F::one();
+    const F s = wave_scan_mul(t);        // inclusive prefix products of the wave totals
+    if (lane < nw) sh[16 + lane] = s;
   }
+  __syncthreads();
+  const F before = wave ? sh[16 + wave - 1] : F::one();
+  *total = sh[16 + nw - 1];
   F ex = wave_up(inc, 1);
   if (lane == 0) ex = F::one();
-  *total = all;
   return before * ex;
 }
 
@@ -208,7 +218,7 @@ template <class F>
 __global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restrict__ tile_n, const F* __restrict__ tile_d,
                                                                       size_t ntiles, F* __restrict__ ctile,
                                                                       int* __restrict__ err) {
-  __shared__ F sh[DPP_CARRY_THREADS / 64];
+  __shared__ F sh[32];
   __shared__ F inv_sh;
   const size_t tid = threadIdx.x, nt = blockDim.x;
   const size_t q = (ntiles + nt - 1) / nt;
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restr
 #pragma unroll
     for (int i = 0; i < F::N; i++) t.v[i] = __builtin_amdgcn_readfirstlane(tot_d.v[i]);
     const bool zero = t.is_zero();
-    const F inv = zero ? F::zero() : t.inverse_gcd();
+    const F inv = zero ? F::zero() : t.inverse_safegcd();
     if (tid == 0) {
       if (zero) atomicExch(err, 1);
       inv_sh = inv;
@@ -260,12 +270,12 @@ __global__ __launch_bounds__(KING_THREADS) void dpp_finish_kernel(const Fp<P>* _
                                                                  const Fp<P>* __restrict__ U /* [l][n], all parties */,
                                                                  const Fp<P>* __restrict__ Pm,
                                                                  const PackL2<Fp<P>>* __restrict__ k2, RngSeed seed,
-                                                                 Fp<P>* __restrict__ out) {
+                                                                 Fp<P>* __restrict__ out, uint32_t tile_elems) {
   using F = Fp<P>;
   constexpr int T = L, N = 4 * L;
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nchunks) return;
-  const F c = load_elem(ctile + (j * L) / DPP_TILE);
+  const F c = load_elem(ctile + (j * L) / tile_elems);
   F sec[L + T];
 #pragma unroll
   for (int i = 0; i < L; i++) sec[i] = load_elem(y + j * L + i) * c;

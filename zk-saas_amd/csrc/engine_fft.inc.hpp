@@ -388,40 +388,51 @@
   // (tile scans, carries + the one inversion, finish).  With `fuse_degred` the finish kernel also carries the deg_red round
   // that follows (:86) -- only valid when every party's share lives on this device.  The zero-denominator flag is read
   // once, after the last launch.
-  template <int L>
-  int dpp_l(const Fr* num, const Fr* den, int np, size_t len, const Fr* U, const Fr* Ufull, const Fr* in_mask,
-            const Fr* out_mask, const RngSeed& seed, Fr* out, hipStream_t st) {
-    const size_t m = len * L, ntiles = (m + DPP_TILE - 1) / DPP_TILE;
+  template <int L, int E>
+  int dpp_le(const Fr* num, const Fr* den, int np, size_t len, const Fr* U, const Fr* Ufull, const Fr* in_mask,
+             const Fr* out_mask, const RngSeed& seed, Fr* out, hipStream_t st) {
+    constexpr size_t TILE = DppGeom<E>::TILE;
+    const size_t m = len * L, ntiles = (m + TILE - 1) / TILE;
     ZK_HIP(scratch_.ensure((m + 3 * ntiles) * sizeof(Fr)));
     Fr* y = (Fr*)scratch_.p;
     Fr* tile_n = y + m;
     Fr* tile_d = tile_n + ntiles;
     Fr* ctile = tile_d + ntiles;
-    constexpr size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * DPP_LDS_SLOTS;
-    if (!dpp_attr_set_) {
-      ZK_HIP(hipFuncSetAttribute((const void*)dpp_tile_kernel<FrP, L>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    constexpr size_t lds = (size_t)(sizeof(Fr) / 16) * 16 * DppGeom<E>::LDS_SLOTS;
+    bool& attr_set = dpp_attr_set_[E == DPP_E_LONG ? 0 : 1];
+    if (!attr_set) {
+      ZK_HIP(hipFuncSetAttribute((const void*)dpp_tile_kernel<FrP, L, E>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-      dpp_attr_set_ = true;
+      attr_set = true;
     }
     ZK_HIP(hipMemsetAsync(err_flag_, 0, sizeof(int), st));
     {
       ProfScope ps_(prof, PROF_DPP_TILE, st, (double)m);
-      dpp_tile_kernel<FrP, L><<<dim3((unsigned)ntiles), dim3(DPP_THREADS), lds, st>>>(num, den, np, len, len, U, y,
-                                                                                       tile_n, tile_d);
+      dpp_tile_kernel<FrP, L, E><<<dim3((unsigned)ntiles), dim3(DPP_THREADS), lds, st>>>(num, den, np, len, len, U, y,
+                                                                                          tile_n, tile_d);
     }
     ZK_HIP(hipGetLastError());
     {
       ProfScope ps_(prof, PROF_DPP_CARRY, st, (double)ntiles);
-      dpp_carry_kernel<Fr><<<dim3(1), dim3(DPP_CARRY_THREADS), 0, st>>>(tile_n, tile_d, ntiles, ctile, err_flag_);
+      // one workgroup; no more waves than there are tiles to own (every wave issues the scans' products)
+      const unsigned cthreads = (unsigned)std::min<size_t>(DPP_CARRY_THREADS, std::max<size_t>(64, (ntiles + 63) / 64 * 64));
+      dpp_carry_kernel<Fr><<<dim3(1), dim3(cthreads), 0, st>>>(tile_n, tile_d, ntiles, ctile, err_flag_);
     }
     ZK_HIP(hipGetLastError());
     {
       ProfScope ps_(prof, PROF_DPP_FINISH, st, (double)m);
       dpp_finish_kernel<FrP, L><<<dim3((unsigned)((len + KING_THREADS - 1) / KING_THREADS)), dim3(KING_THREADS), 0, st>>>(
-          y, ctile, len, in_mask, out_mask, Ufull, pmat_, pack2_, seed, out);
+          y, ctile, len, in_mask, out_mask, Ufull, pmat_, pack2_, seed, out, (uint32_t)TILE);
     }
     ZK_HIP(hipGetLastError());
     return ZK_OK;
+  }
+  template <int L>
+  int dpp_l(const Fr* num, const Fr* den, int np, size_t len, const Fr* U, const Fr* Ufull, const Fr* in_mask,
+            const Fr* out_mask, const RngSeed& seed, Fr* out, hipStream_t st) {
+    // 2048-element tiles at every size: 1024-element ones (E = 4) were measured on the same box and lose at 2^20
+    // (tile 176 vs 169 us, carry 111 vs 93 us with twice the tiles) and tie at 2^24 (3.85 ms both)
+    return dpp_le<L, DPP_E_LONG>(num, den, np, len, U, Ufull, in_mask, out_mask, seed, out, st);
   }
   int d_pp_king(const Fr* num, const Fr* den, const uint32_t* parties, int np, size_t len, uint64_t seed, Fr* out,
                 hipStream_t st, bool fuse_degred = false, const Fr* in_mask = nullptr, const Fr* out_mask = nullptr) {

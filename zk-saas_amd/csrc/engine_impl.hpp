@@ -417,7 +417,7 @@ class Engine : public IEngine {
   bool streams_ready_ = false;
   bool force_simple_ntt = false;
   bool ntt_attr_set_[2] = {false, false};
-  bool dpp_attr_set_ = false;
+  bool dpp_attr_set_[2] = {false, false};
   std::map<std::string, void*> base_tables_;
   DevBuf hwork_;
   Fr* pmat_ = nullptr;
