@@ -251,8 +251,13 @@
     // every internal stream is ordered after the work already queued on the caller's stream (the shares may still
     // be in flight there: found by tools/c5_bls381.py, where the a_share pack kernel of a 2^22 witness was still
     // running when the S/H/V MSMs started reading it)
-    ZK_HIP(hipEventRecord(ev_in_[j.slot], st));
-    for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_[j.slot], 0));
+    // (nothing to order after when the caller's stream has drained -- the case between two proofs of a loop: one query
+    // instead of an event and six waits at the head of every chain of the proof)
+    if (hipStreamQuery(st) != hipSuccess) {
+      (void)hipGetLastError();                       // hipErrorNotReady is not an error here
+      ZK_HIP(hipEventRecord(ev_in_[j.slot], st));
+      for (hipStream_t is : streams_) ZK_HIP(hipStreamWaitEvent(is, ev_in_[j.slot], 0));
+    }
     j.active = true;
     ProveJob* J = &j;
     const size_t cstride = crs->len_a;
@@ -323,7 +328,9 @@
              streams_[0], ws0 + 1, &j.pS, &j.S, j.r_zero ? (P1*)nullptr : &j.H);
     msm_task(Fq_{}, 1, crs->w_d, nullptr, ax_share, (size_t)count * crs->len_w, cf, crs->len_w, streams_[3], ws0 + 4,
              &j.pW, &j.W, (P1*)nullptr);
-    submit_host_terms(J, j.fut, full, first, count);
+    // (the host terms are two dozen pool submissions: behind circom_h's launches when those are still to come -- they
+    // are the head of the proof's longest chain and the terms are not needed before prove_end)
+    if (!(full && !hu_done)) submit_host_terms(J, j.fut, full, first, count);
     // ---- circom_h and the U-MSM that depends on it form a long dependent chain: high-priority internal stream.
     // At the SHA-256 size, holding the other MSM streams (or only their accumulate launches) back until circom_h has
     // finished was measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
@@ -336,6 +343,7 @@
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
                                       ws0 + 0, &j.pU);
       if (rc) return rc;
+      submit_host_terms(J, j.fut, full, first, count);
     }
     return ZK_OK;
   }

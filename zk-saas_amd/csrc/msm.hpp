@@ -1368,8 +1368,14 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_reduce_a_kernel(const XYZ
 // stage B: slice j <= hb: TR_j over the rows, otherwise TC_(j - hb - 1) over the columns; same workgroup layout
 template <class Fld>
 __global__ __launch_bounds__(QUAD_THREADS, 2) void msm_reduce_b_kernel(const XYZZ<Fld>* __restrict__ rc0, uint32_t B, int lo_bits,
-                                                                   int nvl, XYZZ<Fld>* __restrict__ out0) {
+                                                                   int nvl, XYZZ<Fld>* __restrict__ out0,
+                                                                   const uint32_t* __restrict__ cnt_src, size_t cnt_stride,
+                                                                   uint32_t ncnt, uint32_t* __restrict__ cnt_dst) {
   __builtin_amdgcn_s_setprio(3);
+  // out0 and cnt_dst are the slot's pinned host buffer: the last kernel of the chain leaves the slices (and the sorted-entry
+  // counts of the launch's sorts, for zk_msm_stats) where the host folds them -- no copy kernels behind it
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < ncnt)
+    cnt_dst[2 * threadIdx.x] = *(const uint32_t*)((const char*)cnt_src + threadIdx.x * cnt_stride);
   extern __shared__ uint4 smem_red[];
   XYZZ<Fld>* sh = reinterpret_cast<XYZZ<Fld>*>(smem_red);
   const uint32_t LO = 1u << lo_bits, HI = B >> lo_bits;

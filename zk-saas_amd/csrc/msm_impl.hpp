@@ -144,8 +144,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   // ---- per base vector
   size_t o_edge = take(NB * 2 * (size_t)nlanes * sizeof(XYZZ<Fld>)), o_buckets = take(NB * nkeys * sizeof(XYZZ<Fld>)),
          o_hpart = take(NB * msm_heavy_vcap(nlanes) * sizeof(XYZZ<Fld>)),      // chunk sums of split heavy buckets
-         o_rc = take(NB * nsets * red_groups * sizeof(XYZZ<Fld>)),
-         o_out = take(NB * nsets * nslices * sizeof(XYZZ<Fld>));
+         o_rc = take(NB * nsets * red_groups * sizeof(XYZZ<Fld>));
   hipError_t he = slot.ws.ensure(off);
   if (he != hipSuccess) return eng->hip_fail(he, "msm workspace");
   const size_t out_bytes = NB * nsets * nslices * sizeof(XYZZ<Fld>);
@@ -170,7 +169,8 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   XYZZ<KF>* rc = (XYZZ<KF>*)(ws + o_rc);
   XYZZ<KF>* hpart = (XYZZ<KF>*)(ws + o_hpart);
   const uint32_t vcap = (uint32_t)msm_heavy_vcap(nlanes);
-  XYZZ<KF>* out = (XYZZ<KF>*)(ws + o_out);
+  // the slices go straight to the slot's pinned host buffer (device-visible, coherent: hipHostMalloc's default)
+  XYZZ<KF>* out = (XYZZ<KF>*)slot.pinned;
 
 #define MSM_HIP(x)                                           \
 do {                                                       \
@@ -365,15 +365,13 @@ do {                                                                           \
   msm_reduce_a_kernel<KF><<<dim3((red_groups + gpw_a - 1) / gpw_a, NB * (unsigned)nsets), dim3((unsigned)qt), quad_lds, st>>>(
       buckets, B, lo_bits, nvl_a, rc);
   msm_reduce_b_kernel<KF><<<dim3(((unsigned)nslices + gpw_b - 1) / gpw_b, NB * (unsigned)nsets), dim3((unsigned)qt), quad_lds,
-                            st>>>(rc, B, lo_bits, nvl_b, out);
+                            st>>>(rc, B, lo_bits, nvl_b, out,
+                                  // mixed additions actually performed = sorted entries (identity bases and zero digits
+                                  // leave none): one count per sort
+                                  offsets + nkeys, ys, NS, (uint32_t*)((char*)slot.pinned + out_bytes));
   }
   MSM_HIP(hipGetLastError());
   MSM_STAGE("reduce");
-  MSM_HIP(hipMemcpyAsync(slot.pinned, out, out_bytes, hipMemcpyDeviceToHost, st));
-  // mixed additions actually performed = sorted entries (identity bases and zero digits leave none): one count per sort
-  for (unsigned y = 0; y < NS; y++)
-    MSM_HIP(hipMemcpyAsync((char*)slot.pinned + out_bytes + 8 * y, (const char*)(offsets + nkeys) + (size_t)y * ys, 4,
-                           hipMemcpyDeviceToHost, st));
   MSM_HIP(hipEventRecord(slot.ev, st));
 #undef MSM_HIP
 #undef MSM_STAGE
