@@ -135,7 +135,7 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=No
     """The slot with the largest share of the timed region -- also when it is a latency-bound helper.  slot_bytes: per-unit
     algorithmic bytes of another curve (BLS12-381: 128 B per G1 point, 224 B per G2 point); limbs: 32-bit limbs of the base
     field (the multiply-instruction issue bound of a product scales with limbs^2); exclude: slots left out of the choice."""
-    cands = [e for e in prof if e["launches"] and e["kernel"] not in (exclude or ())]
+    cands = [e for e in prof if e["launches"] and e["kernel"] not in (exclude or ()) and not e["kernel"].startswith("host:")]
     if not cands:
         return None
     best = max(cands, key=lambda e: e["total_ms"])
@@ -658,6 +658,16 @@ def main():
         "proof_alu": proof_alu(tm["adds"], tm["offered"], args.steps, tm["dt_last"]),
         "kernels": [{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]],
     }
+    host = {e["kernel"][5:]: e["total_ms"] / e["launches"] * 1e3 for e in prof if e["launches"] and e["kernel"].startswith("host:")}
+    if host:
+        # where the host is during one zk_groth16_prove of the last repetition (steady_clock spans inside the library:
+        # prove_launch = launch.submit + launch.circom_h + launch.u_msm, then prove_wait until the U-MSM's event, then
+        # prove_tail); "outside_the_call" = the rest of the loop period: this Python wrapper and the ctypes call.
+        # (The last repetition runs with the HIP-event slots on: two event records per kernel span inflate the launch spans.)
+        per = tm["dt_last"] / args.steps * 1e6
+        res["host_us_per_proof"] = {**{k: round(v, 1) for k, v in host.items()},
+                                    "outside_the_call": round(per - sum(v for k, v in host.items() if "." not in k), 1),
+                                    "period": round(per, 1)}
     if not args.no_primitives:
         if not args.no_tables:
             # the like-for-like figure: the same K steps without the fixed-base tables (dropped, then rebuilt)

@@ -733,7 +733,9 @@ static const char* const kSlotNames[zk::PROF_NSLOTS] = {"ntt_pass_kernel", "king
                                                          "msm_accumulate_kernel<G2>", "msm_digits+scan+expand",
                                                          "msm_finalize+reduce<G1>", "king_degred_kernel",
                                                          "msm_finalize+reduce<G2>", "dpp_tile_kernel", "dpp_carry_kernel",
-                                                         "dpp_finish_kernel"};
+                                                         "dpp_finish_kernel", "host:prove_launch", "host:prove_wait",
+                                                         "host:prove_tail", "host:launch.submit", "host:launch.circom_h",
+                                                         "host:launch.u_msm"};
 int zk_profile_enable(zk_ctx* ctx, int on) {
   CTX_OR_FAIL();
   e->prof.reset();

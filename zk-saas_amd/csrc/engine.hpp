@@ -28,7 +28,12 @@ struct Status {
 // Per-kernel timing slots: HIP events recorded on the launching stream around selected kernels, so that a
 // host program can read a kernel's average launch duration over exactly its own timed region (bench.py).
 enum ProfSlot { PROF_NTT_PASS = 0, PROF_KING, PROF_MSM_ACC_G1, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE,
-                PROF_DEGRED, PROF_MSM_REDUCE_G2, PROF_DPP_TILE, PROF_DPP_CARRY, PROF_DPP_FINISH, PROF_NSLOTS };
+                PROF_DEGRED, PROF_MSM_REDUCE_G2, PROF_DPP_TILE, PROF_DPP_CARRY, PROF_DPP_FINISH,
+                // host spans of zk_groth16_prove (steady_clock, not HIP events): entry -> everything launched; then -> the event of the
+                // last chain (the U-MSM); then -> return
+                PROF_HOST_LAUNCH, PROF_HOST_WAIT, PROF_HOST_TAIL,
+                // parts of the first: entry -> MSM tasks handed to the pool; circom_h's launches; the U-MSM's launches + host terms
+                PROF_HOST_SUBMIT, PROF_HOST_H, PROF_HOST_U, PROF_NSLOTS };
 
 struct Profiler {
   bool on = false;
@@ -60,6 +65,12 @@ struct Profiler {
   void push(const Rec& r) {
     std::lock_guard<std::mutex> lk(mu);
     recs.push_back(r);
+  }
+  void host_add(int slot, double t_ms) {
+    std::lock_guard<std::mutex> lk(mu);
+    ms[slot] += t_ms;
+    units[slot] += 1;
+    calls[slot]++;
   }
   void collect() {
     std::lock_guard<std::mutex> lk(mu);

@@ -242,6 +242,13 @@
                        const zk_groth16_masks* mk, uint64_t seed, bool full, int first, int count, hipStream_t st,
                        bool gate_sorts) {
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    auto t_mark = std::chrono::steady_clock::now();
+    auto host_span = [&](int slot) {                 // host:launch.* (zk_profile_read)
+      if (!prof.on) return;
+      const auto now = std::chrono::steady_clock::now();
+      prof.host_add(slot, std::chrono::duration<double, std::milli>(now - t_mark).count());
+      t_mark = now;
+    };
     int rc = ensure_streams();
     if (rc) return rc;
     init_job(j, crs, mk, r, s, full, first, count);
@@ -335,15 +342,18 @@
     // At the SHA-256 size, holding the other MSM streams (or only their accumulate launches) back until circom_h has
     // finished was measured and rejected: 8.6-8.8 ms per proof against 6.9 ms when everything is issued at once.
     if (full && !hu_done) {
+      host_span(PROF_HOST_SUBMIT);
       hipStream_t hs = streams_[5];
       hipError_t he = j.hshare.ensure((size_t)n * Lc * sizeof(Fr));
       if (he != hipSuccess) return hip_fail(he, "h share buffer");
       rc = circom_h_ws(qa, qb, qc, log_m, mk, seed, j.hshare.p, j.hwork, hs);
       if (rc) return rc;
+      host_span(PROF_HOST_H);
       rc = msm_.template launch_t<Fq_>(this, crs->u_d, j.hshare.p, (size_t)n * crs->len_u, msm_.coef_d_, crs->len_u, hs,
                                       ws0 + 0, &j.pU);
       if (rc) return rc;
       submit_host_terms(J, j.fut, full, first, count);
+      host_span(PROF_HOST_U);
     }
     return ZK_OK;
   }
@@ -422,16 +432,51 @@
     return ZK_OK;
   }
 
+  // The end of one proof.  The U chain (circom_h, then its MSM) ends last by a margin: everything that does not depend on U
+  // -- the join of the pool tasks, A and B of every party, C without its U term -- is done while it still runs; after U's
+  // event only its fold and one addition per party are left.  (U is always waited for, whatever failed before: its launch
+  // references the job's buffers.)
   int prove_end(ProveJob& j, void* pi_a, void* pi_b, void* pi_c) {
-    P1 S, H, W, U;
-    P2 V;
-    int rc = prove_join(j, &S, &H, &V, &W, &U);
+    const auto t0 = std::chrono::steady_clock::now();
+    drain(j);
+    bool early_ok = !j.err.code;
+    for (int i = 0; i < 8; i++) early_ok = early_ok && !j.rc[i];
+    std::vector<P1> c_part(early_ok ? n : 0);
+    if (early_ok) {
+      const P1 S = xyzz_add_ni(j.S, j.in1[0]), H = j.r_zero ? P1::identity() : xyzz_add_ni(j.H, j.in1[1]),
+               W = xyzz_add_ni(j.W, j.in1[3]);
+      const P2 V = xyzz_add_ni(j.V0, j.in2);
+      int rc = assemble_job(j, S, H, V, W, j.in1[4], pi_a, pi_b, pi_c, c_part.data());
+      if (rc) early_ok = false;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (prof.on && j.pU.active) (void)hipEventSynchronize(j.pU.slot->ev);       // (finish_t waits again: returns at once)
+    const auto t2 = std::chrono::steady_clock::now();
+    struct HostSpans {                                                          // host:prove_wait / host:prove_tail
+      Profiler& pr;
+      std::chrono::steady_clock::time_point a, b;
+      ~HostSpans() {
+        if (!pr.on) return;
+        pr.host_add(PROF_HOST_WAIT, std::chrono::duration<double, std::milli>(b - a).count());
+        pr.host_add(PROF_HOST_TAIL, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b).count());
+      }
+    } spans{prof, t0, t2};
+    (void)t1;
+    int rc = msm_.template finish_t<Fq_>(this, &j.pU, &j.U);
+    j.active = false;
     if (rc) return rc;
-    return assemble_job(j, S, H, V, W, U, pi_a, pi_b, pi_c);
+    for (int i = 0; i < 8; i++)
+      if (j.rc[i]) return j.rc[i];      // a pool task failed: its message was recorded on the engine by msm_launch; keep it
+    if (j.err.code) return fail(j.err.code, j.err.msg);
+    if (!early_ok) return fail(ZK_ERR_GENERIC, "proof assembly failed");
+    Jacobian<Fq_>* oc = (Jacobian<Fq_>*)pi_c;
+    for (int p = 0; p < n; p++) oc[p] = xyzz_to_jacobian(xyzz_add_ni(c_part[p], j.U));
+    return ZK_OK;
   }
   // the n parties' (A, B, C) shares of one proof from its five MSM totals (in-mask terms included) and the host terms
+  // (c_part != nullptr: the C shares stay in extended form there instead of pi_c -- prove_end adds a late term to them)
   int assemble_job(ProveJob& j, const P1& S, const P1& H, const P2& V, const P1& W, const P1& U, void* pi_a, void* pi_b,
-                   void* pi_c) {
+                   void* pi_c, P1* c_part = nullptr) {
     const zk_groth16_masks* mk = j.has_mk ? &j.mk : nullptr;
     // prove.rs:40-56 / 99-110 / 148-158 / 229-235 for every party; C = s*A + r*B1 - rs*delta + W + U by linearity:
     //   s*A_p = s*(a0 + r*delta + alpha) + s*S + s*in0 + s*om0_p     (every term was computed beside the device work)
@@ -456,7 +501,8 @@
       if (uniform && p > 0) {
         oa[p] = oa[0];
         ob[p] = ob[0];
-        oc[p] = oc[0];
+        if (c_part) c_part[p] = c_part[0];
+        else oc[p] = oc[0];
         continue;
       }
       P1 A = A0, C = C0;
@@ -473,7 +519,8 @@
       }
       oa[p] = xyzz_to_jacobian(A);
       ob[p] = xyzz_to_jacobian(B2);
-      oc[p] = xyzz_to_jacobian(C);
+      if (c_part) c_part[p] = C;
+      else oc[p] = xyzz_to_jacobian(C);
     }
     return ZK_OK;
   }
@@ -493,8 +540,10 @@
                     uint64_t seed, void* pi_a, void* pi_b, void* pi_c, hipStream_t st) override {
     if (!pi_a || !pi_b || !pi_c) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     int h = -1;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = groth16_prove_async(crs, qa, qb, qc, a_share, ax_share, r_, s_, log_m, mk, seed, st, &h);
     if (rc) return rc;
+    if (prof.on) prof.host_add(PROF_HOST_LAUNCH, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return groth16_wait(h, pi_a, pi_b, pi_c);
   }
   int groth16_prove_async(const zk_crs_share* crs, const void* qa, const void* qb, const void* qc, const void* a_share,
