@@ -504,7 +504,9 @@ int zk_d_msm_host(zk_ctx* ctx, int group, const void* bases, const void* scalars
 /* ---- per-kernel timing (measurement only) -----------------------------------------------------------------
  * When enabled, HIP events are recorded on the launching stream around the kernels of each slot; zk_profile_read
  * synchronises them and returns the summed duration, the summed work units (elements / chunks / points) and the
- * number of timed launches since zk_profile_enable. */
+ * number of timed launches since zk_profile_enable.  Slots whose name starts with "host:" are host spans of
+ * zk_groth16_prove taken with the steady clock instead (entry -> everything launched -> the event of the last chain ->
+ * return; units = calls). */
 int zk_profile_enable(zk_ctx* ctx, int on);
 /* MSM work counters of this context since creation (measurement only): stats[0] / [1] = mixed additions the G1 / G2
  * accumulate kernels performed (= sorted (point, window) entries: identity bases and zero digits leave none), stats[2] /

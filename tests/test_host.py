@@ -27,6 +27,24 @@ def test_library_exports_every_declared_symbol():
     assert sorted(zk.SYMBOLS) == declared      # the Python binding covers the whole header
 
 
+def test_profile_slots_are_named_and_bench_knows_the_kernel_ones():
+    """zk_profile_name needs no context: every slot has a distinct name; the kernel slots bench.py prices are among them
+    and the host spans of zk_groth16_prove carry the "host:" prefix that keeps them out of the roofline choice."""
+    import ctypes
+    import zksaas_amd as zk
+    import bench
+    lib = ctypes.CDLL(zk.LIB_PATH)
+    lib.zk_profile_name.restype = ctypes.c_char_p
+    names = [lib.zk_profile_name(i).decode() for i in range(lib.zk_profile_slots())]
+    assert all(names) and len(set(names)) == len(names)
+    assert lib.zk_profile_name(len(names)).decode() == "" and lib.zk_profile_name(-1).decode() == ""
+    kernel_slots = [n for n in names if not n.startswith("host:")]
+    assert set(bench.SLOT_BYTES) <= set(kernel_slots)
+    assert {"host:prove_launch", "host:prove_wait", "host:prove_tail"} <= set(names)
+    prof = [{"kernel": n, "total_ms": 9.0 if n.startswith("host:") else 1.0, "units": 1.0, "launches": 1} for n in names]
+    assert not bench.roofline_of(prof, ntt_passes=2, masks_on=False)["kernel"].startswith("host:")
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     import zksaas_amd as zk
