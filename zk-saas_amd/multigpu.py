@@ -233,6 +233,8 @@ def bench(args, rank, local_rank, world):
     wl = args.workload
     curve = "bls12_381" if wl == "c5" else "bn254"
     pp = zk.PackedSharingParams(curve, 2, device=local_rank)
+    for kv in filter(None, os.environ.get("ZK_BENCH_OPTIONS", "").split(",")):     # A/B runs: name=value context options
+        pp.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if pp.n % world:
         raise SystemExit("the number of GPUs must divide n = %d parties" % pp.n)
     king = os.environ.get("ZK_KING", getattr(args, "king", "star"))
