@@ -154,7 +154,8 @@ def roofline_of(prof, ntt_passes, masks_on, pp=None, table_windows=None, adds=No
         pts = int(best["units"] / best["launches"])
         plan = msm_plan(pp, ZK_G2 if "G2" in name else ZK_G1, pts)
         if table_windows:           # fixed-base tables: every MSM runs with the table's window layout
-            plan["windows"], plan["window_bits"], plan["fixed_base_table"] = table_windows, -(-256 // table_windows), True
+            plan["windows"], plan["fixed_base_table"] = table_windows, True
+            plan["window_bits"] = -(-(pp.fr.p.bit_length() + 1) // table_windows)      # signed digits: one extra bit
         muls = pts * plan["windows"] * plan["muls_per_add"]
         if adds is not None:
             # mixed additions the kernel PERFORMED per launch (zk_msm_stats), not points x windows: the sort leaves out

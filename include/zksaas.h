@@ -244,7 +244,7 @@ int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
 /* Tunables of this context (no reference counterpart).  "rng_replay": see "share randomness".  "msm_bigsort_min": point count from which zk_msm sorts with
  * the two-level LDS counting sort instead of global atomics (default 196608: below that the tiles of the two-level sort are too few to fill the chip; tests force both paths with it).
  * "msm_table_c": window bits (8..22, 0 = default; "msm_table_c_g2" sets G2 alone) of tables built by later zk_msm_precompute calls.
- *   Default: by the vector's length -- G1 16 bits below 2^19 points, 17 below 2^22, 20 from there; G2 15 below 2^20, 19 from
+ *   Default: by the vector's length -- G1 15 bits up to 2^17 points, 16 below 2^19, 17 below 2^22, 20 from there; G2 15 below 2^20, 19 from
  *   there (a table folds all windows into one bucket set: too few buckets for a long vector sends every bucket through the
  *   heavy-bucket path; csrc/msm.hpp table_c_auto).
  * "king_alltoall": 1 = the zk_dist_* king rounds of d_fft / d_ifft / deg_red (and everything composed of them) run as

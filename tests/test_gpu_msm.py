@@ -305,8 +305,8 @@ def test_fixed_base_table_gives_the_same_msm(curve, group):
     plain = dec_jacobian(pp, msm(pp, group, bases, sc_d, n), is2)
     assert api.msm_table_info(pp, group, bases)["windows"] == 0
     api.msm_precompute(pp, group, bases, n)
-    # default window: 16 bits in G1; 15 in G2 (half the buckets in the G2 reduction, the chain a proof ends with)
-    bits = 15 if is2 else 16
+    # default window of a short vector: 15 bits in both groups (half the buckets of 16 bits in the reduction a chain ends with)
+    bits = 15
     assert api.msm_table_info(pp, group, bases) == {"window_bits": bits, "windows": -(-(c.r.bit_length() + 1) // bits)}
     agg = [0] * 40
     for i, s in enumerate(sc):
@@ -383,7 +383,7 @@ def test_table_registry_is_process_wide_across_contexts():
     sc_d = up(A, sc)
     buf = zk.DeviceBuffer.from_numpy(A, enc_affine(A, pts_a))             # owned by A
     api.msm_precompute(B, ZK_G1, buf, n)                                   # table built through B
-    assert api.msm_table_info(A, ZK_G1, buf)["windows"] == 16             # ... is found by A's MSMs
+    assert api.msm_table_info(A, ZK_G1, buf)["windows"] == 17             # ... is found by A's MSMs
     assert G.eq(dec_jacobian(A, msm(A, ZK_G1, buf, sc_d, n)), G.msm(pts_a, sc))
     addr = buf.ptr
     buf.free()                                                             # freed through A
@@ -393,7 +393,7 @@ def test_table_registry_is_process_wide_across_contexts():
     assert G.eq(dec_jacobian(B, msm(B, ZK_G1, again, up(B, sc), n)), G.msm(pts_b, sc))
     # a table dies with the context that built it
     api.msm_precompute(B, ZK_G1, again, n)
-    assert api.msm_table_info(A, ZK_G1, again)["windows"] == 16
+    assert api.msm_table_info(A, ZK_G1, again)["windows"] == 17
     B.close()
     assert api.msm_table_info(A, ZK_G1, again)["windows"] == 0
     assert G.eq(dec_jacobian(A, msm(A, ZK_G1, again, sc_d, n)), G.msm(pts_b, sc))

@@ -1954,7 +1954,10 @@ class MsmRunner {
   // bucket goes through the heavy-bucket path meant for degenerate scalars and the MSM is 2-3x slower than table-free
   // (measured, tools/tab_c3.py, G1 d_msm over 2^19 / 2^20 / 2^23 points: c = 16 2.53 / 3.48 / 18.8 ms, c = 17 1.10 /
   // 1.95 / 20.7, c = 20 1.45 / 2.2 / 11.8; table-free 1.59 / 2.77 / 12.7; below 2^19 points c = 16 is best: 0.78 against
-  // 1.15 ms table-free at 2^18).  G1: 16 bits below 2^19 points, 18 below 2^22 (re-rounded to evenly spread windows: 17 bits
+  // 1.15 ms table-free at 2^18).  G1: 15 bits (17 windows, 16 384 buckets) up to 2^17 points -- the SHA-256 proof's four G1
+  // MSMs: 6 % more mixed additions than 16 bits but half the buckets in the reduction every chain ends with: 634 / 649 /
+  // 653 / 651 vs 630 / 639 / 638 / 638 proofs/s, same box, round 5; 14 bits already sends every bucket down the heavy path:
+  // 512-542 --, 16 bits below 2^19 points, 18 below 2^22 (re-rounded to evenly spread windows: 17 bits
   // = 15 windows on BN254's 254-bit Fr, 18 bits on BLS12-381's 255-bit Fr), 20 (13 windows) from there.
   // G2: 15 bits = 17 windows, 16 384 buckets below 2^20 points (6 % more mixed additions than 16 bits but half the
   // buckets in the G2 reduction, the latency chain a proof ends with: 458-477 vs 423-453 proofs/s, same box), 19 (14
@@ -1963,7 +1966,7 @@ class MsmRunner {
   int table_c_g2 = 0;
   static int table_c_auto(size_t len, bool g2) {
     if (g2) return len < ((size_t)1 << 20) ? 15 : 19;
-    return len < ((size_t)1 << 19) ? 16 : len < ((size_t)1 << 22) ? 18 : 20;
+    return len <= ((size_t)1 << 17) ? 15 : len < ((size_t)1 << 19) ? 16 : len < ((size_t)1 << 22) ? 18 : 20;
   }
   template <class Fld>
   int precompute_t(IEngine* eng, const void* bases, size_t len, hipStream_t st) {
