@@ -205,6 +205,8 @@ do {                                                                           \
   uint32_t* skip = nullptr;
   if (skip_on && !none) {
     skip = (uint32_t*)(ws + o_skip);
+    // (one-wave workgroups for this kernel were measured -- its span reads 178-195 us at the head of the table-free U-MSM,
+    // profiles/r05_c4tf_timeline.txt -- and lose: 430-447 vs 440-450 proofs/s table-free, same box; no change with tables)
     msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip, ys);
   }
   const size_t plen = part_len ? part_len : npts;
