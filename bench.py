@@ -467,8 +467,8 @@ def cpu_baseline_c5(pp, zk, log_m_full):
     scale = 1 << (log_m_full - lg)
     return {"value": round(1.0 / (total * scale), 6), "unit": "proofs/s", "cores": min(cores, n * per), "kind": "port",
             "extrapolated": scale > 1,
-            "sample": "one proof of the same synthetic BLS12-381 instance at 2^%d - 2 constraints (zero masks, as the "
-                      "timed GPU workload): %.2f s = circom_h %.2f s + the 5 x %d G::msm %.2f s; `value` = 1 / (that x %d), "
+            "sample": "one proof of the same synthetic BLS12-381 instance at 2^%d - 2 constraints (zero masks -- the "
+                      "timed GPU workload applies all twelve, which costs the CPU no MSM work): %.2f s = circom_h %.2f s + the 5 x %d G::msm %.2f s; `value` = 1 / (that x %d), "
                       "a LINEAR extrapolation to 2^%d constraints" % (lg, total, t1 - t0, n, t2 - t1b, scale, log_m_full),
             "measured_s_at_sample": round(total, 3), "sample_constraints": m - 2, "host_cpus": cores,
             "cpu_model": cpu_model(), "matches_gpu_at_sample": ok}
