@@ -38,6 +38,8 @@ namespace zk {
 #if defined(__HIPCC__)
 
 constexpr size_t MSM_RANGE_MIN = 20, MSM_RANGE = 64;        // entries per accumulate lane: fewest (small MSMs), most
+                                                            // (SHA-256 proof, same box, round 5: 14 -> 622-626, 26 -> 629-630
+                                                            // against 646-649 proofs/s at 20)
 constexpr size_t MSM_RANGE_MIN_G2 = 16, MSM_RANGE_G2 = 64;  // ... per lane quad of the extension-field kernel (32 until
                                                             // round 4; C5: 1.303 s at 32, 1.286 at 64, 1.280 at 128)
 constexpr uint32_t FIN_SEQ = 16;      // a bucket spread over more accumulate lanes than this is summed by a workgroup
