@@ -356,7 +356,7 @@ def cpu_baseline(pp, crs, wit, r, s, seed, masks, gpu_proof):
     if masks is not None:
         inp["fft_masks"] = [(dl(f.in_mask, n * Lc, nl), dl(f.out_mask, n * Lc, nl)) for f in masks.fft]
         inp["degred_mask"] = (dl(masks.degred.in_mask, n * Lc, nl), dl(masks.degred.out_mask, n * Lc, nl))
-    cores = os.cpu_count() or 1
+    cores, host_cpus, quota = host_cores()
     cpu = CpuProver("bn254", pp.l)
     runs = {}
     proof = None
@@ -378,7 +378,33 @@ def cpu_baseline(pp, crs, wit, r, s, seed, masks, gpu_proof):
                       "mirrors arkworks' signed-digit Pippenger (msm_bigint_wnaf, window-parallel) and radix-2 FFTs; "
                       "circom_h runs the reference's SERIAL FFT-form king except in `all_cores_tuned_king`, where pack / "
                       "unpack2 are precomputed matrices split over the cores -- what a tuned CPU prover would do",
-            "runs": runs, "host_cpus": cores, "cpu_model": cpu_model(), "proof_matches_gpu": bool(ok)}
+            "runs": runs, "host_cpus": host_cpus, "cpu_quota_cores": quota, "usable_cores": cores,
+            "cpu_model": cpu_model(), "proof_matches_gpu": bool(ok)}
+
+
+def host_cores():
+    """(cores this process can actually keep busy, logical CPUs of the host, CPU quota of the container or None): the pool's
+    boxes show 256 logical CPUs under a cgroup quota of 16 -- 256 threads there are 16 cores' worth of time."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = n if quota is None else max(1, min(n, int(quota + 0.999)))
+    return usable, os.cpu_count() or 1, quota
 
 
 def cpu_baseline_c5(pp, zk, log_m_full):
@@ -423,7 +449,7 @@ def cpu_baseline_c5(pp, zk, log_m_full):
         ("s", inst.s, inst.len_a, 12), ("h", inst.h, inst.len_a, 12), ("v", inst.v, inst.len_a, 24),
         ("w", inst.wq, inst.len_w, 12), ("u", inst.u, inst.len_u, 12))}
     s_gpu = api.d_msm(pp, ZK_G1, inst.s, wit.a_share, inst.len_a)
-    cores = os.cpu_count() or 1
+    cores, host_cpus, quota = host_cores()
     per = max(1, min(24, cores // n))
     dom = Domain(cv, m)
     w2m = Domain(cv, 2 * m).element(1)
@@ -470,7 +496,8 @@ def cpu_baseline_c5(pp, zk, log_m_full):
             "sample": "one proof of the same synthetic BLS12-381 instance at 2^%d - 2 constraints (zero masks -- the "
                       "timed GPU workload applies all twelve, which costs the CPU no MSM work): %.2f s = circom_h %.2f s + the 5 x %d G::msm %.2f s; `value` = 1 / (that x %d), "
                       "a LINEAR extrapolation to 2^%d constraints" % (lg, total, t1 - t0, n, t2 - t1b, scale, log_m_full),
-            "measured_s_at_sample": round(total, 3), "sample_constraints": m - 2, "host_cpus": cores,
+            "measured_s_at_sample": round(total, 3), "sample_constraints": m - 2, "host_cpus": host_cpus,
+            "cpu_quota_cores": quota, "usable_cores": cores,
             "cpu_model": cpu_model(), "matches_gpu_at_sample": ok}
 
 
@@ -567,6 +594,29 @@ def distinct_witnesses(pp, zg, r1, count, seed):
     return out
 
 
+class AuxGuard:
+    """The line must come out whatever happens after the timed K steps: the auxiliary legs run under a deadline.  When it
+    passes (a leg stuck inside a library call cannot be interrupted from Python), the line is printed with what is
+    finished, `aux_timeout` names the leg that was running, and the process leaves with status 0."""
+
+    def __init__(self, res, seconds):
+        import threading
+        self.res, self.seconds, self.leg = res, seconds, None
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _fire(self):
+        self.res["aux_timeout"] = {"leg": self.leg, "seconds": self.seconds,
+                                   "note": "the legs after the timed K steps did not finish in time; `value` is complete"}
+        sys.stdout.write(json.dumps(self.res, default=str) + "\n")
+        sys.stdout.flush()
+        os._exit(0)
+
+    def done(self):
+        self.timer.cancel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -580,6 +630,9 @@ def main():
                          "scatter: north_star's topology, the default; the same run then also times the all-to-all king and "
                          "reports it as `alltoall`) or every rank king of a chunk range (two all-to-all exchanges)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--aux-timeout", type=float, default=300.0,
+                    help="seconds the legs after the timed K steps (table-free, two in flight, batches, primitives) may take "
+                         "together before the line is printed without the unfinished ones (they normally take ~30 s)")
     ap.add_argument("--no-masks", action="store_true", help="zero masks (the *::zero() variants the reference's "
                     "micro-benchmarks use); default: all twelve masks sampled, as groth16/examples/sha256.rs")
     ap.add_argument("--no-tables", action="store_true", help="headline without the fixed-base tables of the CRS")
@@ -669,8 +722,12 @@ def main():
         res["host_us_per_proof"] = {**{k: round(v, 1) for k, v in host.items()},
                                     "outside_the_call": round(per - sum(v for k, v in host.items() if "." not in k), 1),
                                     "period": round(per, 1)}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(pp, crs, wit, r, s, 2000 + args.steps - 1, masks, proof)
+    guard = AuxGuard(res, args.aux_timeout)
     if not args.no_primitives:
         if not args.no_tables:
+            guard.leg = "table_free"
             # the like-for-like figure: the same K steps without the fixed-base tables (dropped, then rebuilt)
             from zksaas_amd import api
             for buf in (crs.s, crs.h, crs.v, crs.w, crs.u):
@@ -687,6 +744,7 @@ def main():
             res["value_table_free"] = res["table_free"]["value"]
             res["ms_per_step_table_free"] = res["table_free"]["ms_per_step"]
             crs.precompute()
+        guard.leg = "pipelined"
         res["pipelined"], plast = pipelined(zg, pp, crs, wit, r, s, masks, max(8, args.steps), torch)
         res["pipelined"]["same_proof"] = same_shares(pp, plast, proof)
         # throughput mode: batches of proofs against the one CRS (outside the timed K steps; `value` stays one proof at a
@@ -694,12 +752,14 @@ def main():
         nproofs = max(64, args.steps)
         wits = [wit] + distinct_witnesses(pp, zg, r1, 16, 500)[1:]
         refs = [proof] + [zg.prove(pp, crs, wb, r, s, masks=masks, seed=1) for wb in wits[1:]]
-        res["batched"] = [batched(pp, zg, crs, wits, r, s, masks, nb, max(2, nproofs // nb), torch, refs, inflight=fl)
-                          for nb, fl in ((4, 1), (8, 1), (8, 2), (16, 2))]
+        res["batched"] = []
+        for nb, fl in ((4, 1), (8, 1), (8, 2), (16, 2)):
+            guard.leg = "batched %d x %d in flight" % (nb, fl)
+            res["batched"].append(batched(pp, zg, crs, wits, r, s, masks, nb, max(2, nproofs // nb), torch, refs, inflight=fl))
         del wits, refs
+        guard.leg = "primitives"
         res["primitives"] = primitives(pp, zk)
-    if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(pp, crs, wit, r, s, 2000 + args.steps - 1, masks, proof)
+    guard.done()
     print(json.dumps(res))
 
 

@@ -208,6 +208,28 @@ def _alltoall_leg(pp, dist, torch, step, steps, warmup, unit_scale=1.0):
     return {"king": "alltoall", "value": round(unit_scale * steps / dt, 4), "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
+def _step_traffic(pmc_file, parts):
+    """HBM bytes of one step of a primitive from the committed counter summary of the same command (profiles/<pmc_file>,
+    tools/refresh_profiles.sh; FETCH_SIZE / WRITE_SIZE in separate --pmc passes, corrected per access shape):
+    sum over `parts` = [(kernel-name prefix, launches per step)] (None: once per step every msm_* kernel of the file).
+    One-GPU figure (world = 1); None when the file is missing."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", pmc_file)
+    try:
+        ks = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    if parts is None:
+        return int(sum(k["hbm_bytes_per_launch"] for k in ks if k["kernel"].startswith("msm_")))
+    tot = 0
+    for prefix, per_step in parts:
+        hit = [k for k in ks if k["kernel"].startswith(prefix)]
+        if not hit:
+            return None
+        tot += per_step * hit[0]["hbm_bytes_per_launch"]
+    return int(tot)
+
+
 def _king_words(king, world):
     if world == 1:
         return "all parties on one GPU"
@@ -280,7 +302,11 @@ def bench(args, rank, local_rank, world):
                            "m": m, "masks": full_mask is not None},
                    roofline={"bound": "hbm", "kernel": "d_fft end to end (all ranks)", "achieved": round(gbs, 1),
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
-                             "traffic": None, "algorithmic_bytes_per_launch": alg})
+                             "traffic": _step_traffic("r05_c2_pmc_hbm.json", [("ntt_pass_kernel", 2), ("king_fft2_kernel", 1)])
+                             if world == 1 and full_mask is not None else None,
+                             "traffic_source": "profiles/r05_c2_pmc_hbm.json: two ntt_pass_kernel launches + one "
+                                               "king_fft2_kernel launch per d_fft",
+                             "algorithmic_bytes_per_launch": alg})
     elif wl == "c3":
         ln = 1 << 20
         # distinct bases: seeded random multiples of the generator (a tiled single point makes doublings and
@@ -314,7 +340,10 @@ def bench(args, rank, local_rank, world):
                            "plan": plan},
                    roofline={"bound": "hbm", "kernel": "d_msm end to end (all ranks)", "achieved": round(gbs, 1),
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
-                             "traffic": None, "algorithmic_bytes_per_launch": alg,
+                             "traffic": _step_traffic("r05_c3_pmc_hbm.json", None) if world == 1 and not fixed else None,
+                             "traffic_source": "profiles/r05_c3_pmc_hbm.json: every msm_* kernel of one table-free d_msm "
+                                               "(the accumulate kernel's gathers are 13.1 of the 16 GB)",
+                             "algorithmic_bytes_per_launch": alg,
                              "alu": {"achieved": round(gm, 1), "peak": round(MAD_ISSUE_BOUND_G * world, 1),
                                      "unit": "G modmul/s", "frac": round(gm / (MAD_ISSUE_BOUND_G * world), 3)}})
     elif wl == "c4":
