@@ -16,3 +16,15 @@ _zk_api.DEFAULT_OPTIONS["rng_replay"] = 1
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # A GPU test that stops making progress (a library call that never returns cannot be interrupted from Python) ends the
+    # run with thread dumps after ten minutes instead of sitting in the driver's limit: the slowest test takes ~60 s.
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(600, method="thread"))
