@@ -105,3 +105,31 @@ def test_chacha20_block_known_answer():
     ref = list(out)
     lib.zk_chacha20_block(key, 2 | (0x09000000 << 32), 0x4A000000, out)
     assert list(out) != ref
+
+
+def test_bench_line_survives_a_stuck_auxiliary_leg():
+    """bench.AuxGuard: when the legs after the timed K steps do not return, the line is printed with what is finished,
+    `aux_timeout` names the leg and the process leaves with status 0 (the watchdog thread runs while the main thread is
+    blocked); a leg that finishes in time leaves no trace."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "res = {'metric': 'm', 'value': 1.5}\n"
+            "g = bench.AuxGuard(res, 0.3); g.leg = 'batched 8 x 2 in flight'\n"
+            "time.sleep(float(sys.argv[1]))\n"
+            "g.done(); res['late'] = True; print(__import__('json').dumps(res))\n" % ROOT)
+    stuck = subprocess.run([sys.executable, "-c", code, "5"], capture_output=True, text=True, timeout=60)
+    assert stuck.returncode == 0, stuck.stderr
+    line = json.loads(stuck.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1.5 and line["aux_timeout"]["leg"] == "batched 8 x 2 in flight" and "late" not in line
+    fine = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=60)
+    line = json.loads(fine.stdout.strip().splitlines()[-1])
+    assert fine.returncode == 0 and line.get("late") is True and "aux_timeout" not in line
+
+
+def test_host_cores_honours_quota_and_affinity():
+    import bench
+    usable, host, quota = bench.host_cores()
+    assert 1 <= usable <= host == (os.cpu_count() or 1)
+    assert quota is None or (quota > 0 and usable <= int(quota + 0.999))
