@@ -622,9 +622,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5"],
+    ap.add_argument("--workload", default="c4", choices=["c2", "c3", "c4", "c5", "dealer"],
                     help="BASELINE.json config: c4 = SHA-256 Groth16 (default, the headline metric), c2 = d_fft 2^20, "
-                         "c3 = d_msm 2^20 per party, c5 = BLS12-381 2^24-constraint synthetic Groth16")
+                         "c3 = d_msm 2^20 per party, c5 = BLS12-381 2^24-constraint synthetic Groth16, dealer = the preprocessing kernels (CRS share "
+                         "packing, fixed-base multiplication, table build, mask sampling: tools/dealer_bench.py)")
     ap.add_argument("--king", default="star", choices=["star", "alltoall"],
                     help="N > 1: how a king round runs -- the reference's star through rank 0 (king on GPU 0, RCCL gather / "
                          "scatter: north_star's topology, the default; the same run then also times the all-to-all king and "
@@ -662,6 +663,13 @@ def main():
         local_rank = 0           # debugging mode: every rank drives GPU 0
     torch.cuda.set_device(local_rank)
 
+    if args.workload == "dealer":
+        # not a BASELINE config and not a proof rate -- one line of per-kernel timings
+        if rank == 0:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import dealer_bench
+            dealer_bench.main(["--reps", str(max(3, min(args.steps, 10)))])
+        return
     if world > 1 or args.workload != "c4" or os.environ.get("ZK_BENCH_FORCE_SHARDED"):
         from zksaas_amd import multigpu
         res = multigpu.bench(args, rank, local_rank, world)

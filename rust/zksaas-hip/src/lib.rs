@@ -1,24 +1,31 @@
 //! MI355X back end for the zkSaaS hot path, behind the reference's own generic signatures.
 //!
-//! Every public function here has the name, the generic parameters, the argument order and the error type of the
-//! reference function it replaces (file:line in its doc line), so that `dist-primitives`, `secret-sharing` and
-//! `groth16` call sites compile unchanged once their `use` lines point here.  The arithmetic runs in
-//! `libzksaas_hip.so` (hand-written HIP kernels for gfx950) through `zksaas_hip_sys`; nothing here computes on the CPU
-//! and nothing falls back to arkworks when the library reports an error.
+//! Every public `async fn` here has the name, the generic parameters WITH THEIR BOUNDS (`Net: MpcSerNet`, `G: CurveGroup`,
+//! `D: EvaluationDomain<F>`), the argument order and the error type of the reference function it replaces (file:line in
+//! its doc line).  The one systematic difference: the mask structs (`FftMask`, `MsmMask`, `DegRedMask`) are defined in
+//! `dist-primitives`, which depends on THIS crate (never the other way round: cargo rejects cycles), so a mask argument
+//! arrives as its two fields (`in_mask`, `out_mask`).  `dist-primitives` keeps its functions and calls down
+//! (`rust/patches/dist-primitives.diff`, at most ten lines per function); `groth16/` compiles unchanged with
+//! `Net = HipNet`.  `tests/test_rust_ffi.py` compares every signature here with the reference's token for token.
+//! The arithmetic runs in `libzksaas_hip.so` (hand-written HIP kernels for gfx950) through `zksaas_hip_sys`; nothing
+//! here computes on the CPU and nothing falls back to arkworks when the library reports an error.
 //!
 //! Field / curve selection is by `TypeId` of the arkworks scalar field (`Curve::of::<F>()`): BN254, BLS12-381 and
 //! BLS12-377 are the three the library is built for.  Scalars cross the boundary as their in-memory Montgomery limbs
 //! (`Fp<MontBackend<_, N>, N>` is `[u64; N]` little endian, what `include/zksaas.h` specifies); points are repacked to
 //! `x || y` because `ark_ec::short_weierstrass::Affine` is not `repr(C)`.
 //!
+//! Group values are dispatched the same way: `G: CurveGroup` is matched by `TypeId` against the six short-Weierstrass
+//! groups the library is built for (`sw_dispatch!`), inside which `G` IS `Projective<C>` and `G::Affine` IS `Affine<C>`.
+//!
 //! NOT compiled in the build image (no Rust toolchain there): `tests/test_rust_ffi.py` checks every `sys::zk_*` call of
-//! this crate against the header (exported name, argument count).
+//! this crate against the header (exported name, argument count), the signatures against the reference, and the
+//! dependency graph of the three manifests plus the patches.
 pub mod deg_red;
 pub mod dfft;
 pub mod dmsm;
 pub mod dpp;
 pub mod error;
-pub mod groth16;
 pub mod net;
 pub mod pss;
 
@@ -33,6 +40,59 @@ use mpc_net::MpcNetError;
 use zksaas_hip_sys as sys;
 
 pub use error::check;
+pub use net::{HipNet, Transport};
+
+/// `Some(v)` seen as a slice of `B` iff `A` and `B` are the same type (`TypeId`): the monomorphised dispatch from a
+/// generic parameter to the concrete type a branch is written for.  Not a transmute between different types.
+pub(crate) fn same_slice<A: 'static, B: 'static>(v: &[A]) -> Option<&[B]> {
+    if TypeId::of::<A>() == TypeId::of::<B>() {
+        Some(unsafe { &*(v as *const [A] as *const [B]) })
+    } else {
+        None
+    }
+}
+pub(crate) fn same_vec<A: 'static, B: 'static>(v: Vec<A>) -> Result<Vec<B>, Vec<A>> {
+    if TypeId::of::<A>() == TypeId::of::<B>() {
+        let mut v = core::mem::ManuallyDrop::new(v);
+        Ok(unsafe { Vec::from_raw_parts(v.as_mut_ptr() as *mut B, v.len(), v.capacity()) })
+    } else {
+        Err(v)
+    }
+}
+pub(crate) fn same_value<A: 'static + Copy, B: 'static + Copy>(v: A) -> Option<B> {
+    same_slice::<A, B>(core::slice::from_ref(&v)).map(|s| s[0])
+}
+
+/// Runs `$body` with `$C` bound to the `SWCurveConfig` whose `Projective<$C>` IS the generic group `$G` (`TypeId`), for the
+/// six groups of the three curves; `BadInput` for any other group.
+#[macro_export]
+macro_rules! sw_dispatch {
+    ($G:ty, $C:ident => $body:expr) => {{
+        use ark_ec::short_weierstrass::Projective;
+        let t = core::any::TypeId::of::<$G>();
+        if t == core::any::TypeId::of::<Projective<ark_bn254::g1::Config>>() {
+            type $C = ark_bn254::g1::Config;
+            $body
+        } else if t == core::any::TypeId::of::<Projective<ark_bn254::g2::Config>>() {
+            type $C = ark_bn254::g2::Config;
+            $body
+        } else if t == core::any::TypeId::of::<Projective<ark_bls12_381::g1::Config>>() {
+            type $C = ark_bls12_381::g1::Config;
+            $body
+        } else if t == core::any::TypeId::of::<Projective<ark_bls12_381::g2::Config>>() {
+            type $C = ark_bls12_381::g2::Config;
+            $body
+        } else if t == core::any::TypeId::of::<Projective<ark_bls12_377::g1::Config>>() {
+            type $C = ark_bls12_377::g1::Config;
+            $body
+        } else if t == core::any::TypeId::of::<Projective<ark_bls12_377::g2::Config>>() {
+            type $C = ark_bls12_377::g2::Config;
+            $body
+        } else {
+            Err(mpc_net::MpcNetError::BadInput { err: "zksaas-hip: group is not G1 / G2 of BN254, BLS12-381 or BLS12-377" })
+        }
+    }};
+}
 
 /// The three curves `libzksaas_hip.so` is instantiated for (`enum zk_curve`).
 #[derive(Clone, Copy, Debug, PartialEq, Eq)]
@@ -110,6 +170,14 @@ impl Context {
     pub fn raw(&self) -> *mut sys::ZkCtx {
         self.inner.raw
     }
+    /// The context was created for `F`'s curve and this packing factor (`pp.l`): a caller mixing fields gets
+    /// `BadInput`, not a computation over the wrong modulus.
+    pub fn expect_field<F: 'static>(&self, l: usize) -> Result<(), MpcNetError> {
+        if Curve::of::<F>()? != self.curve || l != self.l {
+            return Err(MpcNetError::BadInput { err: "zksaas-hip: the net's context was created for another field or packing factor" });
+        }
+        Ok(())
+    }
     /// `zk_ctx_set_option` (e.g. `"rng_replay"`, `"king_alltoall"`, `"h_first_log_m"`).
     pub fn set_option(&self, name: &str, value: i64) -> Result<(), MpcNetError> {
         let c = std::ffi::CString::new(name).map_err(|_| MpcNetError::BadInput { err: "option name" })?;
@@ -144,6 +212,9 @@ impl DeviceBuf {
         Ok(b)
     }
     pub fn to_vec<T: Copy + Default>(&self, len: usize) -> Result<Vec<T>, MpcNetError> {
+        if len == 0 {
+            return Ok(Vec::new());
+        }
         let mut v = vec![T::default(); len];
         let bytes = core::mem::size_of_val(&v[..]);
         debug_assert!(bytes <= self.bytes);

@@ -3,8 +3,14 @@
   * an INDEPENDENT pass (own header parser, own Rust parser, own type classes) agrees on name, arity and the
     pointer / 32-bit / 64-bit / double class of every argument and return value of every entry point;
   * the generated declarations cover exactly the zk_* symbols the built library exports;
-  * every `sys::zk_*(…)` call in the hand-written shim (rust/zksaas-hip/src/*.rs) names a declared function and passes the
-    number of arguments the header declares; the reference signatures the shim mirrors are all present."""
+  * every `sys::zk_*(…)` call in the hand-written shims (rust/zksaas-hip, rust/zksaas-hip-groth16) names a declared function
+    and passes the number of arguments the header declares;
+  * the three manifests plus the dependency the patches add to the reference form an ACYCLIC graph
+    (groth16 -> dist-primitives -> zksaas-hip -> {zksaas-hip-sys, mpc-net, secret-sharing});
+  * (build container only) every shim `pub async fn` carries the reference's generic bounds, argument list and return
+    type token for token -- a mask struct of dist-primitives arriving as its two fields is the one documented
+    substitution -- and rust/patches/*.diff apply to the reference, touch nothing under groth16/ and add at most ten
+    lines per hunk."""
 import glob
 import os
 import re
@@ -127,11 +133,16 @@ def test_declarations_match_the_built_library():
     assert exported == set(_rust_decls())
 
 
+SHIM_DIRS = [os.path.join(ROOT, "rust", "zksaas-hip", "src"), os.path.join(ROOT, "rust", "zksaas-hip-groth16", "src")]
+REFERENCE = "/root/reference"
+
+
 def test_shim_calls_match_the_declarations():
     decls = _rust_decls()
-    files = sorted(glob.glob(os.path.join(ROOT, "rust", "zksaas-hip", "src", "*.rs")))
-    assert {os.path.basename(f) for f in files} >= {"lib.rs", "error.rs", "net.rs", "pss.rs", "dfft.rs", "dmsm.rs", "dpp.rs",
-                                                   "deg_red.rs", "groth16.rs"}
+    files = sorted(f for d in SHIM_DIRS for f in glob.glob(os.path.join(d, "*.rs")))
+    assert {os.path.relpath(f, os.path.join(ROOT, "rust")) for f in files} >= {
+        "zksaas-hip/src/" + n for n in ("lib.rs", "error.rs", "net.rs", "pss.rs", "dfft.rs", "dmsm.rs", "dpp.rs", "deg_red.rs")
+    } | {"zksaas-hip-groth16/src/lib.rs"}
     used = set()
     for f in files:
         src = open(f).read()
@@ -150,12 +161,198 @@ def test_shim_calls_match_the_declarations():
     # the reference surface the north star names is all routed
     assert used >= {"zk_ctx_create", "zk_pss_pack", "zk_pss_det_pack", "zk_pss_unpack", "zk_pss_unpack2", "zk_dist_d_fft",
                     "zk_dist_d_ifft", "zk_dist_d_msm", "zk_dist_deg_red", "zk_dist_deg_red_points", "zk_dist_d_pp", "zk_d_pp",
-                    "zk_dist_circom_h", "zk_dist_groth16_prove", "zk_net_create", "zk_net_sync", "zk_last_error",
+                    "zk_dist_circom_h", "zk_dist_libsnark_h", "zk_dist_groth16_prove", "zk_net_create", "zk_net_sync",
+                    "zk_net_enter", "zk_net_gather", "zk_net_scatter", "zk_net_bcast_host", "zk_last_error",
                     "zk_fft_mask_sample", "zk_msm_mask_sample", "zk_degred_mask_sample"}
-    sigs = {"dfft.rs": ["pub async fn d_fft<", "pub async fn d_ifft<"], "dmsm.rs": ["pub async fn d_msm<"],
-            "dpp.rs": ["pub async fn d_pp<"], "deg_red.rs": ["pub async fn deg_red<"],
-            "groth16.rs": ["pub async fn circom_h<", "pub async fn dsha256<"]}
-    for fname, needles in sigs.items():
-        src = open(os.path.join(ROOT, "rust", "zksaas-hip", "src", fname)).read()
-        for nd in needles:
-            assert nd in src and "Result<" in src[src.index(nd):src.index(nd) + 1200] and "MpcNetError" in src, (fname, nd)
+
+
+# ---------------------------------------------------------------- the crates can be wired in: no dependency cycle
+def _manifest_deps(path):
+    """[dependencies] names of a Cargo.toml (path + registry; optional ones included)"""
+    text = open(path).read()
+    m = re.search(r"^\[dependencies\]\s*$(.*?)(?=^\[|\Z)", text, flags=re.S | re.M)
+    deps = set()
+    for ln in (m.group(1) if m else "").splitlines():
+        ln = ln.split("#")[0].strip()
+        if "=" in ln:
+            deps.add(ln.split("=")[0].strip())
+    return re.search(r'^name\s*=\s*"([^"]+)"', text, flags=re.M).group(1), deps
+
+
+# what the reference's four crates depend on inside the workspace (dist-primitives/Cargo.toml:16-17, groth16/Cargo.toml:23-25,
+# secret-sharing / mpc-net: nothing in the workspace); re-read from the manifests when the reference is mounted
+REF_EDGES = {"mpc-net": set(), "secret-sharing": set(), "dist-primitives": {"secret-sharing", "mpc-net"},
+             "groth16": {"secret-sharing", "mpc-net", "dist-primitives"}}
+
+
+def _graph():
+    ours = {}
+    for crate in ("zksaas-hip-sys", "zksaas-hip", "zksaas-hip-groth16"):
+        name, deps = _manifest_deps(os.path.join(ROOT, "rust", crate, "Cargo.toml"))
+        assert name == crate
+        ours[name] = deps
+    ref = {k: set(v) for k, v in REF_EDGES.items()}
+    if os.path.isdir(REFERENCE):
+        for crate in ref:
+            name, deps = _manifest_deps(os.path.join(REFERENCE, crate, "Cargo.toml"))
+            assert deps & set(ref) == ref[crate], crate          # the recorded edges are the reference's
+    # the edges the patches add (rust/patches/dist-primitives.diff: `+zksaas-hip = {...}` under [dependencies])
+    patch = open(os.path.join(ROOT, "rust", "patches", "dist-primitives.diff")).read()
+    added = set(re.findall(r"^\+([\w-]+)\s*=\s*\{", patch, flags=re.M))
+    assert added == {"zksaas-hip"}
+    ref["dist-primitives"] |= added
+    assert not re.search(r"^\+[\w-]+\s*=\s*\{", open(os.path.join(ROOT, "rust", "patches", "mpc-net.diff")).read(), flags=re.M)
+    nodes = set(ours) | set(ref)
+    return {n: ({**ours, **ref}[n] & nodes) for n in nodes}
+
+
+def test_dependency_graph_of_crates_and_patches_is_acyclic():
+    g = _graph()
+    # what makes the recipe wire-able: dist-primitives calls DOWN into zksaas-hip, which knows nothing above mpc-net / secret-sharing
+    assert "zksaas-hip" in g["dist-primitives"]
+    assert g["zksaas-hip"] == {"zksaas-hip-sys", "mpc-net", "secret-sharing"}
+    assert g["zksaas-hip-sys"] == set()
+    assert g["zksaas-hip-groth16"] >= {"groth16", "dist-primitives", "zksaas-hip"}
+    state = {}
+
+    def visit(n, path):
+        if state.get(n) == 2:
+            return
+        assert state.get(n) != 1, "dependency cycle: " + " -> ".join(path + [n])
+        state[n] = 1
+        for d in sorted(g[n]):
+            visit(d, path + [n])
+        state[n] = 2
+    for n in sorted(g):
+        visit(n, [])
+    # and the README tells the same story as the manifests
+    readme = open(os.path.join(ROOT, "rust", "README.md")).read()
+    assert "groth16 -> dist-primitives -> zksaas-hip" in readme and "patches/dist-primitives.diff" in readme
+
+
+# ---------------------------------------------------------------- signatures: the reference's, token for token
+def _tokens(s):
+    s = re.sub(r"//[^\n]*", "", s)
+    return re.findall(r"[A-Za-z_][A-Za-z_0-9]*|'[a-z]+|::|->|[<>\[\](){}&*,:;+=]|\d+", s)
+
+
+def _signature(src, name, public=True):
+    m = re.search(r"(pub )?async fn %s\s*<" % name, src)
+    assert m, name
+    i, depth = m.end(), 1
+    while depth:                                   # generics
+        depth += {"<": 1, ">": -1}.get(src[i], 0)
+        if src[i:i + 2] == "->":
+            depth += 1                             # the '>' of an arrow is not a bracket
+        i += 1
+    generics = src[m.end():i - 1]
+    assert src[i:].lstrip()[0] == "("
+    j = src.index("(", i) + 1
+    k, depth = j, 1
+    while depth:
+        depth += {"(": 1, ")": -1}.get(src[k], 0)
+        k += 1
+    args = src[j:k - 1]
+    rest = src[k:]
+    ret = rest[:re.search(r"\bwhere\b|\{", rest).start()]
+    return _tokens(generics), [_tokens(a) for a in _split_top(args) if a.strip()], _tokens(ret)
+
+
+def _strip_mut(arg):
+    return [t for t in arg if t != "mut"]
+
+
+# a mask struct of dist-primitives arrives in zksaas-hip as its two fields (the crate cannot name a type of a crate that depends on it)
+MASK_FIELDS = {
+    ("fft_mask", "& FftMask < F >"): ["in_mask : & [ F ]", "out_mask : & [ F ]"],
+    ("msm_mask", "& MsmMask < G >"): ["in_mask : & G", "out_mask : & G"],
+    ("degred_mask", "& DegRedMask < F , F >"): ["in_mask : & [ F ]", "out_mask : & [ F ]"],
+    ("degred_mask", "& DegRedMask < F , T >"): ["in_mask : & [ T ]", "out_mask : & [ T ]"],
+}
+CORE = [("dfft.rs", "d_fft", "dist-primitives/src/dfft/mod.rs"), ("dfft.rs", "d_ifft", "dist-primitives/src/dfft/mod.rs"),
+        ("dmsm.rs", "d_msm", "dist-primitives/src/dmsm/mod.rs"), ("dpp.rs", "d_pp", "dist-primitives/src/dpp/mod.rs"),
+        ("deg_red.rs", "deg_red", "dist-primitives/src/utils/deg_red.rs")]
+
+
+def _expected_core_signature(ref_sig, name):
+    generics, args, ret = ref_sig
+    out = []
+    for a in args:
+        a = _strip_mut(a)
+        key = (a[0], " ".join(a[2:]))
+        if key in MASK_FIELDS:
+            out += [f.split() for f in MASK_FIELDS[key]]
+        else:
+            out.append(a)
+    if name == "deg_red":                          # the one bound the patch adds to the reference's own deg_red as well
+        at = generics.index("UniformRand")
+        generics = generics[:at + 1] + ["+", "'static"] + generics[at + 1:]
+    return [t for t in generics if True], out, ret
+
+
+def _drop_trailing_comma(toks):
+    return toks[:-1] if toks and toks[-1] == "," else toks
+
+
+def test_shim_signatures_are_the_references():
+    import pytest
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference is mounted in the build container only")
+    for fname, name, ref_file in CORE:
+        ours = _signature(open(os.path.join(SHIM_DIRS[0], fname)).read(), name)
+        want = _expected_core_signature(_signature(open(os.path.join(REFERENCE, ref_file)).read(), name), name)
+        assert _drop_trailing_comma(ours[0]) == _drop_trailing_comma(want[0]), (name, "generic parameters and bounds")
+        assert [_strip_mut(a) for a in ours[1]] == want[1], (name, "argument list")
+        assert ours[2] == want[2], (name, "return type")
+        assert "MpcSerNet" in ours[0], name
+    # the fused forms name groth16's own types: exact
+    g16 = open(os.path.join(SHIM_DIRS[1], "lib.rs")).read()
+    ref = open(os.path.join(REFERENCE, "groth16/src/ext_wit.rs")).read()
+    for name in ("circom_h", "libsnark_h"):
+        ours, want = _signature(g16, name), _signature(ref, name)
+        assert _drop_trailing_comma(ours[0]) == _drop_trailing_comma(want[0]), name
+        assert ours[1] == want[1], name
+        assert ours[2] == want[2], name
+    # dsha256 (private to the reference's example, returns a bare tuple after unwrapping): same argument list, Result around it
+    ours = _signature(g16, "dsha256")
+    want = _signature(open(os.path.join(REFERENCE, "groth16/examples/sha256.rs")).read(), "dsha256")
+    assert ours[1] == want[1]
+    assert ours[0][:3] == want[0][:3] == ["E", ",", "Net"]
+    assert ours[2] == _tokens("-> Result<") + want[2][1:] + _tokens(", MpcNetError>")
+
+
+def test_patches_apply_to_the_reference_and_stay_small():
+    import pytest
+    import shutil
+    import tempfile
+    d = os.path.join(ROOT, "rust", "patches")
+    mp, dp = open(os.path.join(d, "mpc-net.diff")).read(), open(os.path.join(d, "dist-primitives.diff")).read()
+    # nothing under groth16/ is touched, and no hunk adds more than ten lines
+    for text in (mp, dp):
+        assert not re.search(r"^\+\+\+ b/groth16/", text, flags=re.M)
+        for hunk in re.split(r"^@@.*?@@.*$", text, flags=re.M)[1:]:
+            assert sum(1 for ln in hunk.splitlines() if ln.startswith("+") and not ln.startswith("+++")) <= 10
+    assert set(re.findall(r"^\+\+\+ b/(\S+)", mp + dp, flags=re.M)) == {
+        "mpc-net/src/lib.rs", "dist-primitives/Cargo.toml", "dist-primitives/src/dfft/mod.rs", "dist-primitives/src/dmsm/mod.rs",
+        "dist-primitives/src/dpp/mod.rs", "dist-primitives/src/utils/deg_red.rs"}
+    # every hand-off calls a function the shim defines, with as many arguments as it takes
+    for fname, name, _ in CORE:
+        sig = _signature(open(os.path.join(SHIM_DIRS[0], fname)).read(), name)
+        m = re.search(r"zksaas_hip::%s::%s\((.*?)\)\.await" % (fname[:-3], name), dp)
+        assert m, name
+        assert len(_split_top(m.group(1))) == len(sig[1]), name
+    assert "fn hip_backend(&self) -> Option<&(dyn core::any::Any + Send + Sync)>" in mp
+    assert "fn hip_backend(&self) -> Option<&(dyn Any + Send + Sync)>" in open(os.path.join(SHIM_DIRS[0], "net.rs")).read()
+    if not os.path.isdir(REFERENCE) or not shutil.which("patch"):
+        pytest.skip("the reference is mounted in the build container only")
+    import gen_rust_patches  # noqa: F401  (the committed diffs are what the generator writes today)
+    with tempfile.TemporaryDirectory() as tmp:
+        for crate in ("mpc-net", "dist-primitives", "groth16"):
+            shutil.copytree(os.path.join(REFERENCE, crate), os.path.join(tmp, crate))
+        before = {f: open(f).read() for f in glob.glob(os.path.join(tmp, "groth16", "**", "*.rs"), recursive=True)}
+        for f in ("mpc-net.diff", "dist-primitives.diff"):
+            r = subprocess.run(["patch", "-p1", "-s", "-i", os.path.join(d, f)], cwd=tmp, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+        assert before == {f: open(f).read() for f in before}, "groth16/ must stay untouched"
+        patched = open(os.path.join(tmp, "dist-primitives", "src", "dfft", "mod.rs")).read()
+        assert patched.count("net.hip_backend().is_some()") == 2

@@ -74,6 +74,7 @@ class Engine : public IEngine {
     for (auto& kv : sizeinv_) (void)hipFree(kv.second);
     if (pmat_) (void)hipFree(pmat_);
     for (auto& kv : pcoef_) (void)hipFree(kv.second);
+    if (pjsf_) (void)hipFree(pjsf_);
     if (pack2_) (void)hipFree(pack2_);
     if (ident_) (void)hipFree(ident_);
     if (err_flag_) (void)hipFree(err_flag_);
@@ -424,6 +425,7 @@ class Engine : public IEngine {
   std::vector<Fr> pmat_host_;
   DevBuf flag_;   // 4-byte device flag for the validating kernels
   std::map<int, Fr*> pcoef_;
+  uint8_t* pjsf_ = nullptr;     // joint-sparse-form digits of the first two pack columns (pss_pack_points at 2 points per chunk)
   PackL2<Fr>* pack2_ = nullptr;
   Fr* ident_ = nullptr;
   int* err_flag_ = nullptr;

@@ -15,6 +15,7 @@
   }
 
   // ---------------------------------------------------------------- fixed-base multiplication (dealer)
+  static constexpr size_t BASE_MUL_WIDE_FROM = (size_t)1 << 19;      // scalars per call from which 16-bit windows pay
   template <class Fld>
   int base_mul_t(const void* base_affine, const void* scalars, size_t len, void* out_affine, hipStream_t st) {
     if (!len) return ZK_OK;
@@ -46,8 +47,30 @@
       std::lock_guard<std::mutex> lk(mu_);
       base_tables_[key] = table;
     }
-    fixed_base_mul_kernel<FrP, Fld><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
-        (const Fr*)scalars, len, table, nwin, (Affine<Fld>*)out_affine);
+    if (len >= BASE_MUL_WIDE_FROM) {
+      // 16-bit windows (half the mixed additions per scalar), widened on the device from the 8-bit table once per base
+      const int nwin16 = (nwin + 1) / 2;
+      Affine<Fld>* wide = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = base_tables_.find(key + "#16");
+        if (it != base_tables_.end()) wide = (Affine<Fld>*)it->second;
+      }
+      if (!wide) {
+        const size_t entries = (size_t)nwin16 * 65535u;
+        ZK_HIP(hipMalloc((void**)&wide, entries * sizeof(Affine<Fld>)));
+        fixed_base_widen_kernel<Fld><<<dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, st>>>(table, nwin, nwin16, wide);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));          // once per base: a later call on another stream finds a finished table
+        std::lock_guard<std::mutex> lk(mu_);
+        base_tables_[key + "#16"] = wide;
+      }
+      fixed_base_mul_kernel<FrP, Fld, 16><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
+          (const Fr*)scalars, len, wide, nwin16, (Affine<Fld>*)out_affine);
+    } else {
+      fixed_base_mul_kernel<FrP, Fld, 8><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
+          (const Fr*)scalars, len, table, nwin, (Affine<Fld>*)out_affine);
+    }
     ZK_HIP(hipGetLastError());
     return ZK_OK;
   }
@@ -89,8 +112,32 @@
     dim3 grid((unsigned)((total + 127) / 128)), block(128);
     const Affine<Fld>* in = (const Affine<Fld>*)points;
     Affine<Fld>* out = (Affine<Fld>*)shares;
-    if (nv == 2) pss_pack_points_kernel<FrP, Fld, 2><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
-    else if (nv == 4) pss_pack_points_kernel<FrP, Fld, 4><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
+    if (nv == 2) {
+      // the party's two fixed scalars in joint sparse form (host, once per context): [n][jlen] bytes, MSB first
+      constexpr int JLEN = FrP::N * 32 + 1;
+      uint8_t* dig = nullptr;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        dig = pjsf_;
+      }
+      if (!dig) {
+        std::vector<uint8_t> h((size_t)n * JLEN, (uint8_t)(1 | (1 << 2)));          // leading columns: (0, 0)
+        std::vector<int8_t> u0, u1;
+        for (int p = 0; p < n; p++) {
+          const Fr a = pmat_host_[(size_t)p * (l + t)].from_mont(), b = pmat_host_[(size_t)p * (l + t) + 1].from_mont();
+          jsf_digits<FrP::N>(a.v, b.v, u0, u1);
+          for (size_t q = 0; q < u0.size(); q++)
+            h[(size_t)p * JLEN + (JLEN - 1 - q)] = (uint8_t)((u0[q] + 1) | ((u1[q] + 1) << 2));
+        }
+        ZK_HIP(hipMalloc((void**)&dig, h.size()));
+        ZK_HIP(hipMemcpy(dig, h.data(), h.size(), hipMemcpyHostToDevice));
+        std::lock_guard<std::mutex> lk(mu_);
+        if (pjsf_) (void)hipFree(dig), dig = pjsf_;
+        else pjsf_ = dig;
+      }
+      pss_pack_points_jsf_kernel<FrP, Fld><<<dim3((unsigned)((nchunks + 127) / 128), (unsigned)n), block, 0, st>>>(
+          in, nchunks, n, dig, JLEN, out);
+    } else if (nv == 4) pss_pack_points_kernel<FrP, Fld, 4><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
     else return fail(ZK_ERR_BAD_INPUT, "point packing is built for 2 or 4 points per chunk (l = 2, or det_pack at l = 4)");
     ZK_HIP(hipGetLastError());
     return ZK_OK;
