@@ -253,9 +253,21 @@ int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
  * "msm_c" / "msm_c_g2": window bits (2..20, 0 = the cost model) of table-free MSMs (tests force widths with it).
  * "h_first_log_m": domains of 2^value and up run circom_h and every MSM's sort ahead of the accumulate kernels (default 20).
  * "host_threads": workers of the context's host pool (0 = by the core count, else >= 4; before the first proof).
+ * "wait_deadline_ms": bound of every host-side wait inside the prover entry points (an MSM chain's completion event, a gate
+ *   between two launching threads, a pool task; default 120000, 0 = unbounded).  On expiry the call returns ZK_ERR_GENERIC
+ *   naming what it waited for, the state of the job's gates and events goes to stderr, the job's slot is never reused and
+ *   the context refuses further proofs ("wedged": destroy it).  zk_groth16_wait / zk_groth16_batch_wait / zk_msm and the
+ *   zk_dist_* prover calls therefore cannot block for ever (the net's own rounds have zk_net_set_timeout_ms).
  * "dist_deadline": 1 = the zk_dist_* calls return only with their data-plane work done (zk_net_sync inside).
  * Nothing is read from the environment.  Unknown name or value out of range -> ZK_ERR_BAD_INPUT. */
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
+/* Memory-model note (csrc/msm.hpp msm_hist): the last workgroup of a sort's histogram finds out that it is the last through a
+ * RELAXED device-scope ticket (an acquire fence follows in that workgroup; the release side would write back an XCD's L2 per
+ * workgroup: -3.8 % of a SHA-256 proof, measured).  Correctness rests on gfx950 behaviour, not on the HIP memory model: the
+ * counts are device-scope atomic read-modify-writes performed at the memory side, every wave holds the return values of its
+ * adds before the barrier that precedes the ticket, and the scanning workgroup reads them with device-scope atomic loads.
+ * -DZK_HIST_TICKET_ACQ_REL=1 builds the formally ordered form; tests/test_gpu_msm.py::test_concurrent_sorts_stress runs
+ * hundreds of concurrent sorts against serial results on the shipped build. */
 /* MsmMask::sample (dmsm/mod.rs:21-47): l random scalars x_i (stream `seed`), mask values x_i * gen, out value
  * -(sum), both packed with t random group elements each (streams seed^0x1111, seed^0x2222; a random group element
  * is a random multiple of gen).  gen_affine: the group generator (host, affine Montgomery); in_mask / out_mask

@@ -237,6 +237,42 @@ static void dom_ifft(const domain_t* D, fe* a, const field_t* F) {
   distribute_powers(a, D->size, &D->offset_inv, &D->size_inv, F);
 }
 
+/* The LOCAL (non-distributed) witness map, BASELINE configs[0]: ark-circom's CircomReduction::witness_map_from_matrices as the
+ * reference restates it in-tree (groth16/src/ext_wit.rs:239-285 circom_ref; reached from groth16/examples/sha256.rs:191-199
+ * through create_proof_with_reduction_and_matrices): per vector ifft on the domain, coefficient i times w_2m^i, fft; then
+ * a b - c pointwise.  a, b, c: D->size values each (overwritten), h: D->size values.  nthreads >= 3: the three vectors run
+ * in three threads (arkworks' `parallel` feature splits the FFTs with rayon: groth16/Cargo.toml:37-38). */
+typedef struct {
+  const field_t* F;
+  const domain_t* D;
+  fe* v;
+  const fe* w2m;
+} circom_ref_job;
+static void* circom_ref_run(void* arg) {
+  circom_ref_job* j = (circom_ref_job*)arg;
+  fe one;
+  fe_one(&one, j->F);
+  dom_ifft(j->D, j->v, j->F);
+  distribute_powers(j->v, j->D->size, j->w2m, &one, j->F);
+  dom_fft(j->D, j->v, j->F);
+  return NULL;
+}
+void zkref_circom_ref(const field_t* F, const domain_t* D, fe* a, fe* b, fe* c, const fe* w2m, int nthreads, fe* h) {
+  circom_ref_job jobs[3] = {{F, D, a, w2m}, {F, D, b, w2m}, {F, D, c, w2m}};
+  if (nthreads >= 3) {
+    pthread_t th[3];
+    for (int i = 0; i < 3; i++) pthread_create(&th[i], NULL, circom_ref_run, &jobs[i]);
+    for (int i = 0; i < 3; i++) pthread_join(th[i], NULL);
+  } else {
+    for (int i = 0; i < 3; i++) circom_ref_run(&jobs[i]);
+  }
+  for (size_t i = 0; i < D->size; i++) {
+    fe t;
+    fe_mul(&t, &a[i], &b[i], F);
+    fe_sub(&h[i], &t, &c[i], F);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------ PSS */
 typedef struct {
   field_t F;

@@ -143,6 +143,67 @@ class CpuProver:
         t3 = time.perf_counter()
         return (A, B2, Cc), {"circom_h_s": t1 - t0, "msm_s": t2 - t1, "king_assemble_s": t3 - t2, "total_s": t3 - t0}
 
+    def circom_ref(self, a, b, c, log_m, threads=1):
+        """ext_wit.rs:239-285 in C (zkref_circom_ref): a, b, c uint64 [m][4] Montgomery, natural order (copied); returns h [m][4]."""
+        from .cref import _domain
+        cp = self.cp
+        m = 1 << log_m
+        dom = Domain(cp.curve, m)
+        dt = _domain(cp.fr, dom)
+        w2m = Domain(cp.curve, 2 * m).element(1)
+        a, b, c = (np.ascontiguousarray(x).copy() for x in (a, b, c))
+        h = np.empty_like(a)
+        lib().zkref_circom_ref(C.byref(cp.fr.ct), C.byref(dt), _p(a), _p(b), _p(c), cp.fr.mont(w2m), int(threads), _p(h))
+        return h
+
+    def prove_local(self, inp, threads=1):
+        """BASELINE configs[0]: the LOCAL (non-distributed) prover the reference runs first (groth16/examples/sha256.rs:191-199,
+        ark-groth16's create_proof_with_reduction_and_matrices with the circom reduction): h by circom_ref, then the five
+        G::msm over the UNPACKED proving key -- h_query . h, l_query . aux, a_query[1..] / b_g1_query[1..] / b_g2_query[1..] .
+        assignment[1..] -- and the assembly of prove.rs (restated by oracle/groth16.py create_proof_local, against which
+        tests/test_oracle_c.py pins this).  inp: qap_a / qap_b / qap_c [m][4], w [nv][4] (full assignment, Montgomery), ni,
+        a_query / b_g1_query / l_query / h_query [..][8], b_g2_query [..][16], the single elements, r, s (ints).
+        threads: 1 = everything serial; otherwise the three transforms and then the five MSMs run concurrently, each MSM
+        window-parallel over its share of the threads."""
+        cp = self.cp
+        t0 = time.perf_counter()
+        h = self.circom_ref(inp["qap_a"], inp["qap_b"], inp["qap_c"], inp["log_m"], threads)
+        t1 = time.perf_counter()
+        w, ni = inp["w"], inp["ni"]
+        asg, aux = np.ascontiguousarray(w[1:]), np.ascontiguousarray(w[ni:])
+        jobs = [("h", False, inp["h_query"], h), ("l", False, inp["l_query"], aux), ("a", False, inp["a_query"][1:], asg),
+                ("b1", False, inp["b_g1_query"][1:], asg), ("b2", True, inp["b_g2_query"][1:], asg)]
+        per = max(1, threads // len(jobs))
+
+        def run(job):
+            _, g2, bases, sc = job
+            ln = min(len(bases), len(sc))
+            assert len(bases) == len(sc), (job[0], len(bases), len(sc))
+            fn = cp.msm_g2_arrays if g2 else cp.msm_g1_arrays
+            return fn(np.ascontiguousarray(bases), np.ascontiguousarray(sc), ln, per)
+        if threads > 1:
+            with ThreadPoolExecutor(max_workers=min(len(jobs), threads)) as ex:
+                Hm, Lm, Am, B1m, B2m = list(ex.map(run, jobs))
+        else:
+            Hm, Lm, Am, B1m, B2m = [run(j) for j in jobs]
+        t2 = time.perf_counter()
+        r, s = inp["r"], inp["s_"]
+        d1, d2 = self._jac1(inp["delta_g1"]), self._jac2(inp["delta_g2"])
+        A = self._add(False, self._add(False, self._add(False, self._mul(False, d1, r), self._jac1(inp["a_query"][0])), Am),
+                      self._jac1(inp["alpha_g1"]))
+        if r % cp.curve.r == 0:
+            B1 = np.zeros(12, dtype=np.uint64)
+        else:
+            B1 = self._add(False, self._add(False, self._add(False, self._mul(False, d1, s), self._jac1(inp["b_g1_query"][0])),
+                                            B1m), self._jac1(inp["beta_g1"]))
+        B2 = self._add(True, self._add(True, self._add(True, self._mul(True, d2, s), self._jac2(inp["b_g2_query"][0])), B2m),
+                       self._jac2(inp["beta_g2"]))
+        Cc = self._add(False, self._mul(False, A, s), self._mul(False, B1, r))
+        Cc = self._add(False, Cc, self._neg(False, self._mul(False, d1, r * s % cp.curve.r)))
+        Cc = self._add(False, self._add(False, Cc, Lm), Hm)
+        t3 = time.perf_counter()
+        return (A, B2, Cc), {"circom_h_s": t1 - t0, "msm_s": t2 - t1, "assemble_s": t3 - t2, "total_s": t3 - t0}
+
     def affine(self, P, g2=False):
         """Jacobian uint64 -> canonical affine ints (or None)."""
         v = self.cp.fq.dec(P)

@@ -114,6 +114,35 @@ def run(rank, world, net_id, scenario, q, transport="shm"):
             net.close()
             return
 
+        if scenario == "dpp_zero":
+            # a zero denominator (the reference panics at the king: dpp/mod.rs:55): EVERY rank gets Generic at once -- the
+            # king's verdict crosses before the scatter (round 5: the other ranks sat in the scatter until the net's timeout)
+            ln = 1500
+            num, den = rand_fr(n * ln), rand_fr(n * ln)
+            full_n, full_d = DeviceBuffer.from_numpy(pp, num), DeviceBuffer.from_numpy(pp, den)
+            secrets = pp.unpack(full_d, ln)                  # make the packed denominators hold one zero secret
+            host = secrets.to_numpy().reshape(-1, 4).copy()
+            host[777] = 0
+            full_d = pp.pack(DeviceBuffer.from_numpy(pp, host), ln, 11)
+            den_rows = full_d.to_numpy().reshape(n, ln, 4)
+            t0 = time.time()
+            try:
+                znet.dist_d_pp(pp, net, 2, loc(num, ln), DeviceBuffer.from_numpy(pp, np.ascontiguousarray(den_rows[sel])),
+                               DegRedMask.zero(), ln, seed=9)
+                q.put((rank, False, "a zero denominator went through"))
+            except zk.ZkError as e:
+                dt = time.time() - t0
+                q.put((rank, e.code == 1 and "zero denominator" in str(e) and dt < 10.0, "code %d after %.1f s: %s" % (e.code, dt, e)))
+            # the net is still usable: the next round on the same channel runs
+            sh = rand_fr(n * 512)
+            got = znet.dist_d_fft(pp, net, 2, loc(sh, 512), FftMask.zero(), False, 10, seed=3)
+            ref = zk.d_fft(pp, DeviceBuffer.from_numpy(pp, sh), FftMask.zero(), False, 10, seed=3)
+            pp.sync()
+            net.sync(2)
+            q.put((rank, same_rows(got, ref, 512), "d_fft after the failed round"))
+            net.close()
+            return
+
         # ---- d_fft / d_ifft with masks, both output arrangements
         log_m = 12
         m = 1 << log_m

@@ -108,24 +108,31 @@ def test_chacha20_block_known_answer():
 
 
 def test_bench_line_survives_a_stuck_auxiliary_leg():
-    """bench.AuxGuard: when the legs after the timed K steps do not return, the line is printed with what is finished,
-    `aux_timeout` names the leg and the process leaves with status 0 (the watchdog thread runs while the main thread is
-    blocked); a leg that finishes in time leaves no trace."""
+    """bench.AuxGuard: when the legs after the timed K steps do not return, the line is printed ONCE with what is finished,
+    `incomplete` and `aux_timeout` (naming the leg), and the process leaves with a NON-ZERO status -- a leg that hung is
+    not a pass -- while a leg that finishes in time leaves no trace; results published through `put` while the
+    timer fires are either whole in the line or absent (the lock), never a half-mutated dict."""
     import json
     import subprocess
     import sys
     code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
             "res = {'metric': 'm', 'value': 1.5}\n"
             "g = bench.AuxGuard(res, 0.3); g.leg = 'batched 8 x 2 in flight'\n"
-            "time.sleep(float(sys.argv[1]))\n"
-            "g.done(); res['late'] = True; print(__import__('json').dumps(res))\n" % ROOT)
+            "t0 = time.time()\n"
+            "while time.time() - t0 < float(sys.argv[1]): g.put('batched', {'k': list(range(50))}, append=True)\n"
+            "res['late'] = True\n"
+            "if g.done(): print(__import__('json').dumps(res))\n" % ROOT)
     stuck = subprocess.run([sys.executable, "-c", code, "5"], capture_output=True, text=True, timeout=60)
-    assert stuck.returncode == 0, stuck.stderr
-    line = json.loads(stuck.stdout.strip().splitlines()[-1])
-    assert line["value"] == 1.5 and line["aux_timeout"]["leg"] == "batched 8 x 2 in flight" and "late" not in line
+    assert stuck.returncode == 3, (stuck.returncode, stuck.stderr)
+    lines = [ln for ln in stuck.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] == 1.5 and line["incomplete"] is True and "late" not in line
+    assert line["aux_timeout"]["leg"] == "batched 8 x 2 in flight" and all(len(b["k"]) == 50 for b in line["batched"])
     fine = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=60)
-    line = json.loads(fine.stdout.strip().splitlines()[-1])
-    assert fine.returncode == 0 and line.get("late") is True and "aux_timeout" not in line
+    lines = [ln for ln in fine.stdout.strip().splitlines() if ln.startswith("{")]
+    line = json.loads(lines[-1])
+    assert fine.returncode == 0 and len(lines) == 1 and line.get("late") is True and "aux_timeout" not in line and "incomplete" not in line
 
 
 def test_host_cores_honours_quota_and_affinity():

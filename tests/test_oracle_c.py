@@ -213,3 +213,42 @@ def test_threaded_d_fft_equals_the_serial_restatement():
             cp.d_fft_arrays(x, *args)
             cp.d_fft_arrays_mt(y, *args, king_threads=4)
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("threads,r_zero", [(1, False), (8, False), (1, True)])
+def test_local_prover_in_c_equals_the_python_oracle(threads, r_zero):
+    """BASELINE configs[0] (groth16/examples/sha256.rs:191-199): CpuProver.prove_local -- zkref_circom_ref + five G::msm over
+    the unpacked proving key + prove.rs' assembly in C -- gives the proof oracle/groth16.py create_proof_local gives, and
+    its h is circom_ref's (ext_wit.rs:239-285)."""
+    from oracle import groth16 as g
+    from oracle.cpu_prover import CpuProver
+    from test_oracle_groth16 import small_r1cs
+    Cv = BN254
+    P = Cv.r
+    r1, w = small_r1cs(nc=40)
+    key = g.setup_scalars(Cv, r1, g.Trapdoor.from_seed(42, P))
+    r, s = (0 if r_zero else rand_fp(43, 0, P)), rand_fp(43, 1, P)
+    G1, G2 = g1(Cv), g2(Cv)
+    pk = g.proving_key_points(key, G1, G2)
+    want = g.create_proof_local(Cv, r1, pk, G1, G2, w, r, s)
+    cpu = CpuProver("bn254", 2)
+    cp = cpu.cp
+    q = g.qap(Cv, r1, w)
+    log_m = q.domain.log_size
+    h = cpu.circom_ref(cp.fr.enc(q.a), cp.fr.enc(q.b), cp.fr.enc(q.c), log_m, threads)
+    assert cp.fr.dec(h) == g.circom_ref(q.a, q.b, q.c, q.domain)
+
+    def enc1(pts):
+        return np.stack([cp.fq.enc([0, 0] if p is None else [p[0], p[1]]).reshape(-1) for p in pts])
+
+    def enc2(pts):
+        return np.stack([cp.fq.enc([0, 0, 0, 0] if p is None else [p[0][0], p[0][1], p[1][0], p[1][1]]).reshape(-1) for p in pts])
+    inp = {"qap_a": cp.fr.enc(q.a), "qap_b": cp.fr.enc(q.b), "qap_c": cp.fr.enc(q.c), "log_m": log_m, "w": cp.fr.enc(w),
+           "ni": r1.num_instance_variables, "a_query": enc1(pk.a_query), "b_g1_query": enc1(pk.b_g1_query),
+           "b_g2_query": enc2(pk.b_g2_query), "l_query": enc1(pk.l_query), "h_query": enc1(pk.h_query),
+           "delta_g1": enc1([pk.delta_g1])[0], "delta_g2": enc2([pk.delta_g2])[0], "alpha_g1": enc1([pk.alpha_g1])[0],
+           "beta_g1": enc1([pk.beta_g1])[0], "beta_g2": enc2([pk.beta_g2])[0], "r": r, "s_": s}
+    (A, B, Cc), tm = cpu.prove_local(inp, threads)
+    assert cpu.affine(A) == G1.to_affine(want[0]) and cpu.affine(B, True) == G2.to_affine(want[1])
+    assert cpu.affine(Cc) == G1.to_affine(want[2])
+    assert set(tm) == {"circom_h_s", "msm_s", "assemble_s", "total_s"}

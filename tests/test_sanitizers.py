@@ -47,6 +47,23 @@ def test_host_pool_under_sanitizers(kind):
     _run(_build(kind), ["pool"], kind)
 
 
+@pytest.mark.parametrize("workers", [1, 2, 4])
+@pytest.mark.parametrize("kind", ["tsan", "asan"])
+def test_prover_gate_structure_cannot_block(kind, workers):
+    """The batched prover's launch / gate / fold tasks (device taken out) with three batches in flight on pools of 1, 2
+    and 4 workers: every bounded wait returns, every task runs (VERDICT r5 #10: no blocking waits that can starve)."""
+    _run(_build(kind), ["gates", str(workers), "40"], kind)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("kind", ["tsan", "asan"])
+def test_rccl_code_path_call_sequence_with_stubbed_send_recv(kind, world):
+    """csrc/net.hpp's RCCL branches (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd per gather, scatter, all-to-all)
+    driven at worlds 2 / 4 / 8 with the two verbs replaced by shared-memory mailboxes: every byte arrives where the SHM
+    transport puts it, and every rank's call sequence is what the rounds imply.  The real thing needs a GPU per rank."""
+    _run(_build(kind), ["rccl", str(world), "6"], kind)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("kind", ["tsan", "asan"])
 def test_star_network_host_mode_under_sanitizers(kind, world):

@@ -1,5 +1,5 @@
 """Throughput of zk_groth16_prove_batch on the SHA-256 circuit (bench.py's inputs) for a list of batch sizes.
-    python tools/batch_probe.py [B ...] [--reps R] [--no-masks] [--no-tables] [--profile]
+    python tools/batch_probe.py [B ...] [--reps R] [--inflight N] [--options host_threads=4] [--no-masks] [--no-tables] [--profile]
 Prints one JSON line per batch size: proofs/s, ms per batch, and the profile slots (HIP events around the kernels)."""
 import json
 import os
@@ -22,6 +22,11 @@ def main():
         i = args.index("--inflight")
         inflight = int(args[i + 1])
         del args[i:i + 2]
+    options = []
+    if "--options" in args:                      # name=value[,name=value]: context options set before the first proof
+        i = args.index("--options")
+        options = [kv.split("=") for kv in args[i + 1].split(",") if kv]
+        del args[i:i + 2]
     no_masks = "--no-masks" in args
     no_tables = "--no-tables" in args
     prof = "--profile" in args
@@ -31,6 +36,8 @@ def main():
     from zksaas_amd import groth16 as zg
     import bench
     pp = zk.PackedSharingParams("bn254", 2)
+    for name, value in options:
+        pp.set_option(name, int(value))
     r1, w, setup, crs, wit, r, s = bench.build_inputs(pp, zk)
     masks = None if no_masks else zg.ProofMasks(pp, wit.log_m, seed=77)
     if not no_tables:

@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zksaas.h"
@@ -187,6 +189,42 @@ class IEngine {
   virtual ~IEngine() {}
   // the context's host worker pool (nullptr before the first prover call): msm_fold splits a table-free fold over it
   virtual HostPool* host_pool() { return nullptr; }
+  // zk_ctx_set_option("wait_deadline_ms"): no host-side wait of the library (an MSM's completion event, a gate between two
+  // launches, a pool task) outlasts this; on expiry the call returns ZK_ERR_GENERIC naming what it waited for and the
+  // job is aborted.  0 = unbounded.  Default 120 s (a 2^24-constraint BLS12-381 proof takes 1.3 s).
+  std::atomic<int64_t> wait_deadline_ms{120000};
+  std::chrono::steady_clock::time_point deadline_from_now() const {
+    const int64_t ms = wait_deadline_ms.load(std::memory_order_relaxed);
+    return ms > 0 ? std::chrono::steady_clock::now() + std::chrono::milliseconds(ms)
+                  : std::chrono::steady_clock::time_point::max();
+  }
+  // hipEventSynchronize with the deadline: polls (yielding for the first 2 ms, the span of a proof's chain; then in 100 us
+  // sleeps).  hipErrorNotReady = the deadline passed.
+  hipError_t event_wait(hipEvent_t ev) const {
+    using namespace std::chrono;
+    hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    const auto t0 = steady_clock::now(), dl = deadline_from_now();
+    for (;;) {
+      e = hipEventQuery(ev);
+      if (e != hipErrorNotReady) return e;
+      const auto now = steady_clock::now();
+      if (now > dl) return hipErrorNotReady;
+      if (now - t0 < milliseconds(2)) std::this_thread::yield();
+      else std::this_thread::sleep_for(microseconds(100));
+    }
+  }
+  // a host-side gate (a flag another launching thread raises): false = the deadline passed
+  template <class Pred>
+  bool spin_until(Pred ready) const {
+    if (ready()) return true;
+    const auto dl = deadline_from_now();
+    for (unsigned i = 0;; i++) {
+      if (ready()) return true;
+      std::this_thread::yield();
+      if ((i & 1023) == 1023 && std::chrono::steady_clock::now() > dl) return false;
+    }
+  }
   Profiler prof;
   // MSM statistics since creation (zk_msm_stats): mixed additions performed and (point, window) pairs offered, G1 / G2
   std::atomic<uint64_t> msm_adds[2] = {{0}, {0}}, msm_offered[2] = {{0}, {0}};

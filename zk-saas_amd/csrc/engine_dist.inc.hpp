@@ -327,9 +327,21 @@
     if (rc) return rc;
     rc = net_err(net, net->gather(sid, mask, den, bytes, fin ? fin + (size_t)np * len : nullptr));
     if (rc) return rc;
+    // The king's verdict crosses before the scatter (one host message): a zero denominator fails the round on EVERY rank
+    // at once with the king's error -- round 5's king returned ahead of the scatter and left the other ranks waiting for
+    // the net's timeout.
+    int32_t verdict = 0;
+    Status king_err;
     if (net->rank == 0) {
-      rc = d_pp_king(fin, fin + (size_t)np * len, ps.data(), np, len, seed, fout, s);
-      if (rc) return rc;
+      verdict = d_pp_king(fin, fin + (size_t)np * len, ps.data(), np, len, seed, fout, s);
+      if (verdict) king_err = last;
+    }
+    rc = net_err(net, net->bcast_host(sid, mask, &verdict, sizeof(verdict)));
+    if (rc) return rc;
+    if (verdict) {
+      (void)net->end(sid, st);
+      if (net->rank == 0) return fail(king_err.code, king_err.msg);
+      return fail(verdict, "d_pp: the king reported a zero denominator (reference panics: dpp/mod.rs:55)");
     }
     rc = net_err(net, net->scatter(sid, mask, fout, bytes, out));
     if (rc) return rc;

@@ -263,8 +263,9 @@
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     size_t bytes = (size_t)n * (((size_t)1 << log_m) / l) * sizeof(Fr);
-    // the local stages go out of place into a context-owned vector (the first pass reads `shares`), the king reads
-    // that and writes the destination: no copy back, and `shares` is left untouched when `out` is given
+    // the local stages go out of place into the caller stream's working vector (the first pass reads `shares`), the king
+    // reads that and writes the destination: no copy back, and `shares` is left untouched when `out` is given
+    DevBuf& king_tmp_ = ws(st)->king_tmp;
     ZK_HIP(king_tmp_.ensure(bytes));
     NttSrc<Fr> src{};
     src.p[0] = (const Fr*)shares;
@@ -282,6 +283,7 @@
     int log_l = ilog2(l);
     if (log_m < log_l) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     size_t m = (size_t)1 << log_m, Lc = m / l;
+    DevBuf& scratch_ = ws(st)->scratch;
     ZK_HIP(scratch_.ensure(m * sizeof(Fr)));
     Fr* vals = (Fr*)scratch_.p;   // layout [l][Lc]: value k*l+s at [s][k]
     rand_fill_kernel<Fr><<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st>>>(vals, rs(seed), m, (uint32_t)l,
@@ -371,6 +373,7 @@
   int degred_mask_sample(size_t len, uint64_t seed, void* in_mask, void* out_mask, hipStream_t st) override {
     if (!len) return ZK_OK;
     size_t cnt = len * l;
+    DevBuf& scratch_ = ws(st)->scratch;
     ZK_HIP(scratch_.ensure(cnt * sizeof(Fr)));
     Fr* vals = (Fr*)scratch_.p;
     rand_fill_kernel<Fr><<<dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st>>>(vals, rs(seed), cnt, (uint32_t)l,
@@ -393,6 +396,10 @@
              const Fr* out_mask, const RngSeed& seed, Fr* out, hipStream_t st) {
     constexpr size_t TILE = DppGeom<E>::TILE;
     const size_t m = len * L, ntiles = (m + TILE - 1) / TILE;
+    StreamWs* w_ = ws(st);                              // scratch and error word of THIS stream (two d_pp on two stream ids never meet)
+    if (!w_->err) return fail(ZK_ERR_GENERIC, "d_pp: out of device memory");
+    DevBuf& scratch_ = w_->scratch;
+    int* const err_flag_ = w_->err;
     ZK_HIP(scratch_.ensure((m + 3 * ntiles) * sizeof(Fr)));
     Fr* y = (Fr*)scratch_.p;
     Fr* tile_n = y + m;
@@ -448,11 +455,12 @@
       case 1: rc = dpp_l<1>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
       case 2: rc = dpp_l<2>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
       case 4: rc = dpp_l<4>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
-      default: rc = dpp_l<8>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
+      case 8: rc = dpp_l<8>(num, den, np, len, U, Ufull, in_mask, out_mask, r, out, st); break;
+      default: return fail(ZK_ERR_BAD_INPUT, "d_pp is built for packing factors 1, 2, 4 and 8");
     }
     if (rc) return rc;
     int herr = 0;
-    ZK_HIP(hipMemcpyAsync(&herr, err_flag_, sizeof(int), hipMemcpyDeviceToHost, st));
+    ZK_HIP(hipMemcpyAsync(&herr, ws(st)->err, sizeof(int), hipMemcpyDeviceToHost, st));
     ZK_HIP(hipStreamSynchronize(st));
     if (herr) return fail(ZK_ERR_GENERIC, "d_pp: zero denominator (reference panics: dpp/mod.rs:55)");
     return ZK_OK;

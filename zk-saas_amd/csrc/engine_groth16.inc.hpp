@@ -29,7 +29,7 @@
   }
   int circom_h(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
                void* h, hipStream_t st) override {
-    return circom_h_ws(qa, qb, qc, log_m, mk, seed, h, hwork_, st);
+    return circom_h_ws(qa, qb, qc, log_m, mk, seed, h, ws(st)->hwork, st);
   }
   int circom_h_ws(const void* qa, const void* qb, const void* qc, int log_m, const zk_groth16_masks* mk, uint64_t seed,
                   void* h, DevBuf& hwork, hipStream_t st) {
@@ -176,10 +176,56 @@
     memcpy(&a, p, sizeof(a));
     return P2::from_affine(a);
   }
-  void drain(ProveJob& j) {
-    for (auto& f : j.fut)
-      if (f.valid()) f.wait();
-    j.fut.clear();
+  // ---- bounded waits (round 6, VERDICT r5 #10 / ADVICE r5): every wait of a job is bounded by the context's deadline
+  // (engine.hpp wait_deadline_ms).  A wait that expires leaves device work or a pool task that still references the
+  // job's buffers: the job's slot is then never reused (it stays `active`), the context is marked wedged -- later prover
+  // calls fail at once with the first message -- and the state of every gate / event of the job goes to stderr.
+  std::atomic<bool> wedged_{false};
+  std::string wedged_msg_;
+  int wedge(const std::string& what) {
+    bool was = wedged_.exchange(true);
+    if (!was) {
+      std::lock_guard<std::mutex> lk(last_mu);
+      wedged_msg_ = what;
+    }
+    return fail(ZK_ERR_GENERIC, what);
+  }
+  static const char* ev_state(hipEvent_t e) {
+    if (!e) return "none";
+    hipError_t q = hipEventQuery(e);
+    return q == hipSuccess ? "done" : (q == hipErrorNotReady ? "PENDING" : hipGetErrorString(q));
+  }
+  static int futs_pending(std::vector<std::future<void>>& fut) {
+    int np = 0;
+    for (auto& f : fut)
+      if (f.valid() && f.wait_for(std::chrono::seconds(0)) != std::future_status::ready) np++;
+    return np;
+  }
+  // joins the pool tasks of a job; false = some did not finish within the deadline (they stay in `fut`)
+  bool drain_futs(std::vector<std::future<void>>& fut) {
+    const auto dl = deadline_from_now();
+    for (auto& f : fut)
+      if (f.valid() && f.wait_until(dl) != std::future_status::ready) return false;
+    fut.clear();
+    return true;
+  }
+  bool drain(ProveJob& j) { return drain_futs(j.fut); }
+  // waits for a launched MSM's device work without folding it (abort paths); false = deadline
+  bool settle(MsmPending* p) {
+    if (!p->active) return true;
+    hipError_t e = event_wait(p->slot->ev);
+    if (e == hipErrorNotReady) return false;
+    p->active = false;
+    p->tab.reset();
+    p->tab2.reset();
+    return true;
+  }
+  void dump_job(const char* why, ProveJob& j) {
+    fprintf(stderr, "[zksaas] %s: proof slot %d: pool tasks pending %d, sorted_cnt %d; MSM events S+H %s%s, V %s%s, W %s%s, U %s%s\n",
+            why, j.slot, futs_pending(j.fut), j.sorted_cnt.load(), j.pS.active ? "" : "(idle) ",
+            j.pS.slot ? ev_state(j.pS.slot->ev) : "-", j.pV0.active ? "" : "(idle) ", j.pV0.slot ? ev_state(j.pV0.slot->ev) : "-",
+            j.pW.active ? "" : "(idle) ", j.pW.slot ? ev_state(j.pW.slot->ev) : "-", j.pU.active ? "" : "(idle) ",
+            j.pU.slot ? ev_state(j.pU.slot->ev) : "-");
   }
   // engine-level failure recorded from a pool task (IEngine::fail is not thread-safe)
   int task_fail(ProveJob& j, int code, const std::string& msg) {
@@ -415,7 +461,15 @@
   // joins everything; sums[0..4] = S, H, V, W, U including the in-mask terms
   int prove_join(ProveJob& j, P1* S, P1* H, P2* V, P1* W, P1* U) {
     int rc = msm_.template finish_t<Fq_>(this, &j.pU, &j.U);
-    drain(j);
+    if (rc && j.pU.active) {
+      dump_job("prove_join: the U-MSM chain did not finish within the deadline", j);
+      Status keep = last;
+      return wedge(keep.msg);
+    }
+    if (!drain(j)) {
+      dump_job("prove_join: pool tasks did not finish within the deadline", j);
+      return wedge("host tasks of the proof did not finish within the deadline (wait_deadline_ms); the slot is not reused");
+    }
     j.active = false;
     if (rc) return rc;
     for (int i = 0; i < 8; i++)
@@ -438,7 +492,10 @@
   // references the job's buffers.)
   int prove_end(ProveJob& j, void* pi_a, void* pi_b, void* pi_c) {
     const auto t0 = std::chrono::steady_clock::now();
-    drain(j);
+    if (!drain(j)) {
+      dump_job("zk_groth16_wait: pool tasks did not finish within the deadline", j);
+      return wedge("zk_groth16_wait: host tasks of the proof did not finish within the deadline (wait_deadline_ms); the slot is not reused");
+    }
     bool early_ok = !j.err.code;
     for (int i = 0; i < 8; i++) early_ok = early_ok && !j.rc[i];
     std::vector<P1> c_part(early_ok ? n : 0);
@@ -450,7 +507,7 @@
       if (rc) early_ok = false;
     }
     const auto t1 = std::chrono::steady_clock::now();
-    if (prof.on && j.pU.active) (void)hipEventSynchronize(j.pU.slot->ev);       // (finish_t waits again: returns at once)
+    if (prof.on && j.pU.active) (void)event_wait(j.pU.slot->ev);                // (finish_t waits again: returns at once)
     const auto t2 = std::chrono::steady_clock::now();
     struct HostSpans {                                                          // host:prove_wait / host:prove_tail
       Profiler& pr;
@@ -463,6 +520,11 @@
     } spans{prof, t0, t2};
     (void)t1;
     int rc = msm_.template finish_t<Fq_>(this, &j.pU, &j.U);
+    if (rc && j.pU.active) {               // the U chain's event did not signal within the deadline: nothing may be reused
+      dump_job("zk_groth16_wait: the U-MSM chain did not finish within the deadline", j);
+      Status keep = last;
+      return wedge(keep.msg);
+    }
     j.active = false;
     if (rc) return rc;
     for (int i = 0; i < 8; i++)
@@ -527,6 +589,14 @@
 
   int check_prove_args(const zk_crs_share* crs, const void* r_, const void* s_, int log_m) {
     if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
+    if (wedged_.load()) {
+      std::string m;
+      {
+        std::lock_guard<std::mutex> lk(last_mu);
+        m = wedged_msg_;
+      }
+      return fail(ZK_ERR_GENERIC, "the context is wedged by an earlier timed-out wait (destroy it): " + m);
+    }
     if (!crs || !r_ || !s_) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     int log_l = ilog2(l);
     if (log_m < log_l || log_m + 1 > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
@@ -581,15 +651,16 @@
   // joins a job's tasks and device work and marks it free (after an error, or zk_groth16_abort)
   void abort_job(ProveJob& j) {
     j.sorted_cnt.fetch_add(1 << 20, std::memory_order_release);      // tasks waiting at the sort barrier go on (and fail or finish)
-    drain(j);
+    bool ok = drain(j);
     MsmPending* ps[4] = {&j.pS, &j.pV0, &j.pW, &j.pU};
-    for (MsmPending* p : ps)
-      if (p->active) {
-        (void)hipEventSynchronize(p->slot->ev);
-        p->active = false;
-        p->tab.reset();
-        p->tab2.reset();
-      }
+    for (MsmPending* p : ps) ok = settle(p) && ok;
+    if (!ok) {
+      dump_job("abort: work of the proof is still pending after the deadline", j);
+      Status keep = last;
+      wedge("a proof could not be aborted within the deadline (wait_deadline_ms): its slot is not reused");
+      if (keep.code) last = keep;
+      return;                                                        // stays active: nothing of it is reused
+    }
     j.active = false;
   }
   // also the abort of a sharded proof in flight (zk_dist_groth16_prove_async hands out handles of the same space): the
@@ -637,18 +708,26 @@
   };
   BatchJobX bjobs_[NBATCH];
 
-  void abort_batch(BatchJob& B) {
-    for (auto& f : B.fut)
-      if (f.valid()) f.wait();
-    B.fut.clear();
+  void dump_batch(const char* why, BatchJobX& B) {
+    const MsmPending* ps[4] = {&B.pV, &B.pSH, &B.pW, &B.pU};
+    const char* nm[4] = {"V", "S+H", "W", "U"};
+    fprintf(stderr, "[zksaas] %s: batch slot %d (%d proofs): pool tasks pending %d;", why, B.slot, B.nb, futs_pending(B.fut));
+    for (int i = 0; i < 4; i++)
+      fprintf(stderr, " %s: launched-flag %d, accumulate event %s, chain event %s%s;", nm[i], B.acc_flag[i].load(), ev_state(B.ev_acc[i]),
+              ps[i]->slot ? ev_state(ps[i]->slot->ev) : "-", ps[i]->active ? "" : " (idle)");
+    fprintf(stderr, "\n");
+  }
+  void abort_batch(BatchJobX& B) {
+    bool ok = drain_futs(B.fut);
     MsmPending* ps[4] = {&B.pSH, &B.pV, &B.pW, &B.pU};
-    for (MsmPending* p : ps)
-      if (p->active) {
-        (void)hipEventSynchronize(p->slot->ev);
-        p->active = false;
-        p->tab.reset();
-        p->tab2.reset();
-      }
+    for (MsmPending* p : ps) ok = settle(p) && ok;
+    if (!ok) {
+      dump_batch("abort: work of the batch is still pending after the deadline", B);
+      Status keep = last;
+      wedge("a batch could not be aborted within the deadline (wait_deadline_ms): its slot is not reused");
+      if (keep.code) last = keep;
+      return;
+    }
     B.active = false;
   }
 
@@ -834,7 +913,10 @@
       };
       for (int b = 1; b < nb; b++) sub.push_back(pool_->submit([=]() { fin(b); }));
       fin(0);
-      for (auto& f : sub) f.get();
+      // (the sub-tasks reference this frame: the task runs queued work while it waits, HostPool::wait_helping -- a pool
+      // whose workers all sit here with their sub-tasks queued behind them cannot starve)
+      for (auto& f : sub)
+        while (!pool_->wait_helping(f, deadline_from_now())) {}
     }));
     B.fut.push_back(pool_->submit([=]() {
       (void)hipSetDevice(dev);
@@ -863,14 +945,16 @@
     std::vector<P1> ures((size_t)nb);
     int rc = msm_fold_batch<Fq_>(this, B.pU, ures.data(), 1);
     if (rc) {
+      if (B.pU.active) dump_batch("zk_groth16_batch_wait: the U-MSM chain did not finish within the deadline", B);
       Status keep = last;
       abort_batch(B);
       last = keep;
       return rc;
     }
-    for (auto& f : B.fut)
-      if (f.valid()) f.wait();
-    B.fut.clear();
+    if (!drain_futs(B.fut)) {
+      dump_batch("zk_groth16_batch_wait: pool tasks did not finish within the deadline", B);
+      return wedge("zk_groth16_batch_wait: host tasks of the batch did not finish within the deadline (wait_deadline_ms); the slot is not reused");
+    }
     B.active = false;
     for (int i = 0; i < 4; i++)
       if (B.rc[i]) return B.rc[i];
@@ -1016,6 +1100,7 @@
     if (log_m < ilog2(l) || log_m > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "Mismatch of size in FFT");
     if (!qa || !qb || !qc || !h) return fail(ZK_ERR_BAD_INPUT, "null pointer");
     const size_t Lc = ((size_t)1 << log_m) / l, per = (size_t)n * Lc;
+    DevBuf& hwork_ = ws(st)->hwork;
     ZK_HIP(hwork_.ensure(6 * per * sizeof(Fr)));
     Fr* W0 = (Fr*)hwork_.p;
     Fr* W1 = W0 + 3 * per;

@@ -77,7 +77,6 @@ class Engine : public IEngine {
     if (pjsf_) (void)hipFree(pjsf_);
     if (pack2_) (void)hipFree(pack2_);
     if (ident_) (void)hipFree(ident_);
-    if (err_flag_) (void)hipFree(err_flag_);
     if (rng_key_d_) (void)hipFree(rng_key_d_);
     if (u2c_) (void)hipFree(u2c_);
     for (auto& kv : ucanon_) (void)hipFree(kv.second);
@@ -92,7 +91,6 @@ class Engine : public IEngine {
     if (l != 1 && l != 2 && l != 4 && l != 8) return fail(ZK_ERR_BAD_INPUT, "packing factor l must be 1, 2, 4 or 8");
     if (ilog2(n) > FrP::TWO_ADICITY) return fail(ZK_ERR_BAD_INPUT, "domain too large");
     build_matrices();
-    ZK_HIP(hipMalloc(&err_flag_, sizeof(int)));
     // share randomness: ChaCha20 keyed from the operating system's generator (prng.hpp); the context option "rng_replay"
     // selects the documented replayable stream the parity tests compare shares with
     FILE* f = fopen("/dev/urandom", "rb");
@@ -420,7 +418,6 @@ class Engine : public IEngine {
   bool ntt_attr_set_[2] = {false, false};
   bool dpp_attr_set_[2] = {false, false};
   std::map<std::string, void*> base_tables_;
-  DevBuf hwork_;
   Fr* pmat_ = nullptr;
   std::vector<Fr> pmat_host_;
   DevBuf flag_;   // 4-byte device flag for the validating kernels
@@ -428,14 +425,34 @@ class Engine : public IEngine {
   uint8_t* pjsf_ = nullptr;     // joint-sparse-form digits of the first two pack columns (pss_pack_points at 2 points per chunk)
   PackL2<Fr>* pack2_ = nullptr;
   Fr* ident_ = nullptr;
-  int* err_flag_ = nullptr;
   std::map<uint64_t, Fr*> umats_;
   std::map<int, Fr*> gentabs_;
   std::map<int, Fr*> sizeinv_;
   std::map<std::string, GTab> gtabs_;
   std::mutex mu_;
-  DevBuf scratch_;
-  DevBuf king_tmp_;
+  // Working memory of the all-parties-on-one-GPU entry points, ONE SET PER CALLER STREAM (round 6; round 5 had one per context
+  // and documented "concurrent transforms are undefined", against SURVEY.md 8b: up to three d_ifft / d_fft run at once on
+  // three stream ids, ext_wit.rs:127-159).  Calls on one stream are ordered by the stream, so they may share a set; calls on
+  // different streams -- the three channels of a rank, a host that overlaps two transforms -- never meet.  `err`: the
+  // zero-denominator word of d_pp.  Growth frees the old buffer with hipFree, which waits for the device.
+  struct StreamWs {
+    DevBuf scratch, king_tmp, hwork;
+    int* err = nullptr;
+    ~StreamWs() {
+      if (err) (void)hipFree(err);
+    }
+  };
+  std::mutex ws_mu_;
+  std::map<hipStream_t, std::unique_ptr<StreamWs>> ws_;
+  StreamWs* ws(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(ws_mu_);
+    std::unique_ptr<StreamWs>& w = ws_[st];
+    if (!w) {
+      w.reset(new StreamWs());
+      if (hipMalloc((void**)&w->err, sizeof(int)) != hipSuccess) w->err = nullptr;
+    }
+    return w.get();
+  }
   MsmRunner<Cfg> msm_;
 };
 

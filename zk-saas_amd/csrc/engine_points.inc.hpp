@@ -240,6 +240,11 @@
       msm_.table_c_g2 = (int)value;
       return ZK_OK;
     }
+    if (!strcmp(name, "wait_deadline_ms")) {      // bound of every host-side wait of the prover (engine.hpp); 0 = unbounded
+      if (value < 0 || value > 86400000) return fail(ZK_ERR_BAD_INPUT, "wait_deadline_ms must be in 0..86400000");
+      wait_deadline_ms.store(value, std::memory_order_relaxed);
+      return ZK_OK;
+    }
     if (!strcmp(name, "host_threads")) {          // workers of the host pool (MSM launch / fold tasks, scalar multiples)
       if (value < 0 || value > 256) return fail(ZK_ERR_BAD_INPUT, "host_threads must be in 0..256");
       if (value && value < 4) return fail(ZK_ERR_BAD_INPUT, "host_threads must be 0 (automatic) or at least 4");

@@ -726,7 +726,9 @@ struct Fp {
     // V < (NT / 2 + 1) p: subtract 2^j p while it fits, j = J-1 .. 0 with 2^J >= NT / 2 + 1
     constexpr int B = NT / 2 + 1;
     constexpr int J = B <= 2 ? 1 : B <= 4 ? 2 : B <= 8 ? 3 : B <= 16 ? 4 : 5;
-    static_assert(NT <= 32 && (P::MOD[N - 1] >> 31) == 0, "dot_k: bound");
+    // (odd NT: the accumulated value can reach (NT + 1) / 2 + 1/2 times p, above B p with the integer division -- ADVICE r5;
+    // only even term counts are instantiated, and only they are accepted)
+    static_assert(NT % 2 == 0 && NT <= 32 && (P::MOD[N - 1] >> 31) == 0, "dot_k: bound");
 #pragma unroll
     for (int j = J - 1; j >= 0; j--) {
       const ModSh M = mod_shl(j);

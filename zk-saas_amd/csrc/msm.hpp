@@ -419,6 +419,9 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
 #endif
   __syncthreads();
   if (!last_sh) return;
+  // the acquire half of the edge is free (one workgroup per sort invalidates its caches); the release half is what cost
+  // 3.8 % of a proof and stays the hardware argument above (stated in include/zksaas.h, "Memory-model note")
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   uint32_t* bin_base = bins + nbins + 1;
   uint32_t* bin_cursor = bin_base + nbins + 1;
   // all counts into LDS first (independent loads, all in flight), then the scan reads LDS
@@ -1596,7 +1599,13 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
   for (int i = 0; i < nvec * batch; i++) results[i] = XYZZ<Fld>::identity();
   if (!p.active) return ZK_OK;
   p.active = false;
-  hipError_t he = hipEventSynchronize(p.slot->ev);
+  hipError_t he = eng->event_wait(p.slot->ev);
+  if (he == hipErrorNotReady) {
+    // the tables stay referenced (the kernels may still run); the caller aborts the job
+    p.active = true;
+    return eng->fail(ZK_ERR_GENERIC, std::string("msm fold: the completion event of a ") + (p.g2 ? "G2" : "G1") +
+                                         " MSM chain did not signal within the deadline (zk_ctx_set_option wait_deadline_ms)");
+  }
   p.tab.reset();
   p.tab2.reset();
   if (he != hipSuccess) return eng->hip_fail(he, "msm event");
@@ -1653,7 +1662,8 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
         futs.push_back(pool->submit([=, &fold_range]() { *dst = fold_range(h, kwin - 1, 0); }));
       }
       results[0] = fold_range(sets_of(0, 0), kwin - 1, 0);
-      for (auto& f : futs) f.get();
+      for (auto& f : futs)
+        while (!pool->wait_helping(f, eng->deadline_from_now())) {}      // the sub-tasks reference this frame: never leave before them
     } else {
       for (int i = 0; i < jobs; i++) results[i] = fold_range(sets_of(i / batch, i % batch), kwin - 1, 0);
     }
@@ -1709,7 +1719,8 @@ int msm_fold_batch(IEngine* eng, MsmPending& p, XYZZ<Fld>* results, int nvec) {
       futs.push_back(pool->submit([=, &fold_part]() { *dst = fold_part(h, a, b); }));
     }
   part[0][0] = fold_part(hall, hi_w[0], lo_w[0]);
-  for (auto& f : futs) f.get();
+  for (auto& f : futs)
+    while (!pool->wait_helping(f, eng->deadline_from_now())) {}          // the sub-tasks reference this frame: never leave before them
   for (int v = 0; v < nvec; v++) {
     XYZZ<Fld> total = part[v][0];
     for (int g = 1; g < nparts; g++) total = xyzz_add_ni(total, part[v][g]);

@@ -304,13 +304,17 @@ do {                                                                           \
     MSM_HIP(hipEventRecord(tune.gate.sorted_ev, st));
     if (tune.gate.sorted_cnt) tune.gate.sorted_cnt->fetch_add(1, std::memory_order_release);
   }
+  // the two host-side gates are bounded by the context's deadline (round 6): a launch that never comes -- the task that
+  // would raise the flag failed before it, or never ran -- is an error with a name, not a spin for ever
   if (tune.gate.n_wait_sorted) {
-    while (tune.gate.sorted_cnt->load(std::memory_order_acquire) < tune.gate.sorted_need) std::this_thread::yield();
+    if (!eng->spin_until([&] { return tune.gate.sorted_cnt->load(std::memory_order_acquire) >= tune.gate.sorted_need; }))
+      return eng->fail(ZK_ERR_GENERIC, "msm launch: the sorts of the proof's other MSMs were not all enqueued within the deadline (" +
+                                           std::to_string(tune.gate.sorted_cnt->load()) + " of " + std::to_string(tune.gate.sorted_need) + ")");
     for (int i = 0; i < tune.gate.n_wait_sorted; i++) MSM_HIP(hipStreamWaitEvent(st, tune.gate.wait_sorted[i], 0));
   }
   if (tune.gate.wait_ev) {
-    if (tune.gate.wait_flag)
-      while (!tune.gate.wait_flag->load(std::memory_order_acquire)) std::this_thread::yield();
+    if (tune.gate.wait_flag && !eng->spin_until([&] { return tune.gate.wait_flag->load(std::memory_order_acquire) != 0; }))
+      return eng->fail(ZK_ERR_GENERIC, "msm launch: the accumulate kernel ahead of this one in the batch's chain was not enqueued within the deadline");
     MSM_HIP(hipStreamWaitEvent(st, tune.gate.wait_ev, 0));
   }
   if constexpr (G2FLD) {

@@ -87,8 +87,12 @@ struct Rccl {
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   void* handle = nullptr;
+  // TEST HARNESS ONLY (tests/native/net_stress.cpp): the table was filled with stand-ins for ncclSend / ncclRecv so that the
+  // RCCL branches of gather / scatter / alltoall -- group construction, peers, byte counts -- run on a box without GPUs
+  // (host mode).  Nothing in the library sets it.
+  bool stub = false;
   bool load(std::string* err) {
-    if (handle) return true;
+    if (handle || stub) return true;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {
       handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
@@ -180,7 +184,7 @@ class Net {
     }
     if (!id) return fail("net id missing");
     if (transport != ZK_NET_RCCL && transport != ZK_NET_SHM) return fail("unknown transport");
-    if (host_mode && transport == ZK_NET_RCCL) return fail("RCCL needs a GPU context");
+    if (host_mode && transport == ZK_NET_RCCL && !Rccl::inst().stub) return fail("RCCL needs a GPU context");
     uint64_t hsh = 1469598103934665603ull;          // FNV-1a over the id: the name of the shared control block
     for (int i = 0; i < 128 * NET_NSID; i++) hsh = (hsh ^ id[i]) * 1099511628211ull;
     char tag[40];
@@ -364,7 +368,7 @@ class Net {
             continue;
           }
           char* dst = (char*)full + (size_t)pos[party(r, i)] * rb;
-          if (r == 0) rc = hipMemcpyAsync(dst, src, rb, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          if (r == 0) rc = copy_dd(dst, src, rb, sid);
           else rc = R.Recv(dst, rb, 1, r, comm_[sid], stream_[sid]);
         }
       }
@@ -380,7 +384,7 @@ class Net {
         for (int r = 0; r < world && !rc; r++) {
           if (!(mask & (1u << r))) continue;
           char* dst = (char*)full + (size_t)slot * bytes;
-          if (r == 0) rc = hipMemcpyAsync(dst, local, bytes, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          if (r == 0) rc = copy_dd(dst, local, bytes, sid);
           else rc = R.Recv(dst, bytes, /*ncclUint8*/ 1, r, comm_[sid], stream_[sid]);
           slot++;
         }
@@ -446,7 +450,7 @@ class Net {
             continue;
           }
           const char* src = (const char*)full + (size_t)party(r, i) * rb;     // the king's output is [n][len] by party id
-          if (r == 0) rc = hipMemcpyAsync(dst, src, rb, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          if (r == 0) rc = copy_dd(dst, src, rb, sid);
           else rc = R.Send(src, rb, 1, r, comm_[sid], stream_[sid]);
         }
       }
@@ -461,7 +465,7 @@ class Net {
         for (int r = 0; r < world && !rc; r++) {
           if (!(mask & (1u << r))) continue;
           const char* src = (const char*)full + (size_t)r * bytes;        // the king's output is [n][len]: all parties
-          if (r == 0) rc = hipMemcpyAsync(local, src, bytes, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          if (r == 0) rc = copy_dd(local, src, bytes, sid);
           else rc = R.Send(src, bytes, 1, r, comm_[sid], stream_[sid]);
         }
       } else {
@@ -530,7 +534,7 @@ class Net {
         const char* src = (const char*)send + (size_t)r * bytes;
         char* dst = (char*)recv + (size_t)i * bytes;
         if (r == rank) {
-          rc = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_[sid]) == hipSuccess ? 0 : 1;
+          rc = copy_dd(dst, src, bytes, sid);
         } else {
           rc = R.Send(src, bytes, 1, r, comm_[sid], stream_[sid]);
           if (!rc) rc = R.Recv(dst, bytes, 1, r, comm_[sid], stream_[sid]);

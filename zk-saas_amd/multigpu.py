@@ -230,6 +230,42 @@ def _step_traffic(pmc_file, parts):
     return int(tot)
 
 
+XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU (MI355X_MICROARCH.md): a star's traffic crosses GPU 0's links
+
+
+def _net_model(net, dist, torch, world, king, before, steps, s_per_step):
+    """What crossed the net per step (zk_net_stats deltas of every rank over warm-up + timed steps) and what that costs on
+    xGMI by a committed model, so that the first multi-GPU hardware curve can be checked against a prediction made before it
+    (RCCL between several ranks has never run: the pool's boxes have one GPU).
+    Star (gather / scatter through rank 0): every byte crosses exactly one of GPU 0's links, the world - 1 peers' links carry
+    their shares in parallel, gather and scatter of a round follow each other: t = bytes_total / (world - 1) / 153 GB/s.
+    All-to-all king: every rank sends world - 1 equal blocks over world - 1 links at once: t = max_rank(bytes) / (world - 1) / 153 GB/s."""
+    after = net.stats()
+    d = {k: (after[k] - before[k]) / steps for k in after}
+    per_rank = [d["bytes_sent"]]
+    if dist is not None:
+        t = torch.tensor([d["bytes_sent"]], dtype=torch.float64)
+        allr = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, t)
+        per_rank = [float(x.item()) for x in allr]
+    out = {"net_per_step": {"gathers": round(d["gathers"], 2), "scatters": round(d["scatters"], 2),
+                            "alltoalls": round(d["alltoalls"], 2), "bytes_sent_by_rank": [int(b) for b in per_rank],
+                            "bytes_total": int(sum(per_rank))}}
+    if world > 1:
+        links = world - 1
+        if king == "star":
+            t_x = sum(per_rank) / links / (XGMI_LINK_GBS * 1e9)
+        else:
+            t_x = max(per_rank) / links / (XGMI_LINK_GBS * 1e9)
+        out["xgmi_prediction"] = {"links_per_direction": links, "link_GBps": XGMI_LINK_GBS, "king": king,
+                                  "seconds_per_step": round(t_x, 9), "share_of_ms_per_step": round(t_x / s_per_step, 4),
+                                  "model": "star: bytes_total / (world - 1) links / 153 GB/s (every byte crosses one link of GPU 0; "
+                                           "gather and scatter are sequential); all-to-all king: max over ranks instead of the total. "
+                                           "Latency per exchange (~10-20 us per ncclGroupEnd) is NOT in the model: %d exchanges per "
+                                           "step" % int(round(d["gathers"] + d["scatters"] + 2 * d["alltoalls"]))}
+    return out
+
+
 def _king_words(king, world):
     if world == 1:
         return "all parties on one GPU"
@@ -270,6 +306,9 @@ def bench(args, rank, local_rank, world):
             "rccl_ranks": world if transport == "rccl" else 0}
     if note:
         base["transport_note"] = note
+    if world > 1 and transport != "rccl" and os.environ.get("ZK_NET", "rccl") == "rccl":
+        # asked for RCCL over xGMI, measured something else (host-staged shared memory): the number is NOT a scaling point
+        base["degraded"] = True
     eb = pp.fr.nbytes
     per = lambda dt: dt / args.steps
     # ONE dealer: every rank derives the same dealing (witness / QAP shares, masks) from the seeds below and keeps its
@@ -282,7 +321,11 @@ def bench(args, rank, local_rank, world):
     def timed(step):
         if not api.DEFAULT_OPTIONS.get("rng_replay"):
             pp.set_option("rng_replay", 0)
-        return _timed(dist, torch, step, args.steps, args.warmup)
+        before = net.stats()
+        dt = _timed(dist, torch, step, args.steps, args.warmup)
+        if "net_per_step" not in base:               # the headline's region (later calls are side legs)
+            base.update(_net_model(net, dist, torch, world, king, before, args.steps + args.warmup, dt / args.steps))
+        return dt
     if wl == "c2":
         log_m = 20
         m = 1 << log_m
