@@ -532,8 +532,18 @@ def cpu_baseline_c5(pp, zk, log_m_full):
     if not api.DEFAULT_OPTIONS.get("rng_replay"):
         pp.set_option("rng_replay", 0)
     scale = 1 << (log_m_full - lg)
+    growth = None
+    try:      # the measured growth of this same leg from 2^20 to 2^22 (tools/c5_cpu_growth.py, committed), beside the linear guess
+        g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_c5_cpu_growth.json")))
+        per_doubling = (g["seconds_2^22"] / g["seconds_2^20"]) ** 0.5
+        growth = {"measured": g, "per_doubling": round(per_doubling, 4),
+                  "value_with_measured_growth": round(1.0 / (total * per_doubling ** (log_m_full - lg)), 6),
+                  "note": "`value` keeps the linear extrapolation (x2 per doubling); this figure compounds the growth measured "
+                          "between 2^20 and 2^22 over the %d doublings to 2^%d" % (log_m_full - lg, log_m_full)}
+    except (OSError, ValueError, KeyError):
+        pass
     return {"value": round(1.0 / (total * scale), 6), "unit": "proofs/s", "cores": min(cores, n * per), "kind": "port",
-            "extrapolated": scale > 1,
+            "extrapolated": scale > 1, "growth": growth,
             "sample": "one proof of the same synthetic BLS12-381 instance at 2^%d - 2 constraints (zero masks -- the "
                       "timed GPU workload applies all twelve, which costs the CPU no MSM work): %.2f s = circom_h %.2f s + the 5 x %d G::msm %.2f s; `value` = 1 / (that x %d), "
                       "a LINEAR extrapolation to 2^%d constraints" % (lg, total, t1 - t0, n, t2 - t1b, scale, log_m_full),

@@ -100,10 +100,14 @@ int zk_vec_mul_sub(zk_ctx* ctx, void* out_d, const void* a_d, const void* b_d, c
  * zk_d_fft / zk_d_ifft: :99-175 for all n parties resident on this device: shares_d [n][m/l], masks [n][m/l] each or
  *          NULL for FftMask::zero.  The result is written to out_d [n][m/l] (shares_d is then left as it was);
  *          out_d == NULL or == shares_d returns it in shares_d.  The local stages run out of place into a
- *          context-owned vector and the king step writes the destination, so neither form costs a copy.
- *          That vector is ONE per context: d_fft / d_ifft / libsnark_h calls on the same context must be ordered on
- *          one stream (or by events); concurrent transforms need separate contexts.  (The prover's own transforms
- *          use per-proof scratch and are not affected.) */
+ *          working vector and the king step writes the destination, so neither form costs a copy.
+ *          RE-ENTRANT ACROSS STREAMS (round 6): the working memory of zk_d_fft / zk_d_ifft / zk_libsnark_h / zk_circom_h /
+ *          zk_d_pp / zk_fft_mask_sample / zk_degred_mask_sample (and of the zk_dist_* forms, per channel) belongs to the
+ *          `stream` the call is issued on -- calls on one stream are ordered by it and share a set, calls on different
+ *          streams never meet (the reference runs three d_ifft at once on three stream ids, groth16/src/ext_wit.rs:127-159;
+ *          tests/test_gpu_hardening.py runs two streams against the serial results).  d_pp's zero-denominator word is per
+ *          stream as well.  The point kernels (zk_pss_*_points, zk_deg_red_points, zk_groth16_reconstruct) keep
+ *          per-context scratch: order them on one stream. */
 int zk_fft1(zk_ctx* ctx, void* shares_d, int log2_m, int inverse, size_t batch, const void* add_d, void* stream);
 /* Parity-test access to the BASE-field primitives of the group kernels (arkworks' Fq / Fq2 arithmetic, a22; Montgomery Fq
  * elements on the device): op 0: out[i] = a[i] b[i] - c[i] d[i] (the one-reduction form used for Y3 of every XYZZ

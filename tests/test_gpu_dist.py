@@ -107,9 +107,13 @@ def test_bench_ranks_as_the_driver_launches_it(workload, ranks):
     assert res["king"] == "star" and "transport_note" not in res and "degraded" not in res      # (shm was ASKED for here)
     # what crossed the net per step and the committed xGMI prediction for it (the first hardware curve is checked against it)
     nps, xg = res["net_per_step"], res["xgmi_prediction"]
-    assert len(nps["bytes_sent_by_rank"]) == ranks and nps["bytes_total"] == sum(nps["bytes_sent_by_rank"]) > 0
-    assert nps["gathers"] >= 1 and nps["scatters"] >= (0 if workload == "c3" else 1)
-    assert xg["links_per_direction"] == ranks - 1 and 0 < xg["seconds_per_step"] < res["ms_per_step"] / 1e3
+    assert len(nps["bytes_sent_by_rank"]) == ranks and nps["bytes_total"] == sum(nps["bytes_sent_by_rank"])
+    assert xg["links_per_direction"] == ranks - 1
+    if workload == "c3":            # d_msm's king step is one small HOST message per rank and one answer (dmsm/mod.rs:76-92): no device bytes
+        assert nps["bytes_total"] == 0 and xg["seconds_per_step"] == 0
+    else:
+        assert nps["gathers"] >= 1 and nps["scatters"] >= 1 and nps["bytes_total"] > 0
+        assert 0 < xg["seconds_per_step"] < res["ms_per_step"] / 1e3
     if workload == "c2":            # a 2^20 d_fft round: (n - k) parties' 2^19-element rows into GPU 0 and back, 32 B each
         assert nps["bytes_total"] == 2 * (8 - 8 // ranks) * (1 << 19) * 32
     if workload != "c3":

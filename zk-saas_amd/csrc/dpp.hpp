@@ -214,10 +214,20 @@ ZK_D F block_scan_mul_exclusive(const F& v, F* sh, F* total) {
 
 // tile totals -> c_tile = (product of the numerator totals before the tile) * (product of the denominator totals after it)
 // / (product of all denominators).  tile_n is overwritten with the exclusive prefixes.
+//
+// TWO workgroups (round 6).  Round 5 ran one: two block scans (~25 us), then the one inversion on one lane (~45 us,
+// batched divsteps) with every other wave parked, then the c_tile pass -- 94 us at 2^20, a quarter of the call.  The
+// inversion only needs D = the product of all denominator totals, which a tree product gives long before the scans end:
+// workgroup 1 forms D, inverts it and publishes 1 / D; workgroup 0 runs the two scans and the prefix store meanwhile and
+// picks the inverse up when it needs it.  Hand-off without fences (a device-scope release would write back the L2 the tile
+// kernel has just filled): the limbs of 1 / D go out as device-scope atomic exchanges whose RETURN VALUES the wave holds
+// before it raises the flag (so they have been performed at the memory side), the reader polls the flag and reads the
+// limbs with device-scope atomic loads -- the construction of msm_hist's ticket (include/zksaas.h, memory-model note).
+//   sync[0] = error flag (zero denominator), sync[1] = ready flag, sync[8 .. 8 + N) = limbs of 1 / D; sync[0..1] zeroed per call.
 template <class F>
 __global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restrict__ tile_n, const F* __restrict__ tile_d,
                                                                       size_t ntiles, F* __restrict__ ctile,
-                                                                      int* __restrict__ err) {
+                                                                      int* __restrict__ sync) {
   __shared__ F sh[32];
   __shared__ F inv_sh;
   const size_t tid = threadIdx.x, nt = blockDim.x;
@@ -226,30 +236,72 @@ __global__ __launch_bounds__(DPP_CARRY_THREADS) void dpp_carry_kernel(F* __restr
   const size_t nlo = tid * q < ntiles ? tid * q : ntiles, nhi = nlo + q < ntiles ? nlo + q : ntiles;
   const size_t r = nt - 1 - tid;
   const size_t dlo = r * q < ntiles ? r * q : ntiles, dhi = dlo + q < ntiles ? dlo + q : ntiles;
+  uint32_t* const inv_g = reinterpret_cast<uint32_t*>(sync) + 8;
+  uint32_t* const ready = reinterpret_cast<uint32_t*>(sync) + 1;
+  if (blockIdx.x == 1) {
+    // ---- the inverter: D, 1 / D, publish
+    F pd = F::one();
+    for (size_t i = dlo; i < dhi; i++) pd = pd * load_elem(tile_d + i);
+    F tot_d;
+    (void)block_scan_mul_exclusive(pd, sh, &tot_d);
+    if (tid < 64) {
+      // by the batched divsteps on ONE wave: every lane holds the same total, and handing it to the loop through
+      // readfirstlane lets the compiler keep the state in SGPRs instead of running a one-lane vector loop
+      F t;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) t.v[i] = __builtin_amdgcn_readfirstlane(tot_d.v[i]);
+      const bool zero = t.is_zero();
+      const F inv = zero ? F::zero() : t.inverse_safegcd();
+      if (tid == 0 && zero) atomicExch(sync, 1);
+      uint32_t mine = 0;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) mine = (int)tid == i ? inv.v[i] : mine;
+      uint32_t old = 0;
+      if (tid < (size_t)F::N) old = atomicExch(inv_g + tid, mine);
+      asm volatile("" ::"v"(old));                       // the wave has the exchanges' return values: they have been performed
+      if (tid == 0) (void)atomicExch(ready, 1u);         // (a read-modify-write like the limbs: performed at the memory side)
+    }
+    return;
+  }
   F pn = F::one(), pd = F::one();
   for (size_t i = nlo; i < nhi; i++) pn = pn * load_elem(tile_n + i);
   for (size_t i = dlo; i < dhi; i++) pd = pd * load_elem(tile_d + i);
   F tot_n, tot_d;
   F run = block_scan_mul_exclusive(pn, sh, &tot_n);
   F sd = block_scan_mul_exclusive(pd, sh, &tot_d);
-  if (tid < 64) {
-    // the one inversion, by the binary Euclid on the SCALAR unit: every thread holds the same total, and handing it to
-    // the loop through readfirstlane lets the compiler keep u, v, r, s in SGPRs (64-bit shifts, s_addc chains, scalar
-    // branches) instead of running a one-lane vector loop with execution-mask bookkeeping around each branch
-    F t;
-#pragma unroll
-    for (int i = 0; i < F::N; i++) t.v[i] = __builtin_amdgcn_readfirstlane(tot_d.v[i]);
-    const bool zero = t.is_zero();
-    const F inv = zero ? F::zero() : t.inverse_safegcd();
-    if (tid == 0) {
-      if (zero) atomicExch(err, 1);
-      inv_sh = inv;
-    }
-  }
   for (size_t i = nlo; i < nhi; i++) {
     const F t = load_elem(tile_n + i);
     store_elem(tile_n + i, run);
     run = run * t;
+  }
+  if (tid < 64) {
+    // the inverse from workgroup 1 (normally there already: this workgroup's scans take about as long as the inversion)
+    // BOUNDED poll (~50 ms): if workgroup 1 has not been given a slot by then -- a chip held by other work -- this wave
+    // inverts the total itself; the kernel cannot wait for ever on a workgroup that is not resident
+    uint32_t got = 0;
+    if (tid == 0)
+      for (int spin = 0; spin < 400000; spin++) {
+        got = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (got) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    got = __builtin_amdgcn_readfirstlane(got);
+    F inv;
+    if (got) {
+      uint32_t limb = 0;
+      // (lanes 0..N-1 read after lane 0 has seen the flag: one wave, in order)
+      if (tid < (size_t)F::N) limb = __hip_atomic_load(inv_g + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < F::N; i++) inv.v[i] = __shfl(limb, i, 64);
+    } else {
+      F t;
+#pragma unroll
+      for (int i = 0; i < F::N; i++) t.v[i] = __builtin_amdgcn_readfirstlane(tot_d.v[i]);
+      const bool zero = t.is_zero();
+      inv = zero ? F::zero() : t.inverse_safegcd();
+      if (tid == 0 && zero) atomicExch(sync, 1);
+    }
+    if (tid == 0) inv_sh = inv;
   }
   __threadfence_block();
   __syncthreads();

@@ -412,7 +412,7 @@
                                  (int)lds));
       attr_set = true;
     }
-    ZK_HIP(hipMemsetAsync(err_flag_, 0, sizeof(int), st));
+    ZK_HIP(hipMemsetAsync(err_flag_, 0, 2 * sizeof(int), st));      // error flag + the carry kernel's ready flag
     {
       ProfScope ps_(prof, PROF_DPP_TILE, st, (double)m);
       dpp_tile_kernel<FrP, L, E><<<dim3((unsigned)ntiles), dim3(DPP_THREADS), lds, st>>>(num, den, np, len, len, U, y,
@@ -423,7 +423,7 @@
       ProfScope ps_(prof, PROF_DPP_CARRY, st, (double)ntiles);
       // one workgroup; no more waves than there are tiles to own (every wave issues the scans' products)
       const unsigned cthreads = (unsigned)std::min<size_t>(DPP_CARRY_THREADS, std::max<size_t>(64, (ntiles + 63) / 64 * 64));
-      dpp_carry_kernel<Fr><<<dim3(1), dim3(cthreads), 0, st>>>(tile_n, tile_d, ntiles, ctile, err_flag_);
+      dpp_carry_kernel<Fr><<<dim3(2), dim3(cthreads), 0, st>>>(tile_n, tile_d, ntiles, ctile, err_flag_);    // scans | inversion
     }
     ZK_HIP(hipGetLastError());
     {

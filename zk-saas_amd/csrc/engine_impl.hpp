@@ -449,7 +449,9 @@ class Engine : public IEngine {
     std::unique_ptr<StreamWs>& w = ws_[st];
     if (!w) {
       w.reset(new StreamWs());
-      if (hipMalloc((void**)&w->err, sizeof(int)) != hipSuccess) w->err = nullptr;
+      // [0] zero-denominator flag, [1] ready flag, [8 .. 8 + N) the inverse's limbs (dpp_carry_kernel's hand-off)
+      if (hipMalloc((void**)&w->err, 64 * sizeof(int)) != hipSuccess) w->err = nullptr;
+      else (void)hipMemset(w->err, 0, 64 * sizeof(int));
     }
     return w.get();
   }

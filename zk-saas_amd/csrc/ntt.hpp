@@ -111,6 +111,35 @@ struct LdsVec {
   }
 };
 
+// LDS swizzle of the NTT tile (round 6).  The tile is two planes of 16-byte halves; `ds_read_b128` serves a wave in four
+// 16-lane groups over 16 slots of 16 bytes (256 B), `ds_write_b128` in eight 8-lane groups over 8 slots (MI355X_MICROARCH.md,
+// LDS).  The load / store phases walk consecutive elements (conflict free), but a butterfly round trip at stage offset
+// sigma0 reads elements whose index has its lane bits at positions {0..sigma0-1, sigma0+2..}: the first two round trips of a
+// pass without columns (pass 0) put a group's lanes on 2-4 slots -- 6.9 instead of 4 LDS cycles per read and 12.6 instead of
+// 8 per write on average over the pass (r05_c2_sq_counters.json: 6.35 conflict cycles per LDS instruction), 8.0 / 14.4 for
+// the one-wave tile.  Element i is kept at slot i ^ L(i >> 3), L a GF(2)-linear map onto the low four index bits found by
+// search over the access patterns of every pass shape in use (tools/lds_swizzle_search.py): all reads and writes of the
+// 2^11-element tile become conflict free (4.0 / 8.0), the one-wave tile reaches 4.0-4.8 / 8.0.  Linear: the slot of
+// (a ^ b) is slot(a) ^ slot(b), so the four indices of a round trip cost one evaluation and three XORs with uniform values.
+// MEASURED AND LEFT OFF (profiles/r06_ntt_ab.txt, same box, three rounds): with the swizzle d_fft 2^20 reads 0.643-0.647 ms
+// against 0.642-0.643 without, the SHA-256 proof 613-619 against 603-620 proofs/s -- the pass is bound by VALU issue (95 % of
+// its cycles), the conflict cycles hide under it and the swizzle's index arithmetic does not.  -DZK_NTT_SWIZZLE=1 builds it.
+#ifndef ZK_NTT_SWIZZLE
+#define ZK_NTT_SWIZZLE 0
+#endif
+template <int TB>
+ZK_D uint32_t ntt_swz(uint32_t i) {
+#if !ZK_NTT_SWIZZLE
+  return i;
+#else
+  constexpr uint32_t M0 = TB >= 10 ? 0x51u : 0x0Du, M1 = TB >= 10 ? 0xFAu : 0x01u, M2 = TB >= 10 ? 0xE9u : 0x06u,
+                     M3 = TB >= 10 ? 0xBAu : 0x02u;
+  const uint32_t hi = i >> 3;
+  return i ^ ((uint32_t)(__popc(hi & M0) & 1) | ((uint32_t)(__popc(hi & M1) & 1) << 1) | ((uint32_t)(__popc(hi & M2) & 1) << 2) |
+              ((uint32_t)(__popc(hi & M3) & 1) << 3));
+#endif
+}
+
 // One pass of fft1 over a batch of vectors.  grid = (n / TILE, batch), block = TILE / 4 threads, TILE = 2^TB.
 //   data     : [batch][n]
 //   tw_full  : w_m^e (direction of the transform), e in [0, m], m = n << log_l.  Stage twiddles
@@ -179,6 +208,7 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
   for (int j = tid; j <= ((R / 2) >> tws); j += NTT_THREADS)
     twl.put(j, load_elem(tw_full + ((size_t)(j << tws) << tw_sh)));
 
+  const uint32_t stid = ntt_swz<TB>((uint32_t)tid);
   // load 4 elements per thread (coalesced along c), pre-twiddle for later passes
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -194,7 +224,7 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
       e &= ((uint64_t)1 << s1) - 1;
       v = v * load_elem(tw_full + (e << (log_n + log_l - s1)));
     }
-    tile.put(x, v);
+    tile.put(stid ^ ntt_swz<TB>((uint32_t)(q * NTT_THREADS)), v);          // = ntt_swz(x): tid and q * NTT_THREADS share no bit
   }
   __syncthreads();
 
@@ -209,8 +239,8 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
       uint32_t rest = g >> cbits;          // (hb, r_high) with bit 0 of r removed
       uint32_t rh = rest & ((R >> 1) - 1);
       uint32_t hb = rest >> (rbits - 1);
-      uint32_t i0 = ((hb << rbits) + (rh << 1)) * C + c;
-      uint32_t i1 = i0 + C;
+      uint32_t i0 = ntt_swz<TB>(((hb << rbits) + (rh << 1)) * C + c);
+      uint32_t i1 = i0 ^ ntt_swz<TB>((uint32_t)C);                        // index + C: that bit is clear in i0
       F a = tile.get(i0), b = tile.get(i1);
       if (shifted) {
         // twiddle w_2^(0+1) = -1
@@ -233,9 +263,15 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
     uint32_t rh = g & ((1u << (rbits - sigma0 - 2)) - 1);
     uint32_t hb = g >> (rbits - sigma0 - 2);
     uint32_t rbase = (rh << (sigma0 + 2)) | rl;
-    uint32_t ib = ((hb << rbits) + rbase) * C + c;
     uint32_t step = (uint32_t)C << sigma0;
-    F v0 = tile.get(ib), v1 = tile.get(ib + step), v2 = tile.get(ib + 2 * step), v3 = tile.get(ib + 3 * step);
+    // the four elements of the round trip: index bits (cbits + sigma0, + 1) are clear in the base, so + k * step = ^ k * step
+    const uint32_t ib = ntt_swz<TB>(((hb << rbits) + rbase) * C + c);
+    const uint32_t i1 = ib ^ ntt_swz<TB>(step), i2 = ib ^ ntt_swz<TB>(2 * step), i3 = ib ^ ntt_swz<TB>(3 * step);
+    F v0 = tile.get(ib), v1 = tile.get(i1), v2 = tile.get(i2), v3 = tile.get(i3);
+    // (round 6: in the first round trip of a later pass three of the four twiddles are w^0 = 1; a branch that skips those
+    // products was built and measured on the same box -- d_fft 2^20 0.652-0.654 against 0.642-0.643 ms, the SHA-256 proof
+    // 567-603 against 603-620 proofs/s (profiles/r06_ntt_ab.txt): the fifth inlined product site costs more than the three
+    // products it saves; removed)
     // stage sigma0+1: pairs (v0,v1), (v2,v3); twiddle exponent (rl + sh) in units of w_{2^(sigma0+1)}
     {
       F w = stage_tw(rl + sh, rbits - sigma0 - 1);
@@ -256,9 +292,9 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
       v1 = v1 + t3;
     }
     tile.put(ib, v0);
-    tile.put(ib + step, v1);
-    tile.put(ib + 2 * step, v2);
-    tile.put(ib + 3 * step, v3);
+    tile.put(i1, v1);
+    tile.put(i2, v2);
+    tile.put(i3, v3);
     __syncthreads();
   }
 
@@ -270,7 +306,7 @@ __global__ __launch_bounds__((1 << TB) / 4, TB >= 10 ? 4 : 16) void ntt_pass_ker
     uint32_t r = (x >> cbits) & (R - 1);
     uint32_t hb = x >> (cbits + rbits);
     size_t gi = ((h0 + hb) << s1) + ((size_t)r << s0) + c0 + c;
-    F v = tile.get(x);
+    F v = tile.get(stid ^ ntt_swz<TB>((uint32_t)(q * NTT_THREADS)));
     if (addv) v = v + load_elem(addv + gi);
     store_elem(vec + gi, v);
   }

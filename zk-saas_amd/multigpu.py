@@ -539,9 +539,25 @@ def bench(args, rank, local_rank, world):
                                            masks=mct, seed=7 + i)
         step(0)
         pp._check(pp.lib.zk_profile_enable(pp.h, 1))
+        from bench import msm_stats
+        st0 = msm_stats(pp)
         dt = timed(step)
+        st1 = msm_stats(pp)
         prof = read_profile(pp)
         pp._check(pp.lib.zk_profile_enable(pp.h, 0))
+        # whole-proof multiplier utilisation of THIS rank (the per-launch `roofline.alu` divides one
+        # launch's products by a duration during which four other MSMs share the chip): products of the mixed additions the
+        # accumulate kernels performed (zk_msm_stats) over the wall time.  12 limbs: a product is 2 N^2 + N = 300 multiply
+        # instructions; G1 addition 9.47 products as executed, G2 28 (8 Fq2 products + 2 squarings, schoolbook per lane pair).
+        npf = args.steps + args.warmup
+        a1, a2 = (st1[0] - st0[0]) / npf, (st1[1] - st0[1]) / npf
+        muls12 = a1 * 9.47 + a2 * 28.0
+        bound12 = MAD_ISSUE_BOUND_G * 136.0 / 300.0
+        palu = {"modmuls_per_proof_this_rank": int(muls12), "additions_per_proof": {"g1": int(a1), "g2": int(a2)},
+                "achieved": round(muls12 / per(dt) / 1e9, 2), "unit": "G modmul/s (381-bit) over the proof's wall time",
+                "frac_issue_bound": round(muls12 / per(dt) / 1e9 / bound12, 3),
+                "frac_of_measured_multiplier": round(muls12 / per(dt) / 1e9 / 60.1, 3),
+                "issue_bound_G": round(bound12, 1), "measured_multiplier_G": 60.1}
         # dominant slot of the timed region with BLS12-381's algorithmic bytes (affine base + scalar per point:
         # 2 x 48 + 32 = 128 B in G1, 4 x 48 + 32 = 224 B in G2) and the 12-limb multiplier's issue bound
         # (the sort slot is left out of the choice: with five multi-hundred-millisecond MSMs in flight its HIP-event span
@@ -563,7 +579,7 @@ def bench(args, rank, local_rank, world):
                                        "deg_red composed, %s" % (log_m, "zero masks" if masks is None else
                                                                  "all 12 masks sampled and applied"),
                            "masks": masks is not None, "constraints": inst.nc, "parties": pp.n},
-                   roofline=roof, cpu_baseline=cpu,
+                   roofline=roof, proof_alu=palu, cpu_baseline=cpu,
                    kernels=[{**e, "total_ms": round(e["total_ms"], 3)} for e in prof if e["launches"]])
     # N > 1: the headline ran in the mode `king` names (default: north_star's star); the other stage of SURVEY.md 8e in the
     # same run, beside it
