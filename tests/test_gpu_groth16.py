@@ -219,6 +219,41 @@ def test_pack_points_with_random_points_reconstructs():
             assert (v[0], v[1]) == G1.to_affine(want[p_])
 
 
+@pytest.mark.parametrize("curve,group", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g2")])
+def test_det_pack_over_points_edge_cases_match_oracle(curve, group):
+    """proving_key.rs:72-86 (det_pack over curve points, l = 2) chunk by chunk against the oracle's det_pack over GroupOps,
+    with the chunks a CRS never holds: an identity in either slot, both, equal points, opposite points.  G2 runs the
+    quad-split kernel (one base-field value per lane), G1 the one-lane joint-sparse-form kernel."""
+    from oracle.curve import g2 as og2
+    from oracle.params import CURVES
+    from gpu_util import enc_affine
+    cv = CURVES[curve]
+    pp, o = ctx(curve, 2), opp(curve, 2)
+    is2 = group == "g2"
+    G = og2(cv) if is2 else g1(cv)
+    ops = GroupOps(G)
+    gen = G.from_affine(cv.g2 if is2 else cv.g1)
+    a, b, c, d = (G.to_affine(G.mul(gen, rand_fp(77, i, cv.r))) for i in range(4))
+    neg = lambda pt: (pt[0], G.F.neg(pt[1]))
+    chunks = [(a, b), (None, b), (a, None), (None, None), (c, c), (c, neg(c)), (d, a), (b, neg(a))]
+    flat = [pt for ch in chunks for pt in ch]
+    nch = len(chunks)
+    sh = zg.pack_points(pp, zk.api.ZK_G2 if is2 else zk.api.ZK_G1,
+                        zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, flat, g2=is2)), nch, 2)
+    ncoord = 4 if is2 else 2
+    rows = sh.to_numpy().reshape(o.n, nch, ncoord * pp.fq.nl)
+    for j, ch in enumerate(chunks):
+        want = o.det_pack([G.from_affine(ch[0]), G.from_affine(ch[1])], ops)
+        for p_ in range(o.n):
+            v = pp.fq.decode(rows[p_, j].reshape(ncoord, pp.fq.nl))
+            got = ((v[0], v[1]), (v[2], v[3])) if is2 else (v[0], v[1])
+            w = G.to_affine(want[p_])
+            if w is None:
+                assert all(x == 0 for x in v), (j, p_)
+            else:
+                assert got == w, (j, p_)
+
+
 def test_proof_with_fixed_base_tables_equals_proof_without():
     """Crs.precompute() (zk_msm_precompute on the five query vectors): the SHA-256 circuit proof is the same group
     elements with and without the tables, for r = 0 as well (H skipped, S alone)."""

@@ -135,8 +135,14 @@
         if (pjsf_) (void)hipFree(dig), dig = pjsf_;
         else pjsf_ = dig;
       }
-      pss_pack_points_jsf_kernel<FrP, Fld><<<dim3((unsigned)((nchunks + 127) / 128), (unsigned)n), block, 0, st>>>(
-          in, nchunks, n, dig, JLEN, out);
+      if constexpr (IsExtField<Fld>::value) {
+        // extension field: a quad of lanes per (chunk, party), one base-field value per lane (pack_split.hpp; launched from
+        // the curve's G2 translation unit)
+        return pack_points_split_launch<FrP, Fld>(this, in, nchunks, n, dig, JLEN, out, st);
+      } else {
+        pss_pack_points_jsf_kernel<FrP, Fld><<<dim3((unsigned)((nchunks + 127) / 128), (unsigned)n), block, 0, st>>>(
+            in, nchunks, n, dig, JLEN, out);
+      }
     } else if (nv == 4) pss_pack_points_kernel<FrP, Fld, 4><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
     else return fail(ZK_ERR_BAD_INPUT, "point packing is built for 2 or 4 points per chunk (l = 2, or det_pack at l = 4)");
     ZK_HIP(hipGetLastError());
@@ -146,7 +152,9 @@
     using Fq = Fp<typename Cfg::FqP>;
     using Fq2 = Fp2<typename Cfg::FqP>;
     if (group == ZK_G1) return pack_points_t<Fq>(points, nchunks, nv, shares, st);
-    if (group == ZK_G2 && Cfg::HAS_G2) return pack_points_t<Fq2>(points, nchunks, nv, shares, st);
+    if constexpr (Cfg::HAS_G2) {             // (the quad-split kernel exists in the G2 translation units only)
+      if (group == ZK_G2) return pack_points_t<Fq2>(points, nchunks, nv, shares, st);
+    }
     return fail(ZK_ERR_BAD_INPUT, "bad group");
   }
 
@@ -215,6 +223,11 @@
     if (!strcmp(name, "msm_bigsort_min")) {
       if (value < 0) return fail(ZK_ERR_BAD_INPUT, "msm_bigsort_min must be >= 0");
       msm_.bigsort_min = (size_t)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "msm_acc_lds")) {            // dynamic LDS per accumulate workgroup (MsmTuning::acc_lds); 0 = none
+      if (value < 0 || value > 65536) return fail(ZK_ERR_BAD_INPUT, "msm_acc_lds must be in 0..65536");
+      msm_.acc_lds = (unsigned)value;
       return ZK_OK;
     }
     if (!strcmp(name, "rng_replay")) {

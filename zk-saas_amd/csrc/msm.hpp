@@ -1510,6 +1510,10 @@ struct MsmTuning {
   size_t bigsort_min;
   MsmGate gate;
   int c_force = 0;       // window bits asked for by zk_ctx_set_option "msm_c" / "msm_c_g2" (0: the cost model)
+  // dynamic LDS bytes asked for with every accumulate workgroup (zk_ctx_set_option "msm_acc_lds"; the kernels use none):
+  // caps the accumulate workgroups a CU holds, i.e. leaves wave slots and registers free for the short kernels of a
+  // proof's critical chain, which otherwise wait for an accumulate wave to retire before they can become resident
+  unsigned acc_lds = 0;
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -1584,6 +1588,11 @@ template <class FrP, class Fld>
 int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* bases, const void* bases2,
                const void* scalars, size_t npts, const Fp<FrP>* coef_d, size_t part_len, hipStream_t st,
                MsmPending* out, const MsmBatchArg* batch = nullptr);
+// det_pack over extension-field points, quad-split (pack_split.hpp; same translation units: inline 12-limb products).
+// dig: the parties' joint-sparse-form digit columns [n][jlen] (groth16.hpp jsf_digits); G1 instantiations return an error.
+template <class FrP, class Fld>
+int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, int n, const uint8_t* dig, int jlen,
+                             void* shares, hipStream_t st);
 // zk_msm_precompute's table kernel (same translation units)
 template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,
@@ -1783,7 +1792,7 @@ class MsmRunner {
                const MsmBatchArg* batch = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1};
+    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1, acc_lds};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }
@@ -2038,6 +2047,7 @@ class MsmRunner {
 
   // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min")
   size_t bigsort_min = (size_t)1 << 14;
+  unsigned acc_lds = 0;           // zk_ctx_set_option "msm_acc_lds" (MsmTuning::acc_lds)
   MsmSlot slots_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;

@@ -3,6 +3,7 @@
 // kernels are the most expensive part of the build and compile in parallel this way.
 #pragma once
 #include "msm.hpp"
+#include "pack_split.hpp"
 
 namespace zk {
 
@@ -318,10 +319,10 @@ do {                                                                           \
     MSM_HIP(hipStreamWaitEvent(st, tune.gate.wait_ev, 0));
   }
   if constexpr (G2FLD) {
-    msm_accumulate_split_kernel<typename BaseParams<Fld>::type><<<dim3((nlanes + 31) / 32, NB), dim3(128), 0, st>>>(
+    msm_accumulate_split_kernel<typename BaseParams<Fld>::type><<<dim3((nlanes + 31) / 32, NB), dim3(128), tune.acc_lds, st>>>(
         bases, bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge, heavy, k0, ys);
   } else {
-    msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), 0, st>>>(
+    msm_accumulate_kernel<KF><<<dim3((nlanes + 127) / 128, NB), dim3(128), tune.acc_lds, st>>>(
         (const Affine<KF>*)bases, (const Affine<KF>*)bases2, sorted, offsets, (uint32_t)nkeys, nlanes, tmin, cap, buckets, edge,
         heavy, k0, ys, 0);
   }
@@ -410,9 +411,25 @@ int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwi
   return ZK_OK;
 }
 
+template <class FrP, class Fld>
+int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, int n, const uint8_t* dig, int jlen,
+                             void* shares, hipStream_t st) {
+  if constexpr (IsExtField<Fld>::value) {
+    using P = typename BaseParams<Fld>::type;
+    pss_pack_points_jsf_split_kernel<FrP, P><<<dim3((unsigned)((nchunks * 4 + 127) / 128), (unsigned)n), dim3(128), 0, st>>>(
+        (const Affine<Fp2<P>>*)points, nchunks, n, dig, jlen, (Affine<Fp2<P>>*)shares);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return eng->hip_fail(he, "pss_pack_points_jsf_split_kernel");
+    return ZK_OK;
+  } else {
+    return eng->fail(ZK_ERR_BAD_INPUT, "the quad-split pack kernel is for extension-field points");
+  }
+}
+
 #define ZK_INSTANTIATE_MSM(FRP, FLD)                                                                              \
   template int msm_launch<FRP, FLD>(IEngine*, MsmSlot&, const MsmTuning&, const void*, const void*, const void*, \
                                     size_t, const Fp<FRP>*, size_t, hipStream_t, MsmPending*, const MsmBatchArg*);  \
-  template int msm_table_launch<FRP, FLD>(IEngine*, const void*, size_t, int, int, int, void*, hipStream_t);
+  template int msm_table_launch<FRP, FLD>(IEngine*, const void*, size_t, int, int, int, void*, hipStream_t);     \
+  template int pack_points_split_launch<FRP, FLD>(IEngine*, const void*, size_t, int, const uint8_t*, int, void*, hipStream_t);
 
 }  // namespace zk

@@ -98,9 +98,17 @@ struct Rccl {
       handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
       if (handle) break;
     }
+    // Not yet in the process: load it PRIVATELY.  A PyTorch-ROCm wheel bundles its own librccl + librocm_smi64, and
+    // `import torch` AFTER this point brings those in beside /opt/rocm's: two copies of rocm_smi with the same global
+    // objects, which (bound to one another through the global scope) are destroyed twice at exit -- "double free or
+    // corruption", status 134, seen at the end of the whole GPU test suite in round 6 (test_gpu_dist's RCCL net first,
+    // test_gpu_hardening's `import torch` later; backtrace: ~map in librocm_smi64's exit handlers).  RTLD_LOCAL keeps this
+    // copy's symbols out of the global scope (a later copy binds to itself), RTLD_DEEPBIND makes this copy and its
+    // dependencies prefer their own definitions over any copy already there.  The HIP runtime is shared either way (same
+    // SONAME: the loader reuses the one in the process).
     if (!handle)
       for (const char* nm : names) {
-        handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (handle) break;
       }
     if (!handle) {

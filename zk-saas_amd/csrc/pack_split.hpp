@@ -1,0 +1,65 @@
+// det_pack over EXTENSION-field points in the quad-split lane layout (dealer: CRS share packing of b_g2_query,
+// groth16/src/proving_key.rs:72-86).  Own header because the kernel is instantiated in the msm_<curve>_g2.hip translation
+// units (pack_points_split_launch, msm_impl.hpp): those compile the 12-limb base field with INLINE products
+// (ZK_MUL_INLINE_LIMBS = 12), which is what gives s2_mul its single-reduction form (field.hpp mul_pm_mul) -- compiled with
+// the engine's out-of-line 12-limb product the kernel was 1.6x SLOWER than the one-lane form on BLS12-381 (78.9 vs 49.7 ms).
+#pragma once
+#include "ec.hpp"
+#include "quad.hpp"
+
+namespace zk {
+#if defined(__HIPCC__)
+
+// det_pack at l = 2 (groth16.hpp pss_pack_points_jsf_kernel) for EXTENSION-field points (b_g2_query), a QUAD of lanes per (chunk, party) with one base-field
+// value per lane (quad.hpp split_dbl / split_madd: the lane layout of the G2 accumulate kernel).  The one-lane form
+// holds whole Fq2 values -- four affine points and the running sum are 24 base-field values in a lane -- and runs at
+// 0.30 of the multiplier's issue bound with spills (profiles/r06_dealer.json before this kernel); here a lane holds six.
+// P0 + P1 and P0 - P1 come from split_affine_add (two inversions per quad instead of one shared: 1 % of the chain), the
+// result is normalised in the split form too (1 / ZZZ through the norm: one base-field inversion, computed by all four
+// lanes alike).  Digits as above; blockIdx.y = party, so every digit branch is wave-uniform.
+template <class FrP, class P>
+__global__ __launch_bounds__(128, (P::N > 8 ? 2 : 3)) void pss_pack_points_jsf_split_kernel(const Affine<Fp2<P>>* __restrict__ points,
+                                                                       size_t nchunks, int n,
+                                                                       const uint8_t* __restrict__ dig, int jlen,
+                                                                       Affine<Fp2<P>>* __restrict__ shares) {
+  using F = Fp<P>;
+  const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;        // chunk of this quad
+  const int p = (int)blockIdx.y;
+  if (j >= nchunks || p >= n) return;                                           // quad-uniform
+  const int q = threadIdx.x & 3;
+  const bool half = (q >> 1) != 0, comp = (q & 1) != 0;
+  const F* src = reinterpret_cast<const F*>(points + 2 * j);                    // P0: x.c0 x.c1 y.c0 y.c1, then P1
+  const F in0 = load_elem(src + q), in1 = load_elem(src + 4 + q);
+  const bool id0 = quad_all(in0.is_zero()), id1 = quad_all(in1.is_zero());
+  bool idS, idD;
+  const F inS = split_affine_add<P>(in0, id0, in1, id1, half, comp, &idS);
+  const F inD = split_affine_add<P>(in0, id0, qsel(half, in1.neg(), in1), id1, half, comp, &idD);
+  SplitAcc<P> acc = split_identity<P>(comp);
+  const uint8_t* dg = dig + (size_t)p * jlen;
+  for (int b = 0; b < jlen; b++) {
+    acc = split_dbl(acc, half, comp);
+    const uint32_t c = dg[b];
+    const int u0 = (int)(c & 3u) - 1, u1 = (int)((c >> 2) & 3u) - 1;
+    if (u0 | u1) {
+      const bool two = u0 != 0 && u1 != 0;
+      const bool neg = u0 ? u0 < 0 : u1 < 0;
+      const bool same = u0 == u1;
+      F v = two ? (same ? inS : inD) : (u0 ? in0 : in1);
+      const bool idv = two ? (same ? idS : idD) : (u0 ? id0 : id1);
+      if (neg) v = qsel(half, v.neg(), v);
+      if (!idv) acc = split_madd(acc, v, half, comp);
+    }
+  }
+  F* dst = reinterpret_cast<F*>(shares + (size_t)p * nchunks + j) + q;
+  const uint32_t zz = s2_is_zero(acc.c1) ? 1u : 0u;
+  if (qperm_u32<0, 0, 0, 0>(zz)) {                                              // identity: the (0, 0) sentinel
+    store_elem(dst, F::zero());
+    return;
+  }
+  const F zi = split_inv(qperm<2, 3, 2, 3>(acc.c1), comp);                      // 1 / ZZZ, every lane its component
+  const F zi2 = s2_sqr(s2_mul(zi, qperm<0, 1, 0, 1>(acc.c1), comp), comp);      // (ZZ / ZZZ)^2 = 1 / Z^2
+  store_elem(dst, s2_mul(acc.c0, qsel(half, zi, zi2), comp));                   // 0: X / Z^2        1: Y / Z^3
+}
+
+#endif  // __HIPCC__
+}  // namespace zk

@@ -215,6 +215,79 @@ ZK_D SplitAcc<P> split_madd(const SplitAcc<P>& a, const Fp<P>& in, bool half, bo
   return r;
 }
 
+// 2 acc in the same split form (dbl-2008-s-1, a = 0): nine Fq2 products as five rounds of one product per half
+//   round 1   half 0: XX = X^2           half 1: V = U^2 (U = 2 Y)
+//   round 2   half 0: S = X V            half 1: W = U V
+//   round 3   half 0: MM = M^2 (M = 3 XX) half 1: W Y                     X3 = MM - 2 S
+//   round 4   half 0: M (S - X3)         half 1: ZZZ3 = W ZZZ            Y3 = M (S - X3) - W Y
+//   round 5   half 0: ZZ3 = V ZZ         half 1: -
+template <class P>
+ZK_D SplitAcc<P> split_dbl(const SplitAcc<P>& a, bool half, bool comp) {
+  using F = Fp<P>;
+  const uint32_t zz = s2_is_zero(a.c1) ? 1u : 0u;
+  if (qperm_u32<0, 0, 0, 0>(zz)) return a;               // identity (quad-uniform)
+  const F u = qsel(half, a.c0.dbl(), a.c0);              // 0: X                  1: U
+  const F m1 = s2_sqr(u, comp);                          // 0: XX                 1: V
+  const F o1 = hswap(m1);                                // 0: V                  1: XX
+  const F m2 = s2_mul(u, qsel(half, m1, o1), comp);      // 0: S                  1: W
+  const F M = m1.dbl() + m1;                             // 0: 3 XX
+  const F m3 = s2_mul(qsel(half, m2, M), qsel(half, a.c0, M), comp);          // 0: MM           1: W Y
+  const F X3 = m3 - m2.dbl();                            // 0: MM - 2 S
+  const F m4 = s2_mul(qsel(half, m2, M), qsel(half, a.c1, m2 - X3), comp);    // 0: M (S - X3)   1: ZZZ3
+  const F m5 = s2_mul(o1, a.c1, comp);                   // 0: ZZ3 = V ZZ
+  SplitAcc<P> r;
+  r.c0 = qsel(half, hswap(m4) - m3, X3);
+  r.c1 = qsel(half, m4, m5);
+  return r;
+}
+
+// ---- affine extension-field points in the same lane layout (lane q of a quad holds base-field value q of x.c0 x.c1 y.c0 y.c1)
+// 1 / z for an Fq2 value whose component `comp` this lane holds (the same value in both halves of the quad)
+template <class P>
+ZK_D Fp<P> split_inv(const Fp<P>& z, bool comp) {
+  const Fp<P> sq = z * z;
+  const Fp<P> ninv = (sq + cswap(sq)).inverse_fast();    // 1 / (c0^2 + c1^2)
+  const Fp<P> r = z * ninv;
+  return qsel(comp, r.neg(), r);
+}
+ZK_D bool quad_all(bool b) {
+  uint32_t z = b ? 1u : 0u;
+  z &= qperm_u32<1, 0, 3, 2>(z);
+  z &= qperm_u32<2, 3, 0, 1>(z);
+  return z != 0;
+}
+// a + b for two affine points with every special case (identities, equal, opposite); `ida` / `idb` / `idr`: the point is
+// the identity (quad-uniform flags; the coordinates are then ignored).  Out of line: setup code of the pack kernel.
+template <class P>
+__device__ __noinline__ Fp<P> split_affine_add(const Fp<P>& a, bool ida, const Fp<P>& b, bool idb, bool half, bool comp,
+                                               bool* idr) {
+  using F = Fp<P>;
+  *idr = false;
+  if (ida) {
+    *idr = idb;
+    return b;
+  }
+  if (idb) return a;
+  const F d = b - a;                                     // 0: x2 - x1            1: y2 - y1
+  const uint32_t dz = s2_is_zero(d) ? 1u : 0u;
+  const bool xz = qperm_u32<0, 0, 0, 0>(dz) != 0, yz = qperm_u32<2, 2, 2, 2>(dz) != 0;
+  const F xa = qperm<0, 1, 0, 1>(a), ya = qperm<2, 3, 2, 3>(a);        // every lane: its component of x1, of y1
+  F lam;
+  if (xz) {
+    if (!yz) {                                           // opposite points
+      *idr = true;
+      return F::zero();
+    }
+    const F xx = s2_sqr(xa, comp);                       // tangent: 3 x^2 / (2 y)
+    lam = s2_mul(xx.dbl() + xx, split_inv(ya.dbl(), comp), comp);
+  } else {
+    lam = s2_mul(qperm<2, 3, 2, 3>(d), split_inv(qperm<0, 1, 0, 1>(d), comp), comp);
+  }
+  const F x3 = s2_sqr(lam, comp) - xa - qperm<0, 1, 0, 1>(b);
+  const F y3 = s2_mul(lam, xa - x3, comp) - ya;
+  return qsel(half, y3, x3);
+}
+
 // Tree sum inside aligned sub-blocks of `nvl` (power of two) virtual lanes of a workgroup: every quad contributes the
 // point whose coordinates its lanes hold; afterwards the first quad of each sub-block holds the sub-block's total.
 // `sh` is LDS for blockDim.x / 4 points.  log2(nvl) dependent additions.
