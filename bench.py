@@ -100,7 +100,7 @@ PMC_KERNEL = {"msm_accumulate_kernel<G1>": "msm_accumulate_kernel<Fp<", "msm_acc
               "king_degred_kernel": "king_degred_kernel", "msm_finalize+reduce<G1>": "msm_finalize_kernel<Fp<",
               "msm_finalize+reduce<G2>": "msm_finalize_kernel<Fp2", "dpp_tile_kernel": "dpp_tile_kernel",
               "dpp_carry_kernel": "dpp_carry_kernel", "dpp_finish_kernel": "dpp_finish_kernel"}
-PMC_FILE = "r05_c4_pmc_hbm.json"
+PMC_FILE = "r06_c4_pmc_hbm.json"
 
 
 def pmc_traffic(slot_name, pmc_file=None):

@@ -263,6 +263,11 @@ int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
  *   the context refuses further proofs ("wedged": destroy it).  zk_groth16_wait / zk_groth16_batch_wait / zk_msm and the
  *   zk_dist_* prover calls therefore cannot block for ever (the net's own rounds have zk_net_set_timeout_ms).
  * "dist_deadline": 1 = the zk_dist_* calls return only with their data-plane work done (zk_net_sync inside).
+ * "pack_glv": 0 = zk_pss_pack_points at two points per chunk walks the parties' full-length scalars; 1 (default) = the
+ *   scalars are split by the curve's endomorphism phi(x, y) = (beta x, y) = lambda (x, y) into two half-length parts (half
+ *   the doubling chain; the same points).  Before the first zk_pss_pack_points of the context.
+ * "msm_acc_lds": dynamic LDS bytes (0..65536, default 0) launched with every accumulate workgroup, which caps how many of
+ *   them a CU holds (measured on the SHA-256 proof: a loss at every size, profiles/r06_acc_lds_sweep.txt; kept for A/B runs).
  * Nothing is read from the environment.  Unknown name or value out of range -> ZK_ERR_BAD_INPUT. */
 int zk_ctx_set_option(zk_ctx* ctx, const char* name, long long value);
 /* Memory-model note (csrc/msm.hpp msm_hist): the last workgroup of a sort's histogram finds out that it is the last through a

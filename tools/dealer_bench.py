@@ -66,6 +66,8 @@ def pack_points_cost(group, nv, inv):
 
 def run(curve, quick, reps):
     pp = zk.PackedSharingParams(curve, 2)
+    for kv in filter(None, os.environ.get("ZK_BENCH_OPTIONS", "").split(",")):     # A/B runs: name=value context options
+        pp.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     limbs = pp.fq.nl * 2                    # 32-bit limbs of the base field
     out = {"curve": curve, "base_field_limbs": limbs}
     # what the kernels run (csrc/groth16.hpp, csrc/ec.hpp, round 6): divstep inversion (~35 / 25 product equivalents of issue on

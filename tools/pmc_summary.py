@@ -24,7 +24,7 @@ SHAPE = [("ntt_pass_kernel", "ntt"), ("king_fft2_kernel", "rows8"), ("king_degre
          ("pss_", "rows8"), ("bitrev_kernel", "elem32"), ("r1cs_qap_kernel", "elem32"), ("msm_scatter_kernel<", "elem32"),
          ("msm_hist_kernel", "elem32"), ("msm_accumulate_kernel<Fp<", "gather64")]
 CALIB = None
-for cand in ("profiles/r05_pmc_calibration.json",):
+for cand in ("profiles/r05_pmc_calibration.json", "profiles/r06_pmc_calibration.json"):   # the last one found wins
     try:
         import os
         CALIB = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cand)))["shapes"]
@@ -79,7 +79,7 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
 out = {"note": (sys.argv[4] if len(sys.argv) > 4 else "") + " -- rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate "
                "passes (program directly after `--`); KB as reported; hbm_bytes_per_launch = fetch_factor x FETCH + write_factor "
                "x WRITE with the factors of the kernel's access shape measured by tools/pmc_calib.hip (%s)" % (
-                   "profiles/r05_pmc_calibration.json" if CALIB else "no calibration file: the guide's x2 / x1 rule"),
+                   "profiles/r06_pmc_calibration.json (r05 on a tree without it)" if CALIB else "no calibration file: the guide's x2 / x1 rule"),
        "kernels": kernels}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(kernels[:8], indent=1))

@@ -423,6 +423,8 @@ class Engine : public IEngine {
   DevBuf flag_;   // 4-byte device flag for the validating kernels
   std::map<int, Fr*> pcoef_;
   uint8_t* pjsf_ = nullptr;     // joint-sparse-form digits of the first two pack columns (pss_pack_points at 2 points per chunk)
+  int pjsf_len_ = 0;            // ... their columns per party, and whether they are the endomorphism-split form
+  bool pjsf_glv_ = false, pack_glv_ = true;     // zk_ctx_set_option("pack_glv")
   PackL2<Fr>* pack2_ = nullptr;
   Fr* ident_ = nullptr;
   std::map<uint64_t, Fr*> umats_;

@@ -113,35 +113,79 @@
     const Affine<Fld>* in = (const Affine<Fld>*)points;
     Affine<Fld>* out = (Affine<Fld>*)shares;
     if (nv == 2) {
-      // the party's two fixed scalars in joint sparse form (host, once per context): [n][jlen] bytes, MSB first
-      constexpr int JLEN = FrP::N * 32 + 1;
+      // the party's two fixed scalars in joint sparse form (host, once per context): [n][jlen] bytes, MSB first, pair A in
+      // the low nibble and pair B in the high one.  With the curve's endomorphism (glv_params.hpp) each scalar is split
+      // k = k1 + lambda k2 into two half-length parts: pair A = the k1 parts over (P0, P1), pair B = the k2 parts over
+      // (phi P0, phi P1), signs folded into the digits -- half the doubling chain.  Otherwise pair B is all zero digits.
       uint8_t* dig = nullptr;
+      int jlen = 0;
+      bool glv = false;
       {
         std::lock_guard<std::mutex> lk(mu_);
         dig = pjsf_;
+        jlen = pjsf_len_;
+        glv = pjsf_glv_;
       }
       if (!dig) {
-        std::vector<uint8_t> h((size_t)n * JLEN, (uint8_t)(1 | (1 << 2)));          // leading columns: (0, 0)
+        constexpr uint8_t ZZ = (uint8_t)(1 | (1 << 2));                           // the digit pair (0, 0)
+        std::vector<uint8_t> h;
         std::vector<int8_t> u0, u1;
-        for (int p = 0; p < n; p++) {
-          const Fr a = pmat_host_[(size_t)p * (l + t)].from_mont(), b = pmat_host_[(size_t)p * (l + t) + 1].from_mont();
-          jsf_digits<FrP::N>(a.v, b.v, u0, u1);
-          for (size_t q = 0; q < u0.size(); q++)
-            h[(size_t)p * JLEN + (JLEN - 1 - q)] = (uint8_t)((u0[q] + 1) | ((u1[q] + 1) << 2));
+        auto put = [&](int p, int shift, const uint32_t* a, bool na, const uint32_t* b, bool nb) {
+          jsf_digits<FrP::N>(a, b, u0, u1);
+          if ((int)u0.size() > jlen) return false;
+          for (size_t q = 0; q < u0.size(); q++) {
+            const int d0 = na ? -u0[q] : u0[q], d1 = nb ? -u1[q] : u1[q];
+            uint8_t& cell = h[(size_t)p * jlen + (jlen - 1 - q)];
+            cell = (uint8_t)((cell & ~(15u << shift)) | (((d0 + 1) | ((d1 + 1) << 2)) << shift));
+          }
+          return true;
+        };
+        if (pack_glv_ && Glv<FrP>::OK) {
+          if constexpr (Glv<FrP>::OK) {
+            glv = true;
+            jlen = Glv<FrP>::BITS + 2;
+            h.assign((size_t)n * jlen, (uint8_t)(ZZ | (ZZ << 4)));
+            for (int p = 0; p < n && glv; p++) {
+              uint32_t a1[FrP::N], a2[FrP::N], b1[FrP::N], b2[FrP::N];
+              bool na1, na2, nb1, nb2;
+              glv = glv_split<FrP>(pmat_host_[(size_t)p * (l + t)], a1, &na1, a2, &na2) &&
+                    glv_split<FrP>(pmat_host_[(size_t)p * (l + t) + 1], b1, &nb1, b2, &nb2) &&
+                    put(p, 0, a1, na1, b1, nb1) && put(p, 4, a2, na2, b2, nb2);
+            }
+          }
+        }
+        if (!glv) {
+          jlen = FrP::N * 32 + 1;
+          h.assign((size_t)n * jlen, (uint8_t)(ZZ | (ZZ << 4)));
+          for (int p = 0; p < n; p++) {
+            const Fr a = pmat_host_[(size_t)p * (l + t)].from_mont(), b = pmat_host_[(size_t)p * (l + t) + 1].from_mont();
+            if (!put(p, 0, a.v, false, b.v, false)) return fail(ZK_ERR_GENERIC, "joint sparse form longer than the scalar field");
+          }
         }
         ZK_HIP(hipMalloc((void**)&dig, h.size()));
         ZK_HIP(hipMemcpy(dig, h.data(), h.size(), hipMemcpyHostToDevice));
         std::lock_guard<std::mutex> lk(mu_);
-        if (pjsf_) (void)hipFree(dig), dig = pjsf_;
-        else pjsf_ = dig;
+        if (pjsf_) {
+          (void)hipFree(dig);
+          dig = pjsf_, jlen = pjsf_len_, glv = pjsf_glv_;
+        } else {
+          pjsf_ = dig, pjsf_len_ = jlen, pjsf_glv_ = glv;
+        }
+      }
+      using BF = Fp<typename BaseParams<Fld>::type>;
+      BF beta = BF::one();
+      if constexpr (Glv<FrP>::OK) {
+        if (glv) beta = BF::from_limbs(IsExtField<Fld>::value ? Glv<FrP>::BETA_G2 : Glv<FrP>::BETA_G1);
       }
       if constexpr (IsExtField<Fld>::value) {
         // extension field: a quad of lanes per (chunk, party), one base-field value per lane (pack_split.hpp; launched from
         // the curve's G2 translation unit)
-        return pack_points_split_launch<FrP, Fld>(this, in, nchunks, n, dig, JLEN, out, st);
+        return pack_points_split_launch<FrP, Fld>(this, in, nchunks, n, dig, jlen, &beta, out, st);
       } else {
+        // (two waves per SIMD, 197 registers on 8 limbs; the same kernel compiled for three -- 168 registers, 4 spilled
+        // dwords -- measured 3.38 against 3.36 ms per vector: no difference, not kept)
         pss_pack_points_jsf_kernel<FrP, Fld><<<dim3((unsigned)((nchunks + 127) / 128), (unsigned)n), block, 0, st>>>(
-            in, nchunks, n, dig, JLEN, out);
+            in, nchunks, n, dig, jlen, beta, out);
       }
     } else if (nv == 4) pss_pack_points_kernel<FrP, Fld, 4><<<grid, block, 0, st>>>(in, nchunks, n, coef, out);
     else return fail(ZK_ERR_BAD_INPUT, "point packing is built for 2 or 4 points per chunk (l = 2, or det_pack at l = 4)");
@@ -228,6 +272,12 @@
     if (!strcmp(name, "msm_acc_lds")) {            // dynamic LDS per accumulate workgroup (MsmTuning::acc_lds); 0 = none
       if (value < 0 || value > 65536) return fail(ZK_ERR_BAD_INPUT, "msm_acc_lds must be in 0..65536");
       msm_.acc_lds = (unsigned)value;
+      return ZK_OK;
+    }
+    if (!strcmp(name, "pack_glv")) {                // det_pack over points: split the scalars by the curve's endomorphism
+      std::lock_guard<std::mutex> lk(mu_);
+      if (pjsf_) return fail(ZK_ERR_BAD_INPUT, "pack_glv must be set before the first zk_pss_pack_points");
+      pack_glv_ = value != 0;
       return ZK_OK;
     }
     if (!strcmp(name, "rng_replay")) {

@@ -7,6 +7,7 @@
 
 #include "ec.hpp"
 #include "engine.hpp"
+#include "glv.hpp"
 #include "ntt.hpp"
 
 namespace zk {
@@ -107,11 +108,11 @@ ZK_HD_NOINLINE Affine<Fld> affine_add_any(const Affine<Fld>& a, const Affine<Fld
 // of +-P0, +-P1, +-(P0 + P1), +-(P0 - P1) instead of ~256 of P0 / P1; the two sums come from ONE inversion (both slopes
 // divide by x1 - x0); the result is normalised with the divstep inversion.  4 755 -> ~3 500 products per share on 8
 // limbs (5 100 with round 5's Fermat ladder).  Lanes of a wave share the party, so the digit branches are wave-uniform.
-//   dig: [n][jlen] bytes, MOST significant column first, (u0 + 1) | (u1 + 1) << 2
+//   dig: [n][jlen] bytes, MOST significant column first, (u0 + 1) | (u1 + 1) << 2 for pair A, the same << 4 for pair B
 template <class FrP, class Fld>
 __global__ __launch_bounds__(128) void pss_pack_points_jsf_kernel(const Affine<Fld>* __restrict__ points, size_t nchunks,
                                                                  int n, const uint8_t* __restrict__ dig, int jlen,
-                                                                 Affine<Fld>* __restrict__ shares) {
+                                                                 const Fld beta, Affine<Fld>* __restrict__ shares) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // grid.y = party: a wave never straddles two parties
   const int p = (int)blockIdx.y;
   if (j >= nchunks || p >= n) return;
@@ -136,52 +137,30 @@ __global__ __launch_bounds__(128) void pss_pack_points_jsf_kernel(const Affine<F
   const uint8_t* dg = dig + (size_t)p * jlen;
   for (int b = 0; b < jlen; b++) {
     acc = xyzz_dbl(acc);
-    const uint32_t c = dg[b];
-    const int u0 = (int)(c & 3u) - 1, u1 = (int)((c >> 2) & 3u) - 1;
-    if (u0 | u1) {
-      const bool two = u0 != 0 && u1 != 0;
-      const bool neg = u0 ? u0 < 0 : u1 < 0;          // the column is +-(entry): sign of its first non-zero digit
-      Affine<Fld> q = two ? (u0 == u1 ? S : D) : (u0 ? P0 : P1);
-      if (neg) q.y = q.y.neg();
-      if (!q.is_identity()) acc = xyzz_madd(acc, q.x, q.y);
+    const uint32_t cc = dg[b];
+    // pair A (low nibble) over the points themselves, pair B (high nibble) over their images under the endomorphism
+    // phi(x, y) = (beta x, y): the scalars were split k = k1 + lambda k2 on the host (glv_split) and phi(P) = lambda P, so
+    // the chain is half as long.  Without the split every B nibble is (0, 0).  One inlined addition site for both.
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const uint32_t c = h ? cc >> 4 : cc & 15u;
+      const int u0 = (int)(c & 3u) - 1, u1 = (int)((c >> 2) & 3u) - 1;
+      if (u0 | u1) {
+        const bool two = u0 != 0 && u1 != 0;
+        const bool neg = u0 ? u0 < 0 : u1 < 0;        // the column is +-(entry): sign of its first non-zero digit
+        Affine<Fld> q = two ? (u0 == u1 ? S : D) : (u0 ? P0 : P1);
+        if (!q.is_identity()) {
+          if (neg) q.y = q.y.neg();
+          if (h) q.x = q.x * beta;
+          acc = xyzz_madd(acc, q.x, q.y);
+        }
+      }
     }
   }
   store_elem(shares + t, xyzz_to_affine(acc));
 }
 
 #endif  // __HIPCC__
-
-// Solinas' joint sparse form of two N-limb integers (canonical, not Montgomery): digits in {-1, 0, 1}, least
-// significant first, at most 32 N + 1 columns; u0[j] 2^j sums to a, u1[j] 2^j to b.
-template <int N>
-inline void jsf_digits(const uint32_t* a, const uint32_t* b, std::vector<int8_t>& u0, std::vector<int8_t>& u1) {
-  uint32_t k[2][N];
-  for (int i = 0; i < N; i++) k[0][i] = a[i], k[1][i] = b[i];
-  int d[2] = {0, 0};
-  auto nonzero = [&](int i) {
-    uint32_t acc = 0;
-    for (int q = 0; q < N; q++) acc |= k[i][q];
-    return acc != 0 || d[i] != 0;
-  };
-  u0.clear();
-  u1.clear();
-  while (nonzero(0) || nonzero(1)) {
-    int l[2], u[2] = {0, 0};
-    for (int i = 0; i < 2; i++) l[i] = (d[i] + (int)(k[i][0] & 7u)) & 7;
-    for (int i = 0; i < 2; i++)
-      if (l[i] & 1) {
-        u[i] = 2 - (l[i] & 3);
-        if ((l[i] == 3 || l[i] == 5) && (l[1 - i] & 3) == 2) u[i] = -u[i];
-      }
-    for (int i = 0; i < 2; i++) {
-      if (2 * d[i] == 1 + u[i]) d[i] = 1 - d[i];
-      for (int q = 0; q < N - 1; q++) k[i][q] = (k[i][q] >> 1) | (k[i][q + 1] << 31);
-      k[i][N - 1] >>= 1;
-    }
-    u0.push_back((int8_t)u[0]);
-    u1.push_back((int8_t)u[1]);
-  }
-}
 
 // Host-side scalar multiplication k * P (k in Montgomery form), plain double-and-add over XYZZ.
 template <class FrP, class Fld>

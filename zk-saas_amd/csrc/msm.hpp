@@ -1592,7 +1592,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
 // dig: the parties' joint-sparse-form digit columns [n][jlen] (groth16.hpp jsf_digits); G1 instantiations return an error.
 template <class FrP, class Fld>
 int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, int n, const uint8_t* dig, int jlen,
-                             void* shares, hipStream_t st);
+                             const void* beta /* one base-field element, host */, void* shares, hipStream_t st);
 // zk_msm_precompute's table kernel (same translation units)
 template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,

@@ -413,11 +413,13 @@ int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwi
 
 template <class FrP, class Fld>
 int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, int n, const uint8_t* dig, int jlen,
-                             void* shares, hipStream_t st) {
+                             const void* beta, void* shares, hipStream_t st) {
   if constexpr (IsExtField<Fld>::value) {
     using P = typename BaseParams<Fld>::type;
+    Fp<P> b;
+    memcpy(&b, beta, sizeof(b));
     pss_pack_points_jsf_split_kernel<FrP, P><<<dim3((unsigned)((nchunks * 4 + 127) / 128), (unsigned)n), dim3(128), 0, st>>>(
-        (const Affine<Fp2<P>>*)points, nchunks, n, dig, jlen, (Affine<Fp2<P>>*)shares);
+        (const Affine<Fp2<P>>*)points, nchunks, n, dig, jlen, b, (Affine<Fp2<P>>*)shares);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return eng->hip_fail(he, "pss_pack_points_jsf_split_kernel");
     return ZK_OK;
@@ -430,6 +432,6 @@ int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, i
   template int msm_launch<FRP, FLD>(IEngine*, MsmSlot&, const MsmTuning&, const void*, const void*, const void*, \
                                     size_t, const Fp<FRP>*, size_t, hipStream_t, MsmPending*, const MsmBatchArg*);  \
   template int msm_table_launch<FRP, FLD>(IEngine*, const void*, size_t, int, int, int, void*, hipStream_t);     \
-  template int pack_points_split_launch<FRP, FLD>(IEngine*, const void*, size_t, int, const uint8_t*, int, void*, hipStream_t);
+  template int pack_points_split_launch<FRP, FLD>(IEngine*, const void*, size_t, int, const uint8_t*, int, const void*, void*, hipStream_t);
 
 }  // namespace zk

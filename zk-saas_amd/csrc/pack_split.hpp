@@ -21,6 +21,7 @@ template <class FrP, class P>
 __global__ __launch_bounds__(128, (P::N > 8 ? 2 : 3)) void pss_pack_points_jsf_split_kernel(const Affine<Fp2<P>>* __restrict__ points,
                                                                        size_t nchunks, int n,
                                                                        const uint8_t* __restrict__ dig, int jlen,
+                                                                       const Fp<P> beta,
                                                                        Affine<Fp2<P>>* __restrict__ shares) {
   using F = Fp<P>;
   const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;        // chunk of this quad
@@ -38,16 +39,25 @@ __global__ __launch_bounds__(128, (P::N > 8 ? 2 : 3)) void pss_pack_points_jsf_s
   const uint8_t* dg = dig + (size_t)p * jlen;
   for (int b = 0; b < jlen; b++) {
     acc = split_dbl(acc, half, comp);
-    const uint32_t c = dg[b];
-    const int u0 = (int)(c & 3u) - 1, u1 = (int)((c >> 2) & 3u) - 1;
-    if (u0 | u1) {
-      const bool two = u0 != 0 && u1 != 0;
-      const bool neg = u0 ? u0 < 0 : u1 < 0;
-      const bool same = u0 == u1;
-      F v = two ? (same ? inS : inD) : (u0 ? in0 : in1);
-      const bool idv = two ? (same ? idS : idD) : (u0 ? id0 : id1);
-      if (neg) v = qsel(half, v.neg(), v);
-      if (!idv) acc = split_madd(acc, v, half, comp);
+    const uint32_t cc = dg[b];
+    // pair A (low nibble) over the points, pair B (high nibble) over their images under phi(x, y) = (beta x, y), beta in the
+    // BASE field: the x lanes (half 0) multiply their component by it (groth16.hpp pss_pack_points_jsf_kernel, glv_split)
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const uint32_t c = h ? cc >> 4 : cc & 15u;
+      const int u0 = (int)(c & 3u) - 1, u1 = (int)((c >> 2) & 3u) - 1;
+      if (u0 | u1) {
+        const bool two = u0 != 0 && u1 != 0;
+        const bool neg = u0 ? u0 < 0 : u1 < 0;
+        const bool same = u0 == u1;
+        F v = two ? (same ? inS : inD) : (u0 ? in0 : in1);
+        const bool idv = two ? (same ? idS : idD) : (u0 ? id0 : id1);
+        if (!idv) {
+          if (neg) v = qsel(half, v.neg(), v);
+          if (h) v = qsel(half, v, v * beta);
+          acc = split_madd(acc, v, half, comp);
+        }
+      }
     }
   }
   F* dst = reinterpret_cast<F*>(shares + (size_t)p * nchunks + j) + q;

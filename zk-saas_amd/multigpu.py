@@ -345,9 +345,9 @@ def bench(args, rank, local_rank, world):
                            "m": m, "masks": full_mask is not None},
                    roofline={"bound": "hbm", "kernel": "d_fft end to end (all ranks)", "achieved": round(gbs, 1),
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
-                             "traffic": _step_traffic("r05_c2_pmc_hbm.json", [("ntt_pass_kernel", 2), ("king_fft2_kernel", 1)])
+                             "traffic": _step_traffic("r06_c2_pmc_hbm.json", [("ntt_pass_kernel", 2), ("king_fft2_kernel", 1)])
                              if world == 1 and full_mask is not None else None,
-                             "traffic_source": "profiles/r05_c2_pmc_hbm.json: two ntt_pass_kernel launches + one "
+                             "traffic_source": "profiles/r06_c2_pmc_hbm.json: two ntt_pass_kernel launches + one "
                                                "king_fft2_kernel launch per d_fft",
                              "algorithmic_bytes_per_launch": alg})
     elif wl == "c3":
@@ -383,8 +383,8 @@ def bench(args, rank, local_rank, world):
                            "plan": plan},
                    roofline={"bound": "hbm", "kernel": "d_msm end to end (all ranks)", "achieved": round(gbs, 1),
                              "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
-                             "traffic": _step_traffic("r05_c3_pmc_hbm.json", None) if world == 1 and not fixed else None,
-                             "traffic_source": "profiles/r05_c3_pmc_hbm.json: every msm_* kernel of one table-free d_msm "
+                             "traffic": _step_traffic("r06_c3_pmc_hbm.json", None) if world == 1 and not fixed else None,
+                             "traffic_source": "profiles/r06_c3_pmc_hbm.json: every msm_* kernel of one table-free d_msm "
                                                "(the accumulate kernel's gathers are 13.1 of the 16 GB)",
                              "algorithmic_bytes_per_launch": alg,
                              "alu": {"achieved": round(gm, 1), "peak": round(MAD_ISSUE_BOUND_G * world, 1),
@@ -565,7 +565,7 @@ def bench(args, rank, local_rank, world):
         # 0.43 s per sort against 25 ms of execution, profiles/r04_c5_kernel_stats.csv; `kernels` below still lists it)
         roof = roofline_of(prof, ntt_passes=3, masks_on=masks is not None, pp=pp, limbs=12,
                            slot_bytes={"msm_accumulate_kernel<G1>": 128.0, "msm_accumulate_kernel<G2>": 224.0},
-                           pmc_file="r05_c5_pmc_hbm.json")
+                           pmc_file="r06_c5_pmc_hbm.json")
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             del wit
