@@ -65,11 +65,16 @@
         std::lock_guard<std::mutex> lk(mu_);
         base_tables_[key + "#16"] = wide;
       }
-      fixed_base_mul_kernel<FrP, Fld, 16><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
-          (const Fr*)scalars, len, wide, nwin16, (Affine<Fld>*)out_affine);
+      // extension field: a quad of lanes per scalar (pack_split.hpp, launched from the curve's G2 translation unit)
+      if constexpr (IsExtField<Fld>::value) return base_mul_split_launch<FrP, Fld>(this, scalars, len, wide, nwin16, 16, out_affine, st);
+      else
+        fixed_base_mul_kernel<FrP, Fld, 16><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
+            (const Fr*)scalars, len, wide, nwin16, (Affine<Fld>*)out_affine);
     } else {
-      fixed_base_mul_kernel<FrP, Fld, 8><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
-          (const Fr*)scalars, len, table, nwin, (Affine<Fld>*)out_affine);
+      if constexpr (IsExtField<Fld>::value) return base_mul_split_launch<FrP, Fld>(this, scalars, len, table, nwin, 8, out_affine, st);
+      else
+        fixed_base_mul_kernel<FrP, Fld, 8><<<dim3((unsigned)((len + 127) / 128)), dim3(128), 0, st>>>(
+            (const Fr*)scalars, len, table, nwin, (Affine<Fld>*)out_affine);
     }
     ZK_HIP(hipGetLastError());
     return ZK_OK;
@@ -80,8 +85,8 @@
     using Fq2 = Fp2<typename Cfg::FqP>;
     if (group == ZK_G1) return base_mul_t<Fq>(base_affine, scalars, len, out_affine, st);
     if (group == ZK_G2) {
-      if (!Cfg::HAS_G2) return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
-      return base_mul_t<Fq2>(base_affine, scalars, len, out_affine, st);
+      if constexpr (Cfg::HAS_G2) return base_mul_t<Fq2>(base_affine, scalars, len, out_affine, st);     // (quad-split kernel: G2 units only)
+      else return fail(ZK_ERR_BAD_INPUT, "G2 is not available for this curve");
     }
     return fail(ZK_ERR_BAD_INPUT, "group must be ZK_G1 or ZK_G2");
   }

@@ -1593,6 +1593,10 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
 template <class FrP, class Fld>
 int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, int n, const uint8_t* dig, int jlen,
                              const void* beta /* one base-field element, host */, void* shares, hipStream_t st);
+// fixed-base multiplication over extension-field points, quad-split (pack_split.hpp fixed_base_mul_split_kernel); wb = 8 or 16
+template <class FrP, class Fld>
+int base_mul_split_launch(IEngine* eng, const void* scalars, size_t len, const void* table, int nwin, int wb, void* out,
+                          hipStream_t st);
 // zk_msm_precompute's table kernel (same translation units)
 template <class FrP, class Fld>
 int msm_table_launch(IEngine* eng, const void* bases, size_t len, int c, int nwin, int wide, void* table,

@@ -428,10 +428,31 @@ int pack_points_split_launch(IEngine* eng, const void* points, size_t nchunks, i
   }
 }
 
+template <class FrP, class Fld>
+int base_mul_split_launch(IEngine* eng, const void* scalars, size_t len, const void* table, int nwin, int wb, void* out,
+                          hipStream_t st) {
+  if constexpr (IsExtField<Fld>::value) {
+    using P = typename BaseParams<Fld>::type;
+    const dim3 grid((unsigned)((len * 4 + 127) / 128)), block(128);
+    if (wb == 16)
+      fixed_base_mul_split_kernel<FrP, P, 16><<<grid, block, 0, st>>>((const Fp<FrP>*)scalars, len, (const Affine<Fp2<P>>*)table,
+                                                                      nwin, (Affine<Fp2<P>>*)out);
+    else
+      fixed_base_mul_split_kernel<FrP, P, 8><<<grid, block, 0, st>>>((const Fp<FrP>*)scalars, len, (const Affine<Fp2<P>>*)table,
+                                                                     nwin, (Affine<Fp2<P>>*)out);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return eng->hip_fail(he, "fixed_base_mul_split_kernel");
+    return ZK_OK;
+  } else {
+    return eng->fail(ZK_ERR_BAD_INPUT, "the quad-split fixed-base kernel is for extension-field points");
+  }
+}
+
 #define ZK_INSTANTIATE_MSM(FRP, FLD)                                                                              \
   template int msm_launch<FRP, FLD>(IEngine*, MsmSlot&, const MsmTuning&, const void*, const void*, const void*, \
                                     size_t, const Fp<FRP>*, size_t, hipStream_t, MsmPending*, const MsmBatchArg*);  \
   template int msm_table_launch<FRP, FLD>(IEngine*, const void*, size_t, int, int, int, void*, hipStream_t);     \
-  template int pack_points_split_launch<FRP, FLD>(IEngine*, const void*, size_t, int, const uint8_t*, int, const void*, void*, hipStream_t);
+  template int pack_points_split_launch<FRP, FLD>(IEngine*, const void*, size_t, int, const uint8_t*, int, const void*, void*, hipStream_t); \
+  template int base_mul_split_launch<FRP, FLD>(IEngine*, const void*, size_t, const void*, int, int, void*, hipStream_t);
 
 }  // namespace zk

@@ -60,15 +60,37 @@ __global__ __launch_bounds__(128, (P::N > 8 ? 2 : 3)) void pss_pack_points_jsf_s
       }
     }
   }
-  F* dst = reinterpret_cast<F*>(shares + (size_t)p * nchunks + j) + q;
-  const uint32_t zz = s2_is_zero(acc.c1) ? 1u : 0u;
-  if (qperm_u32<0, 0, 0, 0>(zz)) {                                              // identity: the (0, 0) sentinel
-    store_elem(dst, F::zero());
-    return;
+  split_store_affine<P>(acc, reinterpret_cast<F*>(shares + (size_t)p * nchunks + j) + q, half, comp);
+}
+
+// out[i] = scalars[i] * Base for EXTENSION-field points (groth16.hpp fixed_base_mul_kernel: table[w][d-1] = d 2^(WB w) Base) in
+// the same lane layout: a quad of lanes per scalar, one base-field value per lane.  The one-lane form holds whole Fq2
+// values and runs ONE wave per SIMD on 12-limb fields (profiles/r06_c5_sq_counters.json: 0.99 waves in flight, 52 % of
+// the wave's cycles issuing, 0.12 VALU instructions per SIMD cycle against 0.23-0.25 of the saturated kernels).
+template <class FrP, class P, int WB>
+__global__ __launch_bounds__(128, (P::N > 8 ? 2 : 3)) void fixed_base_mul_split_kernel(const Fp<FrP>* __restrict__ scalars, size_t len,
+                                                                                      const Affine<Fp2<P>>* __restrict__ table,
+                                                                                      int nwin, Affine<Fp2<P>>* __restrict__ out) {
+  using F = Fp<P>;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (i >= len) return;                                                         // quad-uniform
+  const int q = threadIdx.x & 3;
+  const bool half = (q >> 1) != 0, comp = (q & 1) != 0;
+  Fp<FrP> s = load_elem(scalars + i).from_mont();                               // the four lanes alike
+  SplitAcc<P> acc = split_identity<P>(comp);
+  constexpr int N = FrP::N;
+  constexpr uint32_t PER = (1u << WB) - 1u;
+  for (int w = 0; w < nwin; w++) {
+    const uint32_t d = s.v[0] & PER;
+#pragma unroll
+    for (int k = 0; k < N - 1; k++) s.v[k] = (s.v[k] >> WB) | (s.v[k + 1] << (32 - WB));
+    s.v[N - 1] >>= WB;
+    if (d) {
+      const F v = load_elem(reinterpret_cast<const F*>(table + (size_t)w * PER + (d - 1)) + q);
+      acc = split_madd(acc, v, half, comp);
+    }
   }
-  const F zi = split_inv(qperm<2, 3, 2, 3>(acc.c1), comp);                      // 1 / ZZZ, every lane its component
-  const F zi2 = s2_sqr(s2_mul(zi, qperm<0, 1, 0, 1>(acc.c1), comp), comp);      // (ZZ / ZZZ)^2 = 1 / Z^2
-  store_elem(dst, s2_mul(acc.c0, qsel(half, zi, zi2), comp));                   // 0: X / Z^2        1: Y / Z^3
+  split_store_affine<P>(acc, reinterpret_cast<F*>(out + i) + q, half, comp);
 }
 
 #endif  // __HIPCC__

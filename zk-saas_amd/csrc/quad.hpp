@@ -288,6 +288,22 @@ __device__ __noinline__ Fp<P> split_affine_add(const Fp<P>& a, bool ida, const F
   return qsel(half, y3, x3);
 }
 
+// Normalise a split running sum and store it as Affine<Fq2> (dst: this lane's base-field element of the point, i.e.
+// reinterpret_cast<Fp<P>*>(point) + q): 1 / ZZZ through the norm -- ONE base-field inversion, computed by the four lanes
+// alike -- then x = X (ZZ / ZZZ)^2, y = Y / ZZZ.  The identity is stored as the (0, 0) sentinel.  Quad-uniform.
+template <class P>
+ZK_D void split_store_affine(const SplitAcc<P>& acc, Fp<P>* dst, bool half, bool comp) {
+  using F = Fp<P>;
+  const uint32_t zz = s2_is_zero(acc.c1) ? 1u : 0u;
+  if (qperm_u32<0, 0, 0, 0>(zz)) {
+    store_elem(dst, F::zero());
+    return;
+  }
+  const F zi = split_inv(qperm<2, 3, 2, 3>(acc.c1), comp);                      // 1 / ZZZ, every lane its component
+  const F zi2 = s2_sqr(s2_mul(zi, qperm<0, 1, 0, 1>(acc.c1), comp), comp);      // (ZZ / ZZZ)^2 = 1 / Z^2
+  store_elem(dst, s2_mul(acc.c0, qsel(half, zi, zi2), comp));                   // 0: X / Z^2        1: Y / Z^3
+}
+
 // Tree sum inside aligned sub-blocks of `nvl` (power of two) virtual lanes of a workgroup: every quad contributes the
 // point whose coordinates its lanes hold; afterwards the first quad of each sub-block holds the sub-block's total.
 // `sh` is LDS for blockDim.x / 4 points.  log2(nvl) dependent additions.
