@@ -274,6 +274,10 @@
       msm_.bigsort_min = (size_t)value;
       return ZK_OK;
     }
+    if (!strcmp(name, "msm_skip_kernel")) {        // A/B only: identity bases through a mask kernel of its own (round 5's form)
+      msm_.skip_kernel = value != 0;
+      return ZK_OK;
+    }
     if (!strcmp(name, "msm_acc_lds")) {            // dynamic LDS per accumulate workgroup (MsmTuning::acc_lds); 0 = none
       if (value < 0 || value > 65536) return fail(ZK_ERR_BAD_INPUT, "msm_acc_lds must be in 0..65536");
       msm_.acc_lds = (unsigned)value;

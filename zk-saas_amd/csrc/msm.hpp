@@ -73,6 +73,41 @@ struct MsmScalars {
   uint32_t sets_per;      // bucket sets per vector
 };
 
+// Identity bases contribute nothing and are left out of the sort: the FIRST sort-stage kernel (the histogram pass, which
+// also writes the canonical scalars the later passes read) looks at the base itself -- the identity sentinel (0, 0) is an
+// affine point whose every byte is zero -- and gives the point a zero scalar.  A Groth16 CRS is full of identities: b_query
+// holds one for every wire that no B-row mentions (59 % of the SHA-256 circuit's wires; half of the PACKED shares), and a
+// lane that loads an identity idles while its wave adds (measured: 49 % of the lanes of the G2 accumulate active).
+// Until round 6 a kernel of its own wrote a bit mask first (msm_skip_mask_kernel): 4 us alone, but on the chain of the
+// table-free U-MSM inside a proof its span read 166-195 us (its 512 four-wave workgroups waiting for wave slots among the
+// bulk accumulate waves: profiles/r06_c4tf_timeline.txt).  One launch, one dependent boundary and one buffer less now --
+// and NO change in proofs/s (same-box A/B against the mask kernel, option "msm_skip_kernel": table-free 450-452 vs 434-456,
+// with tables 645-652 vs 645-651, profiles/r06_skipfold_ab.txt): the chain waits for the chip elsewhere instead.
+struct MsmBaseId {
+  const void* b0 = nullptr;   // nullptr: no base of the launch is the identity (registered vectors know: zk_msm_precompute)
+  const void* b1 = nullptr;   // second base vector of the launch (own sort when ys != 0: blockIdx.y picks the vector)
+  uint32_t elem16 = 0;        // bytes per affine point / 16
+  const uint32_t* skip = nullptr;   // A/B only (zk_ctx_set_option "msm_skip_kernel"): round 5's bit mask, written by a kernel of its own
+  size_t skip_ys = 0;               // ... its stride between the two sorts, in words
+};
+ZK_D bool msm_base_zero(const void* bases, uint32_t elem16, uint32_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(bases) + (size_t)i * elem16;
+  uint4 a = p[0];
+  for (uint32_t k = 1; k < elem16; k++) {
+    const uint4 b = p[k];
+    a.x |= b.x, a.y |= b.y, a.z |= b.z, a.w |= b.w;
+  }
+  return (a.x | a.y | a.z | a.w) == 0u;
+}
+// ys != 0 (grid.y = 2): one sort per base vector, each skips its own identities; ys == 0: one sort, a point is skipped when
+// EVERY vector holds the identity there
+ZK_D bool msm_base_is_identity(const MsmBaseId& id, uint32_t i, size_t ys) {
+  if (id.skip) return ((id.skip[(size_t)blockIdx.y * id.skip_ys + (i >> 5)] >> (i & 31)) & 1u) != 0;
+  if (!id.b0) return false;
+  if (ys) return msm_base_zero(blockIdx.y ? id.b1 : id.b0, id.elem16, i);
+  return msm_base_zero(id.b0, id.elem16, i) && (!id.b1 || msm_base_zero(id.b1, id.elem16, i));
+}
+
 // -------------------------------------------------------------------------------------------------- digits
 // pass 0: histogram; pass 1: scatter.  coef (optional): per-part multiplier, part = i / part_len.
 template <class FrP, int PASS>
@@ -82,27 +117,30 @@ __global__ void msm_digits_kernel(MsmScalars<Fp<FrP>> sc, const Fp<FrP>* __restr
                                   window; all windows share ONE bucket set; 0 = no table */, uint32_t pre_off,
                                   uint32_t* __restrict__ counts /* [nsets*B] */,
                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
-                                  const uint32_t* __restrict__ skip /* bit i: base i is the identity */,
+                                  MsmBaseId bid /* identity bases get a zero scalar in pass 0 */,
                                   Fp<FrP>* __restrict__ canon /* canonical scalars: written by pass 0, read by pass 1 */,
                                   size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(counts);
   ZK_YSHIFT(cursor);
   ZK_YSHIFT(sorted);
-  ZK_YSHIFT(skip);
   ZK_YSHIFT(canon);
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)sc.npts * sc.nb) return;
   const uint32_t vb = (uint32_t)(g / sc.npts), i = (uint32_t)(g % sc.npts);
-  if (skip && ((skip[i >> 5] >> (i & 31)) & 1u)) return;
   Fp<FrP> s;
   if (PASS == 0) {
+    if (msm_base_is_identity(bid, i, ys)) {
+      store_elem(canon + g, Fp<FrP>::zero());
+      return;
+    }
     s = load_elem(sc.p[vb] + i);
     if (coef) s = s * coef[i / part_len];
     s = s.from_mont();
     store_elem(canon + g, s);
   } else {
     s = load_elem(canon + g);
+    if (s.is_zero()) return;
   }
   const uint32_t set0 = vb * sc.sets_per;
   uint32_t carry = 0;
@@ -167,10 +205,9 @@ inline hipError_t msm_lds_attr(const void* fn, size_t bytes, int device) {
   return e;
 }
 
-// Identity bases contribute nothing: bit i of `skip` is set when base i is the identity in EVERY base vector of the
-// launch, and the sort then emits no entry for point i.  A Groth16 CRS is full of them -- b_query holds the identity for
-// every wire that no B-row mentions (59 % of the SHA-256 circuit's wires; half of the PACKED shares) -- and a lane
-// that loads an identity idles while its wave adds (measured: 49 % of the lanes of the G2 accumulate active).
+// Bit mask of the identity bases of a vector (bit i of `skip`).  Since round 6 only zk_msm_precompute runs it, once per
+// registered vector, to learn whether the vector holds an identity AT ALL (MsmTable::any_identity); the sorts look at the
+// bases themselves (MsmBaseId above).
 template <class Fld>
 __global__ __launch_bounds__(256) void msm_skip_mask_kernel(const Affine<Fld>* __restrict__ bases0,
                                                             const Affine<Fld>* __restrict__ bases1, size_t npts,
@@ -330,9 +367,9 @@ ZK_HD size_t msm_bins_words(size_t nbins) { return 3 * nbins + 2; }
 // scalar of (vector vb of the batch, point i); identity bases give zero (no digit, no entry)
 template <class FrP>
 __device__ __forceinline__ Fp<FrP> msm_canon_scalar(const MsmScalars<Fp<FrP>>& sc, const Fp<FrP>* coef, size_t part_len,
-                                                    uint32_t vb, uint32_t i, const uint32_t* skip) {
+                                                    uint32_t vb, uint32_t i, const MsmBaseId& bid, size_t ys) {
   Fp<FrP> s = Fp<FrP>::zero();
-  if (!(skip && ((skip[i >> 5] >> (i & 31)) & 1u))) {
+  if (!msm_base_is_identity(bid, i, ys)) {
     s = load_elem(sc.p[vb] + i);
     if (coef) s = s * coef[i / part_len];
     s = s.from_mont();
@@ -350,7 +387,7 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
                                                                int w_begin /* the launch sorts windows [w_begin, nwin)
                                                                only (a window group of a split MSM): set = w - w_begin */,
                                                                uint32_t* __restrict__ bins,
-                                                               const uint32_t* __restrict__ skip,
+                                                               MsmBaseId bid,
                                                                Fp<FrP>* __restrict__ canon,
                                                                uint16_t* __restrict__ tile_counts /* optional
                                                                [tiles][bins of one vector]: the staged scatter, whose
@@ -358,7 +395,6 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
                                                                size_t ys) {
   __builtin_amdgcn_s_setprio(3);   // short sort-stage kernel: win issue arbitration against the bulk accumulate waves
   ZK_YSHIFT(bins);
-  ZK_YSHIFT(skip);
   ZK_YSHIFT(canon);
   ZK_YSHIFT(tile_counts);
   extern __shared__ uint32_t big_lds[];
@@ -368,10 +404,19 @@ __global__ __launch_bounds__(BIG_THREADS) void msm_hist_kernel(MsmScalars<Fp<FrP
   const uint32_t pt0 = (blockIdx.x % tiles_per_vec) * (uint32_t)(BIG_THREADS * ppt);
   for (uint32_t b = threadIdx.x; b < nbl; b += BIG_THREADS) big_lds[b] = 0;
   __syncthreads();
+  // the identity tests of the thread's points first: independent loads, in flight together (inside the loop below each
+  // would sit in front of its scalar's load: two dependent memory latencies per point)
+  uint32_t idmask = 0;
+  if (bid.b0 || bid.skip)
+    for (int k = 0; k < ppt; k++) {
+      const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
+      if (i < sc.npts && msm_base_is_identity(bid, i, ys)) idmask |= 1u << k;
+    }
+  const MsmBaseId no_id{};
   for (int k = 0; k < ppt; k++) {
     const uint32_t i = pt0 + (uint32_t)k * BIG_THREADS + threadIdx.x;
     if (i >= sc.npts) break;
-    const Fp<FrP> s = msm_canon_scalar<FrP>(sc, coef, part_len, vb, i, skip);
+    const Fp<FrP> s = ((idmask >> k) & 1u) ? Fp<FrP>::zero() : msm_canon_scalar<FrP>(sc, coef, part_len, vb, i, no_id, ys);
     store_elem(canon + (size_t)vb * sc.npts + i, s);
     msm_for_each_digit<FrP>(s, c, nwin, wide, [&](int w, uint32_t b, uint32_t) {
       if (w >= w_begin) atomicAdd(&big_lds[(((uint32_t)(w - w_begin) & wmask) << hi_bits) | (b >> lo_bits)], 1u);
@@ -1514,6 +1559,7 @@ struct MsmTuning {
   // caps the accumulate workgroups a CU holds, i.e. leaves wave slots and registers free for the short kernels of a
   // proof's critical chain, which otherwise wait for an accumulate wave to retire before they can become resident
   unsigned acc_lds = 0;
+  bool skip_kernel = false;   // A/B only: identity bases through round 5's separate mask kernel instead of MsmBaseId's test
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -1796,7 +1842,7 @@ class MsmRunner {
                const MsmBatchArg* batch = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1, acc_lds};
+    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1, acc_lds, skip_kernel};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }
@@ -2052,6 +2098,7 @@ class MsmRunner {
   // two-level sort from this many points on (zk_ctx_set_option "msm_bigsort_min")
   size_t bigsort_min = (size_t)1 << 14;
   unsigned acc_lds = 0;           // zk_ctx_set_option "msm_acc_lds" (MsmTuning::acc_lds)
+  bool skip_kernel = false;       // zk_ctx_set_option "msm_skip_kernel" (MsmTuning::skip_kernel)
   MsmSlot slots_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;

@@ -20,7 +20,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
   if (npts == 0) return ZK_OK;
   if (npts * batch >= ((size_t)1 << 31)) return eng->fail(ZK_ERR_BAD_INPUT, "msm too large");
   constexpr bool G2FLD = IsExtField<Fld>::value;
-  const void* const bases_in = bases;            // the caller's points (the skip mask reads them, not the table rows)
+  const void* const bases_in = bases;            // the caller's points (the identity test reads them, not the table rows)
   const void* const bases2_in = bases2;
   // fixed-base table registered for this base vector (and the same window layout / offset for the second one)?
   size_t toff = 0, toff2 = 0;
@@ -71,7 +71,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
-  // identity bases are left out of the sort (msm_skip_mask_kernel).
+  // identity bases are left out of the sort (msm.hpp MsmBaseId: the first sort-stage kernel gives them a zero scalar).
   // Two base vectors over the same scalars then get their OWN sorts (their identities differ: a fused sort could only
   // skip a point that is the identity in both) -- same kernels, grid.y = 2, the sort-stage arrays in two copies of one
   // workspace region (ZK_YSHIFT in the kernels).
@@ -203,12 +203,18 @@ do {                                                                           \
   sc.nb = (uint32_t)batch;
   sc.sets_per = (uint32_t)kwin;
   Fr* canon = (Fr*)(ws + o_canon);
-  uint32_t* skip = nullptr;
+  // identity bases: the first sort-stage kernel looks at the caller's points itself (msm.hpp MsmBaseId)
+  MsmBaseId bid;
   if (skip_on && !none) {
-    skip = (uint32_t*)(ws + o_skip);
-    // (one-wave workgroups for this kernel were measured -- its span reads 178-195 us at the head of the table-free U-MSM,
-    // profiles/r05_c4tf_timeline.txt -- and lose: 430-447 vs 440-450 proofs/s table-free, same box; no change with tables)
-    msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip, ys);
+    bid.b0 = bases_in;
+    bid.b1 = bases2_in;
+    bid.elem16 = (uint32_t)(sizeof(Affine<KF>) / 16);
+    if (tune.skip_kernel) {
+      uint32_t* skip = (uint32_t*)(ws + o_skip);
+      msm_skip_mask_kernel<KF><<<pg, pb, 0, st>>>((const Affine<KF>*)bases_in, (const Affine<KF>*)bases2_in, npts, skip, ys);
+      bid.skip = skip;
+      bid.skip_ys = ys / 4;
+    }
   }
   const size_t plen = part_len ? part_len : npts;
   {
@@ -226,7 +232,7 @@ do {                                                                           \
       const size_t hl = (nbins_tot + BIG_THREADS / 64) * 4;      // tile histogram (one vector's bins); all bins for the last workgroup's scan
       if (hl > 48 * 1024) MSM_HIP(msm_lds_attr((const void*)msm_hist_kernel<FrP>, hl, eng->device));
       msm_hist_kernel<FrP><<<dim3(tpv * (unsigned)batch, NS), dim3(BIG_THREADS), hl, st>>>(
-          sc, coef_d, plen, c, w_end, wide, sort_hi, sort_lo, hp, tpv, wmask, w_begin, bins, skip, canon, tcnt, ys);
+          sc, coef_d, plen, c, w_end, wide, sort_hi, sort_lo, hp, tpv, wmask, w_begin, bins, bid, canon, tcnt, ys);
     }
     if (large) {
       const unsigned tpv = (unsigned)((npts + tile_pts - 1) / tile_pts);
@@ -284,7 +290,7 @@ do {                                                                           \
     MSM_STAGE("big sort");
   } else {
     msm_digits_kernel<FrP, 0><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, counts, nullptr,
-                                                 nullptr, skip, canon, ys);
+                                                 nullptr, bid, canon, ys);
     MSM_STAGE("digits/count");
     iscan_block_kernel<<<dim3((unsigned)iscan_blocks, NS), dim3(ISCAN_THREADS), 0, st>>>(counts, nkeys, bt, nullptr,
                                                                                          nullptr, nullptr, 0, ys);
@@ -294,7 +300,7 @@ do {                                                                           \
     MSM_STAGE("scan");
     msm_lane_start_kernel<<<dim3((nlanes + 255) / 256, NS), dim3(256), 0, st>>>(offsets, (uint32_t)nkeys, nlanes, tmin, cap, k0, ys);
     msm_digits_kernel<FrP, 1><<<pgb, pb, 0, st>>>(sc, coef_d, plen, c, nwin, wide, pre_stride, pre_off, nullptr, cursor,
-                                                 sorted, skip, canon, ys);
+                                                 sorted, bid, canon, ys);
   }
   }
   }
