@@ -242,7 +242,9 @@ def test_msm_both_sort_paths_agree_and_match_oracle(curve, group):
     n = 4096 + 777
     distinct = _points(G, c, 48, 64)
     pts = [distinct[i % 48] for i in range(n)]
-    pts[5] = None                                  # an identity base
+    ident = {5} | {i for i in range(n) if i % 11 == 3}     # identity bases: one early, then every eleventh (a CRS is full of them)
+    for i in ident:
+        pts[i] = None
     bases = zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, pts, is2))
     cases = {
         "random": rand_vec(65, n, c.r),
@@ -252,13 +254,15 @@ def test_msm_both_sort_paths_agree_and_match_oracle(curve, group):
     for name, sc in cases.items():
         sc_d = up(pp, sc)
         outs = []
-        for big_min in (0, 1 << 40):
+        # both sorts, and the identity bases found by the histogram kernel itself (default) or by round 5's mask kernel
+        for big_min, skip_kernel in ((0, 0), (1 << 40, 0), (0, 1), (1 << 40, 1)):
             pp.set_option("msm_bigsort_min", big_min)
+            pp.set_option("msm_skip_kernel", skip_kernel)
             outs.append(dec_jacobian(pp, msm(pp, group, bases, sc_d, n), is2))
-        assert G.eq(outs[0], outs[1]), name
-        agg = [0] * 48                                   # sum_i s_i * P_(i mod 48), identity base skipped
+        assert all(G.eq(outs[0], o) for o in outs[1:]), name
+        agg = [0] * 48                                   # sum_i s_i * P_(i mod 48), identity bases skipped
         for i, s in enumerate(sc):
-            if i != 5:
+            if i not in ident:
                 agg[i % 48] = (agg[i % 48] + s) % c.r
         assert G.eq(outs[0], G.msm(distinct, agg)), name
     with pytest.raises(zk.ZkError):
