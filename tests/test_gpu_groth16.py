@@ -219,11 +219,13 @@ def test_pack_points_with_random_points_reconstructs():
             assert (v[0], v[1]) == G1.to_affine(want[p_])
 
 
-@pytest.mark.parametrize("curve,group", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g2")])
+@pytest.mark.parametrize("curve,group", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bls12_381", "g2"),
+                                         ("bls12_377", "g1")])
 def test_det_pack_over_points_edge_cases_match_oracle(curve, group):
     """proving_key.rs:72-86 (det_pack over curve points, l = 2) chunk by chunk against the oracle's det_pack over GroupOps,
     with the chunks a CRS never holds: an identity in either slot, both, equal points, opposite points.  G2 runs the
-    quad-split kernel (one base-field value per lane), G1 the one-lane joint-sparse-form kernel."""
+    quad-split kernel (one base-field value per lane), G1 the one-lane joint-sparse-form kernel; both walk the scalars split
+    by the curve's endomorphism (csrc/glv.hpp), and a second context with pack_glv = 0 must give the same shares."""
     from oracle.curve import g2 as og2
     from oracle.params import CURVES
     from gpu_util import enc_affine
@@ -242,6 +244,12 @@ def test_det_pack_over_points_edge_cases_match_oracle(curve, group):
                         zk.DeviceBuffer.from_numpy(pp, enc_affine(pp, flat, g2=is2)), nch, 2)
     ncoord = 4 if is2 else 2
     rows = sh.to_numpy().reshape(o.n, nch, ncoord * pp.fq.nl)
+    plain = zk.PackedSharingParams(curve, 2)
+    plain.set_option("pack_glv", 0)
+    sh0 = zg.pack_points(plain, zk.api.ZK_G2 if is2 else zk.api.ZK_G1,
+                         zk.DeviceBuffer.from_numpy(plain, enc_affine(plain, flat, g2=is2)), nch, 2)
+    assert np.array_equal(sh0.to_numpy(), sh.to_numpy())
+    plain.close()
     for j, ch in enumerate(chunks):
         want = o.det_pack([G.from_affine(ch[0]), G.from_affine(ch[1])], ops)
         for p_ in range(o.n):
