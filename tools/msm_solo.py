@@ -12,7 +12,9 @@ import zksaas_amd as zk                          # noqa: E402
 from zksaas_amd import api, groth16 as zg        # noqa: E402
 from zksaas_amd.api import ZK_G1, ZK_G2, DeviceBuffer   # noqa: E402
 
-pp = zk.PackedSharingParams("bn254", 2)
+pp = zk.PackedSharingParams(os.environ.get("CURVE", "bn254"), 2)
+for kv in filter(None, os.environ.get("ZK_BENCH_OPTIONS", "").split(",")):     # A/B runs: name=value context options
+    pp.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 n = int(os.environ.get("NPTS", 8 * 14911))
 rng = np.random.default_rng(3)
 
@@ -32,7 +34,7 @@ for _ in range(3):
     api.msm(pp, grp, bases, sc, n)
 pp.sync()
 t0 = time.perf_counter()
-reps = 20
+reps = int(os.environ.get("REPS", "20"))
 for _ in range(reps):
     api.msm(pp, grp, bases, sc, n)
 pp.sync()
