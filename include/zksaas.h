@@ -268,6 +268,8 @@ int zk_msm_table_info(zk_ctx* ctx, int group, const void* bases_d, int info[2]);
  *   the doubling chain; the same points).  Before the first zk_pss_pack_points of the context.
  * "msm_skip_kernel": 1 = identity bases are found by a mask kernel of its own ahead of every sort (round 5's form) instead of
  *   by the first sort kernel looking at the bases (default 0; same results, measured equal: profiles/r06_skipfold_ab.txt).
+ * "msm_sort_lo_tab": low bucket bits per bin (4..10, 0 = the default 7) of a small sort over a fixed-base table, i.e. 2^(c-1-value)
+ *   bins / bin-sort workgroups (A/B only; 6 and 8 measured against 7 on the SHA-256 proof: no gain, profiles/r06_sort_bins_ab.txt).
  * "msm_acc_lds": dynamic LDS bytes (0..65536, default 0) launched with every accumulate workgroup, which caps how many of
  *   them a CU holds (measured on the SHA-256 proof: a loss at every size, profiles/r06_acc_lds_sweep.txt; kept for A/B runs).
  * Nothing is read from the environment.  Unknown name or value out of range -> ZK_ERR_BAD_INPUT. */

@@ -274,6 +274,11 @@
       msm_.bigsort_min = (size_t)value;
       return ZK_OK;
     }
+    if (!strcmp(name, "msm_sort_lo_tab")) {        // A/B only: low bucket bits per bin of a small sort over a fixed-base table
+      if (value != 0 && (value < 4 || value > 10)) return fail(ZK_ERR_BAD_INPUT, "msm_sort_lo_tab must be 0 or in 4..10");
+      msm_.sort_lo_tab = (int)value;
+      return ZK_OK;
+    }
     if (!strcmp(name, "msm_skip_kernel")) {        // A/B only: identity bases through a mask kernel of its own (round 5's form)
       msm_.skip_kernel = value != 0;
       return ZK_OK;

@@ -1560,6 +1560,7 @@ struct MsmTuning {
   // proof's critical chain, which otherwise wait for an accumulate wave to retire before they can become resident
   unsigned acc_lds = 0;
   bool skip_kernel = false;   // A/B only: identity bases through round 5's separate mask kernel instead of MsmBaseId's test
+  int sort_lo_tab = 0;        // A/B only (zk_ctx_set_option "msm_sort_lo_tab"): low bucket bits per bin of a small TABLE sort (0 = 7)
 };
 
 // Window width: minimise nwin * (npts + 4 * buckets) -- mixed additions plus the per-bucket reduction work --
@@ -1842,7 +1843,7 @@ class MsmRunner {
                const MsmBatchArg* batch = nullptr) {
     if (wslot < 0 || wslot >= MSM_WS) return eng->fail(ZK_ERR_BAD_INPUT, "bad msm workspace slot");
     if (pend->active) return eng->fail(ZK_ERR_GENERIC, "msm workspace slot still in flight");
-    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1, acc_lds, skip_kernel};
+    MsmTuning tune{bigsort_min, gate, IsExtField<Fld>::value ? c_g2 : c_g1, acc_lds, skip_kernel, sort_lo_tab};
     return msm_launch<FrP, Fld>(eng, slots_[wslot], tune, bases, bases2, scalars, npts, coef_d, part_len, st, pend,
                                 batch);
   }
@@ -2099,6 +2100,7 @@ class MsmRunner {
   size_t bigsort_min = (size_t)1 << 14;
   unsigned acc_lds = 0;           // zk_ctx_set_option "msm_acc_lds" (MsmTuning::acc_lds)
   bool skip_kernel = false;       // zk_ctx_set_option "msm_skip_kernel" (MsmTuning::skip_kernel)
+  int sort_lo_tab = 0;            // zk_ctx_set_option "msm_sort_lo_tab" (MsmTuning::sort_lo_tab)
   MsmSlot slots_[MSM_WS];
   Fr* coef_d_ = nullptr;
   std::vector<Fr> coef_h_;

@@ -92,7 +92,7 @@ int msm_launch(IEngine* eng, MsmSlot& slot, const MsmTuning& tune, const void* b
     while (ppt > 1 && (size_t)nwin * sthr * ppt > stage_max) ppt >>= 1;       // with a table the whole tile is one round
   // small launches: at least 7 low bits per bin (a table-free proof has 12-bit buckets in 20 sets: 8 top bits made 5120
   // bins of 16 buckets, one workgroup each -- measured 428 -> 442-447 proofs/s table-free with 5 top bits)
-  int sort_hi = std::min(msm_big_hi(nsets), std::max(1, c - 1 - 7)), sort_lo;
+  int sort_hi = std::min(msm_big_hi(nsets), std::max(1, c - 1 - (tab && tune.sort_lo_tab ? tune.sort_lo_tab : 7))), sort_lo;
   if (large) {
     // runs of level 1 are (tile entries per bucket set) / 2^hi long, runs of level 2 (chunk) / 2^lo: balance them
     auto lg = [](size_t v) { int l = 0; while (((size_t)1 << (l + 1)) <= v) l++; return l; };
